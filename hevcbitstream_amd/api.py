@@ -1,0 +1,137 @@
+"""ctypes binding of include/hevcbitstream_amd.h over torch device tensors."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# layout of hbs_nal_entry / hbs_summary (include/hevcbitstream_amd.h)
+NAL_ENTRY = np.dtype([("start", "<u8"), ("end", "<u8"), ("rbsp_off", "<u8"),
+                      ("rbsp_len", "<u4"), ("status", "<i4")])
+SUMMARY = np.dtype([("nal_count", "<u8"), ("nal_found", "<u8"), ("rbsp_bytes", "<u8"),
+                    ("stream_bytes", "<u8"), ("stop_reason", "<i4"), ("error", "<i4"),
+                    ("reserved", "<u8", (3,))])
+ST_ERROR, ST_TRAILING03, ST_UNTERMINATED = 1, 2, 4
+
+EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stream", "hbs_ctx_use_own_stream",
+           "hbs_ctx_get_stream",
+           "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_read_summary",
+           "hbs_workspace_bytes"]
+
+
+class HbsError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libhevcbitstream_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load the gfx950 library.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = library_path()
+    if not os.path.exists(p):
+        raise HbsError("%s not built: run `make lib` (hipcc --offload-arch=gfx950); "
+                       "there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    lib.hbs_version.restype = C.c_char_p
+    lib.hbs_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.hbs_ctx_destroy.argtypes = [C.c_void_p]
+    lib.hbs_ctx_destroy.restype = None
+    lib.hbs_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hbs_ctx_use_own_stream.argtypes = [C.c_void_p]
+    lib.hbs_ctx_get_stream.argtypes = [C.c_void_p]
+    lib.hbs_ctx_get_stream.restype = C.c_void_p
+    lib.hbs_ctx_synchronize.argtypes = [C.c_void_p]
+    lib.hbs_last_error.argtypes = [C.c_void_p]
+    lib.hbs_last_error.restype = C.c_char_p
+    lib.hbs_index_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                      C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.hbs_read_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hbs_workspace_bytes.argtypes = [C.c_uint64]
+    lib.hbs_workspace_bytes.restype = C.c_uint64
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One per GPU (per rank).  Device buffers are torch uint8 CUDA tensors; the
+    library runs on torch's current stream so that ordering with torch ops is
+    the stream order."""
+
+    def __init__(self, device=0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.hbs_ctx_create(C.byref(h), self.device)
+        if rc != 0:
+            raise HbsError("hbs_ctx_create(device=%d) failed: %d (no gfx950 GPU? there is no CPU fallback)"
+                           % (self.device, rc))
+        self.h = h
+        self._bind_stream()
+
+    def _bind_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.hbs_ctx_set_stream(self.h, C.c_void_p(s))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hbs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HbsError("%s failed: %d (%s)" % (what, rc, self.lib.hbs_last_error(self.h).decode()))
+
+    def alloc_outputs(self, stream_bytes, index_cap=None, want_rbsp=True):
+        """Device buffers sized for a stream: (index[u8, cap*32], rbsp[u8] or None, summary[u8, 64])."""
+        t = self.torch
+        dev = t.device("cuda", self.device)
+        if index_cap is None:
+            index_cap = stream_bytes // 3 + 2
+        index = t.empty(max(index_cap, 1) * NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
+        rbsp = t.empty(stream_bytes + 16, dtype=t.uint8, device=dev) if want_rbsp else None
+        summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
+        return index, rbsp, summary, index_cap
+
+    def index_extract_async(self, stream, index, index_cap, rbsp, summary):
+        """Enqueue K12 on the current torch stream.  All arguments are device tensors."""
+        self._bind_stream()
+        rc = self.lib.hbs_index_extract(self.h, C.c_void_p(stream.data_ptr() if stream.numel() else None),
+                                        stream.numel(), C.c_void_p(index.data_ptr()), index_cap,
+                                        C.c_void_p(rbsp.data_ptr()) if rbsp is not None else None,
+                                        rbsp.numel() if rbsp is not None else 0,
+                                        C.c_void_p(summary.data_ptr()))
+        self._check(rc, "hbs_index_extract")
+
+    def read_summary(self, summary):
+        out = np.zeros(1, dtype=SUMMARY)
+        rc = self.lib.hbs_read_summary(self.h, C.c_void_p(summary.data_ptr()), out.ctypes.data)
+        self._check(rc, "hbs_read_summary")
+        return out[0]
+
+    def index_extract(self, stream, index_cap=None, want_rbsp=True):
+        """Convenience: run K12 and bring the results to the host.
+        Returns (entries ndarray[NAL_ENTRY], arena ndarray[u8] or None, summary record)."""
+        index, rbsp, summary, cap = self.alloc_outputs(stream.numel(), index_cap, want_rbsp)
+        self.index_extract_async(stream, index, cap, rbsp, summary)
+        s = self.read_summary(summary)
+        n = int(s["nal_count"])
+        ent = index[: n * NAL_ENTRY.itemsize].cpu().numpy().view(NAL_ENTRY).copy()
+        arena = rbsp[: int(s["rbsp_bytes"])].cpu().numpy() if want_rbsp else None
+        return ent, arena, s

@@ -1,0 +1,158 @@
+/*
+ * hbs_capi.hip -- the extern "C" boundary (include/hevcbitstream_amd.h).
+ * Thin: owns the per-GPU context (HIP stream, look-back workspace) and turns
+ * each call into kernel launches.  No CPU implementation of any entry point
+ * exists here: without a gfx950 device the context cannot be created.
+ */
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include "hbs_scan.h"
+
+struct hbs_ctx {
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    int grid_blocks;
+    int blocks_per_cu;
+    unsigned long long* desc;
+    uint64_t desc_tiles;
+    hbs::RunHeader* hdr;
+    char err[256];
+};
+
+namespace {
+
+int fail(hbs_ctx* c, hipError_t e, const char* what)
+{
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+    return HBS_E_HIP;
+}
+
+int ensure_workspace(hbs_ctx* c, uint64_t stream_bytes)
+{
+    const uint64_t tiles = (stream_bytes + hbs::kTileBytes - 1) / hbs::kTileBytes + 1;
+    if (tiles > c->desc_tiles) {
+        if (c->desc) { (void)hipFree(c->desc); c->desc = nullptr; c->desc_tiles = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->desc), tiles * 16);
+        if (e != hipSuccess) return fail(c, e, "hipMalloc(look-back descriptors)");
+        c->desc_tiles = tiles;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* hbs_version(void)
+{
+    return "hevcbitstream_amd 0.1 (gfx950 HIP; K12 fused scan/index/extract)";
+}
+
+int hbs_ctx_create(hbs_ctx** out, int device)
+{
+    if (!out) return HBS_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return HBS_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return HBS_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HBS_E_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "hevcbitstream_amd: device %d is %s; this library carries gfx950 code only\n", device, prop.gcnArchName);
+        return HBS_E_NO_DEVICE;
+    }
+    hbs_ctx* c = new (std::nothrow) hbs_ctx();
+    if (!c) return HBS_E_HIP;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return HBS_E_HIP; }
+    c->stream = c->own_stream;
+    e = hipMalloc(reinterpret_cast<void**>(&c->hdr), sizeof(hbs::RunHeader));
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    c->grid_blocks = hbs::scan_grid_blocks(device, &c->blocks_per_cu);
+    if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
+    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
+    *out = c;
+    return 0;
+}
+
+void hbs_ctx_destroy(hbs_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->desc) (void)hipFree(c->desc);
+    if (c->hdr) (void)hipFree(c->hdr);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int hbs_ctx_set_stream(hbs_ctx* c, void* s)
+{
+    if (!c) return HBS_E_ARG;
+    c->stream = reinterpret_cast<hipStream_t>(s);     /* NULL = the HIP null stream */
+    return 0;
+}
+
+int hbs_ctx_use_own_stream(hbs_ctx* c)
+{
+    if (!c) return HBS_E_ARG;
+    c->stream = c->own_stream;
+    return 0;
+}
+
+void* hbs_ctx_get_stream(hbs_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+
+int hbs_ctx_synchronize(hbs_ctx* c)
+{
+    if (!c) return HBS_E_ARG;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hipStreamSynchronize");
+}
+
+const char* hbs_last_error(hbs_ctx* c) { return c ? c->err : "no context"; }
+
+uint64_t hbs_workspace_bytes(uint64_t stream_bytes)
+{
+    return ((stream_bytes + hbs::kTileBytes - 1) / hbs::kTileBytes + 1) * 16 + sizeof(hbs::RunHeader);
+}
+
+int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
+                      hbs_nal_entry* d_index, uint64_t index_cap,
+                      uint8_t* d_rbsp, uint64_t rbsp_cap, hbs_summary* d_summary)
+{
+    if (!c || !d_summary || (n && !d_stream) || (index_cap && !d_index)) return HBS_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_stream) & 15) || (reinterpret_cast<uintptr_t>(d_rbsp) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_index) & 7)) {
+        snprintf(c->err, sizeof(c->err), "stream/rbsp pointers must be 16-byte aligned");
+        return HBS_E_ARG;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    int rc = ensure_workspace(c, n);
+    if (rc) return rc;
+    hbs::ScanArgs a;
+    a.stream = d_stream; a.n = n;
+    a.index = d_index; a.index_cap = index_cap;
+    a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
+    a.desc = c->desc; a.hdr = c->hdr; a.summary = d_summary;
+    a.grid_blocks = c->grid_blocks;
+    hipError_t e = hbs::launch_scan_extract(a, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "launch_scan_extract");
+}
+
+int hbs_read_summary(hbs_ctx* c, const hbs_summary* d_summary, hbs_summary* h_summary)
+{
+    if (!c || !d_summary || !h_summary) return HBS_E_ARG;
+    hipError_t e = hipMemcpyAsync(h_summary, d_summary, sizeof(hbs_summary), hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return fail(c, e, "hipMemcpyAsync(summary)");
+    e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hipStreamSynchronize");
+}
+
+} // extern "C"

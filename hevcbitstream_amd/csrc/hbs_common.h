@@ -1,0 +1,87 @@
+/*
+ * hbs_common.h -- shared definitions of the HIP kernels and their host shim.
+ *
+ * The per-tile logic in hbs_tile.h / hbs_emit.h is written as plain C++ that
+ * hipcc compiles for gfx950 and that tests/sim/ can also compile with g++ to
+ * single-step the same code on the CPU against the oracle (HBS_HOST_SIM).
+ * That CPU build exists only under tests/; the product library contains the
+ * device code alone and never falls back to it.
+ */
+#ifndef HBS_COMMON_H
+#define HBS_COMMON_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/hevcbitstream_amd.h"
+
+#if defined(__HIPCC__) && !defined(HBS_HOST_SIM)
+#define HBS_HD __host__ __device__ __forceinline__
+#define HBS_D  __device__ __forceinline__
+#else
+#define HBS_HD static inline
+#define HBS_D  static inline
+#endif
+
+namespace hbs {
+
+/* ---- geometry of the scan/extract kernel --------------------------------- */
+constexpr int kThreads    = 256;                 /* 4 wavefronts per workgroup  */
+constexpr int kBlockBytes = 64;                  /* contiguous bytes per thread */
+constexpr int kTileBytes  = kThreads * kBlockBytes;   /* 16 KiB per tile        */
+constexpr int kHalo       = 16;                  /* bytes of context either side */
+
+/* state carried between tiles: are we inside a NAL payload? */
+enum : uint32_t { kKindNone = 0, kKindStart = 1, kKindStop = 2 };
+
+/* Device-side header: results of the main kernel handed to the finalize
+ * kernels.  Zeroed (memset) before every launch except first_empty. */
+struct RunHeader {
+    uint64_t final_kept;      /* RBSP bytes produced by the tile passes          */
+    uint64_t final_nals;      /* valid start codes seen by the tile passes       */
+    uint32_t final_inside;    /* state after the last stream byte                */
+    uint32_t error;           /* HBS_E_* (positive magnitude) or 0               */
+    unsigned long long first_empty;  /* ordinal of the first empty NAL (min), init ~0 */
+    uint32_t abort_flag;      /* set when a look-back wait timed out             */
+    uint32_t pad;
+};
+
+HBS_HD uint32_t popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+HBS_HD uint32_t ctz64(uint64_t v)  { return (uint32_t)__builtin_ctzll(v); }
+/* bits [0, n) set; n in [0, 64] */
+HBS_HD uint64_t below(uint32_t n)  { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+/* bytes [n, n+4) of the 8-byte little-endian value {hi,lo}; n in 0..3 */
+HBS_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, n);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8u * n));
+#endif
+}
+
+/* 0x80 in every byte of v that is zero (exact, no cross-byte carries) */
+HBS_HD uint32_t zero_bytes(uint32_t v)
+{
+    uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | v | 0x7F7F7F7Fu);
+}
+
+/* gather the four 0x80 marks of m into bits 0..3 */
+HBS_HD uint32_t movemask4(uint32_t m)
+{
+    return (((m >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+
+/* SplitMix64 finaliser: the synthetic-stream PRNG */
+HBS_HD uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t kSalt   = 0xD1B54A32D192ED03ull;
+
+} // namespace hbs
+#endif

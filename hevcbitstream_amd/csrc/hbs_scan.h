@@ -1,0 +1,28 @@
+/* hbs_scan.h -- host-visible launcher of the fused scan/extract kernel (K12). */
+#ifndef HBS_SCAN_H
+#define HBS_SCAN_H
+
+#include <hip/hip_runtime_api.h>
+#include "hbs_common.h"
+
+namespace hbs {
+
+struct ScanArgs {
+    const uint8_t* stream;        /* device, 16-byte aligned                      */
+    uint64_t n;                   /* stream bytes                                 */
+    hbs_nal_entry* index;         /* device, index_cap entries                    */
+    uint64_t index_cap;
+    uint8_t* rbsp;                /* device arena or nullptr (index only)         */
+    uint64_t rbsp_cap;
+    unsigned long long* desc;     /* workspace: 2 words per 16 KiB tile           */
+    RunHeader* hdr;               /* workspace                                    */
+    hbs_summary* summary;         /* device                                       */
+    int grid_blocks;              /* persistent workgroups (<= resident capacity) */
+};
+
+/* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
+int scan_grid_blocks(int device, int* blocks_per_cu_out);
+hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st);
+
+} // namespace hbs
+#endif

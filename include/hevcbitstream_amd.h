@@ -1,0 +1,132 @@
+/*
+ * hevcbitstream_amd.h -- batch C ABI of the MI355X (gfx950) Annex-B indexer /
+ * RBSP extractor.  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * This is the 64-bit, whole-stream form of the reference's per-NAL byte layer:
+ *
+ *   hbs_index_extract   replaces the loop  find_nal_unit() + nal_to_rbsp()
+ *                       reference: h264_nal.c:38-76 (find_nal_unit),
+ *                       h264_nal.c:147-200 (nal_to_rbsp), driven as in
+ *                       hevc_analyze.c:135-205 and hevc_stream.c:161-165
+ *   hbs_emit_annexb     replaces  rbsp_to_nal() per NAL + start-code emission
+ *                       reference: h264_nal.c:92-132, hevc_stream.c:1324-1327
+ *   hbs_parse_headers   replaces  read_hevc_nal_unit() per NAL
+ *                       reference: hevc_stream.c:155-240 and the readers it
+ *                       dispatches to (:243-1218)
+ *   hbs_synth_*         synthetic stream S(seed, n_nals, mode) of SURVEY.md
+ *                       8(d) (no reference counterpart: it ships no streams)
+ *
+ * All `d_` pointers are DEVICE pointers of the context's GPU (hipMalloc'ed or
+ * torch-allocated), 16-byte aligned.  Calls enqueue work on the context's HIP
+ * stream and return without synchronising unless stated otherwise.  Return
+ * value: 0 on success, a negative HBS_E_* code otherwise.  There is no CPU
+ * fallback: without a usable gfx950 device every call fails with
+ * HBS_E_NO_DEVICE.
+ *
+ * The legacy single-NAL symbols of the reference (find_nal_unit, nal_to_rbsp,
+ * rbsp_to_nal, read_hevc_nal_unit, ...) are declared in h264_stream.h /
+ * hevc_stream.h next to this file and are thin host wrappers over this API.
+ */
+#ifndef HEVCBITSTREAM_AMD_H
+#define HEVCBITSTREAM_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HBS_E_NO_DEVICE   (-1)   /* no gfx950 GPU / HIP runtime failure at init  */
+#define HBS_E_HIP         (-2)   /* a HIP call failed (see hbs_last_error)       */
+#define HBS_E_ARG         (-3)   /* bad argument (alignment, null, capacity 0)   */
+#define HBS_E_CAPACITY    (-4)   /* index / arena / output capacity too small    */
+#define HBS_E_TIMEOUT     (-5)   /* in-kernel look-back wait gave up (bug guard) */
+
+/* per-NAL status flags */
+#define HBS_ST_ERROR        1    /* nal_to_rbsp() would return -1 (h264_nal.c:156-167) */
+#define HBS_ST_TRAILING03   2    /* NAL ends in 00 00 03: the 03 is dropped and
+                                    nal_to_rbsp() consumes len-1 (h264_nal.c:170-173) */
+#define HBS_ST_UNTERMINATED 4    /* last NAL: find_nal_unit() returned -1 with
+                                    nal_end = size (h264_nal.c:71)                */
+
+/* One NAL of the whole-stream index: what find_nal_unit() reports for it when
+ * the stream is walked as in hevc_analyze.c:135-205, with 64-bit offsets, plus
+ * where nal_to_rbsp() of it went. 32 bytes. */
+typedef struct hbs_nal_entry {
+    uint64_t start;      /* offset of the first payload byte (after 00 00 01)   */
+    uint64_t end;        /* offset one past the last payload byte               */
+    uint64_t rbsp_off;   /* offset of this NAL's RBSP in the RBSP arena         */
+    uint32_t rbsp_len;   /* RBSP bytes = (end-start) - emulation-prevention bytes */
+    int32_t  status;     /* HBS_ST_* flags                                      */
+} hbs_nal_entry;
+
+/* Result block of hbs_index_extract (written on the DEVICE; copy it with
+ * hbs_read_summary). */
+typedef struct hbs_summary {
+    uint64_t nal_count;     /* NALs in the index (what the reference loop visits) */
+    uint64_t nal_found;     /* start codes found before truncation/capacity clip  */
+    uint64_t rbsp_bytes;    /* bytes written to the RBSP arena                    */
+    uint64_t stream_bytes;  /* bytes scanned                                      */
+    int32_t  stop_reason;   /* 0: no more start codes; -1: last NAL unterminated;
+                               1: stopped at an empty NAL (find_nal_unit == 0 with
+                               a start code found, hevc_analyze.c:135)            */
+    int32_t  error;         /* 0 or HBS_E_CAPACITY / HBS_E_TIMEOUT                */
+    uint64_t reserved[3];
+} hbs_summary;
+
+typedef struct hbs_ctx hbs_ctx;
+
+/* Create a context on HIP device `device` (one per GPU / per rank). */
+int  hbs_ctx_create(hbs_ctx** out, int device);
+void hbs_ctx_destroy(hbs_ctx* ctx);
+/* A new context enqueues on a non-blocking stream of its own.  set_stream
+ * makes it use the caller's HIP stream instead (hipStream_t passed as void*;
+ * NULL = the HIP null stream); use_own_stream goes back. */
+int  hbs_ctx_set_stream(hbs_ctx* ctx, void* hip_stream);
+int  hbs_ctx_use_own_stream(hbs_ctx* ctx);
+void* hbs_ctx_get_stream(hbs_ctx* ctx);
+int  hbs_ctx_synchronize(hbs_ctx* ctx);
+/* Text of the last HIP/driver error seen by this context. */
+const char* hbs_last_error(hbs_ctx* ctx);
+/* Library/self description: "hevcbitstream_amd <ver> gfx950 ..." */
+const char* hbs_version(void);
+
+/*
+ * Start-code scan + NAL index + RBSP extraction over one stream resident in
+ * HBM (single pass: every stream byte is read once, every RBSP byte written
+ * once).
+ *
+ *   d_stream, stream_bytes   Annex-B bytes
+ *   d_index, index_cap       out: hbs_nal_entry[index_cap]; the call zeroes it
+ *   d_rbsp, rbsp_cap         out: packed RBSP arena (NAL k at rbsp_off, rbsp_len);
+ *                            NULL = index only (rbsp_off/rbsp_len still filled)
+ *   d_summary                out: hbs_summary on the device
+ *
+ * Semantics (bit-exact with the reference on the same bytes):
+ *   - entries are the NALs the loop `while (find_nal_unit(p, sz, &s, &e) > 0)`
+ *     of hevc_analyze.c:135-177 visits over the whole stream, followed by the
+ *     "last NAL" of the -1 path (:190-205), offsets relative to d_stream;
+ *   - RBSP of NAL k is what nal_to_rbsp() writes for it; for a NAL it rejects
+ *     (HBS_ST_ERROR) the arena holds every byte except 00 00 03 emulation
+ *     bytes (the reference leaves its output unspecified there);
+ *   - bytes past the end of the stream are taken as 0xFF where the reference
+ *     reads them unchecked (h264_nal.c:47-48, 65-66).
+ */
+int hbs_index_extract(hbs_ctx* ctx,
+                      const uint8_t* d_stream, uint64_t stream_bytes,
+                      hbs_nal_entry* d_index, uint64_t index_cap,
+                      uint8_t* d_rbsp, uint64_t rbsp_cap,
+                      hbs_summary* d_summary);
+
+/* Synchronising copy of a device hbs_summary to the host. */
+int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_summary);
+
+/* Upper bound of the scratch the context will hold for a stream this long
+ * (look-back descriptors; allocated lazily, reused between calls). */
+uint64_t hbs_workspace_bytes(uint64_t stream_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,135 @@
+"""Parity tests proper for K12 (scan + index + RBSP extraction): the HIP path,
+called through the C ABI, against the oracle and the golden fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import hevcbitstream_amd as hbs
+    assert torch.cuda.is_available()
+    c = hbs.Context(0)
+    yield c
+    c.close()
+
+
+def run(ctx, stream, **kw):
+    import torch
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    d = torch.from_numpy(stream).cuda() if len(stream) else torch.empty(0, dtype=torch.uint8, device="cuda")
+    return ctx.index_extract(d, **kw)
+
+
+def check(ctx, orc, stream):
+    want_idx, want_arena, why = orc.index_extract(stream)
+    got_idx, got_arena, s = run(ctx, stream)
+    hx = bytes(np.asarray(stream[:64], dtype=np.uint8)).hex()
+    assert int(s["error"]) == 0, s
+    assert int(s["stop_reason"]) == why, hx
+    assert len(got_idx) == len(want_idx), hx
+    for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+        assert np.array_equal(got_idx[f], want_idx[f]), (f, hx)
+    tot = int(want_idx["rbsp_off"][-1] + want_idx["rbsp_len"][-1]) if len(want_idx) else 0
+    assert np.array_equal(got_arena[:tot], want_arena[:tot]), hx
+
+
+def test_ten_nal_golden(ctx):
+    stream = np.fromfile(os.path.join(HERE, "golden", "ten_nal.hevc"), dtype=np.uint8)
+    want = json.load(open(os.path.join(HERE, "golden", "ten_nal.index.json")))
+    idx, arena, s = run(ctx, stream)
+    assert [[int(a), int(b)] for a, b in zip(idx["start"], idx["end"])] == [w[:2] for w in want]
+    assert int(s["stop_reason"]) == -1
+
+
+def test_find_golden_first_nal(ctx):
+    """first NAL of every golden find_nal_unit vector (reference answers)."""
+    gold = json.load(open(os.path.join(HERE, "golden", "l2_vectors.json")))
+    for hx, (r, st, en) in gold["find"][:120]:
+        idx, _, s = run(ctx, np.frombuffer(bytes.fromhex(hx), dtype=np.uint8))
+        if r > 0 or r == -1:
+            assert len(idx) >= 1 and int(idx["start"][0]) == st and int(idx["end"][0]) == en, hx
+        elif st == 0 and en == 0:
+            assert len(idx) == 0 and int(s["stop_reason"]) == 0, hx
+        else:   # empty NAL: loop stops there
+            assert len(idx) == 0 and int(s["stop_reason"]) == 1, hx
+
+
+def test_empty_and_tiny(ctx, orc):
+    for n in range(0, 9):
+        check(ctx, orc, np.zeros(n, dtype=np.uint8))
+        check(ctx, orc, np.array(([0, 0, 1] * 3)[:n], dtype=np.uint8))
+
+
+def test_fuzz_small(ctx, orc):
+    rng = np.random.RandomState(5)
+    for _ in range(150):
+        n = rng.randint(0, 400)
+        s = ALPHA[rng.randint(0, len(ALPHA), size=n)].copy()
+        s[rng.rand(n) < 0.5] = 0x77
+        check(ctx, orc, s)
+
+
+def test_fuzz_multi_tile(ctx, orc):
+    """many 16 KiB tiles: exercises the look-back chain under real concurrency."""
+    rng = np.random.RandomState(6)
+    for trial in range(6):
+        n = rng.randint(1 << 20, 3 << 20)
+        s = rng.randint(0, 256, size=n).astype(np.uint8)
+        # sprinkle start codes / EPBs / zero runs / errors
+        for pat, cnt in ((b"\x00\x00\x01", n // 5000), (b"\x00\x00\x00\x01", n // 9000), (b"\x00\x00\x03", n // 700),
+                         (b"\x00\x00\x00", n // 40000), (b"\x00\x00\x02", n // 200000 + 1), (b"\x00" * 70, 3)):
+            for at in rng.randint(0, n - 80, size=cnt):
+                s[at:at + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+        check(ctx, orc, s)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_synthetic_64mib(ctx, orc, mode):
+    stream, idx, arena = orc.gen_stream(0x1234 + mode, 6400, mode)
+    got_idx, got_arena, s = run(ctx, stream)
+    assert int(s["error"]) == 0 and int(s["stop_reason"]) == -1
+    assert np.array_equal(got_idx, idx)
+    assert np.array_equal(got_arena, arena)
+
+
+def test_tile_edges(ctx, orc):
+    rng = np.random.RandomState(8)
+    pats = [bytes([0, 0, 1]), bytes([0, 0, 0, 1]), bytes([0, 0, 3]), bytes([0, 0, 3, 0, 0, 3]), bytes([0, 0, 0]),
+            bytes([0, 0, 2]), bytes([0, 0, 3, 9]), bytes([0] * 9)]
+    for trial in range(40):
+        n = 16384 * 3 + rng.randint(0, 200)
+        s = rng.randint(4, 256, size=n).astype(np.uint8)
+        s[0:4] = [0, 0, 1, 0x40]
+        for edge in (64, 128, 4096, 16384, 16384 + 64, 32768, 49152):
+            for _ in range(2):
+                p = pats[rng.randint(len(pats))]
+                at = edge - rng.randint(0, len(p) + 2)
+                if at >= 4 and at + len(p) <= n:
+                    s[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+        check(ctx, orc, s)
+
+
+def test_index_only_and_capacity(ctx, orc):
+    stream, idx, arena = orc.gen_stream(7, 300, 1)
+    got_idx, got_arena, s = run(ctx, stream, want_rbsp=False)
+    assert got_arena is None and np.array_equal(got_idx, idx)
+    got_idx, _, s = run(ctx, stream, index_cap=100)
+    assert int(s["error"]) == -4 and int(s["nal_found"]) == 300 and len(got_idx) == 100
+    assert np.array_equal(got_idx["start"], idx["start"][:100])
+
+
+def test_repeatable(ctx, orc):
+    """same context, back-to-back calls (descriptor workspace is reused)."""
+    stream, idx, arena = orc.gen_stream(99, 500, 0)
+    for _ in range(3):
+        got_idx, got_arena, s = run(ctx, stream)
+        assert np.array_equal(got_idx, idx) and np.array_equal(got_arena, arena)
