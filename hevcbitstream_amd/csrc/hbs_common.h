@@ -17,18 +17,49 @@
 #if defined(__HIPCC__) && !defined(HBS_HOST_SIM)
 #define HBS_HD __host__ __device__ __forceinline__
 #define HBS_D  __device__ __forceinline__
+#define HBS_M  __host__ __device__ __forceinline__      /* member functions */
 #else
 #define HBS_HD static inline
 #define HBS_D  static inline
+#define HBS_M  inline
 #endif
 
 namespace hbs {
 
 /* ---- geometry of the scan/extract kernel --------------------------------- */
-constexpr int kThreads    = 256;                 /* 4 wavefronts per workgroup  */
-constexpr int kBlockBytes = 64;                  /* contiguous bytes per thread */
-constexpr int kTileBytes  = kThreads * kBlockBytes;   /* 16 KiB per tile        */
-constexpr int kHalo       = 16;                  /* bytes of context either side */
+constexpr int kThreads         = 512;            /* 8 wavefronts per workgroup          */
+constexpr int kWaves           = kThreads / 64;
+constexpr int kBlockBytes      = 64;             /* unit of classification (one u64 mask) */
+constexpr int kBlocksPerThread = 2;              /* contiguous blocks per thread        */
+constexpr int kThreadBytes     = kBlockBytes * kBlocksPerThread;     /* 128 B           */
+constexpr int kTileBytes       = kThreads * kThreadBytes;            /* 64 KiB per tile */
+constexpr int kBlocks          = kThreads * kBlocksPerThread;        /* 1024 per tile   */
+constexpr int kPad             = 256;            /* image bytes kept before/after the tile */
+constexpr int kImageBytes      = kPad + kTileBytes + kPad;
+
+struct alignas(16) Quad { uint32_t x, y, z, w; };
+
+/*
+ * View of the tile image in LDS.  Logical offset o (bytes, relative to the
+ * tile's first stream byte, o in [-kPad, kTileBytes + kPad)) lives at phys(o).
+ * The image is XOR-swizzled at 16-byte granularity inside each 256-byte row
+ * (slot ^= row & 15) so that both access shapes are bank-conflict free:
+ *   - staging: consecutive lanes write consecutive 16-byte slots;
+ *   - classification: lane t reads its own 128 contiguous bytes (8 slots).
+ */
+struct TileView {
+    const uint8_t* img;
+    HBS_M static uint32_t phys(int32_t o)
+    {
+        const uint32_t a = (uint32_t)(o + kPad);
+        uint32_t slot = a >> 4;
+        slot ^= (slot >> 4) & 15u;
+        return (slot << 4) | (a & 15u);
+    }
+    HBS_M uint32_t byte(int32_t o) const { return img[phys(o)]; }
+    HBS_M uint32_t dword(int32_t o) const { return *reinterpret_cast<const uint32_t*>(img + phys(o)); }   /* o % 4 == 0 */
+    HBS_M Quad quad(int32_t o) const { return *reinterpret_cast<const Quad*>(img + phys(o)); }            /* o % 16 == 0 */
+};
 
 /* state carried between tiles: are we inside a NAL payload? */
 enum : uint32_t { kKindNone = 0, kKindStart = 1, kKindStop = 2 };

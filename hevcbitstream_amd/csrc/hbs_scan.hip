@@ -7,9 +7,10 @@
  * (hevc_analyze.c:135-177 driving h264_nal.c:38-76 and :147-200) with a
  * chained scan:
  *
- *   - persistent workgroups (256 threads = 4 wave64), tile i -> workgroup
- *     i mod grid; a tile is 16 KiB staged in LDS with coalesced 16-byte loads;
- *   - each thread classifies 64 contiguous bytes (hbs_tile.h), a workgroup
+ *   - persistent workgroups (512 threads = 8 wave64, 2 per CU), tile i ->
+ *     workgroup i mod grid; a tile is 64 KiB fetched with coalesced 16-byte
+ *     loads one tile ahead (registers) and staged in a swizzled LDS image;
+ *   - each thread classifies 128 contiguous bytes (hbs_tile.h), a workgroup
  *     scan turns that into a tile aggregate {NAL starts, kept bytes as a
  *     function of the carried inside/outside state, state after the tile};
  *   - decoupled look-back over per-tile descriptors (two self-validating
@@ -20,7 +21,7 @@
  *     threads that own the start / end events.
  *
  * HBM traffic: stream read once (1 B/B), RBSP written once (~1 B/B), index
- * 32 B/NAL, descriptors 16 B per 16 KiB tile.  No MFMA: byte scan, HBM-bound.
+ * 32 B/NAL, descriptors 16 B per 64 KiB tile.  No MFMA: byte scan, HBM-bound.
  */
 #include <hip/hip_runtime.h>
 #include "hbs_tile.h"
@@ -28,54 +29,126 @@
 
 namespace hbs {
 
-struct TileLds {
-    alignas(16) uint8_t raw[kHalo + kTileBytes + kHalo];  /* raw[kHalo+i] = S[tile_base+i] */
-    uint64_t keep[kThreads];
-    uint32_t rank[kThreads + 1];
-    uint32_t wave_last[4];
-    uint32_t wave_cnt[4];
-    uint32_t wave_known[4];
-    uint32_t wave_sig[4];
-    /* exclusive prefix of this tile, broadcast by wave 0 */
-    uint64_t ex_kept;
-    uint64_t ex_nals;
-    uint32_t ex_inside;
+/* Diagnostic build only (-DHBS_PHASE_TIMING, scripts/phase_timing.py): per-phase
+ * shader-clock sums of every workgroup, never part of the shipped library. */
+#ifdef HBS_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[1024][8];
+#define HBS_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(), t_acc[8] = {0,0,0,0,0,0,0,0};
+#define HBS_T_MARK(i) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
+#define HBS_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles[blockIdx.x][i] = t_acc[i]; }
+#else
+#define HBS_T_DECL
+#define HBS_T_MARK(i)
+#define HBS_T_FLUSH
+#endif
+
+constexpr int kSlowCap = 256;        /* deferred general-path words per tile (overflow is handled inline) */
+
+/* one wave's view of its 64-tile look-back window */
+struct WaveSlot {
+    uint32_t status;                 /* 0 some needed tile not ready, 1 all 64 aggregates, 2 prefix at lane lstar */
     uint32_t abort;
+    TileAgg win;                     /* aggregate of the lanes in front of the prefix (or of all 64) */
+    uint64_t pre_kept, pre_nals;     /* the prefix found (status 2)                */
+    uint32_t pre_inside, pad;
 };
 
-/* 16 stream bytes at offset g (may straddle or exceed n): 0xFF outside [0,n) */
-__device__ __forceinline__ uint4 load16_guarded(const uint8_t* __restrict__ s, int64_t g, uint64_t n)
+struct TileLds {
+    alignas(16) uint8_t img[kImageBytes];      /* swizzled tile image (TileView)      */
+    uint64_t keep[kBlocks + 1];                /* pass 1: pattern masks; pass 2: keep masks per 64-byte block */
+    uint32_t rank[kBlocks + 1];                /* tile rank of each block's first kept byte */
+    uint16_t slow[kSlowCap];                   /* chunks with holes, compacted after the whole ones */
+    uint32_t slow_cnt;
+    uint32_t wave_last[kWaves];
+    uint32_t wave_cnt[kWaves];
+    uint32_t wave_known[kWaves];
+    uint32_t wave_sig[kWaves];
+    WaveSlot lb[2][4];
+};
+
+/* 16 stream bytes at offset g (may straddle or exceed [0,n)): 0xFF outside */
+__device__ __forceinline__ uint4 load16_edge(const uint8_t* __restrict__ s, int64_t g, uint64_t n)
 {
-    if (g >= 0 && (uint64_t)g + 16 <= n) return *reinterpret_cast<const uint4*>(s + g);
-    uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (g + 16 > 0 && g < (int64_t)n) {
-        for (int b = 0; b < 16; ++b) {
-            const int64_t q = g + b;
-            if (q >= 0 && (uint64_t)q < n) {
-                w[b >> 2] &= ~(0xFFu << (8 * (b & 3)));
-                w[b >> 2] |= (uint32_t)s[q] << (8 * (b & 3));
-            }
+    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu, w3 = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+        const int64_t q = g + b;
+        if (q >= 0 && (uint64_t)q < n) {
+            const uint32_t m = ~(0xFFu << (8 * (b & 3)));
+            const uint32_t v = (uint32_t)s[q] << (8 * (b & 3));
+            if ((b >> 2) == 0) w0 = (w0 & m) | v;
+            else if ((b >> 2) == 1) w1 = (w1 & m) | v;
+            else if ((b >> 2) == 2) w2 = (w2 & m) | v;
+            else w3 = (w3 & m) | v;
         }
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return make_uint4(w0, w1, w2, w3);
 }
 
-__device__ __forceinline__ void stage_tile(TileLds& l, const uint8_t* __restrict__ s, uint64_t tile_base, uint64_t n, int tid)
+__device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ s, int64_t g, uint64_t n)
 {
-    uint4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        v[u] = load16_guarded(s, (int64_t)(tile_base + 16ull * (uint32_t)(u * kThreads + tid)), n);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        *reinterpret_cast<uint4*>(&l.raw[kHalo + 16 * (u * kThreads + tid)]) = v[u];
-    if (tid == 0)
-        *reinterpret_cast<uint4*>(&l.raw[0]) = load16_guarded(s, (int64_t)tile_base - 16, n);
-    if (tid == 64)
-        *reinterpret_cast<uint4*>(&l.raw[kHalo + kTileBytes]) = load16_guarded(s, (int64_t)(tile_base + kTileBytes), n);
+    if (g >= 0 && (uint64_t)g + 16 <= n) return *reinterpret_cast<const uint4*>(s + g);
+    return load16_edge(s, g, n);
 }
 
-/* inclusive wave scan by DPP-free shuffles (6 steps) */
+constexpr int kChunksPerThread = kThreadBytes / 16;     /* 16-byte loads per thread per tile */
+
+/* The prefetched tile lives in named vector registers (an array here is not
+ * promoted out of scratch by hipcc once its fill is conditional). */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));    /* plain vector: loads/stores stay SSA values */
+static_assert(kChunksPerThread == 8, "HBS_REPC lists the chunks of one thread");
+#define HBS_REPC(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+struct TileRegs {
+#define HBS_DECL(u) u32x4 r##u;
+    HBS_REPC(HBS_DECL)
+#undef HBS_DECL
+};
+
+/* coalesced fetch of one FULL tile into registers: lane-contiguous 16-byte chunks */
+__device__ __forceinline__ void fetch_tile(TileRegs& t, const uint8_t* __restrict__ s, uint64_t tile_base, int tid)
+{
+    const u32x4* p = reinterpret_cast<const u32x4*>(s + tile_base) + tid;
+#define HBS_LD(u) t.r##u = p[u * kThreads];
+    HBS_REPC(HBS_LD)
+#undef HBS_LD
+}
+
+/* registers -> swizzled LDS image */
+__device__ __forceinline__ void stage_tile(TileLds& l, const TileRegs& t, int tid)
+{
+#define HBS_ST(u) *reinterpret_cast<u32x4*>(&l.img[TileView::phys(16 * (u * kThreads + tid))]) = t.r##u;
+    HBS_REPC(HBS_ST)
+#undef HBS_ST
+}
+
+/* the (single) partial tile at the end of the stream: straight to LDS, guarded */
+__device__ __forceinline__ void stage_tile_edge(TileLds& l, const uint8_t* __restrict__ s, uint64_t tile_base, uint64_t n, int tid)
+{
+#pragma unroll 1
+    for (int u = 0; u < kChunksPerThread; ++u) {
+        const int c = u * kThreads + tid;
+        *reinterpret_cast<uint4*>(&l.img[TileView::phys(16 * c)]) = load16(s, (int64_t)(tile_base + 16ull * (uint32_t)c), n);
+    }
+}
+
+/* the 16 bytes either side of the tile */
+__device__ __forceinline__ void stage_halo(TileLds& l, const uint8_t* __restrict__ s, uint64_t tile_base, uint64_t n, int tid)
+{
+    if (tid == 0)
+        *reinterpret_cast<uint4*>(&l.img[TileView::phys(-16)]) = load16(s, (int64_t)tile_base - 16, n);
+    if (tid == 64)
+        *reinterpret_cast<uint4*>(&l.img[TileView::phys(kTileBytes)]) = load16(s, (int64_t)(tile_base + kTileBytes), n);
+}
+
+/* Opaque copy of a lane-constant value.  hipcc hoists every address that only
+ * depends on threadIdx out of the tile loop and then spills them all around it;
+ * laundering the thread id once per phase keeps those addresses phase-local. */
+__device__ __forceinline__ int launder(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
 #pragma unroll
@@ -86,17 +159,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
 enum : uint32_t { kInOutside = 0, kInInside = 1, kInCarry = 2 };
 
 struct ThreadPrefix {
-    uint32_t in_state;   /* kIn*: state at the first byte of the block     */
-    uint32_t cnt;        /* NAL starts before the block (tile-relative)    */
-    uint32_t known;      /* kept bytes before the block, state-independent */
-    uint32_t sig;        /* kept bytes before the block if tile carry-in is inside */
+    uint32_t in_state;   /* kIn*: state at the thread's first byte          */
+    uint32_t cnt;        /* NAL starts before the thread (tile-relative)    */
+    uint32_t known;      /* kept bytes before the thread, state-independent */
+    uint32_t sig;        /* kept bytes before the thread if the tile's carry-in is inside */
 };
 
-/* workgroup scan of the block summaries -> per-thread exclusive prefix + tile aggregate */
-__device__ __forceinline__ ThreadPrefix block_scan(TileLds& l, const BlockSum& s, int tid, TileAgg& agg)
+/* workgroup scan of the per-thread summaries -> exclusive prefix per thread + tile aggregate */
+__device__ __forceinline__ ThreadPrefix block_scan(TileLds& l, const TileAgg& s, int tid, TileAgg& agg)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const uint64_t m_ev = __ballot(s.last != kKindNone);
@@ -120,10 +200,10 @@ __device__ __forceinline__ ThreadPrefix block_scan(TileLds& l, const BlockSum& s
     if (in_state == kInCarry && carry_kind != kKindNone)
         in_state = (carry_kind == kKindStart) ? kInInside : kInOutside;
 
-    const uint32_t known = s.known + (in_state == kInInside ? s.carry : 0u);
-    const uint32_t sig = (in_state == kInCarry) ? s.carry : 0u;
+    const uint32_t known = s.known + (in_state == kInInside ? s.sig : 0u);
+    const uint32_t sig = (in_state == kInCarry) ? s.sig : 0u;
 
-    /* per-wave sums fit 13 bits each: scan known|sig packed, cnt separately */
+    /* per-wave sums are <= 64 * kThreadBytes: scan known|sig packed, cnt separately */
     const uint32_t packed = known | (sig << 16);
     const uint32_t ip = wave_incl_scan(packed, lane);
     const uint32_t ic = wave_incl_scan(s.cnt, lane);
@@ -141,7 +221,7 @@ __device__ __forceinline__ ThreadPrefix block_scan(TileLds& l, const BlockSum& s
     p.cnt = ic - s.cnt;
     uint32_t tk = 0, ts = 0, tc = 0, tl = kKindNone;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kWaves; ++w) {
         if (w < wv) { p.known += l.wave_known[w]; p.sig += l.wave_sig[w]; p.cnt += l.wave_cnt[w]; }
         tk += l.wave_known[w]; ts += l.wave_sig[w]; tc += l.wave_cnt[w];
         if (l.wave_last[w] != kKindNone) tl = l.wave_last[w];
@@ -159,37 +239,62 @@ __device__ __forceinline__ void st_desc(unsigned long long* p, uint64_t v)
     __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ TileAgg readlane_agg(const TileAgg& a, int l)
+/*
+ * Aggregate of the tiles held by lanes [0, lstar) of a look-back window, lane l
+ * holding tile (win_hi - l): higher lanes are EARLIER tiles.  Wave-parallel
+ * form of folding combine() from lane lstar-1 down to lane 0.
+ */
+__device__ __forceinline__ TileAgg window_fold(const TileAgg& a, int lstar, int lane)
 {
-    TileAgg r;
-    r.cnt = __builtin_amdgcn_readlane(a.cnt, l);
-    r.known = __builtin_amdgcn_readlane(a.known, l);
-    r.sig = __builtin_amdgcn_readlane(a.sig, l);
-    r.last = __builtin_amdgcn_readlane(a.last, l);
-    return r;
+    const uint64_t need = (lstar >= 64) ? ~0ull : ((1ull << lstar) - 1ull);
+    const bool mine = lane < lstar;
+    const uint64_t m_ev = __ballot(mine && a.last != kKindNone) & need;
+    const uint64_t m_st = __ballot(mine && a.last == kKindStart) & need;
+    /* state in front of my tile = kind of the nearest earlier tile (higher lane) that has an event */
+    const uint64_t above = (lane >= 63) ? 0ull : (m_ev & ~((2ull << lane) - 1ull));
+    uint32_t st = kInCarry;
+    if (above != 0) st = (uint32_t)((m_st >> __builtin_ctzll(above)) & 1ull);
+    uint32_t k = 0, g = 0, c = 0;
+    if (mine) {
+        k = a.known + (st == kInInside ? a.sig : 0u);
+        g = (st == kInCarry) ? a.sig : 0u;
+        c = a.cnt;
+    }
+    TileAgg w;
+    w.known = wave_sum(k);
+    w.sig = wave_sum(g);
+    w.cnt = wave_sum(c);
+    w.last = kKindNone;
+    if (m_ev != 0) w.last = ((m_st >> __builtin_ctzll(m_ev)) & 1ull) ? kKindStart : kKindStop;
+    return w;
 }
 
 /*
- * Decoupled look-back, executed by wave 0.  desc[2*t], desc[2*t+1] are the two
- * words of tile t.  Returns the exclusive prefix of `tile`; false on timeout.
+ * Decoupled look-back over 256 predecessors per step: wave w inspects tiles
+ * win_hi - 64w - lane, folds its window, and the four windows are chained
+ * through LDS.  Every thread of the workgroup calls this (it contains
+ * barriers) and gets the same answer.  desc[2*t], desc[2*t+1] are the two words
+ * of tile t.  Returns false on timeout/abort.
  */
-__device__ __forceinline__ bool look_back(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
-                                          RunHeader* hdr, int lane, Prefix& excl)
+__device__ __forceinline__ bool look_back(TileLds& l, unsigned long long* desc, uint64_t tile, const TileAgg& mine,
+                                          RunHeader* hdr, int tid, Prefix& excl)
 {
+    const int lane = tid & 63, wv = tid >> 6;
+    bool ok = true;
     if (tile == 0) {
         excl.kept = 0; excl.nals = 0; excl.inside = 0;
     } else {
-        if (lane == 0) {
+        if (tid == 0) {
             st_desc(&desc[2 * tile], pack_agg0(mine));
             st_desc(&desc[2 * tile + 1], pack_agg1(mine));
         }
-        TileAgg acc = {0u, 0u, 0u, kKindNone};       /* tiles between the window and `tile` */
-        int64_t win_hi = (int64_t)tile - 1;           /* nearest tile of the current window  */
-        uint32_t spins = 0;
+        TileAgg acc = {0u, 0u, 0u, kKindNone};       /* tiles between the windows and `tile` */
+        int64_t win_hi = (int64_t)tile - 1;           /* nearest tile of the current step      */
+        uint32_t spins = 0, par = 0;
         for (;;) {
-            const int64_t t = win_hi - lane;           /* lane l looks at tile win_hi - l     */
+            const int64_t t = win_hi - (64 * wv + lane);
             uint64_t w0 = kDescPrefix, w1 = kDescPrefix;   /* virtual tile -1: empty prefix   */
-            if (t >= 0) {
+            if (t >= 0 && wv < 4) {
                 w0 = ld_desc(&desc[2 * t]);
                 w1 = ld_desc(&desc[2 * t + 1]);
             }
@@ -198,123 +303,191 @@ __device__ __forceinline__ bool look_back(unsigned long long* desc, uint64_t til
             const bool is_pre = ready && (s0 == kDescPrefix);
             const uint64_t m_pre = __ballot(is_pre);
             const uint64_t m_ready = __ballot(ready);
-            const int lstar = m_pre ? (int)__builtin_ctzll(m_pre) : 64;      /* nearest prefix */
+            const int lstar = m_pre ? (int)__builtin_ctzll(m_pre) : 64;      /* nearest prefix in my window */
             const uint64_t need = (lstar >= 64) ? ~0ull : ((1ull << lstar) - 1ull);
-            if ((m_ready & need) != need) {                                    /* a nearer tile is not ready */
-                if (++spins > (1u << 22) || __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    if (lane == 0) {
-                        __hip_atomic_store(&hdr->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        atomicMax(&hdr->error, (uint32_t)(-HBS_E_TIMEOUT));
-                    }
-                    return false;
+            const bool win_ok = (m_ready & need) == need;
+            const TileAgg win = window_fold(unpack_agg(w0, w1), lstar, lane);
+            const Prefix p = unpack_pre(w0, w1);
+            if (lane == (lstar & 63) && wv < 4) {
+                WaveSlot& sl = l.lb[par][wv];
+                sl.status = win_ok ? (lstar < 64 ? 2u : 1u) : 0u;
+                sl.abort = (wv == 0) ? __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                sl.win = win;
+                sl.pre_kept = p.kept; sl.pre_nals = p.nals; sl.pre_inside = p.inside;
+            }
+            __syncthreads();
+            /* chain the windows, nearest first; identical in every thread */
+            bool done = false, stall = false;
+            TileAgg a2 = acc;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (done || stall) continue;
+                const WaveSlot& sl = l.lb[par][w];
+                if (sl.status == 0u) { stall = true; continue; }
+                a2 = combine(sl.win, a2);
+                if (sl.status == 2u) {
+                    Prefix q;
+                    q.kept = sl.pre_kept; q.nals = sl.pre_nals; q.inside = sl.pre_inside;
+                    excl = fold(q, a2);
+                    done = true;
                 }
-                __builtin_amdgcn_s_sleep(2);
+            }
+            const bool aborted = l.lb[par][0].abort != 0u;
+            par ^= 1u;
+            if (done) break;
+            if (stall) {
+                if (++spins > (1u << 20) || aborted) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
                 continue;
             }
-            const TileAgg a = unpack_agg(w0, w1);
-            TileAgg win = {0u, 0u, 0u, kKindNone};
-            const int top = (lstar >= 64) ? 63 : lstar - 1;
-            for (int l = top; l >= 0; --l) win = combine(win, readlane_agg(a, l));   /* earliest first */
-            acc = combine(win, acc);
-            if (lstar < 64) {
-                Prefix p = unpack_pre(w0, w1);
-                p.kept = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(p.kept >> 32), lstar) << 32) |
-                         __builtin_amdgcn_readlane((uint32_t)p.kept, lstar);
-                p.nals = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(p.nals >> 32), lstar) << 32) |
-                         __builtin_amdgcn_readlane((uint32_t)p.nals, lstar);
-                p.inside = __builtin_amdgcn_readlane(p.inside, lstar);
-                excl = fold(p, acc);
-                break;
-            }
-            win_hi -= 64;
+            acc = a2;
+            win_hi -= 256;
         }
     }
-    if (lane == 0) {
-        const Prefix incl = fold(excl, mine);
-        st_desc(&desc[2 * tile], pack_pre0(incl));
-        st_desc(&desc[2 * tile + 1], pack_pre1(incl));
+    if (tid == 0) {
+        if (ok) {
+            const Prefix incl = fold(excl, mine);
+            st_desc(&desc[2 * tile], pack_pre0(incl));
+            st_desc(&desc[2 * tile + 1], pack_pre1(incl));
+        } else {
+            __hip_atomic_store(&hdr->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(&hdr->error, (uint32_t)(-HBS_E_TIMEOUT));
+        }
     }
-    return true;
+    return ok;
 }
 
-__device__ __forceinline__ void store_word(uint8_t* dst, const GatherOut& g)
+/* 16 bytes to a byte-aligned destination (one global_store_dwordx4) */
+struct __attribute__((packed, aligned(1))) Unaligned16 { u32x4 v; };
+__device__ __forceinline__ void store16_unaligned(uint8_t* dst, const Quad& q)
 {
-    if (g.lo == 0 && g.hi == 16) {
-        *reinterpret_cast<uint4*>(dst) = make_uint4(g.w[0], g.w[1], g.w[2], g.w[3]);
-    } else {
-        for (uint32_t o = g.lo; o < g.hi; ++o) dst[o] = (uint8_t)(g.w[o >> 2] >> (8u * (o & 3u)));
-    }
+    u32x4 v;
+    v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+    reinterpret_cast<Unaligned16*>(dst)->v = v;
 }
 
-__global__ __launch_bounds__(kThreads)
+/* a chunk with removed bytes: compact, then 8/4/2/1-byte pieces */
+__device__ __forceinline__ void store_holes(const TileView& v, uint8_t* out, uint32_t c, const ChunkDest& d)
+{
+    uint64_t lo, hi;
+    uint32_t cnt = compact_chunk(v, c, d.sub, lo, hi);
+    uint8_t* p = out + d.rank;
+    struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+    struct __attribute__((packed, aligned(1))) U2 { uint16_t v; };
+    if (cnt & 8u) { reinterpret_cast<U8*>(p)->v = lo; p += 8; lo = hi; }
+    if (cnt & 4u) { reinterpret_cast<U4*>(p)->v = (uint32_t)lo; p += 4; lo >>= 32; }
+    if (cnt & 2u) { reinterpret_cast<U2*>(p)->v = (uint16_t)lo; p += 2; lo >>= 16; }
+    if (cnt & 1u) { *p = (uint8_t)lo; }
+}
+
+__global__ __launch_bounds__(kThreads, 4)
 void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                     hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                     uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr)
 {
     __shared__ TileLds l;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int tid0 = threadIdx.x;
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
+    TileView view;
+    view.img = l.img;
 
-    for (uint64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const uint64_t full_tiles = n / (uint64_t)kTileBytes;      /* tiles [0, full_tiles) are complete */
+    TileRegs nxt;
+    uint64_t tile = blockIdx.x;
+    if (tile < full_tiles) fetch_tile(nxt, stream, tile * (uint64_t)kTileBytes, tid0);
+    HBS_T_DECL
+
+    for (; tile < num_tiles; tile += gridDim.x) {
         const uint64_t tile_base = tile * (uint64_t)kTileBytes;
-        stage_tile(l, stream, tile_base, n, tid);
-        __syncthreads();
-
-        const uint8_t* blk = &l.raw[kHalo + kBlockBytes * tid];
-        const uint64_t g0 = tile_base + (uint64_t)(kBlockBytes * tid);
-        BlockMarks marks;
-        BlockSum sum;
-        classify_block(blk, g0, n, marks, sum);
-
-        TileAgg agg;
-        const ThreadPrefix tp = block_scan(l, sum, tid, agg);
-
-        if (wv == 0) {
-            Prefix excl;
-            const bool ok = look_back(desc, tile, agg, hdr, lane, excl);
-            if (lane == 0) {
-                l.ex_kept = excl.kept; l.ex_nals = excl.nals; l.ex_inside = excl.inside;
-                l.abort = ok ? 0u : 1u;
-                if (ok && tile == num_tiles - 1) {
-                    const Prefix incl = fold(excl, agg);
-                    hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
-                }
-            }
+        {
+            const int t0 = launder(tid0);
+            if (tile < full_tiles) stage_tile(l, nxt, t0);
+            else stage_tile_edge(l, stream, tile_base, n, t0);
+            stage_halo(l, stream, tile_base, n, t0);
         }
         __syncthreads();
-        if (l.abort) return;
+        HBS_T_MARK(0)
+        const int tid = launder(tid0);
+        const int lane = tid & 63, wv = tid >> 6;
 
-        const uint64_t ex_kept = l.ex_kept, ex_nals = l.ex_nals;
-        const bool ex_inside = l.ex_inside != 0;
-        const bool inside = (tp.in_state == kInInside) || (tp.in_state == kInCarry && ex_inside);
-        const uint32_t rank0 = tp.known + (ex_inside ? tp.sig : 0u);
-        const uint32_t tile_kept = agg.known + (ex_inside ? agg.sig : 0u);
+        const int32_t o0 = kThreadBytes * tid;
+        const uint64_t g0 = tile_base + (uint64_t)o0;
+        const TileAgg mine = classify_thread(view, o0, g0, n, l.keep, tid);
+        HBS_T_MARK(1)
 
-        const uint64_t keep = emit_block(blk, g0, marks, inside, ex_nals + tp.cnt, ex_kept + rank0, tgt);
-        l.keep[tid] = keep;
-        l.rank[tid] = rank0;
-        if (tid == 0) l.rank[kThreads] = tile_kept;
+        TileAgg agg;
+        const ThreadPrefix tp = block_scan(l, mine, tid, agg);
+        HBS_T_MARK(2)
+
+        Prefix excl;
+        if (!look_back(l, desc, tile, agg, hdr, tid, excl)) return;
+        HBS_T_MARK(3)
+        if (tid == 0 && tile == num_tiles - 1) {
+            const Prefix incl = fold(excl, agg);
+            hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
+        }
+        /* Next tile's HBM reads fly under the emit and the gather.  They are issued
+         * behind the look-back because loads return in order: a descriptor read
+         * queued behind 16 tile loads would wait for all of them. */
+        if (tile + gridDim.x < full_tiles) fetch_tile(nxt, stream, (tile + gridDim.x) * (uint64_t)kTileBytes, launder(tid0));
+
+        const uint64_t ex_kept = excl.kept;
+        const uint32_t tile_kept = agg.known + (excl.inside ? agg.sig : 0u);
+        ThreadStart ts;
+        ts.in_state = tp.in_state; ts.cnt = tp.cnt; ts.known = tp.known; ts.sig = tp.sig;
+        {
+            const int te = launder(tid0);
+            emit_thread(view, kThreadBytes * te, tile_base + (uint64_t)(kThreadBytes * te), n, te, ts, excl, l.keep, l.rank, tgt);
+        }
+        if (tid == 0) l.slow_cnt = 0;
         __syncthreads();
+        HBS_T_MARK(4)
 
         if (rbsp != nullptr && tile_kept != 0) {
             if (ex_kept + tile_kept <= rbsp_cap) {
-                const uint32_t ob = (uint32_t)(ex_kept & 15ull);
-                const uint32_t nwords = (ob + tile_kept + 15u) >> 4;
-                uint8_t* out = rbsp + (ex_kept - ob);
-                for (uint32_t wi = tid; wi < nwords; wi += kThreads) {
-                    const GatherOut g = gather_word(&l.raw[kHalo], l.rank, l.keep, wi, ob, tile_kept);
-                    store_word(out + 16ull * wi, g);
+                uint8_t* out = rbsp + ex_kept;
+                /* whole chunks now (lane-contiguous: coalesced image reads and arena
+                 * stores); the few with holes are queued and done together so that
+                 * they do not serialise whole waves */
+                const uint32_t c0 = (uint32_t)launder(tid0);
+#pragma unroll 2
+                for (uint32_t c = c0; c < (uint32_t)(kTileBytes / 16); c += kThreads) {
+                    const ChunkDest d = chunk_dest(l.rank, l.keep, c);
+                    if (d.sub == 0xFFFFu) {
+                        const Quad qd = view.quad((int32_t)(16u * c));
+                        store16_unaligned(out + d.rank, qd);
+                    } else if (d.sub != 0u) {
+                        const uint32_t slot = atomicAdd(&l.slow_cnt, 1u);
+                        if (slot < (uint32_t)kSlowCap) l.slow[slot] = (uint16_t)c;
+                        else store_holes(view, out, c, d);
+                    }
+                }
+                __syncthreads();
+                HBS_T_MARK(5)
+                const uint32_t nslow = l.slow_cnt < (uint32_t)kSlowCap ? l.slow_cnt : (uint32_t)kSlowCap;
+                for (uint32_t i = (uint32_t)launder(tid0); i < nslow; i += kThreads) {
+                    const uint32_t c = l.slow[i];
+                    store_holes(view, out, c, chunk_dest(l.rank, l.keep, c));
                 }
             } else if (tid == 0) {
                 atomicMax(&hdr->error, (uint32_t)(-HBS_E_CAPACITY));
             }
         }
         __syncthreads();
+        HBS_T_MARK(6)
     }
+    HBS_T_FLUSH
 }
+
+#ifdef HBS_PHASE_TIMING
+extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] */)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 __global__ void k_init_header(RunHeader* hdr)
 {
@@ -349,11 +522,10 @@ int scan_grid_blocks(int device, int* blocks_per_cu_out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_scan_extract, kThreads, 0) != hipSuccess) return -1;
-    /* All workgroups must be co-resident (tile i waits on tiles < i).  The
-     * occupancy query can over-report by one block per CU on ROCm 7.2
-     * (MI355X_MICROARCH.md, Residency), so stay one below it and at most 8. */
-    if (per_cu > 1) per_cu -= 1;
-    if (per_cu > 8) per_cu = 8;
+    /* All workgroups must be co-resident (tile i waits on tiles < i).  LDS
+     * (78 KiB per workgroup) admits two per CU; never ask for more than the
+     * occupancy query grants. */
+    if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     if (blocks_per_cu_out) *blocks_per_cu_out = per_cu;
     return prop.multiProcessorCount * per_cu;

@@ -1,10 +1,11 @@
 /*
  * hbs_tile.h -- per-tile logic of the fused scan / index / RBSP-extract kernel.
  *
- * A tile is 16 KiB of the stream staged in LDS; each of the 256 threads owns
- * 64 contiguous bytes ("block").  Everything here is per-thread code over the
- * LDS image plus a few words of carried state, so it compiles for gfx950 and,
- * under tests/sim, for the host (see hbs_common.h).
+ * A tile is 64 KiB of the stream staged in LDS (swizzled image, TileView);
+ * each of the 512 threads owns 128 contiguous bytes = two 64-byte "blocks",
+ * the unit of classification (one 64-bit mask per property).  Everything here
+ * is per-thread code over the LDS image plus a few words of carried state, so
+ * it compiles for gfx950 and, under tests/sim, for the host (hbs_common.h).
  *
  * What is restated, and from where (reference = leslie-wang/hevcbitstream):
  *   - start/end of a NAL: find_nal_unit, h264_nal.c:46-53 (start search for
@@ -64,7 +65,7 @@ HBS_HD Prefix fold(Prefix p, TileAgg a)
 
 /* look-back descriptor words (two self-validating 8-byte granules per tile) */
 enum : uint64_t { kDescEmpty = 0, kDescAgg = 1, kDescPrefix = 2 };
-HBS_HD uint64_t pack_agg0(TileAgg a)   { return kDescAgg | ((uint64_t)a.last << 2) | ((uint64_t)a.known << 4) | ((uint64_t)a.sig << 20); }
+HBS_HD uint64_t pack_agg0(TileAgg a)   { return kDescAgg | ((uint64_t)a.last << 2) | ((uint64_t)a.known << 4) | ((uint64_t)a.sig << 24); }
 HBS_HD uint64_t pack_agg1(TileAgg a)   { return kDescAgg | ((uint64_t)a.cnt << 2); }
 HBS_HD uint64_t pack_pre0(Prefix p)    { return kDescPrefix | ((uint64_t)p.inside << 2) | (p.kept << 3); }
 HBS_HD uint64_t pack_pre1(Prefix p)    { return kDescPrefix | (p.nals << 2); }
@@ -82,8 +83,8 @@ HBS_HD TileAgg unpack_agg(uint64_t w0, uint64_t w1)
 {
     TileAgg a;
     a.last = (uint32_t)(w0 >> 2) & 3u;
-    a.known = (uint32_t)(w0 >> 4) & 0xFFFFu;
-    a.sig = (uint32_t)(w0 >> 20) & 0xFFFFu;
+    a.known = (uint32_t)(w0 >> 4) & 0xFFFFFu;
+    a.sig = (uint32_t)(w0 >> 24) & 0xFFFFFu;
     a.cnt = (uint32_t)(w1 >> 2);
     return a;
 }
@@ -108,94 +109,135 @@ enum : int { kPatEpb = 0, kPatErr = 1, kPatStart = 2, kPatStop = 3, kPatSkip = 4
  *   a start code found while advancing needs i+4 < size (:52): gj <= n-3 always
  *   satisfies it; the two later positions are settled by tail_fixup().
  */
-HBS_HD int pattern_kind(const uint8_t* at, uint64_t gj, uint64_t n)
+HBS_HD int pattern_kind(const TileView& v, int32_t o, uint64_t gj, uint64_t n)
 {
-    const uint32_t v = at[0];
-    if (v == 3) return kPatEpb;
-    if (v == 2) return kPatErr;
-    if (v == 0 && at[-3] == 0) return kPatSkip;          /* not the first 00 00 00 of a zero run */
+    const uint32_t b = v.byte(o);
+    if (b == 3) return kPatEpb;
+    if (b == 2) return kPatErr;
+    if (b == 0 && v.byte(o - 3) == 0) return kPatSkip;   /* not the first 00 00 00 of a zero run */
     bool term_ok = gj + 2 <= n;
-    if (!term_ok) term_ok = (at[-5] == 0 && at[-4] == 0 && at[-3] == 1);
+    if (!term_ok) term_ok = (v.byte(o - 5) == 0 && v.byte(o - 4) == 0 && v.byte(o - 3) == 1);
     if (!term_ok) return kPatErr;
-    return (v == 1 && gj + 3 <= n) ? kPatStart : kPatStop;
+    return (b == 1 && gj + 3 <= n) ? kPatStart : kPatStop;
+}
+
+/* 0x80 marks of the bytes of x that end a pattern 00 00 {00..03}; zprev = zero
+ * marks of the previous dword (in/out) */
+HBS_HD uint32_t pattern_marks(uint32_t x, uint32_t& zprev)
+{
+    const uint32_t z = zero_bytes(x);
+    const uint32_t lo = zero_bytes(x & 0xFCFCFCFCu);          /* bytes <= 3        */
+    const uint32_t z1 = alignbyte(z, zprev, 3);               /* byte j-1 is zero  */
+    const uint32_t z2 = alignbyte(z, zprev, 2);               /* byte j-2 is zero  */
+    zprev = z;
+    return z1 & z2 & lo;
 }
 
 /*
- * Classify one 64-byte block.  `blk` points at the block's first byte inside
- * the LDS image (4-byte aligned; at least 8 valid bytes before and after).
- * g0 = stream offset of the block.
+ * Cheap, conservative zero-byte marks: 0x80 in the lowest zero byte of x for
+ * sure, possibly also in 0x01 bytes above a zero byte (borrow).  Good enough
+ * to decide that a block holds no two adjacent zero bytes at all.
  */
-HBS_HD void classify_block(const uint8_t* blk, uint64_t g0, uint64_t n, BlockMarks& m, BlockSum& s)
+HBS_HD uint32_t zero_bytes_approx(uint32_t x)
 {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(blk);
-    uint32_t p[17];
-    uint32_t any = 0;
-    uint32_t zprev = zero_bytes(w[-1]);
+    return (x - 0x01010101u) & ~x & 0x80808080u;
+}
+
+/* exact pattern-end mask of the 64-byte block at logical offset o; zprev = exact
+ * zero marks of the dword in front of it */
+HBS_HD uint64_t block_patterns_exact(const TileView& v, int32_t o, uint32_t zprev)
+{
+    uint64_t pat = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 17; ++k) {
-        const uint32_t x = w[k];
-        const uint32_t z = zero_bytes(x);
-        const uint32_t lo = zero_bytes(x & 0xFCFCFCFCu);          /* bytes <= 3              */
-        const uint32_t z1 = alignbyte(z, zprev, 3);               /* byte j-1 is zero        */
-        const uint32_t z2 = alignbyte(z, zprev, 2);               /* byte j-2 is zero        */
-        p[k] = z1 & z2 & lo;                                      /* 00 00 {00..03} ends at j */
-        any |= p[k];
-        zprev = z;
+    for (int q = 0; q < 4; ++q) {
+        const Quad d = v.quad(o + 16 * q);
+        const uint32_t p0 = pattern_marks(d.x, zprev);
+        const uint32_t p1 = pattern_marks(d.y, zprev);
+        const uint32_t p2 = pattern_marks(d.z, zprev);
+        const uint32_t p3 = pattern_marks(d.w, zprev);
+        const uint32_t m16 = movemask4(p0) | (movemask4(p1) << 4) | (movemask4(p2) << 8) | (movemask4(p3) << 12);
+        pat |= (uint64_t)m16 << (16 * q);
     }
+    return pat;
+}
 
+/*
+ * Pattern-end mask of the 64-byte block at logical offset o.  First a cheap
+ * pass looks for any pair of adjacent zero bytes that could sit in front of a
+ * pattern byte of this block (approximate marks, 5 ops per dword); only blocks
+ * that have one -- about 1 in 1000 for entropy-coded payload -- run the exact
+ * SWAR pass.  aprev = approximate marks of the dword in front of the block
+ * (in/out: on return, of the block's last dword).
+ */
+HBS_HD uint64_t block_patterns(const TileView& v, int32_t o, uint32_t& aprev)
+{
+    uint32_t any = 0;
+    uint32_t prev = aprev;
+    /* a pair that ENDS in the byte before the block (bytes -2,-1) also matters */
+    const uint32_t lead = prev & (prev << 8) & 0x80000000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 4; ++q) {
+        const Quad d = v.quad(o + 16 * q);
+        const uint32_t a0 = zero_bytes_approx(d.x), a1 = zero_bytes_approx(d.y);
+        const uint32_t a2 = zero_bytes_approx(d.z), a3 = zero_bytes_approx(d.w);
+        any |= (a0 & alignbyte(a0, prev, 3)) | (a1 & alignbyte(a1, a0, 3)) | (a2 & alignbyte(a2, a1, 3)) | (a3 & alignbyte(a3, a2, 3));
+        prev = a3;
+    }
+    aprev = prev;
+    /* pairs ending at byte 63 only feed the next block, which sees them as `lead` */
+    if ((any | lead) == 0) return 0;
+    return block_patterns_exact(v, o, zero_bytes(v.dword(o - 4)));
+}
+
+/*
+ * Turn the pattern mask of one block into its marks and scan summary.
+ * o = logical offset of the block in the tile image, g0 = its stream offset,
+ * pat_next = patterns ending in the first two bytes of the next block.
+ */
+HBS_HD void walk_block(const TileView& v, int32_t o, uint64_t g0, uint64_t n,
+                       uint64_t pat, uint32_t pat_next, BlockMarks& m, BlockSum& s)
+{
     const uint32_t nvalid = (g0 >= n) ? 0u : (n - g0 >= 64 ? 64u : (uint32_t)(n - g0));
     m.cand = below(nvalid);
     m.ev = m.ev_start = m.err = 0;
 
-    if (any != 0) {
-        uint64_t pat = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int k = 0; k < 16; ++k) pat |= (uint64_t)movemask4(p[k]) << (4 * k);
-        const uint32_t pat_next = movemask4(p[16]) & 3u;          /* patterns ending at 64, 65 */
-
-        for (uint64_t r = pat; r != 0; r &= r - 1) {
-            const uint32_t j = ctz64(r);
-            const uint64_t bit = 1ull << j;
-            const int kind = pattern_kind(blk + j, g0 + j, n);
-            if (kind == kPatEpb) {
-                m.cand &= ~bit;
-                /* 00 00 03 followed by a byte > 3 that is still part of the stream
-                 * (h264_nal.c:164: i < nal_size-1 && next > 3) */
-                if (blk[j + 1] > 3 && g0 + j + 1 < n) m.err |= bit;
-            } else if (kind == kPatErr) {
-                m.err |= bit;
-            } else if (kind == kPatStart || kind == kPatStop) {
-                m.ev |= bit;
-                if (kind == kPatStart) m.ev_start |= bit;
-                /* the three pattern bytes are outside every NAL */
-                m.cand &= ~(bit | (bit >> 1) | (bit >> 2));
-            }
+    for (uint64_t r = pat; r != 0; r &= r - 1) {
+        const uint32_t j = ctz64(r);
+        const uint64_t bit = 1ull << j;
+        const int kind = pattern_kind(v, o + (int32_t)j, g0 + j, n);
+        if (kind == kPatEpb) {
+            m.cand &= ~bit;
+            /* 00 00 03 followed by a byte > 3 that is still part of the stream
+             * (h264_nal.c:164: i < nal_size-1 && next > 3) */
+            if (v.byte(o + (int32_t)j + 1) > 3 && g0 + j + 1 < n) m.err |= bit;
+        } else if (kind == kPatErr) {
+            m.err |= bit;
+        } else if (kind == kPatStart || kind == kPatStop) {
+            m.ev |= bit;
+            if (kind == kPatStart) m.ev_start |= bit;
+            /* the three pattern bytes are outside every NAL */
+            m.cand &= ~(bit | (bit >> 1) | (bit >> 2));
         }
-        /* terminators that end in the next block exclude our last bytes */
-        for (uint32_t b = 0; b < 2; ++b) {
-            if (pat_next & (1u << b)) {
-                const uint32_t j = 64 + b;
-                const int kind = pattern_kind(blk + j, g0 + j, n);
-                if (kind == kPatStart || kind == kPatStop)
-                    m.cand &= ~((b == 0) ? (3ull << 62) : (1ull << 63));
-            }
+    }
+    /* terminators that end in the next block exclude our last bytes */
+    for (uint32_t b = 0; b < 2; ++b) {
+        if (pat_next & (1u << b)) {
+            const uint32_t j = 64 + b;
+            const int kind = pattern_kind(v, o + (int32_t)j, g0 + j, n);
+            if (kind == kPatStart || kind == kPatStop)
+                m.cand &= ~((b == 0) ? (3ull << 62) : (1ull << 63));
         }
     }
 
     /* summary: bytes before the first event follow the carried state */
-    s.cnt = popc64(m.ev_start);
-    if (m.ev == 0) {
-        s.known = 0;
-        s.carry = popc64(m.cand);
-        s.last = kKindNone;
-    } else {
+    uint32_t carry = popc64(m.cand), known = 0, last = kKindNone;
+    if (m.ev != 0) {
         uint32_t cur = ctz64(m.ev);
-        s.carry = popc64(m.cand & below(cur));
-        uint32_t known = 0;
+        carry = popc64(m.cand & below(cur));
         bool inside = false;
         for (uint64_t r = m.ev; r != 0; r &= r - 1) {
             const uint32_t e = ctz64(r);
@@ -204,9 +246,51 @@ HBS_HD void classify_block(const uint8_t* blk, uint64_t g0, uint64_t n, BlockMar
             cur = e + 1;
         }
         if (inside) known += popc64(m.cand & ~below(cur));
-        s.known = known;
-        s.last = inside ? kKindStart : kKindStop;
+        last = inside ? kKindStart : kKindStop;
     }
+    s.cnt = popc64(m.ev_start);
+    s.known = known;
+    s.carry = carry;
+    s.last = last;
+}
+
+/* summary of a block as an element of the tile algebra */
+HBS_HD TileAgg as_agg(const BlockSum& s) { TileAgg a; a.cnt = s.cnt; a.known = s.known; a.sig = s.carry; a.last = s.last; return a; }
+
+/*
+ * Pass 1 for one thread: pattern masks of its four consecutive blocks go to
+ * pats[4*tid .. 4*tid+3] (LDS), the return value is the thread's summary.
+ * o0 = logical offset of the thread's first byte (multiple of 256), g0 = its
+ * stream offset.  The last thread of the tile also records the patterns that
+ * end in the first two bytes after the tile (pats[kBlocks]).
+ */
+HBS_D TileAgg classify_thread(const TileView& v, int32_t o0, uint64_t g0, uint64_t n, uint64_t* pats, int tid)
+{
+    uint32_t aprev = zero_bytes_approx(v.dword(o0 - 4));
+    uint64_t pat = block_patterns(v, o0, aprev);
+    TileAgg acc = {0u, 0u, 0u, kKindNone};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int b = 0; b < kBlocksPerThread; ++b) {
+        const int32_t o = o0 + kBlockBytes * b;
+        uint64_t nxt;
+        if (b + 1 < kBlocksPerThread) {
+            nxt = block_patterns(v, o + kBlockBytes, aprev);
+        } else {
+            /* patterns ending in the first two bytes behind this thread's bytes */
+            uint32_t z = zero_bytes(v.dword(o + kBlockBytes - 4));
+            nxt = movemask4(pattern_marks(v.dword(o + kBlockBytes), z)) & 3u;
+        }
+        pats[kBlocksPerThread * tid + b] = pat;
+        if (b + 1 == kBlocksPerThread && tid == kThreads - 1) pats[kBlocks] = nxt;
+        BlockMarks m;
+        BlockSum s;
+        walk_block(v, o, g0 + (uint64_t)(kBlockBytes * b), n, pat, (uint32_t)(nxt & 3u), m, s);
+        acc = combine(acc, as_agg(s));
+        pat = nxt;
+    }
+    return acc;
 }
 
 /* where the emit pass writes to */
@@ -215,6 +299,15 @@ struct EmitTarget {
     uint64_t index_cap;
     RunHeader* hdr;
 };
+
+/* workgroup barrier on the device; the CPU single-stepper runs the two halves of
+ * emit_thread as separate loops instead (see tests/sim/hbs_sim.cpp) */
+HBS_D void tile_barrier()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+}
 
 HBS_D void atomic_or_status(hbs_nal_entry* e, int32_t bits)
 {
@@ -247,7 +340,7 @@ HBS_D void flag_error(RunHeader* hdr, uint32_t code)
  * mask.  nal_ord = number of NAL starts before this block (global ordinal of
  * the next NAL to open); rbsp_pos = arena offset of the block's first kept byte.
  */
-HBS_D uint64_t emit_block(const uint8_t* blk, uint64_t g0, const BlockMarks& m, bool inside,
+HBS_D uint64_t emit_block(const TileView& v, int32_t o, uint64_t g0, const BlockMarks& m, bool inside,
                           uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
 {
     uint64_t inside_mask = 0;
@@ -260,13 +353,14 @@ HBS_D uint64_t emit_block(const uint8_t* blk, uint64_t g0, const BlockMarks& m, 
             inside_mask |= below(e) & ~below(cur);
             /* NAL ord-1 ends where the terminator begins (h264_nal.c:74) */
             const uint64_t k = ord - 1;
-            const uint8_t* t = blk + e - 2;                   /* first byte of the terminator */
+            const int32_t t = o + (int32_t)e - 2;             /* first byte of the terminator */
+            const uint32_t b3 = v.byte(t - 3), b2 = v.byte(t - 2), b1 = v.byte(t - 1);
             if (k < tgt.index_cap) {
                 tgt.index[k].end = g0 + e - 2;
-                if (t[-3] == 0 && t[-2] == 0 && t[-1] == 3)   /* h264_nal.c:170-173 */
+                if (b3 == 0 && b2 == 0 && b1 == 3)            /* h264_nal.c:170-173 */
                     atomic_or_status(&tgt.index[k], HBS_ST_TRAILING03);
             }
-            if (t[-3] == 0 && t[-2] == 0 && t[-1] == 1)       /* empty NAL: loop of hevc_analyze.c:135 stops */
+            if (b3 == 0 && b2 == 0 && b1 == 1)                /* empty NAL: loop of hevc_analyze.c:135 stops */
                 atomic_min_u64(&tgt.hdr->first_empty, k);
         }
         if ((m.ev_start >> e) & 1ull) {
@@ -294,73 +388,87 @@ HBS_D uint64_t emit_block(const uint8_t* blk, uint64_t g0, const BlockMarks& m, 
 }
 
 /*
- * Output-driven compaction.  The tile's kept bytes, in order, go to
- * arena[kept_base, kept_base + tile_kept).  Output is produced in 16-byte words
- * aligned in the ARENA; word `wi` of the tile covers tile ranks
- * [16*wi - ob, 16*wi - ob + 16) with ob = kept_base & 15.  rank[b] is the tile
- * rank of block b's first kept byte (rank[256] = tile_kept), keep[b] its keep
- * mask, raw the tile image.  Returns the number of valid bytes and their
- * position inside the word via lo/hi (bytes [lo,hi) of the word are ours).
+ * Pass 2 for one thread, once the tile's exclusive prefix is known: re-derive
+ * each block's marks from its stored pattern mask, emit its events, and leave
+ * the final keep masks and ranks in LDS for the gather.  keep[] holds the
+ * pattern masks on entry (pass 1) and the keep masks on exit; a thread needs
+ * its right neighbour's first mask, so all of those are read ahead of a
+ * barrier before anyone overwrites an entry.
  */
-struct GatherOut { uint32_t w[4]; uint32_t lo, hi; };
+struct ThreadStart {
+    uint32_t in_state;   /* 0 outside, 1 inside, 2 = the tile's carried state */
+    uint32_t cnt, known, sig;   /* exclusive prefix at the thread's first byte */
+};
 
-HBS_D GatherOut gather_word(const uint8_t* raw_tile /* image of stream byte tile_base */,
-                            const uint32_t* rank, const uint64_t* keep,
-                            uint32_t wi, uint32_t ob, uint32_t tile_kept)
+HBS_D void emit_thread(const TileView& v, int32_t o0, uint64_t g0, uint64_t n, int tid,
+                       const ThreadStart& ts, const Prefix& excl, uint64_t* keep, uint32_t* rank,
+                       const EmitTarget& tgt)
 {
-    GatherOut g;
-    const int32_t r_first = (int32_t)(16u * wi) - (int32_t)ob;     /* rank of byte 0 of the word */
-    const int32_t r_lo = r_first < 0 ? 0 : r_first;
-    const int32_t r_hi = (r_first + 16 > (int32_t)tile_kept) ? (int32_t)tile_kept : r_first + 16;
-    g.lo = (uint32_t)(r_lo - r_first);
-    g.hi = (uint32_t)(r_hi - r_first);
-    g.w[0] = g.w[1] = g.w[2] = g.w[3] = 0;
-    if (r_hi <= r_lo) { g.hi = g.lo; return g; }
+    const uint64_t right = keep[kBlocksPerThread * tid + kBlocksPerThread];   /* neighbour's first mask */
+    tile_barrier();          /* every neighbour mask is read before any keep mask is written */
 
-    /* block holding rank r_lo: rank[b] <= r_lo < rank[b+1]; rank[b] <= 64 b */
-    uint32_t b = (uint32_t)r_lo >> 6;
-    if (rank[b + 1] <= (uint32_t)r_lo) {
-        uint32_t lo_b = b + 1, hi_b = kThreads - 1;                /* binary search, rare */
-        while (lo_b < hi_b) {
-            const uint32_t mid = (lo_b + hi_b) >> 1;
-            if (rank[mid + 1] <= (uint32_t)r_lo) lo_b = mid + 1; else hi_b = mid;
-        }
-        b = lo_b;
+    uint32_t st = ts.in_state, pk = ts.known, ps = ts.sig, pc = ts.cnt;
+    uint64_t pat = keep[kBlocksPerThread * tid];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int b = 0; b < kBlocksPerThread; ++b) {
+        const int32_t o = o0 + kBlockBytes * b;
+        const uint64_t gb = g0 + (uint64_t)(kBlockBytes * b);
+        const uint64_t nxt = (b + 1 < kBlocksPerThread) ? keep[kBlocksPerThread * tid + b + 1] : right;
+        BlockMarks m;
+        BlockSum s;
+        walk_block(v, o, gb, n, pat, (uint32_t)(nxt & 3u), m, s);
+        const bool inside = (st == 1u) || (st == 2u && excl.inside);
+        const uint32_t rank0 = pk + (excl.inside ? ps : 0u);
+        const uint64_t km = emit_block(v, o, gb, m, inside, excl.nals + pc, excl.kept + rank0, tgt);
+        keep[kBlocksPerThread * tid + b] = km;
+        rank[kBlocksPerThread * tid + b] = rank0;
+        pk += s.known + (st == 1u ? s.carry : 0u);
+        ps += (st == 2u) ? s.carry : 0u;
+        pc += s.cnt;
+        if (s.last != kKindNone) st = (s.last == kKindStart) ? 1u : 0u;
+        pat = nxt;
     }
-    const uint32_t skip = (uint32_t)r_lo - rank[b];                 /* kept bytes of block b before ours */
-    uint64_t km = keep[b];
+}
 
-    /* fast path: a full word whose 16 source bytes are contiguous */
-    if (g.lo == 0 && g.hi == 16) {
-        bool contiguous = false;
-        uint32_t src = 0;
-        if (km == ~0ull) {
-            src = 64u * b + skip;
-            contiguous = (skip <= 48) || (b + 1 < (uint32_t)kThreads && keep[b + 1] == ~0ull);
-        }
-        if (contiguous) {
-            const uint32_t* a = reinterpret_cast<const uint32_t*>(raw_tile + (src & ~3u));
-            const uint32_t sh = src & 3u;
-            const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
-            g.w[0] = alignbyte(d1, d0, sh);
-            g.w[1] = alignbyte(d2, d1, sh);
-            g.w[2] = alignbyte(d3, d2, sh);
-            g.w[3] = alignbyte(d4, d3, sh);
-            return g;
-        }
-    }
+/*
+ * Compaction, input driven.  The tile is cut into 16-byte chunks; chunk c
+ * (bytes [16c, 16c+16) of the tile, quarter c&3 of block c>>2) knows where its
+ * kept bytes go: tile rank = rank[block] + kept bytes of the block in front of
+ * the quarter.  A chunk that is kept whole -- nearly all of them -- is one
+ * 16-byte load from the image and one 16-byte store to arena + rank; the
+ * destination is byte-aligned only, which gfx950 global stores handle at ~92 %
+ * of the aligned rate (scripts/ubench/unaligned_store.hip).  Chunks with holes
+ * are compacted byte by byte.
+ */
+struct ChunkDest {
+    uint32_t sub;        /* keep bits of the chunk's 16 bytes            */
+    uint32_t rank;       /* tile rank of its first kept byte             */
+};
 
-    /* general path: walk the keep masks byte by byte */
-    for (uint32_t i = 0; i < skip; ++i) km &= km - 1;
-    for (uint32_t o = g.lo; o < g.hi; ++o) {
-        while (km == 0 && b + 1 < (uint32_t)kThreads) { ++b; km = keep[b]; }
-        if (km == 0) break;                                   /* cannot happen: ranks are consistent */
-        const uint32_t pos = ctz64(km);
-        km &= km - 1;
-        const uint32_t v = raw_tile[64u * b + pos];
-        g.w[o >> 2] |= v << (8u * (o & 3u));
+HBS_D ChunkDest chunk_dest(const uint32_t* rank, const uint64_t* keep, uint32_t c)
+{
+    ChunkDest d;
+    const uint32_t b = c >> 2, q = c & 3u;
+    const uint64_t km = keep[b];
+    d.sub = (uint32_t)(km >> (16u * q)) & 0xFFFFu;
+    d.rank = rank[b] + popc64(km & below(16u * q));
+    return d;
+}
+
+/* kept bytes of a chunk with holes, packed low-to-high into lo/hi; returns how many */
+HBS_D uint32_t compact_chunk(const TileView& v, uint32_t c, uint32_t sub, uint64_t& lo, uint64_t& hi)
+{
+    lo = 0; hi = 0;
+    uint32_t o = 0;
+    for (uint32_t r = sub; r != 0; r &= r - 1, ++o) {
+        const uint32_t pos = (uint32_t)__builtin_ctz(r);
+        const uint64_t val = (uint64_t)v.byte((int32_t)(16u * c + pos)) << (8u * (o & 7u));
+        lo |= (o < 8) ? val : 0ull;
+        hi |= (o < 8) ? 0ull : val;
     }
-    return g;
+    return o;
 }
 
 /*

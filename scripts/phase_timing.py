@@ -1,0 +1,36 @@
+"""Diagnostic: build the library with -DHBS_PHASE_TIMING into gpurun_out/diag and print
+where a workgroup of K12 spends its shader clocks (shares, not absolute speed)."""
+import ctypes as C, os, subprocess, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+os.makedirs("gpurun_out/diag", exist_ok=True)
+so = "gpurun_out/diag/libhbs_diag.so"
+srcs = ["hevcbitstream_amd/csrc/hbs_scan.hip", "hevcbitstream_amd/csrc/hbs_capi.hip"]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Iinclude",
+                       "-DHBS_PHASE_TIMING", "-o", so] + srcs)
+import hevcbitstream_amd.api as api
+api.library_path = lambda: so
+import hevcbitstream_amd as hbs
+from tests import _orc
+orc = _orc.oracle()
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+want_rbsp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
+d = torch.from_numpy(base).cuda().repeat(64)
+ctx = hbs.Context(0)
+index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * 64 + 16)
+for _ in range(3):
+    ctx.index_extract_async(d, index, cap, rbsp if want_rbsp else None, summary)
+torch.cuda.synchronize()
+out = np.zeros((1024, 8), dtype=np.uint64)
+lib = api.load_library()
+lib.hbs_debug_phase_cycles.argtypes = [C.c_void_p]
+assert lib.hbs_debug_phase_cycles(out.ctypes.data) == 0
+names = ["stage+wait", "classify", "scan", "lookback", "emit", "gather-fast", "gather-slow+sync", "-"]
+act = out[:512].astype(np.float64)
+tiles = d.numel() / 65536 / 512
+tot = act.sum(axis=1).mean()
+print("mode", mode, "rbsp", want_rbsp, "tiles/WG %.1f  total cycles/WG %.0f  -> cycles/tile %.0f" % (tiles, tot, tot / tiles))
+for i, nm in enumerate(names[:7]):
+    print("  %-18s %8.0f cyc/tile  %5.1f%%   (min WG %.0f, max WG %.0f)" % (nm, act[:, i].mean() / tiles, 100 * act[:, i].mean() / tot,
+                                                                   act[:, i].min() / tiles, act[:, i].max() / tiles))

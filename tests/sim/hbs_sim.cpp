@@ -21,9 +21,9 @@ namespace {
 uint8_t byte_at(const uint8_t* s, int64_t q, uint64_t n) { return (q >= 0 && (uint64_t)q < n) ? s[q] : 0xFF; }
 
 struct SimTile {
-    alignas(16) uint8_t raw[kHalo + kTileBytes + kHalo];
-    uint64_t keep[kThreads];
-    uint32_t rank[kThreads + 1];
+    alignas(16) uint8_t img[kImageBytes];
+    uint64_t keep[kBlocks + 1];
+    uint32_t rank[kBlocks + 1];
 };
 
 } // namespace
@@ -41,25 +41,27 @@ extern "C" int sim_index_extract(const uint8_t* stream, uint64_t n,
     const uint64_t num_tiles = (n + kTileBytes - 1) / kTileBytes;
     Prefix run{0, 0, 0};
     static SimTile t;
-    static BlockMarks marks[kThreads];
-    static BlockSum sums[kThreads];
+    static TileAgg sums[kThreads];
+    TileView view;
+    view.img = t.img;
 
     for (uint64_t tile = 0; tile < num_tiles; ++tile) {
         const uint64_t tile_base = tile * (uint64_t)kTileBytes;
-        for (int i = -kHalo; i < kTileBytes + kHalo; ++i)
-            t.raw[kHalo + i] = byte_at(stream, (int64_t)tile_base + i, n);
+        memset(t.img, 0xCD, sizeof(t.img));                       /* poison: only staged bytes may be read */
+        for (int i = -16; i < kTileBytes + 16; ++i)
+            t.img[TileView::phys(i)] = byte_at(stream, (int64_t)tile_base + i, n);
 
         for (int tid = 0; tid < kThreads; ++tid)
-            classify_block(&t.raw[kHalo + kBlockBytes * tid], tile_base + (uint64_t)kBlockBytes * tid, n, marks[tid], sums[tid]);
+            sums[tid] = classify_thread(view, kThreadBytes * tid, tile_base + (uint64_t)kThreadBytes * tid, n, t.keep, tid);
 
         /* sequential meaning of block_scan() */
-        uint32_t in_state[kThreads], pk[kThreads], ps[kThreads], pc[kThreads];
+        ThreadStart ts[kThreads];
         uint32_t state = 2 /* carry */, k = 0, s = 0, c = 0;
         TileAgg agg{0, 0, 0, kKindNone};
         for (int tid = 0; tid < kThreads; ++tid) {
-            in_state[tid] = state; pk[tid] = k; ps[tid] = s; pc[tid] = c;
-            k += sums[tid].known + (state == 1 ? sums[tid].carry : 0u);
-            s += (state == 2) ? sums[tid].carry : 0u;
+            ts[tid].in_state = state; ts[tid].known = k; ts[tid].sig = s; ts[tid].cnt = c;
+            k += sums[tid].known + (state == 1 ? sums[tid].sig : 0u);
+            s += (state == 2) ? sums[tid].sig : 0u;
             c += sums[tid].cnt;
             if (sums[tid].last != kKindNone) { state = (sums[tid].last == kKindStart) ? 1u : 0u; agg.last = sums[tid].last; }
         }
@@ -68,10 +70,7 @@ extern "C" int sim_index_extract(const uint8_t* stream, uint64_t n,
         /* cross-check the aggregate algebra used by the look-back */
         {
             TileAgg viaCombine{0, 0, 0, kKindNone};
-            for (int tid = 0; tid < kThreads; ++tid) {
-                TileAgg b{sums[tid].cnt, sums[tid].known, sums[tid].carry, sums[tid].last};
-                viaCombine = combine(viaCombine, b);
-            }
+            for (int tid = 0; tid < kThreads; ++tid) viaCombine = combine(viaCombine, sums[tid]);
             if (viaCombine.cnt != agg.cnt || viaCombine.known != agg.known || viaCombine.sig != agg.sig || viaCombine.last != agg.last) return -100;
             const TileAgg rt = unpack_agg(pack_agg0(agg), pack_agg1(agg));
             if (rt.cnt != agg.cnt || rt.known != agg.known || rt.sig != agg.sig || rt.last != agg.last) return -101;
@@ -85,23 +84,24 @@ extern "C" int sim_index_extract(const uint8_t* stream, uint64_t n,
         }
         const uint32_t tile_kept = agg.known + (excl.inside ? agg.sig : 0u);
 
-        for (int tid = 0; tid < kThreads; ++tid) {
-            const bool inside = (in_state[tid] == 1) || (in_state[tid] == 2 && excl.inside);
-            const uint32_t rank0 = pk[tid] + (excl.inside ? ps[tid] : 0u);
-            t.keep[tid] = emit_block(&t.raw[kHalo + kBlockBytes * tid], tile_base + (uint64_t)kBlockBytes * tid, marks[tid],
-                                     inside, excl.nals + pc[tid], excl.kept + rank0, tgt);
-            t.rank[tid] = rank0;
-        }
-        t.rank[kThreads] = tile_kept;
+        /* ascending thread order: thread t reads keep[4t..4t+4] before anyone wrote them */
+        for (int tid = 0; tid < kThreads; ++tid)
+            emit_thread(view, kThreadBytes * tid, tile_base + (uint64_t)kThreadBytes * tid, n, tid, ts[tid], excl, t.keep, t.rank, tgt);
+        t.rank[kBlocks] = tile_kept;
 
         if (rbsp != nullptr && tile_kept != 0) {
             if (excl.kept + tile_kept <= rbsp_cap) {
-                const uint32_t ob = (uint32_t)(excl.kept & 15ull);
-                const uint32_t nwords = (ob + tile_kept + 15u) >> 4;
-                uint8_t* out = rbsp + (excl.kept - ob);
-                for (uint32_t wi = 0; wi < nwords; ++wi) {
-                    const GatherOut g = gather_word(&t.raw[kHalo], t.rank, t.keep, wi, ob, tile_kept);
-                    for (uint32_t o = g.lo; o < g.hi; ++o) out[16ull * wi + o] = (uint8_t)(g.w[o >> 2] >> (8u * (o & 3u)));
+                uint8_t* out = rbsp + excl.kept;
+                for (uint32_t c = 0; c < (uint32_t)(kTileBytes / 16); ++c) {
+                    const ChunkDest d = chunk_dest(t.rank, t.keep, c);
+                    if (d.sub == 0) continue;
+                    if (d.sub == 0xFFFFu) {
+                        for (int i = 0; i < 16; ++i) out[d.rank + i] = (uint8_t)view.byte((int32_t)(16 * c + i));
+                    } else {
+                        uint64_t lo, hi;
+                        const uint32_t cnt = compact_chunk(view, c, d.sub, lo, hi);
+                        for (uint32_t i = 0; i < cnt; ++i) out[d.rank + i] = (uint8_t)(((i < 8) ? lo : hi) >> (8 * (i & 7)));
+                    }
                 }
             } else {
                 flag_error(&hdr, (uint32_t)(-HBS_E_CAPACITY));

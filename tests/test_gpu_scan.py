@@ -79,10 +79,10 @@ def test_fuzz_small(ctx, orc):
 
 
 def test_fuzz_multi_tile(ctx, orc):
-    """many 16 KiB tiles: exercises the look-back chain under real concurrency."""
+    """many 64 KiB tiles: exercises the look-back chain under real concurrency."""
     rng = np.random.RandomState(6)
     for trial in range(6):
-        n = rng.randint(1 << 20, 3 << 20)
+        n = rng.randint(4 << 20, 12 << 20)
         s = rng.randint(0, 256, size=n).astype(np.uint8)
         # sprinkle start codes / EPBs / zero runs / errors
         for pat, cnt in ((b"\x00\x00\x01", n // 5000), (b"\x00\x00\x00\x01", n // 9000), (b"\x00\x00\x03", n // 700),
@@ -106,10 +106,10 @@ def test_tile_edges(ctx, orc):
     pats = [bytes([0, 0, 1]), bytes([0, 0, 0, 1]), bytes([0, 0, 3]), bytes([0, 0, 3, 0, 0, 3]), bytes([0, 0, 0]),
             bytes([0, 0, 2]), bytes([0, 0, 3, 9]), bytes([0] * 9)]
     for trial in range(40):
-        n = 16384 * 3 + rng.randint(0, 200)
+        n = 65536 * 3 + rng.randint(0, 200)
         s = rng.randint(4, 256, size=n).astype(np.uint8)
         s[0:4] = [0, 0, 1, 0x40]
-        for edge in (64, 128, 4096, 16384, 16384 + 64, 32768, 49152):
+        for edge in (64, 128, 256, 4096, 16384, 65536, 65536 + 64, 65536 + 256, 131072, 196608):
             for _ in range(2):
                 p = pats[rng.randint(len(pats))]
                 at = edge - rng.randint(0, len(p) + 2)

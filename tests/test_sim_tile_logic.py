@@ -59,15 +59,15 @@ def test_synthetic_stream(orc, mode):
 
 
 def test_tile_boundaries(orc):
-    """patterns straddling 64-byte block and 16 KiB tile boundaries."""
+    """patterns straddling 64-byte block, 256-byte thread and 64 KiB tile boundaries."""
     rng = np.random.RandomState(3)
     pats = [bytes([0, 0, 1]), bytes([0, 0, 0, 1]), bytes([0, 0, 3]), bytes([0, 0, 3, 0, 0, 3]), bytes([0, 0, 0]),
             bytes([0, 0, 2]), bytes([0, 0, 3, 9]), bytes([0] * 9)]
-    for trial in range(300):
-        n = 16384 * 2 + rng.randint(0, 200)
+    for trial in range(80):
+        n = 65536 * 2 + rng.randint(0, 200)
         s = rng.randint(4, 256, size=n).astype(np.uint8)
         s[0:4] = [0, 0, 1, 0x40]
-        for edge in (64, 128, 16384, 16384 + 64, 32768):
+        for edge in (64, 128, 256, 512, 16384, 65536, 65536 + 64, 65536 + 256, 131072):
             for _ in range(2):
                 p = pats[rng.randint(len(pats))]
                 at = edge - rng.randint(0, len(p) + 2)
