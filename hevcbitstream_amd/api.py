@@ -17,7 +17,8 @@ ST_ERROR, ST_TRAILING03, ST_UNTERMINATED = 1, 2, 4
 EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stream", "hbs_ctx_use_own_stream",
            "hbs_ctx_get_stream",
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_read_summary",
-           "hbs_workspace_bytes"]
+           "hbs_workspace_bytes", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
+           "hbs_synth_rbsp_bound"]
 
 
 class HbsError(RuntimeError):
@@ -57,6 +58,14 @@ def load_library():
     lib.hbs_read_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hbs_workspace_bytes.argtypes = [C.c_uint64]
     lib.hbs_workspace_bytes.restype = C.c_uint64
+    lib.hbs_emit_annexb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.hbs_annexb_bound.argtypes = [C.c_uint64, C.c_uint64]
+    lib.hbs_annexb_bound.restype = C.c_uint64
+    lib.hbs_synth_rbsp.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64,
+                                   C.c_void_p, C.c_void_p]
+    lib.hbs_synth_rbsp_bound.argtypes = [C.c_uint64]
+    lib.hbs_synth_rbsp_bound.restype = C.c_uint64
     _lib = lib
     return lib
 
@@ -135,3 +144,61 @@ class Context:
         ent = index[: n * NAL_ENTRY.itemsize].cpu().numpy().view(NAL_ENTRY).copy()
         arena = rbsp[: int(s["rbsp_bytes"])].cpu().numpy() if want_rbsp else None
         return ent, arena, s
+
+    # ---- K3 and the synthetic workload -------------------------------------------------
+
+    def emit_annexb_async(self, rbsp, rbsp_bytes, index, n_nals, gap_mode, out, index_out, summary):
+        """Enqueue K3.  rbsp/index/out/index_out/summary are device tensors (index_out may be None)."""
+        self._bind_stream()
+        rc = self.lib.hbs_emit_annexb(self.h, C.c_void_p(rbsp.data_ptr()), rbsp_bytes, C.c_void_p(index.data_ptr()),
+                                      n_nals, gap_mode, C.c_void_p(out.data_ptr()), out.numel(),
+                                      C.c_void_p(index_out.data_ptr()) if index_out is not None else None,
+                                      C.c_void_p(summary.data_ptr()))
+        self._check(rc, "hbs_emit_annexb")
+
+    def emit_annexb(self, rbsp, index_entries, gap_mode=0):
+        """Convenience: entries is a host ndarray[NAL_ENTRY]; returns (stream ndarray, entries_out)."""
+        t = self.torch
+        dev = t.device("cuda", self.device)
+        n = len(index_entries)
+        d_idx = t.from_numpy(np.ascontiguousarray(index_entries).view(np.uint8).copy()).to(dev) if n else \
+            t.zeros(NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
+        rbsp_bytes = int(rbsp.numel())
+        out = t.empty(int(self.lib.hbs_annexb_bound(rbsp_bytes, n)) + 64 + (int(index_entries["start"].max()) if n else 0),
+                      dtype=t.uint8, device=dev)
+        d_out_idx = t.empty(max(n, 1) * NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
+        summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
+        if rbsp_bytes == 0:
+            rbsp = t.zeros(16, dtype=t.uint8, device=dev)
+        self.emit_annexb_async(rbsp, rbsp_bytes, d_idx, n, gap_mode, out, d_out_idx, summary)
+        s = self.read_summary(summary)
+        if int(s["error"]) != 0:
+            raise HbsError("hbs_emit_annexb: error %d" % int(s["error"]))
+        return (out[: int(s["stream_bytes"])].cpu().numpy(),
+                d_out_idx[: n * NAL_ENTRY.itemsize].cpu().numpy().view(NAL_ENTRY).copy())
+
+    def synth_stream(self, seed, n_nals, mode=0):
+        """Generate S(seed, n_nals, mode) in HBM.  Returns device tensors and sizes:
+        dict(stream=u8[stream_bytes...], stream_bytes, rbsp=u8[...], rbsp_bytes, index=u8[n*32])."""
+        t = self.torch
+        dev = t.device("cuda", self.device)
+        rbsp_cap = int(self.lib.hbs_synth_rbsp_bound(n_nals))
+        rbsp = t.empty(rbsp_cap, dtype=t.uint8, device=dev)
+        index = t.empty(max(n_nals, 1) * NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
+        summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
+        self._bind_stream()
+        rc = self.lib.hbs_synth_rbsp(self.h, seed, n_nals, mode, C.c_void_p(rbsp.data_ptr()), rbsp_cap,
+                                     C.c_void_p(index.data_ptr()), C.c_void_p(summary.data_ptr()))
+        self._check(rc, "hbs_synth_rbsp")
+        s = self.read_summary(summary)
+        if int(s["error"]) != 0:
+            raise HbsError("hbs_synth_rbsp: error %d" % int(s["error"]))
+        rbsp_bytes = int(s["stream_bytes"])
+        out_cap = int(self.lib.hbs_annexb_bound(rbsp_bytes, n_nals))
+        stream = t.empty(out_cap, dtype=t.uint8, device=dev)
+        self.emit_annexb_async(rbsp, rbsp_bytes, index, n_nals, 1, stream, index, summary)
+        s = self.read_summary(summary)
+        if int(s["error"]) != 0:
+            raise HbsError("hbs_emit_annexb: error %d" % int(s["error"]))
+        return dict(stream=stream, stream_bytes=int(s["stream_bytes"]), rbsp=rbsp, rbsp_bytes=rbsp_bytes,
+                    index=index, n_nals=n_nals)

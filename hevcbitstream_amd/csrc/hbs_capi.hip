@@ -10,6 +10,8 @@
 #include <cstring>
 #include <new>
 #include "hbs_scan.h"
+#include "hbs_emit_launch.h"
+#include "hbs_emit.h"
 
 struct hbs_ctx {
     int device;
@@ -20,6 +22,8 @@ struct hbs_ctx {
     unsigned long long* desc;
     uint64_t desc_tiles;
     hbs::RunHeader* hdr;
+    /* K3 / generator workspace */
+    void* ws; uint64_t ws_bytes;
     char err[256];
 };
 
@@ -42,6 +46,19 @@ int ensure_workspace(hbs_ctx* c, uint64_t stream_bytes)
     }
     return 0;
 }
+
+int ensure_ws(hbs_ctx* c, uint64_t bytes)
+{
+    if (bytes > c->ws_bytes) {
+        if (c->ws) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+        hipError_t e = hipMalloc(&c->ws, bytes);
+        if (e != hipSuccess) return fail(c, e, "hipMalloc(workspace)");
+        c->ws_bytes = bytes;
+    }
+    return 0;
+}
+
+uint64_t round256(uint64_t v) { return (v + 255) & ~255ull; }
 
 } // namespace
 
@@ -89,6 +106,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->desc) (void)hipFree(c->desc);
     if (c->hdr) (void)hipFree(c->hdr);
+    if (c->ws) (void)hipFree(c->ws);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -145,6 +163,51 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     hipError_t e = hbs::launch_scan_extract(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_scan_extract");
 }
+
+int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
+                    const hbs_nal_entry* d_index_in, uint64_t n_nals, int gap_mode,
+                    uint8_t* d_out, uint64_t out_cap, hbs_nal_entry* d_index_out, hbs_summary* d_summary)
+{
+    if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index_in || !d_out))) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    const uint64_t nseg = rbsp_bytes / hbs::kSegBytes + n_nals + 2;
+    const uint64_t b_seg = round256(nseg * 2), b_n = round256((n_nals + 1) * 8);
+    int rc = ensure_ws(c, b_seg + 2 * b_n + 512);
+    if (rc) return rc;
+    uint8_t* w = static_cast<uint8_t*>(c->ws);
+    hbs::EmitArgs a;
+    a.rbsp = d_rbsp; a.rbsp_bytes = rbsp_bytes; a.index_in = d_index_in; a.n = n_nals; a.gap_mode = gap_mode;
+    a.out = d_out; a.out_cap = out_cap; a.index_out = d_index_out; a.summary = d_summary;
+    a.seg_cnt = reinterpret_cast<uint16_t*>(w);
+    a.nal_total = reinterpret_cast<unsigned long long*>(w + b_seg);
+    a.out_off = reinterpret_cast<unsigned long long*>(w + b_seg + b_n);
+    a.total = reinterpret_cast<unsigned long long*>(w + b_seg + 2 * b_n);
+    a.err = reinterpret_cast<uint32_t*>(w + b_seg + 2 * b_n + 256);
+    hipError_t e = hbs::launch_emit_annexb(a, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "launch_emit_annexb");
+}
+
+int hbs_synth_rbsp(hbs_ctx* c, uint64_t seed, uint64_t n_nals, int mode,
+                   uint8_t* d_rbsp, uint64_t rbsp_cap, hbs_nal_entry* d_index, hbs_summary* d_summary)
+{
+    if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index)) || (mode != 0 && mode != 1)) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    const uint64_t b_n = round256((n_nals + 1) * 8);
+    int rc = ensure_ws(c, 2 * b_n + 512);
+    if (rc) return rc;
+    uint8_t* w = static_cast<uint8_t*>(c->ws);
+    hbs::SynthArgs a;
+    a.seed = seed; a.n = n_nals; a.mode = mode; a.rbsp = d_rbsp; a.rbsp_cap = rbsp_cap; a.index = d_index; a.summary = d_summary;
+    a.lens = reinterpret_cast<unsigned long long*>(w);
+    a.offs = reinterpret_cast<unsigned long long*>(w + b_n);
+    a.total = reinterpret_cast<unsigned long long*>(w + 2 * b_n);
+    a.err = reinterpret_cast<uint32_t*>(w + 2 * b_n + 256);
+    hipError_t e = hbs::launch_synth_rbsp(a, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "launch_synth_rbsp");
+}
+
+uint64_t hbs_synth_rbsp_bound(uint64_t n_nals) { return n_nals * 12288ull + 16; }
+uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals) { return rbsp_bytes + rbsp_bytes / 2 + 4 * n_nals + 16; }
 
 int hbs_read_summary(hbs_ctx* c, const hbs_summary* d_summary, hbs_summary* h_summary)
 {

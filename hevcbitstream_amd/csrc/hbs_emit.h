@@ -1,0 +1,130 @@
+/*
+ * hbs_emit.h -- per-segment logic of K3 (RBSP -> Annex-B: emulation-prevention
+ * insertion + start codes) and of the synthetic-stream generator.
+ *
+ * Restates rbsp_to_nal (reference h264_nal.c:92-132): walking the RBSP bytes
+ * with `count` = zero bytes seen since the last non-zero byte or inserted 03;
+ * before a byte <= 3 that arrives with count == 2 a 03 is emitted and count
+ * restarts (:110-116); no 03 is appended after a trailing 00 00 (:130).
+ * Parallel form: a NAL's RBSP is cut into 256-byte segments; the state a
+ * segment starts in only depends on the run of zeros in front of it
+ * (z zeros -> count 0, 1 (z odd) or 2 (z even, >= 2)), so segments are
+ * independent once their insert counts are prefix-summed.
+ * Compiles for gfx950 and, under tests/sim, for the host.
+ */
+#ifndef HBS_EMIT_H
+#define HBS_EMIT_H
+
+#include "hbs_common.h"
+
+namespace hbs {
+
+constexpr uint32_t kSegBytes = 256;
+
+/* value of the reference's `count` on entering byte p of a NAL that begins at
+ * nal_begin (arena offsets) */
+HBS_HD uint32_t lead_count(const uint8_t* rbsp, uint64_t nal_begin, uint64_t p)
+{
+    uint64_t z = 0;
+    while (p - z > nal_begin && rbsp[p - 1 - z] == 0) ++z;
+    return z == 0 ? 0u : ((z & 1ull) ? 1u : 2u);
+}
+
+/* emulation-prevention bytes rbsp_to_nal inserts while copying [seg_begin, seg_end) */
+HBS_HD uint32_t count_segment(const uint8_t* rbsp, uint64_t nal_begin, uint64_t seg_begin, uint64_t seg_end)
+{
+    uint32_t count = lead_count(rbsp, nal_begin, seg_begin), ins = 0;
+    for (uint64_t p = seg_begin; p < seg_end; ++p) {
+        const uint32_t v = rbsp[p];
+        if (count == 2 && v <= 3) { ++ins; count = 0; }
+        count = (v == 0) ? count + 1 : 0;
+    }
+    return ins;
+}
+
+/* 16-byte staging register for byte-aligned output */
+struct OutBuf {
+    uint64_t lo, hi;
+    uint32_t n;
+    uint8_t* dst;
+};
+
+HBS_D void out_store16(uint8_t* dst, uint64_t lo, uint64_t hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(1))) U16 { v4 v; };
+    v4 v;
+    v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
+    reinterpret_cast<U16*>(dst)->v = v;
+#else
+    for (int i = 0; i < 8; ++i) { dst[i] = (uint8_t)(lo >> (8 * i)); dst[8 + i] = (uint8_t)(hi >> (8 * i)); }
+#endif
+}
+
+HBS_D void out_push(OutBuf& b, uint32_t v)
+{
+    const uint64_t x = (uint64_t)v << (8u * (b.n & 7u));
+    if (b.n < 8) b.lo |= x; else b.hi |= x;
+    if (++b.n == 16) {
+        out_store16(b.dst, b.lo, b.hi);
+        b.dst += 16; b.lo = 0; b.hi = 0; b.n = 0;
+    }
+}
+
+HBS_D void out_flush(OutBuf& b)
+{
+    uint64_t lo = b.lo;
+    uint8_t* p = b.dst;
+    if (b.n & 8u) { for (int i = 0; i < 8; ++i) p[i] = (uint8_t)(lo >> (8 * i)); p += 8; lo = b.hi; }
+    for (uint32_t i = 0; i < (b.n & 7u); ++i) p[i] = (uint8_t)(lo >> (8 * i));
+    b.n = 0;
+}
+
+/* copy [seg_begin, seg_end) of the arena to dst with emulation prevention */
+HBS_D void emit_segment(const uint8_t* rbsp, uint64_t nal_begin, uint64_t seg_begin, uint64_t seg_end, uint8_t* dst)
+{
+    uint32_t count = lead_count(rbsp, nal_begin, seg_begin);
+    OutBuf b;
+    b.lo = 0; b.hi = 0; b.n = 0; b.dst = dst;
+    for (uint64_t p = seg_begin; p < seg_end; ++p) {
+        const uint32_t v = rbsp[p];
+        if (count == 2 && v <= 3) { out_push(b, 3u); count = 0; }
+        out_push(b, v);
+        count = (v == 0) ? count + 1 : 0;
+    }
+    out_flush(b);
+}
+
+/* ---- synthetic stream S(seed, n_nals, mode): SURVEY.md 8(d) ---------------- */
+
+HBS_HD uint32_t synth_rbsp_len(uint64_t seed, uint64_t k)
+{
+    return 8192u + (uint32_t)(mix64(seed ^ ((k + 1) * kGolden)) % 4097u);
+}
+
+/* 8 RBSP bytes [8w, 8w+8) of NAL k, little-endian in the result; len = the NAL's RBSP length */
+HBS_HD uint64_t synth_rbsp_word(uint64_t seed, uint64_t k, uint32_t w, uint32_t len, int mode)
+{
+    const uint64_t key = seed ^ ((k + 1) * kGolden);
+    uint64_t x = mix64((key ^ kSalt) + (uint64_t)(w + 1) * kGolden);
+    if (mode == 1) {
+        uint64_t y = 0;
+        for (int i = 0; i < 8; ++i) {
+            uint32_t b = (uint32_t)(x >> (8 * i)) & 0xFFu;
+            if (b < 26) b = 0;
+            else if (b < 39) b = 1 + (b - 26) % 3;
+            y |= (uint64_t)b << (8 * i);
+        }
+        x = y;
+    }
+    if (w == 0) x = (x & ~0xFFFFull) | 0x0102ull;                       /* bytes 0,1 = 02 01 */
+    const uint32_t last = len - 1;
+    if ((last >> 3) == w) x = (x & ~(0xFFull << (8 * (last & 7)))) | (0x80ull << (8 * (last & 7)));
+    return x;
+}
+
+HBS_HD uint32_t synth_gap(uint64_t k) { return (k % 4 == 0) ? 4u : 3u; }
+
+} // namespace hbs
+#endif

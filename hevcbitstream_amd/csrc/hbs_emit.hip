@@ -1,0 +1,225 @@
+/*
+ * hbs_emit.hip -- K3: RBSP arena + NAL index -> Annex-B stream (emulation
+ * prevention insertion and start codes), and the device generator of the
+ * synthetic stream S(seed, n_nals, mode).
+ *
+ * Replaces rbsp_to_nal() per NAL (reference h264_nal.c:92-132, called from
+ * write_hevc_nal_unit, hevc_stream.c:1324-1327) plus the start-code bytes the
+ * reference's callers put in front of each NAL.
+ *
+ * One wavefront per NAL; a lane owns 256-byte segments of that NAL's RBSP
+ * (hbs_emit.h).  Pass 1 counts the bytes each segment inserts, a scan turns
+ * NAL sizes into output offsets, pass 2 copies with insertion into byte-aligned
+ * 16-byte stores.  Traffic: RBSP read twice, stream written once (3 B/B); the
+ * round-1 kernel favours being obviously right over the last factor of speed.
+ */
+#include <hip/hip_runtime.h>
+#include "hbs_emit.h"
+#include "hbs_emit_launch.h"
+
+namespace hbs {
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t& total)
+{
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(x, d, 64);
+        if (lane >= d) x += t;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+__device__ __forceinline__ uint64_t gap_of(const hbs_nal_entry* __restrict__ idx, uint64_t k, int gap_mode)
+{
+    if (gap_mode == 1) return synth_gap(k);
+    const uint64_t prev_end = k ? idx[k - 1].end : 0ull;
+    return idx[k].start - prev_end;
+}
+
+__global__ __launch_bounds__(256)
+void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+              uint16_t* __restrict__ seg_cnt, unsigned long long* __restrict__ nal_total)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t k = wave; k < n; k += nwaves) {
+        const uint64_t begin = idx[k].rbsp_off;
+        const uint32_t len = idx[k].rbsp_len;
+        const uint32_t nseg = (len + kSegBytes - 1) / kSegBytes;
+        const uint64_t slot0 = begin / kSegBytes + k;
+        uint32_t acc = 0;
+        for (uint32_t s = lane; s < nseg; s += 64) {
+            const uint64_t sb = begin + (uint64_t)s * kSegBytes;
+            const uint64_t se = (s + 1 == nseg) ? begin + len : sb + kSegBytes;
+            const uint32_t c = count_segment(rbsp, begin, sb, se);
+            seg_cnt[slot0 + s] = (uint16_t)c;
+            acc += c;
+        }
+        acc = wave_sum_u32(acc);
+        if (lane == 0) nal_total[k] = gap_of(idx, k, gap_mode) + len + acc;
+    }
+}
+
+/* exclusive scan of v[0..n) into out[0..n), total to *total; one workgroup */
+__global__ __launch_bounds__(1024)
+void k_scan_u64(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
+                unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned long long s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += v[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        unsigned long long t = (tid >= d) ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - s;
+    for (uint64_t i = lo; i < hi; ++i) { const unsigned long long x = v[i]; out[i] = run; run += x; }
+    if (tid == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256)
+void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+             const uint16_t* __restrict__ seg_cnt, const unsigned long long* __restrict__ out_off,
+             uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t k = wave; k < n; k += nwaves) {
+        const uint64_t begin = idx[k].rbsp_off;
+        const uint32_t len = idx[k].rbsp_len;
+        const uint32_t nseg = (len + kSegBytes - 1) / kSegBytes;
+        const uint64_t slot0 = begin / kSegBytes + k;
+        const uint64_t gap = gap_of(idx, k, gap_mode);
+        const uint64_t base = out_off[k];
+        const uint64_t nal_start = base + gap;
+        uint32_t carry = 0;                                   /* inserted bytes before the current batch */
+        bool fits = true;
+        for (uint32_t s0 = 0; s0 < nseg; s0 += 64) {
+            const uint32_t s = s0 + lane;
+            const uint32_t c = (s < nseg) ? seg_cnt[slot0 + s] : 0u;
+            uint32_t tot;
+            const uint32_t before = wave_excl_scan_u32(c, lane, tot);
+            if (s < nseg) {
+                const uint64_t sb = begin + (uint64_t)s * kSegBytes;
+                const uint64_t se = (s + 1 == nseg) ? begin + len : sb + kSegBytes;
+                const uint64_t dst = nal_start + (uint64_t)s * kSegBytes + carry + before;
+                if (dst + (se - sb) + c <= out_cap) emit_segment(rbsp, begin, sb, se, out + dst);
+                else fits = false;
+            }
+            carry += tot;
+        }
+        if (lane == 0) {
+            if (nal_start <= out_cap) {
+                for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;      /* zero_byte / leading zeros */
+                if (gap) out[nal_start - 1] = 1;
+            } else {
+                fits = false;
+            }
+            if (idx_out) {
+                hbs_nal_entry e;
+                e.start = nal_start; e.end = nal_start + len + carry;
+                e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
+                idx_out[k] = e;
+            }
+        }
+        if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+    }
+}
+
+__global__ void k3_summary(const unsigned long long* total, uint64_t n, uint64_t rbsp_bytes, const uint32_t* err, hbs_summary* sum)
+{
+    sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes; sum->stream_bytes = *total;
+    sum->stop_reason = n ? -1 : 0; sum->error = -(int32_t)*err;
+    sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
+}
+
+/* ---- synthetic RBSP ---------------------------------------------------------- */
+
+__global__ void k_synth_len(uint64_t seed, uint64_t n, unsigned long long* __restrict__ lens)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        lens[k] = synth_rbsp_len(seed, k);
+}
+
+__global__ __launch_bounds__(256)
+void k_synth_fill(uint64_t seed, uint64_t n, int mode, const unsigned long long* __restrict__ lens,
+                  const unsigned long long* __restrict__ offs, uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
+                  hbs_nal_entry* __restrict__ idx, uint32_t* __restrict__ err)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };
+    for (uint64_t k = wave; k < n; k += nwaves) {
+        const uint32_t len = (uint32_t)lens[k];
+        const uint64_t off = offs[k];
+        if (off + len > rbsp_cap) { if (lane == 0) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY)); continue; }
+        const uint32_t nw = (len + 7) / 8;
+        for (uint32_t w = lane; w < nw; w += 64) {
+            const uint64_t x = synth_rbsp_word(seed, k, w, len, mode);
+            uint8_t* p = rbsp + off + 8ull * w;
+            if (8 * w + 8 <= len) reinterpret_cast<U8*>(p)->v = x;
+            else for (uint32_t i = 0; 8 * w + i < len; ++i) p[i] = (uint8_t)(x >> (8 * i));
+        }
+        if (lane == 0) {
+            hbs_nal_entry e;
+            e.start = 0; e.end = 0; e.rbsp_off = off; e.rbsp_len = len; e.status = 0;
+            idx[k] = e;
+        }
+    }
+}
+
+/* ---- host side --------------------------------------------------------------- */
+
+hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    const unsigned grid = 256 * 8;
+    if (a.n) {
+        k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.seg_cnt, a.nal_total);
+        k_scan_u64<<<1, 1024, 0, st>>>(a.nal_total, a.out_off, a.n, a.total);
+        k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.seg_cnt, a.out_off, a.out, a.out_cap, a.index_out, a.err);
+    } else {
+        e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
+    }
+    k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (a.n) {
+        k_synth_len<<<1024, 256, 0, st>>>(a.seed, a.n, a.lens);
+        k_scan_u64<<<1, 1024, 0, st>>>(a.lens, a.offs, a.n, a.total);
+        k_synth_fill<<<256 * 8, 256, 0, st>>>(a.seed, a.n, a.mode, a.lens, a.offs, a.rbsp, a.rbsp_cap, a.index, a.err);
+    } else {
+        e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
+    }
+    k3_summary<<<1, 1, 0, st>>>(a.total, a.n, 0, a.err, a.summary);   /* stream_bytes <- total RBSP bytes here */
+    return hipGetLastError();
+}
+
+} // namespace hbs

@@ -1,0 +1,42 @@
+/* hbs_emit_launch.h -- host-visible launchers of K3 and the synthetic generator. */
+#ifndef HBS_EMIT_LAUNCH_H
+#define HBS_EMIT_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+#include "hbs_common.h"
+
+namespace hbs {
+
+struct EmitArgs {
+    const uint8_t* rbsp;              /* device RBSP arena                         */
+    uint64_t rbsp_bytes;              /* informational (goes to the summary)       */
+    const hbs_nal_entry* index_in;    /* rbsp_off/rbsp_len (+ start/end for gaps)  */
+    uint64_t n;
+    int gap_mode;                     /* 0: gaps from index_in; 1: synthetic rule  */
+    uint8_t* out; uint64_t out_cap;
+    hbs_nal_entry* index_out;         /* nullable                                  */
+    hbs_summary* summary;
+    /* workspace */
+    uint16_t* seg_cnt;                /* rbsp_bytes/256 + n + 1 entries            */
+    unsigned long long* nal_total;    /* n                                         */
+    unsigned long long* out_off;      /* n                                         */
+    unsigned long long* total;        /* 1                                         */
+    uint32_t* err;                    /* 1                                         */
+};
+
+struct SynthArgs {
+    uint64_t seed; uint64_t n; int mode;
+    uint8_t* rbsp; uint64_t rbsp_cap;
+    hbs_nal_entry* index;
+    hbs_summary* summary;
+    unsigned long long* lens;         /* n */
+    unsigned long long* offs;         /* n */
+    unsigned long long* total;
+    uint32_t* err;
+};
+
+hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st);
+hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st);
+
+} // namespace hbs
+#endif

@@ -35,10 +35,12 @@ namespace hbs {
 __device__ unsigned long long g_phase_cycles[1024][8];
 #define HBS_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(), t_acc[8] = {0,0,0,0,0,0,0,0};
 #define HBS_T_MARK(i) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
+#define HBS_T_COUNT(i, v) { t_acc[i] += (v); }
 #define HBS_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles[blockIdx.x][i] = t_acc[i]; }
 #else
 #define HBS_T_DECL
 #define HBS_T_MARK(i)
+#define HBS_T_COUNT(i, v)
 #define HBS_T_FLUSH
 #endif
 
@@ -277,8 +279,9 @@ __device__ __forceinline__ TileAgg window_fold(const TileAgg& a, int lstar, int 
  * of tile t.  Returns false on timeout/abort.
  */
 __device__ __forceinline__ bool look_back(TileLds& l, unsigned long long* desc, uint64_t tile, const TileAgg& mine,
-                                          RunHeader* hdr, int tid, Prefix& excl)
+                                          RunHeader* hdr, int tid, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
 {
+    dbg_iters = 0; dbg_stalls = 0;
     const int lane = tid & 63, wv = tid >> 6;
     bool ok = true;
     if (tile == 0) {
@@ -334,8 +337,10 @@ __device__ __forceinline__ bool look_back(TileLds& l, unsigned long long* desc, 
             }
             const bool aborted = l.lb[par][0].abort != 0u;
             par ^= 1u;
+            ++dbg_iters;
             if (done) break;
             if (stall) {
+                ++dbg_stalls;
                 if (++spins > (1u << 20) || aborted) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(1);
                 continue;
@@ -411,7 +416,6 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
         __syncthreads();
         HBS_T_MARK(0)
         const int tid = launder(tid0);
-        const int lane = tid & 63, wv = tid >> 6;
 
         const int32_t o0 = kThreadBytes * tid;
         const uint64_t g0 = tile_base + (uint64_t)o0;
@@ -423,8 +427,10 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
         HBS_T_MARK(2)
 
         Prefix excl;
-        if (!look_back(l, desc, tile, agg, hdr, tid, excl)) return;
+        uint32_t lb_iters, lb_stalls;
+        if (!look_back(l, desc, tile, agg, hdr, tid, excl, lb_iters, lb_stalls)) return;
         HBS_T_MARK(3)
+        HBS_T_COUNT(7, ((unsigned long long)lb_stalls << 32) | lb_iters)
         if (tid == 0 && tile == num_tiles - 1) {
             const Prefix incl = fold(excl, agg);
             hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;

@@ -119,6 +119,43 @@ int hbs_index_extract(hbs_ctx* ctx,
                       uint8_t* d_rbsp, uint64_t rbsp_cap,
                       hbs_summary* d_summary);
 
+/*
+ * K3: re-emit Annex-B from an RBSP arena: for every NAL, the bytes between the
+ * previous NAL and this one (zeros and the 01 of the start code) followed by
+ * rbsp_to_nal() of its RBSP (h264_nal.c:92-132: a 03 is inserted in front of
+ * any byte <= 3 that follows two zeros; nothing is appended after a trailing
+ * 00 00).
+ *
+ *   d_index_in[k].rbsp_off/rbsp_len   where NAL k's RBSP lives in d_rbsp
+ *   gap_mode 0   gap of NAL k = d_index_in[k].start - d_index_in[k-1].end
+ *                (start of NAL 0 for k = 0): what hbs_index_extract recorded
+ *   gap_mode 1   synthetic rule: 00 00 00 01 when k % 4 == 0, else 00 00 01
+ *   d_index_out  (optional) entries with start/end in the emitted stream
+ *   d_summary    stream_bytes = bytes emitted; error = HBS_E_CAPACITY if
+ *                out_cap was too small (hbs_annexb_bound() is always enough)
+ *
+ * Emitting what hbs_index_extract extracted reproduces the input stream byte
+ * for byte when every NAL was accepted (no HBS_ST_ERROR), none ended in
+ * 00 00 03 (HBS_ST_TRAILING03: the reference drops that byte for good), the
+ * bytes between NALs were zeros + 01, and the stream ends with its last NAL.
+ */
+int hbs_emit_annexb(hbs_ctx* ctx, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
+                    const hbs_nal_entry* d_index_in, uint64_t n_nals, int gap_mode,
+                    uint8_t* d_out, uint64_t out_cap, hbs_nal_entry* d_index_out, hbs_summary* d_summary);
+uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals);
+
+/*
+ * Synthetic workload S(seed, n_nals, mode) of SURVEY.md 8(d), generated in HBM:
+ * RBSP of NAL k is 8192 + mix(k) % 4097 pseudo-random bytes (mode 0 uniform,
+ * mode 1 "zero-heavy": ~10 % 00 and ~5 % 01..03), first bytes 02 01, last byte
+ * 80.  Fills d_rbsp (packed) and d_index[k].rbsp_off/rbsp_len; follow with
+ * hbs_emit_annexb(..., gap_mode 1, ...) to obtain the Annex-B stream.
+ * d_summary->stream_bytes receives the RBSP bytes written.
+ */
+int hbs_synth_rbsp(hbs_ctx* ctx, uint64_t seed, uint64_t n_nals, int mode,
+                   uint8_t* d_rbsp, uint64_t rbsp_cap, hbs_nal_entry* d_index, hbs_summary* d_summary);
+uint64_t hbs_synth_rbsp_bound(uint64_t n_nals);
+
 /* Synchronising copy of a device hbs_summary to the host. */
 int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_summary);
 

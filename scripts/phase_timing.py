@@ -31,6 +31,10 @@ act = out[:512].astype(np.float64)
 tiles = d.numel() / 65536 / 512
 tot = act.sum(axis=1).mean()
 print("mode", mode, "rbsp", want_rbsp, "tiles/WG %.1f  total cycles/WG %.0f  -> cycles/tile %.0f" % (tiles, tot, tot / tiles))
+lb = out[:512, 7]
+print("  look-back steps/tile %.2f, of which stalled %.2f" % ((lb & 0xFFFFFFFF).astype(np.float64).mean() / tiles, (lb >> 32).astype(np.float64).mean() / tiles))
+act[:, 7] = 0
+tot = act.sum(axis=1).mean()
 for i, nm in enumerate(names[:7]):
     print("  %-18s %8.0f cyc/tile  %5.1f%%   (min WG %.0f, max WG %.0f)" % (nm, act[:, i].mean() / tiles, 100 * act[:, i].mean() / tot,
                                                                    act[:, i].min() / tiles, act[:, i].max() / tiles))

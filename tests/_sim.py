@@ -25,6 +25,10 @@ def lib():
         _lib.sim_index_extract.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.sim_index_extract.restype = C.c_int
+        _lib.sim_emit_annexb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+        _lib.sim_emit_annexb.restype = C.c_int64
+        _lib.sim_synth_rbsp.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.sim_synth_rbsp.restype = C.c_int64
     return _lib
 
 
@@ -42,3 +46,23 @@ def index_extract(stream, index_cap=None, want_rbsp=True):
     s = summ[0]
     assert (arena[n + 16:] == 0xAB).all()
     return idx[:int(s["nal_count"])].copy(), arena[:int(s["rbsp_bytes"])].copy(), s
+
+
+def emit_annexb(arena, idx, gap_mode=0):
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    idx = np.ascontiguousarray(idx)
+    cap = len(arena) * 3 // 2 + 16 * len(idx) + int(idx["start"].max() if len(idx) else 0) + 64
+    out = np.full(cap + 32, 0xAB, dtype=np.uint8)
+    idx_out = np.zeros(max(len(idx), 1), dtype=NAL_ENTRY)
+    pad = np.concatenate([arena, np.full(32, 0xCD, dtype=np.uint8)])
+    n = lib().sim_emit_annexb(pad.ctypes.data, idx.ctypes.data, len(idx), gap_mode, out.ctypes.data, cap, idx_out.ctypes.data)
+    assert n >= 0
+    assert (out[cap:] == 0xAB).all() and (out[n:n + 16] == 0xAB).all()
+    return out[:n].copy(), idx_out[:len(idx)]
+
+
+def synth_rbsp(seed, n_nals, mode):
+    arena = np.zeros(n_nals * 12289 + 16, dtype=np.uint8)
+    idx = np.zeros(max(n_nals, 1), dtype=NAL_ENTRY)
+    tot = lib().sim_synth_rbsp(seed, n_nals, mode, arena.ctypes.data, idx.ctypes.data)
+    return arena[:tot].copy(), idx[:n_nals]

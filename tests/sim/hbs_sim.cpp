@@ -13,6 +13,7 @@
 #include <cstring>
 #include <vector>
 #include "../../hevcbitstream_amd/csrc/hbs_tile.h"
+#include "../../hevcbitstream_amd/csrc/hbs_emit.h"
 
 using namespace hbs;
 
@@ -115,4 +116,47 @@ extern "C" int sim_index_extract(const uint8_t* stream, uint64_t n,
     tail_fixup(&hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum);
     for (uint64_t k = 0; k < hdr.final_nals; ++k) fill_rbsp_len(&hdr, index, index_cap, k);
     return 0;
+}
+
+/* K3 per-segment logic stepped in NAL order (see hbs_emit.hip for the wave-level driver) */
+extern "C" int64_t sim_emit_annexb(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n, int gap_mode,
+                                   uint8_t* out, uint64_t out_cap, hbs_nal_entry* idx_out)
+{
+    uint64_t base = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t begin = idx[k].rbsp_off;
+        const uint32_t len = idx[k].rbsp_len;
+        const uint64_t gap = (gap_mode == 1) ? synth_gap(k) : idx[k].start - (k ? idx[k - 1].end : 0ull);
+        const uint64_t nal_start = base + gap;
+        if (nal_start + len + len / 2 + 2 > out_cap) return -1;
+        for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;
+        if (gap) out[nal_start - 1] = 1;
+        uint64_t dst = nal_start;
+        const uint32_t nseg = (len + kSegBytes - 1) / kSegBytes;
+        for (uint32_t s = 0; s < nseg; ++s) {
+            const uint64_t sb = begin + (uint64_t)s * kSegBytes;
+            const uint64_t se = (s + 1 == nseg) ? begin + len : sb + kSegBytes;
+            const uint32_t c = count_segment(rbsp, begin, sb, se);
+            emit_segment(rbsp, begin, sb, se, out + dst);
+            dst += (se - sb) + c;
+        }
+        if (idx_out) { idx_out[k] = idx[k]; idx_out[k].start = nal_start; idx_out[k].end = dst; idx_out[k].status = 0; }
+        base = dst;
+    }
+    return (int64_t)base;
+}
+
+extern "C" int64_t sim_synth_rbsp(uint64_t seed, uint64_t n, int mode, uint8_t* rbsp, hbs_nal_entry* idx)
+{
+    uint64_t off = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint32_t len = synth_rbsp_len(seed, k);
+        for (uint32_t w = 0; w < (len + 7) / 8; ++w) {
+            const uint64_t x = synth_rbsp_word(seed, k, w, len, mode);
+            for (uint32_t i = 0; i < 8 && 8 * w + i < len; ++i) rbsp[off + 8 * w + i] = (uint8_t)(x >> (8 * i));
+        }
+        idx[k].start = idx[k].end = 0; idx[k].rbsp_off = off; idx[k].rbsp_len = len; idx[k].status = 0;
+        off += len;
+    }
+    return (int64_t)off;
 }

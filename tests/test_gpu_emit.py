@@ -1,0 +1,97 @@
+"""Parity tests for K3 (RBSP -> Annex-B) and the device generator of the
+synthetic workload, through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+from tests._orc import NAL_ENTRY
+
+pytestmark = pytest.mark.gpu
+ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    yield c
+    c.close()
+
+
+def fake_index(lens, gaps):
+    idx = np.zeros(len(lens), dtype=NAL_ENTRY)
+    off = pos = 0
+    for k, (n, g) in enumerate(zip(lens, gaps)):
+        idx["start"][k] = pos + g
+        idx["end"][k] = pos + g + n
+        idx["rbsp_off"][k] = off
+        idx["rbsp_len"][k] = n
+        pos += g + n
+        off += n
+    return idx
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_emit_random_rbsp(ctx, orc):
+    rng = np.random.RandomState(31)
+    for _ in range(60):
+        nn = rng.randint(1, 40)
+        lens = [int(rng.randint(1, 3000)) for _ in range(nn)]
+        gaps = [int(rng.randint(3, 7)) for _ in range(nn)]
+        arena = ALPHA[rng.randint(0, len(ALPHA), size=sum(lens))].copy()
+        if rng.rand() < 0.5:
+            arena[rng.rand(len(arena)) < 0.6] = 0x55
+        idx = fake_index(lens, gaps)
+        got, _ = ctx.emit_annexb(dev(arena), idx)
+        assert np.array_equal(got, orc.emit_annexb(arena, idx))
+
+
+def test_emit_zero_runs(ctx, orc):
+    for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
+        for tail in ([], [1], [4], [0, 0, 1]):
+            arena = np.array([7] * 3 + [0] * z + tail, dtype=np.uint8)
+            idx = fake_index([len(arena)], [4])
+            got, _ = ctx.emit_annexb(dev(arena), idx)
+            assert np.array_equal(got, orc.emit_annexb(arena, idx)), (z, tail)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_device_generator_matches_oracle(ctx, orc, mode):
+    n = 3000
+    stream, idx, arena = orc.gen_stream(0x1234 + mode, n, mode)
+    g = ctx.synth_stream(0x1234 + mode, n, mode)
+    assert g["stream_bytes"] == len(stream) and g["rbsp_bytes"] == len(arena)
+    assert np.array_equal(g["rbsp"][: g["rbsp_bytes"]].cpu().numpy(), arena)
+    assert np.array_equal(g["stream"][: g["stream_bytes"]].cpu().numpy(), stream)
+    got_idx = g["index"].cpu().numpy().view(NAL_ENTRY)
+    for f in ("start", "end", "rbsp_off", "rbsp_len"):
+        assert np.array_equal(got_idx[f], idx[f]), f
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_roundtrip_1gib(ctx, mode):
+    """config 4 at full size, by property: generate ~1 GiB on the device, extract
+    (K12), re-emit (K3) -> byte-identical stream; extracted arena == generated arena."""
+    import torch
+    n = 104858
+    g = ctx.synth_stream(0x1234, n, mode)
+    sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    assert 1.0e9 < sb < 1.2e9
+    stream = g["stream"][:sb]
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
+    ctx.index_extract_async(stream, index, cap, rbsp, summary)
+    s = ctx.read_summary(summary)
+    assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["rbsp_bytes"]) == rb and int(s["stop_reason"]) == -1
+    assert torch.equal(rbsp[:rb], g["rbsp"][:rb])
+    a = index[: n * 32].view(torch.int64).view(n, 4)
+    b = g["index"][: n * 32].view(torch.int64).view(n, 4)
+    assert torch.equal(a[:, :3], b[:, :3])                        # start, end, rbsp_off
+    assert torch.equal(a[:-1, 3], b[:-1, 3])                      # rbsp_len|status (last NAL: UNTERMINATED flag)
+    out = torch.empty(int(ctx.lib.hbs_annexb_bound(rb, n)), dtype=torch.uint8, device="cuda")
+    ctx.emit_annexb_async(rbsp, rb, index, n, 0, out, None, summary)
+    s2 = ctx.read_summary(summary)
+    assert int(s2["error"]) == 0 and int(s2["stream_bytes"]) == sb
+    assert torch.equal(out[:sb], stream)
