@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Annex-B indexer / RBSP extractor.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+             --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Metric (BASELINE.json): Annex-B GB/s scanned (+ NAL units/s) on a 16 GiB synthetic
+stream per GPU.  One "step" = one pass of the hot path -- start-code scan + NAL
+index + RBSP extraction (hbs_index_extract, the fused K12 kernel plus its
+end-of-stream fix-up) -- over a stream that is already resident in HBM; with
+N > 1 each rank owns an independent 16 GiB shard (weak scaling) and the step
+ends with the one real exchange of the path, the RCCL all-gather of the NAL
+index.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the fused kernel against the 8 TB/s HBM3E peak: algorithmic bytes
+                per launch (stream read + RBSP written + 32 B/NAL index) divided by
+                its mean duration, measured here with HIP events recorded around
+                that kernel on the stream it runs on (hbs_ctx_enable_timing).
+  cpu_baseline  the oracle's byte-at-a-time restatement of the reference loop
+                (find_nal_unit + nal_to_rbsp per NAL, oracle/hbs_oracle_nal.c) timed
+                on ONE host core over a bounded prefix of rank 0's stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_NALS_16GIB = 1_677_000       # S(seed, n) with ~10 KiB NALs: 16.0 GiB of Annex-B
+SEED = 0x1234
+
+
+def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
+    """Oracle ("port") on one host core over the first `sample_nals` NALs of the stream."""
+    import numpy as np
+    from tests import _orc
+    orc = _orc.oracle()
+    ent = index_dev[: sample_nals * 32].cpu().numpy().view(_orc.NAL_ENTRY)
+    nbytes = int(ent["end"][-1])
+    # keep the following start code so that the sampled prefix ends like the full stream does not:
+    # the last sampled NAL is then terminated exactly as in the full stream
+    host = stream_dev[: nbytes + 4].cpu().numpy()
+    arena = np.zeros(nbytes + 64, dtype=np.uint8)          # pre-faulted output
+    idx = np.zeros(sample_nals + 8, dtype=_orc.NAL_ENTRY)
+    arena[:] = 1
+    import ctypes as C
+    why = C.c_int(0)
+    t0 = time.perf_counter()
+    n = orc.lib.orc_index_stream(host.ctypes.data_as(C.POINTER(C.c_uint8)), len(host), idx.ctypes.data, len(idx), C.byref(why))
+    tot = orc.lib.orc_extract_rbsp(host.ctypes.data_as(C.POINTER(C.c_uint8)), idx.ctypes.data, n,
+                                   arena.ctypes.data_as(C.POINTER(C.c_uint8)), len(arena))
+    dt = time.perf_counter() - t0
+    assert n >= sample_nals and tot > 0
+    assert np.array_equal(idx["start"][:sample_nals], ent["start"]) and np.array_equal(idx["rbsp_off"][:sample_nals], ent["rbsp_off"])
+    return {"value": round(len(host) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "nal_per_s": round(n / dt, 1),
+            "sample": "first %d NALs (%.2f GiB) of rank 0's stream: find_nal_unit loop + nal_to_rbsp per NAL, "
+                      "oracle/hbs_oracle_nal.c, gcc -O2, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nals", type=int, default=N_NALS_16GIB, help="NALs per GPU (default: 16 GiB of stream)")
+    ap.add_argument("--mode", type=int, default=0, help="0 uniform payload (headline), 1 zero-heavy")
+    ap.add_argument("--cpu-sample-nals", type=int, default=400_000, help="0 disables the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import hevcbitstream_amd as hbs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = hbs.Context(local_rank)
+    ctx.enable_timing(True)
+    n = args.nals
+    g = ctx.synth_stream(SEED + rank, n, args.mode)            # independent shard per rank, generated in HBM
+    sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    stream = g["stream"][:sb]
+    gen_rbsp, gen_index = g["rbsp"], g["index"]
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
+
+    gathered = counts = None
+    if world > 1:
+        gathered = torch.empty(world * (n + 8) * 32, dtype=torch.uint8, device="cuda")
+        counts = torch.empty(world * 64, dtype=torch.uint8, device="cuda")
+
+    def step():
+        ctx.index_extract_async(stream, index, cap, rbsp, summary)
+        if world > 1:       # the one exchange of the path: per-rank summaries, then the index arrays
+            dist.all_gather_into_tensor(counts, summary)
+            dist.all_gather_into_tensor(gathered, index)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    # kernel duration of the last launch per step needs a sync, so sample it in a separate short loop
+    for _ in range(min(args.steps, 5)):
+        ctx.index_extract_async(stream, index, cap, rbsp, summary)
+        kms.append(ctx.kernel_ms())
+    s = ctx.read_summary(summary)
+
+    # parity properties at full size (outside the timed region)
+    assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["stop_reason"]) == -1, s
+    assert int(s["rbsp_bytes"]) == rb
+    assert torch.equal(rbsp[:rb], gen_rbsp[:rb]), "extracted RBSP != generated RBSP"
+    a = index[: n * 32].view(torch.int64).view(n, 4)
+    b = gen_index[: n * 32].view(torch.int64).view(n, 4)
+    assert torch.equal(a[:, :3], b[:, :3]), "NAL index != generator's index"
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([float(sb), float(n)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bytes, total_nals = float(tot[0].item()), float(tot[1].item())
+    else:
+        total_bytes, total_nals = float(sb), float(n)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        k_ms = sum(kms) / len(kms)
+        algo_bytes = sb + rb + 32 * n
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        blocks, per_cu = ctx.grid()
+        out = {
+            "metric": "Annex-B GB/s scanned + NAL units/s, 16 GiB synthetic stream, 1/2/4/8 MI355X",
+            "value": round(total_bytes * args.steps / dt / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "nal_units_per_s": round(total_nals * args.steps / dt, 1),
+            "config": {"workload": "start-code scan + NAL index + RBSP extraction (hbs_index_extract) over "
+                                   "S(seed=0x1234+rank, n_nals=%d, mode=%s): %.3f GiB Annex-B per GPU, ~10 KiB NALs, "
+                                   "resident in HBM%s" % (n, "uniform" if args.mode == 0 else "zero-heavy", sb / 2**30,
+                                                          "; + RCCL all-gather of the NAL index" if world > 1 else ""),
+                       "stream_bytes_per_gpu": sb, "nals_per_gpu": n,
+                       "parallelism": "%d independent shard(s), one per GPU" % world,
+                       "grid": "%d persistent workgroups (%d per CU) x 512 threads, 64 KiB tiles" % (blocks, per_cu)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "hbs::k_scan_extract", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes": algo_bytes,
+                         "note": "bytes = stream read once + RBSP written once + 32 B/NAL index; "
+                                 "read-only fraction = %.4f" % (sb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
+        }
+        if args.cpu_sample_nals > 0:
+            out["cpu_baseline"] = cpu_baseline(stream, gen_index, n, min(args.cpu_sample_nals, n))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_ctx_get_stream",
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
-           "hbs_synth_rbsp_bound"]
+           "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid"]
 
 
 class HbsError(RuntimeError):
@@ -51,6 +51,9 @@ def load_library():
     lib.hbs_ctx_get_stream.argtypes = [C.c_void_p]
     lib.hbs_ctx_get_stream.restype = C.c_void_p
     lib.hbs_ctx_synchronize.argtypes = [C.c_void_p]
+    lib.hbs_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.hbs_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.hbs_ctx_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hbs_last_error.argtypes = [C.c_void_p]
     lib.hbs_last_error.restype = C.c_char_p
     lib.hbs_index_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -106,6 +109,20 @@ class Context:
     def _check(self, rc, what):
         if rc != 0:
             raise HbsError("%s failed: %d (%s)" % (what, rc, self.lib.hbs_last_error(self.h).decode()))
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.hbs_ctx_enable_timing(self.h, 1 if on else 0), "hbs_ctx_enable_timing")
+
+    def kernel_ms(self):
+        """Duration of the last fused scan/extract kernel (HIP events on its own stream)."""
+        ms = C.c_float()
+        self._check(self.lib.hbs_ctx_kernel_ms(self.h, C.byref(ms)), "hbs_ctx_kernel_ms")
+        return ms.value
+
+    def grid(self):
+        a, b = C.c_int(), C.c_int()
+        self.lib.hbs_ctx_grid(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def alloc_outputs(self, stream_bytes, index_cap=None, want_rbsp=True):
         """Device buffers sized for a stream: (index[u8, cap*32], rbsp[u8] or None, summary[u8, 64])."""

@@ -24,6 +24,8 @@ struct hbs_ctx {
     hbs::RunHeader* hdr;
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
+    /* optional timing of the dominant kernel */
+    int timing; hipEvent_t ev0, ev1; int ev_valid;
     char err[256];
 };
 
@@ -107,6 +109,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->desc) (void)hipFree(c->desc);
     if (c->hdr) (void)hipFree(c->hdr);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->ev0) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -115,6 +118,34 @@ int hbs_ctx_set_stream(hbs_ctx* c, void* s)
 {
     if (!c) return HBS_E_ARG;
     c->stream = reinterpret_cast<hipStream_t>(s);     /* NULL = the HIP null stream */
+    return 0;
+}
+
+int hbs_ctx_enable_timing(hbs_ctx* c, int on)
+{
+    if (!c) return HBS_E_ARG;
+    if (on && !c->ev0) {
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return HBS_E_HIP;
+    }
+    c->timing = on ? 1 : 0;
+    c->ev_valid = 0;
+    return 0;
+}
+
+int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
+{
+    if (!c || !ms || !c->ev_valid) return HBS_E_ARG;
+    hipError_t e = hipEventSynchronize(c->ev1);
+    if (e != hipSuccess) return fail(c, e, "hipEventSynchronize");
+    e = hipEventElapsedTime(ms, c->ev0, c->ev1);
+    return e == hipSuccess ? 0 : fail(c, e, "hipEventElapsedTime");
+}
+
+int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
+{
+    if (!c) return HBS_E_ARG;
+    if (blocks) *blocks = c->grid_blocks;
+    if (blocks_per_cu) *blocks_per_cu = c->blocks_per_cu;
     return 0;
 }
 
@@ -160,6 +191,9 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
     a.desc = c->desc; a.hdr = c->hdr; a.summary = d_summary;
     a.grid_blocks = c->grid_blocks;
+    a.ev_begin = c->timing ? c->ev0 : nullptr;
+    a.ev_end = c->timing ? c->ev1 : nullptr;
+    c->ev_valid = (c->timing && n) ? 1 : 0;
     hipError_t e = hbs::launch_scan_extract(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_scan_extract");
 }

@@ -18,6 +18,7 @@ struct ScanArgs {
     RunHeader* hdr;               /* workspace                                    */
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) */
+    hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
 };
 
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */

@@ -87,6 +87,13 @@ int  hbs_ctx_set_stream(hbs_ctx* ctx, void* hip_stream);
 int  hbs_ctx_use_own_stream(hbs_ctx* ctx);
 void* hbs_ctx_get_stream(hbs_ctx* ctx);
 int  hbs_ctx_synchronize(hbs_ctx* ctx);
+/* Measurement aid: when enabled, hbs_index_extract records HIP events on the
+ * context's stream around its dominant kernel (the fused scan/extract kernel)
+ * only; hbs_ctx_kernel_ms waits for the last such launch and returns its
+ * duration.  hbs_ctx_grid reports the persistent grid used. */
+int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
+int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
+int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
 /* Text of the last HIP/driver error seen by this context. */
 const char* hbs_last_error(hbs_ctx* ctx);
 /* Library/self description: "hevcbitstream_amd <ver> gfx950 ..." */
