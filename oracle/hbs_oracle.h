@@ -72,6 +72,21 @@ int64_t orc_extract_rbsp(const uint8_t* buf, orc_nal_entry* idx, int64_t n, uint
  * bytes written. */
 int64_t orc_emit_annexb(const uint8_t* arena, const orc_nal_entry* idx, int64_t n, uint8_t* out, int64_t out_cap);
 
+/* ---- HEVC header layer (reference: hevc_stream.c read direction) --------- */
+
+typedef struct orc_hevc orc_hevc;
+/* hevc_nal.c:34-57 / :64-91 */
+orc_hevc* orc_hevc_new(void);
+void orc_hevc_free(orc_hevc* o);
+/* the parser object (include/hevc_stream.h layout, as the reference's hevc_stream_t) */
+struct hevc_stream_s;
+void* orc_hevc_stream_ptr(orc_hevc* o);
+/* hevc_stream.c:155-240 */
+int orc_read_hevc_nal_unit(orc_hevc* o, const uint8_t* buf, int size);
+/* RBSP of the NAL read last, and where its slice payload copy starts (-1: none) */
+const uint8_t* orc_hevc_rbsp(orc_hevc* o, int* size);
+int orc_hevc_slice_data_off(orc_hevc* o);
+
 #ifdef __cplusplus
 }
 #endif

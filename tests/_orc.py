@@ -150,3 +150,104 @@ def reference():
         p = os.path.join(ORC_DIR, "_ref", "libhevcref.so")
         _reference = Reference(p) if os.path.exists(p) else None
     return _reference
+
+
+# ---- HEVC header layer ---------------------------------------------------------------
+
+import json as _json
+
+_LAYOUT = None
+STRUCTS = ("nal", "vps", "sps", "pps", "aud", "sh")          # pointer order in hevc_stream_t
+STRUCT_TYPES = {"nal": "hevc_nal_t", "vps": "hevc_vps_t", "sps": "hevc_sps_t", "pps": "hevc_pps_t",
+                "sh": "hevc_slice_header_t"}
+
+
+def layout():
+    global _LAYOUT
+    if _LAYOUT is None:
+        _LAYOUT = _json.load(open(os.path.join(ROOT, "tests", "golden", "field_layout.json")))
+    return _LAYOUT
+
+
+def flat_fields(type_name, prefix="", base=0):
+    """[(dotted name, int32 index, count)] of every int member, nested structs expanded."""
+    out = []
+    for f in layout()[type_name]["fields"]:
+        if f is None:
+            continue
+        name, off, dims, sub = f
+        if sub is None:
+            cnt = int(np.prod(dims)) if dims else 1
+            out.append((prefix + name, (base + off) // 4, cnt))
+        else:
+            n = dims[0] if dims else 1
+            size = layout()[sub]["size"]
+            for i in range(n):
+                tag = "%s%s[%d]." % (prefix, name, i) if dims else "%s%s." % (prefix, name)
+                out.extend(flat_fields(sub, tag, base + off + i * size))
+    return out
+
+
+class _HevcParser:
+    """hevc_stream_t-shaped parser object of either library, viewed as int32 arrays."""
+
+    def _views(self, hptr):
+        ptrs = (C.c_void_p * 7).from_address(hptr)       # nal vps sps pps aud sh slice_data
+        self.v = {}
+        for i, nm in enumerate(STRUCTS):
+            if nm in STRUCT_TYPES:
+                size = layout()[STRUCT_TYPES[nm]]["size"]
+                self.v[nm] = np.ctypeslib.as_array((C.c_int32 * (size // 4)).from_address(ptrs[i]))
+        self._slice_data = ptrs[6]
+
+    def slice_data(self):
+        size = C.c_int.from_address(self._slice_data).value
+        ptr = C.c_void_p.from_address(self._slice_data + 8).value
+        if size < 0 or not ptr:
+            return size, None
+        return size, bytes((C.c_uint8 * size).from_address(ptr))
+
+    def snapshot(self):
+        return {k: a.copy() for k, a in self.v.items()}
+
+
+class OracleHevc(_HevcParser):
+    def __init__(self):
+        o = oracle()
+        L = o.lib
+        L.orc_hevc_new.restype = C.c_void_p
+        L.orc_hevc_free.argtypes = [C.c_void_p]
+        L.orc_hevc_stream_ptr.argtypes = [C.c_void_p]
+        L.orc_hevc_stream_ptr.restype = C.c_void_p
+        L.orc_read_hevc_nal_unit.argtypes = [C.c_void_p, _u8p, C.c_int]
+        self.L = L
+        self.o = L.orc_hevc_new()
+        self._views(L.orc_hevc_stream_ptr(self.o))
+
+    def read(self, nal):
+        buf = np.frombuffer(bytes(nal) + b"\xff" * 8, dtype=np.uint8).copy()
+        return self.L.orc_read_hevc_nal_unit(self.o, _ptr(buf), len(nal))
+
+    def close(self):
+        self.L.orc_hevc_free(self.o)
+
+
+class ReferenceHevc(_HevcParser):
+    def __init__(self):
+        r = reference()
+        assert r is not None
+        L = r.lib
+        L.hevc_new.restype = C.c_void_p
+        L.hevc_free.argtypes = [C.c_void_p]
+        L.read_hevc_nal_unit.argtypes = [C.c_void_p, _u8p, C.c_int]
+        L.write_hevc_nal_unit.argtypes = [C.c_void_p, _u8p, C.c_int]
+        self.L = L
+        self.h = L.hevc_new()
+        self._views(self.h)
+
+    def read(self, nal):
+        buf = np.frombuffer(bytes(nal) + b"\xff" * 8, dtype=np.uint8).copy()
+        return self.L.read_hevc_nal_unit(self.h, _ptr(buf), len(nal))
+
+    def close(self):
+        pass        # the reference leaks slice_data->rbsp_buf; keep the object alive instead
