@@ -20,9 +20,9 @@ sys.path.insert(0, ROOT)
 from tests import _orc  # noqa: E402
 from tests.hevc_synth import Synth  # noqa: E402
 
-ref = _orc.ReferenceHevc()
 out = []
 for seed in range(1000, 1040):
+    ref = _orc.ReferenceHevc()          # a fresh hevc_new() per sequence, as the tests do
     g = Synth(seed, rich=True)
     rng = np.random.RandomState(seed)
     seq = [g.vps(), g.sps_nal(int(rng.randint(64, 4096)), int(rng.randint(64, 2304))), g.pps_nal()]
