@@ -13,12 +13,16 @@ SUMMARY = np.dtype([("nal_count", "<u8"), ("nal_found", "<u8"), ("rbsp_bytes", "
                     ("stream_bytes", "<u8"), ("stop_reason", "<i4"), ("error", "<i4"),
                     ("reserved", "<u8", (3,))])
 ST_ERROR, ST_TRAILING03, ST_UNTERMINATED = 1, 2, 4
+# layout of hbs_parsed_nal
+PARSED = np.dtype([("rc", "<i4"), ("nal_unit_type", "<i4"), ("nal_layer_id", "<i4"), ("nal_temporal_id_plus1", "<i4"),
+                   ("struct_off", "<u8"), ("slice_data_size", "<i4"), ("slice_data_off", "<u4")])
 
 EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stream", "hbs_ctx_use_own_stream",
            "hbs_ctx_get_stream",
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
-           "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid"]
+           "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
+           "hbs_parse_headers"]
 
 
 class HbsError(RuntimeError):
@@ -67,6 +71,8 @@ def load_library():
     lib.hbs_annexb_bound.restype = C.c_uint64
     lib.hbs_synth_rbsp.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64,
                                    C.c_void_p, C.c_void_p]
+    lib.hbs_parse_headers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_void_p]
     lib.hbs_synth_rbsp_bound.argtypes = [C.c_uint64]
     lib.hbs_synth_rbsp_bound.restype = C.c_uint64
     _lib = lib
@@ -219,3 +225,29 @@ class Context:
             raise HbsError("hbs_emit_annexb: error %d" % int(s["error"]))
         return dict(stream=stream, stream_bytes=int(s["stream_bytes"]), rbsp=rbsp, rbsp_bytes=rbsp_bytes,
                     index=index, n_nals=n_nals)
+
+    # ---- K4 ---------------------------------------------------------------------------
+
+    def parse_headers_async(self, rbsp, index, n_nals, parsed, structs, summary):
+        """Enqueue K4.  All arguments are device tensors; structs may be None (plan only)."""
+        self._bind_stream()
+        rc = self.lib.hbs_parse_headers(self.h, C.c_void_p(rbsp.data_ptr()), C.c_void_p(index.data_ptr()), n_nals,
+                                        C.c_void_p(parsed.data_ptr()),
+                                        C.c_void_p(structs.data_ptr()) if structs is not None else None,
+                                        structs.numel() if structs is not None else 0, C.c_void_p(summary.data_ptr()))
+        self._check(rc, "hbs_parse_headers")
+
+    def parse_headers(self, rbsp, index, n_nals):
+        """Plan, allocate the struct arena, parse.  Returns (parsed ndarray[PARSED], structs device tensor)."""
+        t = self.torch
+        dev = t.device("cuda", self.device)
+        parsed = t.empty(max(n_nals, 1) * PARSED.itemsize, dtype=t.uint8, device=dev)
+        summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
+        self.parse_headers_async(rbsp, index, n_nals, parsed, None, summary)
+        need = int(self.read_summary(summary)["reserved"][0])
+        structs = t.empty(need + 16, dtype=t.uint8, device=dev)
+        self.parse_headers_async(rbsp, index, n_nals, parsed, structs, summary)
+        s = self.read_summary(summary)
+        if int(s["error"]) != 0:
+            raise HbsError("hbs_parse_headers: error %d" % int(s["error"]))
+        return parsed[: n_nals * PARSED.itemsize].cpu().numpy().view(PARSED).copy(), structs

@@ -12,6 +12,8 @@
 #include "hbs_scan.h"
 #include "hbs_emit_launch.h"
 #include "hbs_emit.h"
+#include "hbs_parse_launch.h"
+#include "hbs_parse.h"
 
 struct hbs_ctx {
     int device;
@@ -24,6 +26,7 @@ struct hbs_ctx {
     hbs::RunHeader* hdr;
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
+    uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
     /* optional timing of the dominant kernel */
     int timing; hipEvent_t ev0, ev1; int ev_valid;
     char err[256];
@@ -109,6 +112,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->desc) (void)hipFree(c->desc);
     if (c->hdr) (void)hipFree(c->hdr);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->zeros) (void)hipFree(c->zeros);
     if (c->ev0) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -242,6 +246,38 @@ int hbs_synth_rbsp(hbs_ctx* c, uint64_t seed, uint64_t n_nals, int mode,
 
 uint64_t hbs_synth_rbsp_bound(uint64_t n_nals) { return n_nals * 12288ull + 16; }
 uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals) { return rbsp_bytes + rbsp_bytes / 2 + 4 * n_nals + 16; }
+
+int hbs_parse_headers(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                      hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary)
+{
+    static_assert(sizeof(hbs_parsed_nal) == sizeof(hbs::ParsedNal), "public record == kernel record");
+    if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index || !d_parsed))) return HBS_E_ARG;
+    if (reinterpret_cast<uintptr_t>(d_structs) & 15) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    if (!c->zeros) {
+        const size_t zb = (sizeof(hevc_sps_t) + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->zeros), zb);
+        if (e != hipSuccess) return fail(c, e, "hipMalloc(zero structs)");
+        e = hipMemsetAsync(c->zeros, 0, zb, c->stream);
+        if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(zero structs)");
+    }
+    const uint64_t b_n = round256((n_nals + 1) * 8);
+    int rc = ensure_ws(c, 3 * b_n + 512);
+    if (rc) return rc;
+    uint8_t* w = static_cast<uint8_t*>(c->ws);
+    hbs::ParseArgs a;
+    a.rbsp = d_rbsp; a.index = d_index; a.n = n_nals;
+    a.parsed = reinterpret_cast<hbs::ParsedNal*>(d_parsed);
+    a.structs = d_structs; a.structs_cap = d_structs ? structs_cap : 0; a.summary = d_summary;
+    a.slot_size = reinterpret_cast<unsigned long long*>(w);
+    a.ctx_sps = reinterpret_cast<long long*>(w + b_n);
+    a.ctx_pps = reinterpret_cast<long long*>(w + 2 * b_n);
+    a.zeros = c->zeros;
+    a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
+    a.err = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256);
+    hipError_t e = hbs::launch_parse_headers(a, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
+}
 
 int hbs_read_summary(hbs_ctx* c, const hbs_summary* d_summary, hbs_summary* h_summary)
 {

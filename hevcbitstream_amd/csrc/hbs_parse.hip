@@ -1,0 +1,183 @@
+/*
+ * hbs_parse.hip -- K4 driver: one NAL per wavefront header parse over the RBSP
+ * arena that K12 produced (see hbs_parse.h for the syntax readers).
+ *
+ *   k4_plan    per NAL: type from RBSP bytes 0-1 (reference hevc_stream.c:176-179),
+ *              bytes of the struct it parses into
+ *   k4_scan    one workgroup: struct arena offsets; for every NAL the ordinal of
+ *              the last SPS / PPS in front of it (the reference's "h->sps / h->pps
+ *              as left by the last parse", hevc_stream.c:800-801)
+ *   k4_parse   wave per NAL; pass 1 parameter sets, pass 2 slices against them
+ */
+#include <hip/hip_runtime.h>
+#include "hbs_parse.h"
+#include "hbs_parse_launch.h"
+
+namespace hbs {
+
+constexpr uint32_t kWinBytes = 512;                 /* RBSP bytes staged in LDS per NAL */
+
+__global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
+                        ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const hbs_nal_entry e = idx[k];
+        ParsedNal p;
+        p.rc = -1; p.nal_unit_type = -1; p.nal_layer_id = -1; p.nal_temporal_id_plus1 = -1;
+        p.struct_off = ~0ull; p.slice_data_size = 0; p.slice_data_off = 0;
+        uint64_t sz = 0;
+        if (!(e.status & HBS_ST_ERROR)) {            /* nal_to_rbsp failed: read_hevc_nal_unit returns before the header (:167) */
+            nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
+            sz = slot_bytes_of(p.nal_unit_type);
+        }
+        parsed[k] = p;
+        slot_size[k] = sz;
+    }
+}
+
+/* one workgroup: exclusive sum of slot sizes, and last SPS / PPS ordinal before each NAL */
+__global__ __launch_bounds__(1024)
+void k4_scan(const ParsedNal* parsed_in, ParsedNal* parsed, const unsigned long long* __restrict__ slot_size,
+             uint64_t n, long long* __restrict__ ctx_sps, long long* __restrict__ ctx_pps, unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ long long lsps[1024], lpps[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned long long s = 0;
+    long long ms = -1, mp = -1;
+    for (uint64_t i = lo; i < hi; ++i) {
+        s += slot_size[i];
+        const int t = parsed_in[i].nal_unit_type;
+        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) ms = (long long)i;
+        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) mp = (long long)i;
+    }
+    part[tid] = s; lsps[tid] = ms; lpps[tid] = mp;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        unsigned long long t = 0; long long a = -1, b = -1;
+        if (tid >= d) { t = part[tid - d]; a = lsps[tid - d]; b = lpps[tid - d]; }
+        __syncthreads();
+        part[tid] += t;
+        if (a > lsps[tid]) lsps[tid] = a;
+        if (b > lpps[tid]) lpps[tid] = b;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - s;
+    long long cs = (tid > 0) ? lsps[tid - 1] : -1, cp = (tid > 0) ? lpps[tid - 1] : -1;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const unsigned long long sz = slot_size[i];
+        parsed[i].struct_off = sz ? run : ~0ull;
+        run += sz;
+        ctx_sps[i] = cs; ctx_pps[i] = cp;
+        const int t = parsed_in[i].nal_unit_type;
+        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) cs = (long long)i;
+        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) cp = (long long)i;
+    }
+    if (tid == 1023) *total = part[1023];
+}
+
+/* pass 0: parameter sets; pass 1: slices */
+__global__ __launch_bounds__(256)
+void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int pass,
+              ParsedNal* __restrict__ parsed, uint8_t* __restrict__ structs, uint64_t structs_cap,
+              const long long* __restrict__ ctx_sps, const long long* __restrict__ ctx_pps,
+              const uint8_t* __restrict__ zeros, uint32_t* __restrict__ err)
+{
+    __shared__ uint8_t win[4][kWinBytes];
+    __shared__ RpsRow own_rows[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+
+    for (uint64_t k = wave; k < n; k += nwaves) {
+        const int type = parsed[k].nal_unit_type;
+        const bool slice = is_slice_type_nal(type);
+        const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
+        if (type < 0) continue;                                  /* nal_to_rbsp failed: rc stays -1 */
+        if (!slice && !pset) continue;                            /* unsupported type: rc -1, header fields kept (:221) */
+        if ((pass == 0) != pset) continue;
+
+        const hbs_nal_entry e = idx[k];
+        const uint64_t off = parsed[k].struct_off;
+        const uint64_t slot = slot_bytes_of(type);
+        if (off + slot > structs_cap) {
+            if (lane == 0) { atomicMax(err, (uint32_t)(-HBS_E_CAPACITY)); parsed[k].struct_off = ~0ull; }
+            continue;
+        }
+        uint8_t* dst = structs + off;
+        /* memset (hevc_stream.c:250, :310, :425, init_slice_hevc :19-24) by the whole wave */
+        {
+            uint4* q = reinterpret_cast<uint4*>(dst);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t i = lane; i < slot / 16; i += 64) q[i] = z;
+        }
+        /* first bytes of the RBSP into LDS */
+        const uint8_t* src = rbsp + e.rbsp_off;
+        const uint32_t wb = e.rbsp_len < kWinBytes ? e.rbsp_len : kWinBytes;
+        for (uint32_t i = lane; i < wb; i += 64) win[wv][i] = src[i];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+        if (lane == 0) {
+            Parser ps;
+            ps.b.win = win[wv]; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
+            ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+            const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
+            const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
+            const hevc_sps_t* last_sps = zero_sps;
+            const hevc_pps_t* last_pps = zero_pps;
+            if (slice) {
+                static_cast<void>(0);
+                reinterpret_cast<hevc_slice_header_t*>(dst)->collocated_from_l0_flag = 1;
+                const long long cs = ctx_sps[k], cp = ctx_pps[k];
+                if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
+                    last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[cs].struct_off);
+                    ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[cs].struct_off + round16(sizeof(hevc_sps_t)));
+                }
+                if (cp >= 0 && parsed[cp].struct_off != ~0ull)
+                    last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
+                RpsRow* row = &own_rows[wv];
+                row->NumDeltaPocs = row->NumNegativePics = row->NumPositivePics = 0;
+                for (int i = 0; i < 32; ++i) { row->DeltaPocS0[i] = row->UsedByCurrPicS0[i] = row->DeltaPocS1[i] = row->UsedByCurrPicS1[i] = 0; }
+                ps.own = row;
+            } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+                ps.out_rps = reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
+            }
+            const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
+            ParsedNal out = parsed[k];
+            parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
+            parsed[k] = out;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void k4_summary(uint64_t n, const unsigned long long* total, const uint32_t* err, hbs_summary* sum)
+{
+    sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = 0; sum->stream_bytes = 0;
+    sum->stop_reason = 0; sum->error = -(int32_t)*err;
+    sum->reserved[0] = *total;                       /* struct arena bytes needed */
+    sum->reserved[1] = sum->reserved[2] = 0;
+}
+
+hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    if (a.n) {
+        k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size);
+        k4_scan<<<1, 1024, 0, st>>>(a.parsed, a.parsed, a.slot_size, a.n, a.ctx_sps, a.ctx_pps, a.total);
+        if (a.structs) {
+            k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.err);
+            k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.err);
+        }
+    }
+    k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);
+    return hipGetLastError();
+}
+
+} // namespace hbs

@@ -1,0 +1,32 @@
+/* hbs_parse_launch.h -- host-visible launcher of K4 (header parse). */
+#ifndef HBS_PARSE_LAUNCH_H
+#define HBS_PARSE_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+#include "hbs_common.h"
+
+namespace hbs {
+
+struct ParsedNal;
+
+struct ParseArgs {
+    const uint8_t* rbsp;
+    const hbs_nal_entry* index;
+    uint64_t n;
+    ParsedNal* parsed;               /* n records (device)                        */
+    uint8_t* structs;                /* struct arena or nullptr (plan only)       */
+    uint64_t structs_cap;
+    hbs_summary* summary;
+    /* workspace */
+    unsigned long long* slot_size;   /* n */
+    long long* ctx_sps;              /* n */
+    long long* ctx_pps;              /* n */
+    const uint8_t* zeros;            /* >= sizeof(hevc_sps_t) zero bytes */
+    unsigned long long* total;
+    uint32_t* err;
+};
+
+hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);
+
+} // namespace hbs
+#endif

@@ -152,6 +152,40 @@ int hbs_emit_annexb(hbs_ctx* ctx, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
 uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals);
 
 /*
+ * K4: header parse, one NAL per wavefront, over the RBSP arena and index that
+ * hbs_index_extract produced.  For NAL k it does what read_hevc_nal_unit()
+ * does after nal_to_rbsp (hevc_stream.c:175-239): NAL header, then by type the
+ * VPS / SPS / PPS / slice-segment-header reader, into structs laid out exactly
+ * as hevc_stream.h's (include/hevc_stream.h).  The state the reference threads
+ * through one mutable parser object is resolved per NAL: a slice is read
+ * against the last SPS and PPS that precede it in the stream.
+ *
+ *   d_parsed[k]     rc (read_hevc_nal_unit's return value: consumed NAL bytes,
+ *                   or -1: bad emulation pattern, unsupported type -- AUD, SEI,
+ *                   EOS, ... -- or bit-reader overrun), the hevc_nal_t fields
+ *                   (-1 when nal_to_rbsp already failed), where its struct is in
+ *                   d_structs, and for slices h->slice_data: payload size and
+ *                   where the payload starts inside the NAL's RBSP
+ *   d_structs       struct arena: hevc_vps_t / hevc_sps_t / hevc_pps_t /
+ *                   hevc_slice_header_t per NAL at d_parsed[k].struct_off
+ *                   (an SPS slot is followed by its derived RPS tables);
+ *                   NULL = plan only
+ *   d_summary       reserved[0] = arena bytes needed; error HBS_E_CAPACITY when
+ *                   structs_cap was smaller (NALs that did not fit keep
+ *                   struct_off = ~0)
+ */
+typedef struct hbs_parsed_nal {
+    int32_t  rc;
+    int32_t  nal_unit_type, nal_layer_id, nal_temporal_id_plus1;
+    uint64_t struct_off;
+    int32_t  slice_data_size;
+    uint32_t slice_data_off;
+} hbs_parsed_nal;
+
+int hbs_parse_headers(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                      hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary);
+
+/*
  * Synthetic workload S(seed, n_nals, mode) of SURVEY.md 8(d), generated in HBM:
  * RBSP of NAL k is 8192 + mix(k) % 4097 pseudo-random bytes (mode 0 uniform,
  * mode 1 "zero-heavy": ~10 % 00 and ~5 % 01..03), first bytes 02 01, last byte

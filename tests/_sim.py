@@ -66,3 +66,20 @@ def synth_rbsp(seed, n_nals, mode):
     idx = np.zeros(max(n_nals, 1), dtype=NAL_ENTRY)
     tot = lib().sim_synth_rbsp(seed, n_nals, mode, arena.ctypes.data, idx.ctypes.data)
     return arena[:tot].copy(), idx[:n_nals]
+
+
+def parse_headers(rbsp, idx):
+    """K4 single-stepped on the CPU.  Returns (parsed ndarray[PARSED], struct arena uint8)."""
+    from tests._parsecmp import PARSED
+    L = lib()
+    L.sim_parse_headers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.sim_parse_headers.restype = C.c_int64
+    rbsp = np.ascontiguousarray(np.concatenate([rbsp, np.zeros(16, dtype=np.uint8)]))
+    idx = np.ascontiguousarray(idx)
+    n = len(idx)
+    parsed = np.zeros(max(n, 1), dtype=PARSED)
+    need = L.sim_parse_headers(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, None, 0)
+    structs = np.full(need + 64, 0xA5, dtype=np.uint8)
+    got = L.sim_parse_headers(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, structs.ctypes.data, need)
+    assert got == need
+    return parsed[:n], structs[:need]

@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../hevcbitstream_amd/csrc/hbs_tile.h"
 #include "../../hevcbitstream_amd/csrc/hbs_emit.h"
+#include "../../hevcbitstream_amd/csrc/hbs_parse.h"
 
 using namespace hbs;
 
@@ -159,4 +160,70 @@ extern "C" int64_t sim_synth_rbsp(uint64_t seed, uint64_t n, int mode, uint8_t* 
         off += len;
     }
     return (int64_t)off;
+}
+
+/* K4 in stream order: plan, context resolution and the per-NAL parse of hbs_parse.hip */
+extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n,
+                                     ParsedNal* parsed, uint8_t* structs, uint64_t structs_cap)
+{
+    static std::vector<uint8_t> zeros(sizeof(hevc_sps_t) + 64, 0);
+    uint64_t run = 0;
+    long long cs = -1, cp = -1;
+    std::vector<long long> ctx_sps(n), ctx_pps(n);
+    for (uint64_t k = 0; k < n; ++k) {
+        ParsedNal p;
+        p.rc = -1; p.nal_unit_type = p.nal_layer_id = p.nal_temporal_id_plus1 = -1;
+        p.struct_off = ~0ull; p.slice_data_size = 0; p.slice_data_off = 0;
+        uint64_t sz = 0;
+        if (!(idx[k].status & HBS_ST_ERROR)) {
+            nal_header_of(rbsp + idx[k].rbsp_off, idx[k].rbsp_len, p);
+            sz = slot_bytes_of(p.nal_unit_type);
+        }
+        p.struct_off = sz ? run : ~0ull;
+        run += sz;
+        ctx_sps[k] = cs; ctx_pps[k] = cp;
+        if (p.nal_unit_type == HEVC_NAL_UNIT_TYPE_SPS_NUT) cs = (long long)k;
+        if (p.nal_unit_type == HEVC_NAL_UNIT_TYPE_PPS_NUT) cp = (long long)k;
+        parsed[k] = p;
+    }
+    if (!structs) return (int64_t)run;
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint64_t k = 0; k < n; ++k) {
+            const int type = parsed[k].nal_unit_type;
+            const bool slice = is_slice_type_nal(type);
+            const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
+            if (type < 0 || (!slice && !pset) || ((pass == 0) != pset)) continue;
+            const uint64_t off = parsed[k].struct_off, slot = slot_bytes_of(type);
+            if (off + slot > structs_cap) { parsed[k].struct_off = ~0ull; continue; }
+            uint8_t* dst = structs + off;
+            memset(dst, 0, slot);
+            Parser ps;
+            const uint8_t* src = rbsp + idx[k].rbsp_off;
+            ps.b.win = src; ps.b.full = src; ps.b.win_bytes = idx[k].rbsp_len < 512u ? idx[k].rbsp_len : 512u;
+            ps.b.size = idx[k].rbsp_len; ps.b.pos = 16;
+            ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+            const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
+            const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
+            const hevc_sps_t* last_sps = zero_sps;
+            const hevc_pps_t* last_pps = zero_pps;
+            RpsRow row;
+            if (slice) {
+                reinterpret_cast<hevc_slice_header_t*>(dst)->collocated_from_l0_flag = 1;
+                if (ctx_sps[k] >= 0 && parsed[ctx_sps[k]].struct_off != ~0ull) {
+                    last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[ctx_sps[k]].struct_off);
+                    ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[ctx_sps[k]].struct_off + round16(sizeof(hevc_sps_t)));
+                }
+                if (ctx_pps[k] >= 0 && parsed[ctx_pps[k]].struct_off != ~0ull)
+                    last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[ctx_pps[k]].struct_off);
+                memset(&row, 0, sizeof(row));
+                ps.own = &row;
+            } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+                ps.out_rps = reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
+            }
+            const int consumed = (int)(idx[k].end - idx[k].start) - ((idx[k].status & HBS_ST_TRAILING03) ? 1 : 0);
+            ParsedNal out = parsed[k];
+            parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
+            parsed[k] = out;
+        }
+    return (int64_t)run;
 }

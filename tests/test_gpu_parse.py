@@ -1,0 +1,111 @@
+"""Parity tests for K4 (one-NAL-per-wavefront header parse) through the C ABI:
+NAL header, VPS/SPS/PPS/slice-segment-header structs and slice payload location
+against the oracle parser, on streams from tests/hevc_synth.py."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests._parsecmp import compare, oracle_pass
+from tests.hevc_synth import Synth, annexb, stream_4k30
+from tests.test_sim_parse_logic import broken, sequence
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_parse(ctx, stream_bytes):
+    import torch
+    s = np.frombuffer(stream_bytes, dtype=np.uint8).copy()
+    d = torch.from_numpy(s).cuda()
+    index, rbsp, summary, cap = ctx.alloc_outputs(d.numel())
+    ctx.index_extract_async(d, index, cap, rbsp, summary)
+    sm = ctx.read_summary(summary)
+    n = int(sm["nal_count"])
+    parsed, structs = ctx.parse_headers(rbsp, index, n)
+    import hevcbitstream_amd as hbs
+    idx = index[: n * 32].cpu().numpy().view(hbs.NAL_ENTRY)
+    return s, idx, rbsp[: int(sm["rbsp_bytes"])].cpu().numpy(), parsed, structs.cpu().numpy()
+
+
+def run(ctx, nals):
+    s, idx, arena, parsed, structs = gpu_parse(ctx, annexb(nals))
+    assert len(idx) == len(nals)
+    compare(parsed, structs, arena, idx, oracle_pass(nals))
+
+
+def test_rich_sequences(ctx):
+    # many sequences in ONE stream would share parser state; the reference parses one stream at a time too
+    for seed in range(40):
+        run(ctx, sequence(seed))
+
+
+def test_long_mixed_stream(ctx):
+    """one stream with 60 parameter-set changes and ~700 slices: context resolution across the stream"""
+    nals = []
+    for seed in range(200, 260):
+        nals += sequence(seed)
+    run(ctx, nals)
+
+
+def test_broken_slices_and_parameter_sets(ctx):
+    for seed in range(25):
+        run(ctx, broken(sequence(seed), np.random.RandomState(1000 + seed), lambda t: t not in (33, 34)))
+    for seed in range(25):
+        g = Synth(seed, rich=True)
+        rng = np.random.RandomState(2000 + seed)
+        seq = [g.vps(), g.sps_nal(int(rng.randint(64, 4096)), int(rng.randint(64, 2304))), g.pps_nal(), g.vps()]
+        run(ctx, broken(seq, rng, lambda t: True))
+
+
+def test_ten_nal_fixture(ctx):
+    data = open(os.path.join(HERE, "golden", "ten_nal.hevc"), "rb").read()
+    idx = json.load(open(os.path.join(HERE, "golden", "ten_nal.index.json")))
+    run(ctx, [data[s:e] for s, e, _ in idx[:4]])
+
+
+def test_golden_struct_dumps(ctx):
+    """reference answers (parse_vectors.json) straight against the GPU parse"""
+    gold = json.load(open(os.path.join(HERE, "golden", "parse_vectors.json")))
+    from tests import _orc
+    for seq in gold[:12]:
+        nals = [bytes.fromhex(st["nal"]) for st in seq["steps"]]
+        s, idx, arena, parsed, structs = gpu_parse(ctx, annexb(nals))
+        for k, st in enumerate(seq["steps"]):
+            assert int(parsed["rc"][k]) == st["rc"]
+            t = (nals[k][0] >> 1) & 0x3F
+            kind = "sh" if (t <= 9 or 16 <= t <= 21) else {32: "vps", 33: "sps", 34: "pps"}.get(t)
+            if kind is None:
+                continue
+            size = _orc.layout()[_orc.STRUCT_TYPES[kind]]["size"]
+            got = structs[int(parsed["struct_off"][k]): int(parsed["struct_off"][k]) + size].view(np.int32)
+            want = np.zeros(size // 4, dtype=np.int32)
+            for i, v in st["structs"][kind]:
+                want[i] = v
+            assert np.array_equal(got, want), (seq["seed"], k, kind)
+
+
+def test_config3_4k30_100k_nals(ctx):
+    """Config 3: synthetic 3840x2160 stream, ~100k NALs (12.5k pictures x 8 slice segments + parameter
+    sets every 60 pictures).  Full field parity on a prefix the oracle finishes quickly; for the whole
+    stream: every rc >= 0, every slice resolved against the right parameter sets (spot fields)."""
+    t0 = time.time()
+    stream, n = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
+    s, idx, arena, parsed, structs = gpu_parse(ctx, stream)
+    assert len(idx) == n and n > 100000
+    assert (parsed["rc"] >= 0).all()
+    nals = [bytes(s[int(a):int(b)]) for a, b in zip(idx["start"][:3000], idx["end"][:3000])]
+    compare(parsed[:3000], structs, arena, idx[:3000], oracle_pass(nals))
+    # whole stream: slice_data_size + header bytes + 1 == rbsp_len for every slice
+    sl = (parsed["nal_unit_type"] == 1) | (parsed["nal_unit_type"] == 19)
+    assert (parsed["slice_data_size"][sl] + parsed["slice_data_off"][sl].astype(np.int64) == idx["rbsp_len"][sl]).all()

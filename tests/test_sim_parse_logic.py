@@ -1,0 +1,103 @@
+"""CPU single-step of the product's header readers (hbs_parse.h, the code K4
+runs per wavefront) against the oracle parser, on streams from tests/hevc_synth."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _sim
+from tests._parsecmp import compare, oracle_pass
+from tests.hevc_synth import Synth, annexb, stream_4k30
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(nals):
+    stream = np.frombuffer(annexb(nals) , dtype=np.uint8)
+    idx, arena, s = _sim.index_extract(stream)
+    assert len(idx) == len(nals)
+    parsed, structs = _sim.parse_headers(arena, idx)
+    compare(parsed, structs, arena, idx, oracle_pass(nals))
+
+
+def sequence(seed, rich=True):
+    g = Synth(seed, rich=rich)
+    rng = np.random.RandomState(seed)
+    seq = [g.vps(), g.sps_nal(int(rng.randint(64, 4096)), int(rng.randint(64, 2304))), g.pps_nal()]
+    for k in range(10):
+        t = int(rng.choice([0, 1, 8, 9, 16, 19, 20, 21]))
+        seq.append(g.slice_nal(t, first=bool(rng.randint(0, 2)),
+                               payload=rng.randint(0, 256, size=rng.randint(1, 80)).astype(np.uint8).tobytes(),
+                               address=int(rng.randint(0, 100))))
+        if k == 3 and rng.rand() < 0.5:
+            seq.append(g.pps_nal())
+        if k == 6 and rng.rand() < 0.5:
+            seq.append(g.sps_nal(int(rng.randint(64, 4096)), int(rng.randint(64, 2304))))
+            seq.append(g.pps_nal())
+    seq.append(bytes([35 << 1, 1, 0x50]))              # AUD: not dispatched by the reference (rc -1)
+    seq.append(bytes([39 << 1, 1, 1, 2, 3, 0x80]))     # SEI: idem
+    return seq
+
+
+def test_rich_sequences():
+    for seed in range(150):
+        run(sequence(seed))
+
+
+def test_slices_before_any_parameter_set():
+    g = Synth(5, rich=True)
+    g.sps_nal(640, 480)
+    g.pps_nal()
+    sl = [g.slice_nal(1, first=True, payload=b"\x11\x22\x33"), g.slice_nal(19, first=False, payload=b"\x44" * 9, address=3)]
+    # the stream itself carries no parameter sets: the reference parses against its zeroed structs
+    run(sl)
+
+
+def broken(seq, rng, which):
+    """cut NALs short (zeros past the end, overrun) or plant 00 00 02 (nal_to_rbsp rejects)"""
+    out = []
+    for nal in seq:
+        t = (nal[0] >> 1) & 0x3F
+        r = rng.rand()
+        if which(t) and r < 0.3 and len(nal) > 4:
+            nal = nal[: rng.randint(2, len(nal))]
+            if nal[-1] == 0:
+                nal = nal + b"\x80"
+        elif which(t) and r < 0.4:
+            nal = nal[:3] + b"\x00\x00\x02" + nal[3:]
+        out.append(nal)
+    return out
+
+
+def test_truncated_and_broken_slices():
+    """Slices and VPS damaged, SPS/PPS intact: every NAL must still agree with the reference
+    semantics (a slice parsed against damaged parameter sets is outside the envelope where the
+    reference is deterministic: it reads RPS table rows left behind by earlier slices)."""
+    for seed in range(60):
+        run(broken(sequence(seed), np.random.RandomState(1000 + seed), lambda t: t not in (33, 34)))
+
+
+def test_truncated_parameter_sets():
+    for seed in range(60):
+        g = Synth(seed, rich=True)
+        rng = np.random.RandomState(2000 + seed)
+        seq = [g.vps(), g.sps_nal(int(rng.randint(64, 4096)), int(rng.randint(64, 2304))), g.pps_nal(), g.vps()]
+        run(broken(seq, rng, lambda t: True))
+
+
+def test_ten_nal_parameter_sets_and_idr():
+    data = open(os.path.join(HERE, "golden", "ten_nal.hevc"), "rb").read()
+    idx = json.load(open(os.path.join(HERE, "golden", "ten_nal.index.json")))
+    run([data[s:e] for s, e, _ in idx[:4]])
+
+
+def test_config3_downsized():
+    stream, n = stream_4k30(3, n_pictures=10, slices_per_picture=8, idr_every=4, payload_bytes=(200, 400))
+    s = np.frombuffer(stream, dtype=np.uint8)
+    idx, arena, summ = _sim.index_extract(s)
+    assert len(idx) == n
+    nals = [bytes(s[int(a):int(b)]) for a, b in zip(idx["start"], idx["end"])]
+    parsed, structs = _sim.parse_headers(arena, idx)
+    compare(parsed, structs, arena, idx, oracle_pass(nals))
+    assert (parsed["rc"] >= 0).all()
