@@ -10,12 +10,30 @@ LIB   := hevcbitstream_amd/libhevcbitstream_amd.so
 HIP_SRCS := $(wildcard $(CSRC)/*.hip)
 HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
 
-all: lib oracle sim
+all: lib oracle sim analyze
 
 lib: $(LIB)
 
-$(LIB): $(HIP_SRCS) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+# the legacy single-NAL API is plain C over the C ABI (no HIP headers): gcc compiles it
+LEGACY_OBJ := $(CSRC)/hbs_legacy.o
+$(LEGACY_OBJ): $(CSRC)/hbs_legacy.c $(HDRS)
+	$(CC) -std=c99 -O2 -fPIC -Wall -Wextra -Iinclude -c -o $@ $<
+
+HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
+%.hip.o: %.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(HIP_OBJS) $(LEGACY_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) $(LEGACY_OBJ)
+	ln -sf libhevcbitstream_amd.so hevcbitstream_amd/libhevcbitstream.so
+
+# the reference's own CLI, unmodified, against OUR headers and library (dev container only)
+REF ?= /root/reference
+analyze: $(LIB)
+	@if [ -f $(REF)/hevc_analyze.c ]; then mkdir -p oracle/_ref && \
+	  $(CC) -std=c99 -O2 -w -D_GNU_SOURCE -Iinclude -o oracle/_ref/hevc_analyze_amd $(REF)/hevc_analyze.c \
+	    -Lhevcbitstream_amd -lhevcbitstream_amd -Wl,-rpath,'$$ORIGIN/../../hevcbitstream_amd' && echo built oracle/_ref/hevc_analyze_amd; \
+	 else echo "reference sources absent: keeping prebuilt oracle/_ref/hevc_analyze_amd (if any)"; fi
 
 oracle:
 	$(MAKE) -C oracle all
@@ -27,4 +45,4 @@ clean:
 	rm -f $(LIB) tests/sim/libhbs_sim.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle sim clean
+.PHONY: all lib oracle sim clean analyze

@@ -244,11 +244,21 @@ int hbs_synth_rbsp(hbs_ctx* c, uint64_t seed, uint64_t n_nals, int mode,
     return e == hipSuccess ? 0 : fail(c, e, "launch_synth_rbsp");
 }
 
+uint64_t hbs_sps_slot_bytes(void) { return hbs::slot_bytes_of(HEVC_NAL_UNIT_TYPE_SPS_NUT); }
+uint64_t hbs_sps_tables_offset(void) { return hbs::round16(sizeof(hevc_sps_t)); }
+
 uint64_t hbs_synth_rbsp_bound(uint64_t n_nals) { return n_nals * 12288ull + 16; }
 uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals) { return rbsp_bytes + rbsp_bytes / 2 + 4 * n_nals + 16; }
 
 int hbs_parse_headers(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                       hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary)
+{
+    return hbs_parse_headers_ctx(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, nullptr, nullptr, d_summary);
+}
+
+int hbs_parse_headers_ctx(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                          hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                          const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary)
 {
     static_assert(sizeof(hbs_parsed_nal) == sizeof(hbs::ParsedNal), "public record == kernel record");
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index || !d_parsed))) return HBS_E_ARG;
@@ -273,10 +283,55 @@ int hbs_parse_headers(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_
     a.ctx_sps = reinterpret_cast<long long*>(w + b_n);
     a.ctx_pps = reinterpret_cast<long long*>(w + 2 * b_n);
     a.zeros = c->zeros;
+    a.initial_sps_slot = d_initial_sps_slot;
+    a.initial_pps = d_initial_pps;
     a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256);
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
+}
+
+/* plain device-memory helpers so that C callers (hbs_legacy.c) need no HIP headers */
+int hbs_dev_alloc(hbs_ctx* c, uint64_t bytes, void** out)
+{
+    if (!c || !out) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    return e == hipSuccess ? 0 : fail(c, e, "hipMalloc");
+}
+
+int hbs_dev_free(hbs_ctx* c, void* p)
+{
+    if (!c) return HBS_E_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    hipError_t e = hipFree(p);
+    return e == hipSuccess ? 0 : fail(c, e, "hipFree");
+}
+
+int hbs_copy_to_device(hbs_ctx* c, void* d_dst, const void* h_src, uint64_t bytes)
+{
+    if (!c) return HBS_E_ARG;
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      /* the host buffer may be reused at once */
+    return e == hipSuccess ? 0 : fail(c, e, "hipMemcpy(H2D)");
+}
+
+int hbs_copy_to_host(hbs_ctx* c, void* h_dst, const void* d_src, uint64_t bytes)
+{
+    if (!c) return HBS_E_ARG;
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hipMemcpy(D2H)");
+}
+
+int hbs_fill_device(hbs_ctx* c, void* d_dst, int value, uint64_t bytes)
+{
+    if (!c) return HBS_E_ARG;
+    if (!bytes) return 0;
+    hipError_t e = hipMemsetAsync(d_dst, value, bytes, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hipMemsetAsync");
 }
 
 int hbs_read_summary(hbs_ctx* c, const hbs_summary* d_summary, hbs_summary* h_summary)

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256)
 void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int pass,
               ParsedNal* __restrict__ parsed, uint8_t* __restrict__ structs, uint64_t structs_cap,
               const long long* __restrict__ ctx_sps, const long long* __restrict__ ctx_pps,
-              const uint8_t* __restrict__ zeros, uint32_t* __restrict__ err)
+              const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot,
+              const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err)
 {
     __shared__ uint8_t win[4][kWinBytes];
     __shared__ RpsRow own_rows[4];
@@ -135,9 +136,14 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
                     last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[cs].struct_off);
                     ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[cs].struct_off + round16(sizeof(hevc_sps_t)));
+                } else if (cs < 0 && init_sps_slot) {              /* context handed in by the caller */
+                    last_sps = reinterpret_cast<const hevc_sps_t*>(init_sps_slot);
+                    ps.sps_rps = reinterpret_cast<const RpsTables*>(init_sps_slot + round16(sizeof(hevc_sps_t)));
                 }
                 if (cp >= 0 && parsed[cp].struct_off != ~0ull)
                     last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
+                else if (cp < 0 && init_pps)
+                    last_pps = reinterpret_cast<const hevc_pps_t*>(init_pps);
                 RpsRow* row = &own_rows[wv];
                 row->NumDeltaPocs = row->NumNegativePics = row->NumPositivePics = 0;
                 for (int i = 0; i < 32; ++i) { row->DeltaPocS0[i] = row->UsedByCurrPicS0[i] = row->DeltaPocS1[i] = row->UsedByCurrPicS1[i] = 0; }
@@ -172,8 +178,8 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size);
         k4_scan<<<1, 1024, 0, st>>>(a.parsed, a.parsed, a.slot_size, a.n, a.ctx_sps, a.ctx_pps, a.total);
         if (a.structs) {
-            k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.err);
-            k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.err);
+            k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err);
+            k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err);
         }
     }
     k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);

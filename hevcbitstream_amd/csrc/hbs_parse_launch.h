@@ -22,6 +22,8 @@ struct ParseArgs {
     long long* ctx_sps;              /* n */
     long long* ctx_pps;              /* n */
     const uint8_t* zeros;            /* >= sizeof(hevc_sps_t) zero bytes */
+    const uint8_t* initial_sps_slot; /* optional: SPS slot (struct + RPS tables) in force before NAL 0 */
+    const uint8_t* initial_pps;      /* optional: hevc_pps_t in force before NAL 0 */
     unsigned long long* total;
     uint32_t* err;
 };

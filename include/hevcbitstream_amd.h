@@ -184,6 +184,15 @@ typedef struct hbs_parsed_nal {
 
 int hbs_parse_headers(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                       hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary);
+/* Same, for a batch that continues an earlier one: d_initial_sps_slot (an SPS
+ * slot = hevc_sps_t followed at hbs_sps_tables_offset() by its derived RPS
+ * tables, hbs_sps_slot_bytes() in all) and d_initial_pps (hevc_pps_t) are the
+ * parameter sets in force before NAL 0; NULL = none parsed yet. */
+int hbs_parse_headers_ctx(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                          hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                          const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary);
+uint64_t hbs_sps_slot_bytes(void);
+uint64_t hbs_sps_tables_offset(void);
 
 /*
  * Synthetic workload S(seed, n_nals, mode) of SURVEY.md 8(d), generated in HBM:
@@ -196,6 +205,14 @@ int hbs_parse_headers(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* 
 int hbs_synth_rbsp(hbs_ctx* ctx, uint64_t seed, uint64_t n_nals, int mode,
                    uint8_t* d_rbsp, uint64_t rbsp_cap, hbs_nal_entry* d_index, hbs_summary* d_summary);
 uint64_t hbs_synth_rbsp_bound(uint64_t n_nals);
+
+/* Device-memory helpers for callers without HIP headers (the legacy C layer):
+ * allocate / free on the context's GPU, synchronising copies, async fill. */
+int hbs_dev_alloc(hbs_ctx* ctx, uint64_t bytes, void** out);
+int hbs_dev_free(hbs_ctx* ctx, void* p);
+int hbs_copy_to_device(hbs_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+int hbs_copy_to_host(hbs_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+int hbs_fill_device(hbs_ctx* ctx, void* d_dst, int value, uint64_t bytes);
 
 /* Synchronising copy of a device hbs_summary to the host. */
 int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_summary);

@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the library loads without a GPU and
+exports every symbol the headers in include/ declare (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for hdr in ("hevcbitstream_amd.h", "h264_stream.h", "hevc_stream.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"^\s*#.*?$", "", src, flags=re.M)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src):
+            n = m.group(1)
+            if n not in ("defined", "sizeof"):
+                names.add(n)
+    return names
+
+
+def test_library_exports_everything_declared():
+    import hevcbitstream_amd as hbs
+    lib = hbs.load_library()
+    names = declared_functions()
+    assert {"hbs_index_extract", "hbs_emit_annexb", "hbs_parse_headers", "find_nal_unit", "nal_to_rbsp",
+            "rbsp_to_nal", "read_hevc_nal_unit", "write_hevc_nal_unit", "hevc_new", "hevc_free",
+            "read_debug_hevc_nal_unit", "debug_bytes"} <= names
+    for n in sorted(names):
+        assert hasattr(lib, n), "declared in include/ but not exported: " + n
+    C.c_void_p.in_dll(lib, "h264_dbgfile")          # data symbol hevc_analyze.c uses
+
+
+def test_python_binding_lists_the_same_batch_api():
+    from hevcbitstream_amd.api import EXPORTS
+    for n in EXPORTS:
+        assert n in declared_functions(), n
+
+
+def test_no_gpu_fails_loudly():
+    """without a GPU the context cannot be created: there is no CPU fallback"""
+    import torch
+    import hevcbitstream_amd as hbs
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = hbs.load_library()
+    h = C.c_void_p()
+    assert lib.hbs_ctx_create(C.byref(h), 0) == -1
+
+
+def test_struct_sizes_of_public_records():
+    import hevcbitstream_amd as hbs
+    assert hbs.NAL_ENTRY.itemsize == 32 and hbs.SUMMARY.itemsize == 64 and hbs.PARSED.itemsize == 32

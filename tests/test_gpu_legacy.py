@@ -1,0 +1,114 @@
+"""The reference's single-NAL C API served by the GPU (hbs_legacy.c over the
+batch C ABI): golden vectors generated from the real reference, the parse
+goldens, and the reference's unmodified hevc_analyze linked against this library."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _orc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def leg():
+    import hevcbitstream_amd as hbs
+    return _orc._L2(hbs.load_library(), "")
+
+
+def test_find_nal_unit_golden(leg):
+    gold = json.load(open(os.path.join(HERE, "golden", "l2_vectors.json")))
+    for hx, want in gold["find"]:
+        assert list(leg.find_nal_unit(bytes.fromhex(hx))) == want, hx
+
+
+def test_nal_to_rbsp_golden(leg):
+    gold = json.load(open(os.path.join(HERE, "golden", "l2_vectors.json")))
+    for hx, (r, ns, rs, data) in gold["n2r"]:
+        got = leg.nal_to_rbsp(bytes.fromhex(hx))
+        assert got[0] == r and got[1] == ns and got[2] == rs, hx
+        if r >= 0:
+            assert got[3].hex() == data, hx
+
+
+def test_rbsp_to_nal_golden(leg):
+    gold = json.load(open(os.path.join(HERE, "golden", "l2_vectors.json")))
+    for hx, (r, data) in gold["r2n"]:
+        got = leg.rbsp_to_nal(bytes.fromhex(hx))
+        assert got[0] == r and got[2].hex() == data, hx
+
+
+def test_find_nal_unit_large_buffer(leg, orc):
+    """NALs far larger than the first 64 KiB prefix the wrapper uploads"""
+    rng = np.random.RandomState(3)
+    body = rng.randint(4, 256, size=700000).astype(np.uint8).tobytes()
+    buf = b"\x11\x22\x00\x00\x01" + body + b"\x00\x00\x01\x40\x41" + body[:1000]
+    assert leg.find_nal_unit(buf) == orc.find_nal_unit(buf)
+    assert leg.find_nal_unit(buf[:400000]) == orc.find_nal_unit(buf[:400000])        # no end: -1
+
+
+class LegacyHevc(_orc._HevcParser):
+    def __init__(self, lib):
+        lib.hevc_new.restype = C.c_void_p
+        lib.read_hevc_nal_unit.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+        self.L = lib
+        self.h = lib.hevc_new()
+        self._views(self.h)
+
+    def read(self, nal):
+        buf = np.frombuffer(bytes(nal) + b"\xff" * 8, dtype=np.uint8).copy()
+        return self.L.read_hevc_nal_unit(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), len(nal))
+
+
+def test_read_hevc_nal_unit_golden():
+    """hevc_new + read_hevc_nal_unit per NAL, against the reference's struct dumps"""
+    import hevcbitstream_amd as hbs
+    gold = json.load(open(os.path.join(HERE, "golden", "parse_vectors.json")))
+    for seq in gold[:15]:
+        p = LegacyHevc(hbs.load_library())
+        for step in seq["steps"]:
+            nal = bytes.fromhex(step["nal"])
+            assert p.read(nal) == step["rc"], (seq["seed"], step["nal"][:8])
+            snap = p.snapshot()
+            for k, pairs in step["structs"].items():
+                want = np.zeros_like(snap[k])
+                for i, v in pairs:
+                    want[i] = v
+                assert np.array_equal(snap[k], want), (seq["seed"], k, step["nal"][:8])
+            if "slice_data" in step:
+                size, data = p.slice_data()
+                assert size == step["slice_data"][0]
+                if data is not None:
+                    assert hashlib.md5(data).hexdigest() == step["slice_data"][1]
+
+
+def test_reference_hevc_analyze_links_and_runs():
+    """the reference's own CLI (hevc_analyze.c, unmodified) built against include/ + this library
+    by `make analyze`: its NAL walk (find_nal_unit on the GPU) must print the golden offsets/sizes,
+    the debug_bytes dumps and the NAL-header lines of the golden stdout."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "hevc_analyze_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hevc_analyze_amd not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, os.path.join(HERE, "golden", "ten_nal.hevc")], stdout=subprocess.PIPE, check=True).stdout.decode()
+    want = open(os.path.join(HERE, "golden", "ten_nal.analyze.txt")).read()
+
+    def keep(text):
+        lines = text.splitlines()
+        sel = []
+        for i, l in enumerate(lines):
+            if l.startswith("!! Found NAL"):
+                sel.append(l)
+                sel.append(lines[i + 1][12:])        # hex dump without the 4 bytes in front of the buffer
+            elif l.startswith(("0.8: forbidden", "0.7: nal->", "0.1: nal->", "1.3: nal->")):
+                sel.append(l)
+        return sel
+
+    assert keep(out) == keep(want)
+    assert len(keep(out)) == 10 * 6
