@@ -94,22 +94,19 @@ def main():
     ctx = hbs.Context(local_rank)
     ctx.enable_timing(True)
     n = args.nals
-    g = ctx.synth_stream(SEED + rank, n, args.mode)            # independent shard per rank, generated in HBM
+    from hevcbitstream_amd.shard import shard_seed
+    g = ctx.synth_stream(shard_seed(SEED, rank), n, args.mode)   # independent shard per rank, generated in HBM
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
     stream = g["stream"][:sb]
     gen_rbsp, gen_index = g["rbsp"], g["index"]
     index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
 
-    gathered = counts = None
-    if world > 1:
-        gathered = torch.empty(world * (n + 8) * 32, dtype=torch.uint8, device="cuda")
-        counts = torch.empty(world * 64, dtype=torch.uint8, device="cuda")
+    from hevcbitstream_amd import shard
 
     def step():
         ctx.index_extract_async(stream, index, cap, rbsp, summary)
-        if world > 1:       # the one exchange of the path: per-rank summaries, then the index arrays
-            dist.all_gather_into_tensor(counts, summary)
-            dist.all_gather_into_tensor(gathered, index)
+        if world > 1:       # the one exchange of the path: counts, then the padded index arrays (RCCL all-gather)
+            shard.gather_index(torch, dist, index, n, sb, rb, cap)
 
     def fence():
         if world > 1:

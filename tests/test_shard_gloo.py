@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: two processes, gloo backend.  Each rank owns an independent
+stream shard; the gathered + rebased index must equal the index of the
+concatenated stream.  (On the GPU box the same code runs over RCCL; the shard's
+index then comes from hbs_index_extract instead of the oracle.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _orc
+    from hevcbitstream_amd import shard
+    orc = _orc.oracle()
+    n = 7 + rank                                           # ragged: shards of different NAL counts
+    stream, idx, arena = orc.gen_stream(shard.shard_seed(0x1234, rank), n, rank % 2)
+    cap = 16
+    local = np.zeros(cap, dtype=_orc.NAL_ENTRY)
+    local[:n] = idx
+    t = torch.from_numpy(local.view(np.uint8).copy())
+    all_index, meta = shard.gather_index(torch, dist, t, n, len(stream), len(arena), cap)
+    glob = shard.global_entries(all_index, meta)
+    # every rank got the same thing; rank 0 checks it against the concatenated stream
+    streams = [None] * world
+    dist.all_gather_object(streams, stream.tobytes())
+    if rank == 0:
+        cat = np.frombuffer(b"".join(streams), dtype=np.uint8)
+        want, want_arena, why = orc.index_extract(cat)
+        ok = len(glob) == len(want) and all(np.array_equal(glob[f], want[f]) for f in ("start", "end", "rbsp_off", "rbsp_len"))
+        ret.put(bool(ok) and int(meta[:, 0].sum()) == len(want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_index_gather():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
