@@ -2,6 +2,10 @@
 #   make lib     -> hevcbitstream_amd/libhevcbitstream_amd.so   (hipcc, gfx950 only)
 #   make oracle  -> oracle/liboracle.so (+ oracle/_ref/* when /root/reference exists)
 #   make sim     -> tests/sim/libhbs_sim.so
+# no built-in rules: `%: %.o` would try to LINK a source file from its object and delete it on failure
+MAKEFLAGS += -r
+.SUFFIXES:
+
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := hevcbitstream_amd/csrc
@@ -15,12 +19,14 @@ all: lib oracle sim analyze
 lib: $(LIB)
 
 # the legacy single-NAL API is plain C over the C ABI (no HIP headers): gcc compiles it
-LEGACY_OBJ := $(CSRC)/hbs_legacy.o
+LEGACY_OBJ := build/obj/hbs_legacy_c.o
 $(LEGACY_OBJ): $(CSRC)/hbs_legacy.c $(HDRS)
+	@mkdir -p build/obj
 	$(CC) -std=c99 -O2 -fPIC -Wall -Wextra -Iinclude -c -o $@ $<
 
-HIP_OBJS := $(HIP_SRCS:.hip=.hip.o)
-%.hip.o: %.hip $(HDRS)
+HIP_OBJS := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(HIP_SRCS))
+build/obj/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(HIP_OBJS) $(LEGACY_OBJ)
@@ -45,4 +51,11 @@ clean:
 	rm -f $(LIB) tests/sim/libhbs_sim.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle sim clean analyze
+# diagnostic build with per-phase shader-clock sums (scripts/phase_timing*.py); never the shipped library
+DIAG_OBJS := $(patsubst $(CSRC)/%.hip,build/diag/%.o,$(HIP_SRCS))
+build/diag/%.o: $(CSRC)/%.hip $(HDRS)
+	mkdir -p build/diag && $(HIPCC) $(HIPFLAGS) -DHBS_PHASE_TIMING -c -o $@ $<
+diag: $(DIAG_OBJS) $(LEGACY_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/diag/libhbs_diag.so $(DIAG_OBJS) $(LEGACY_OBJ)
+
+.PHONY: all lib oracle sim clean analyze diag

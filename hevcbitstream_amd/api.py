@@ -22,7 +22,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
-           "hbs_parse_headers"]
+           "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel"]
 
 
 class HbsError(RuntimeError):
@@ -58,6 +58,8 @@ def load_library():
     lib.hbs_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.hbs_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.hbs_ctx_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.hbs_ctx_set_kernel.argtypes = [C.c_void_p, C.c_int]
+    lib.hbs_ctx_get_kernel.argtypes = [C.c_void_p]
     lib.hbs_last_error.argtypes = [C.c_void_p]
     lib.hbs_last_error.restype = C.c_char_p
     lib.hbs_index_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -115,6 +117,13 @@ class Context:
     def _check(self, rc, what):
         if rc != 0:
             raise HbsError("%s failed: %d (%s)" % (what, rc, self.lib.hbs_last_error(self.h).decode()))
+
+    def set_kernel(self, variant):
+        """2 = LDS-image scan/extract kernel, 3 = register-resident one"""
+        self._check(self.lib.hbs_ctx_set_kernel(self.h, variant), "hbs_ctx_set_kernel")
+
+    def kernel(self):
+        return self.lib.hbs_ctx_get_kernel(self.h)
 
     def enable_timing(self, on=True):
         self._check(self.lib.hbs_ctx_enable_timing(self.h, 1 if on else 0), "hbs_ctx_enable_timing")

@@ -15,12 +15,18 @@
 #include "hbs_parse_launch.h"
 #include "hbs_parse.h"
 
+#ifndef HBS_DEFAULT_KERNEL
+#define HBS_DEFAULT_KERNEL 2
+#endif
+
 struct hbs_ctx {
     int device;
     hipStream_t own_stream;
     hipStream_t stream;
     int grid_blocks;
     int blocks_per_cu;
+    int grid_blocks3, blocks_per_cu3;   /* register-resident kernel */
+    int variant;
     unsigned long long* desc;
     uint64_t desc_tiles;
     hbs::RunHeader* hdr;
@@ -98,8 +104,12 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks = hbs::scan_grid_blocks(device, &c->blocks_per_cu);
     if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    c->grid_blocks3 = hbs::scan3_grid_blocks(device, &c->blocks_per_cu3);
+    if (c->grid_blocks3 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
-    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
+    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) { c->grid_blocks = atoi(g); c->grid_blocks3 = atoi(g) < c->grid_blocks3 ? atoi(g) : c->grid_blocks3; }
+    const char* kv = getenv("HBS_KERNEL");              /* 2 = LDS-image kernel, 3 = register-resident kernel */
+    c->variant = (kv && atoi(kv) == 2) ? 2 : ((kv && atoi(kv) == 3) ? 3 : HBS_DEFAULT_KERNEL);
     *out = c;
     return 0;
 }
@@ -148,10 +158,19 @@ int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
 int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 {
     if (!c) return HBS_E_ARG;
-    if (blocks) *blocks = c->grid_blocks;
-    if (blocks_per_cu) *blocks_per_cu = c->blocks_per_cu;
+    if (blocks) *blocks = (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
+    if (blocks_per_cu) *blocks_per_cu = (c->variant == 3) ? c->blocks_per_cu3 : c->blocks_per_cu;
     return 0;
 }
+
+int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
+{
+    if (!c || (variant != 2 && variant != 3)) return HBS_E_ARG;
+    c->variant = variant;
+    return 0;
+}
+
+int hbs_ctx_get_kernel(hbs_ctx* c) { return c ? c->variant : HBS_E_ARG; }
 
 int hbs_ctx_use_own_stream(hbs_ctx* c)
 {
@@ -194,7 +213,8 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.index = d_index; a.index_cap = index_cap;
     a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
     a.desc = c->desc; a.hdr = c->hdr; a.summary = d_summary;
-    a.grid_blocks = c->grid_blocks;
+    a.variant = c->variant;
+    a.grid_blocks = (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
     a.ev_begin = c->timing ? c->ev0 : nullptr;
     a.ev_end = c->timing ? c->ev1 : nullptr;
     c->ev_valid = (c->timing && n) ? 1 : 0;

@@ -1,0 +1,78 @@
+/*
+ * hbs_chunk.h -- 16-byte-chunk form of the tile logic for the register-resident
+ * scan/extract kernel (hbs_scan3.hip): a lane holds one 16-byte chunk of the
+ * stream in four VGPRs plus the dword in front (xp) and behind (xn), and
+ * everything hbs_tile.h does per 64-byte block of an LDS image happens here
+ * per chunk straight from registers: same window rules, same walk_block /
+ * emit_block code (instantiated with B = 16 over a RegView).
+ * Compiles for gfx950 and, under tests/sim, for the host.
+ */
+#ifndef HBS_CHUNK_H
+#define HBS_CHUNK_H
+
+#include "hbs_tile.h"
+
+namespace hbs {
+
+constexpr int kChunk = 16;
+
+/* bytes [-4, 20) around a chunk come from registers, anything else from the stream */
+struct RegView {
+    uint32_t xp, x0, x1, x2, x3, xn;
+    const uint8_t* stream;
+    uint64_t g0;          /* stream offset of the chunk's first byte */
+    uint64_t n;
+
+    HBS_M uint32_t byte(int32_t o) const
+    {
+        if (o >= -4 && o < 20) {
+            const uint32_t k = (uint32_t)(o + 4) >> 2;
+            uint32_t d = (k == 0) ? xp : (k == 1) ? x0 : (k == 2) ? x1 : (k == 3) ? x2 : (k == 4) ? x3 : xn;
+            return (d >> (8u * ((uint32_t)(o + 4) & 3u))) & 0xFFu;
+        }
+        const int64_t q = (int64_t)g0 + o;
+        return (q >= 0 && (uint64_t)q < n) ? stream[q] : 0xFFu;
+    }
+};
+
+/* conservative filter: may any pattern 00 00 {<=3} end at bytes [0, 18) of this chunk? */
+HBS_HD bool chunk_maybe_pattern(uint32_t xp, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t xn)
+{
+    const uint32_t ap = zero_bytes_approx(xp), a0 = zero_bytes_approx(x0), a1 = zero_bytes_approx(x1);
+    const uint32_t a2 = zero_bytes_approx(x2), a3 = zero_bytes_approx(x3), an = zero_bytes_approx(xn);
+    /* adjacent zero pairs ending at bytes -1 .. 16 (a pattern ending at j needs the pair ending at j-1) */
+    const uint32_t lead = ap & (ap << 8) & 0x80000000u;                       /* pair (-2,-1) */
+    const uint32_t mid = (a0 & alignbyte(a0, ap, 3)) | (a1 & alignbyte(a1, a0, 3)) |
+                         (a2 & alignbyte(a2, a1, 3)) | (a3 & alignbyte(a3, a2, 3));   /* pairs ending at 0..15 */
+    const uint32_t tail = an & alignbyte(an, a3, 3) & 0x80u;                   /* pair (15,16) */
+    return (lead | mid | tail) != 0;
+}
+
+/* exact pattern-end masks: bits 0..15 = patterns ending inside the chunk, bits 16,17 = in the
+ * first two bytes behind it */
+HBS_HD uint32_t chunk_patterns(uint32_t xp, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t xn)
+{
+    uint32_t z = zero_bytes(xp);
+    const uint32_t p0 = pattern_marks(x0, z), p1 = pattern_marks(x1, z), p2 = pattern_marks(x2, z), p3 = pattern_marks(x3, z);
+    const uint32_t pn = pattern_marks(xn, z);
+    return movemask4(p0) | (movemask4(p1) << 4) | (movemask4(p2) << 8) | (movemask4(p3) << 12) | ((movemask4(pn) & 3u) << 16);
+}
+
+/* kept bytes of a chunk with holes, packed low-to-high into lo/hi, straight from registers */
+HBS_HD uint32_t compact_chunk_regs(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t keep16, uint64_t& lo, uint64_t& hi)
+{
+    const uint64_t src_lo = ((uint64_t)x1 << 32) | x0, src_hi = ((uint64_t)x3 << 32) | x2;
+    lo = 0; hi = 0;
+    uint32_t o = 0;
+    for (uint32_t r = keep16; r != 0; r &= r - 1, ++o) {
+        const uint32_t pos = (uint32_t)__builtin_ctz(r);
+        const uint64_t b = (((pos < 8) ? src_lo : src_hi) >> (8u * (pos & 7u))) & 0xFFull;
+        const uint64_t val = b << (8u * (o & 7u));
+        lo |= (o < 8) ? val : 0ull;
+        hi |= (o < 8) ? 0ull : val;
+    }
+    return o;
+}
+
+} // namespace hbs
+#endif

@@ -552,8 +552,11 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         uint64_t grid = (uint64_t)a.grid_blocks;
         if (grid > num_tiles) grid = num_tiles;
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
-        k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
-            a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr);
+        if (a.variant == 3)
+            launch_scan_extract3_kernel(a, num_tiles, st);
+        else
+            k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
+                a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr);
         if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
     }
     k_tail_fixup<<<1, 1, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);

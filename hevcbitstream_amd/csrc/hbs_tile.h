@@ -109,7 +109,8 @@ enum : int { kPatEpb = 0, kPatErr = 1, kPatStart = 2, kPatStop = 3, kPatSkip = 4
  *   a start code found while advancing needs i+4 < size (:52): gj <= n-3 always
  *   satisfies it; the two later positions are settled by tail_fixup().
  */
-HBS_HD int pattern_kind(const TileView& v, int32_t o, uint64_t gj, uint64_t n)
+template <class View>
+HBS_HD int pattern_kind(const View& v, int32_t o, uint64_t gj, uint64_t n)
 {
     const uint32_t b = v.byte(o);
     if (b == 3) return kPatEpb;
@@ -198,10 +199,11 @@ HBS_HD uint64_t block_patterns(const TileView& v, int32_t o, uint32_t& aprev)
  * o = logical offset of the block in the tile image, g0 = its stream offset,
  * pat_next = patterns ending in the first two bytes of the next block.
  */
-HBS_HD void walk_block(const TileView& v, int32_t o, uint64_t g0, uint64_t n,
-                       uint64_t pat, uint32_t pat_next, BlockMarks& m, BlockSum& s)
+template <int B, class View>
+HBS_HD void walk_block_t(const View& v, int32_t o, uint64_t g0, uint64_t n,
+                         uint64_t pat, uint32_t pat_next, BlockMarks& m, BlockSum& s)
 {
-    const uint32_t nvalid = (g0 >= n) ? 0u : (n - g0 >= 64 ? 64u : (uint32_t)(n - g0));
+    const uint32_t nvalid = (g0 >= n) ? 0u : (n - g0 >= (uint64_t)B ? (uint32_t)B : (uint32_t)(n - g0));
     m.cand = below(nvalid);
     m.ev = m.ev_start = m.err = 0;
 
@@ -226,10 +228,10 @@ HBS_HD void walk_block(const TileView& v, int32_t o, uint64_t g0, uint64_t n,
     /* terminators that end in the next block exclude our last bytes */
     for (uint32_t b = 0; b < 2; ++b) {
         if (pat_next & (1u << b)) {
-            const uint32_t j = 64 + b;
+            const uint32_t j = (uint32_t)B + b;
             const int kind = pattern_kind(v, o + (int32_t)j, g0 + j, n);
             if (kind == kPatStart || kind == kPatStop)
-                m.cand &= ~((b == 0) ? (3ull << 62) : (1ull << 63));
+                m.cand &= ~((b == 0) ? (3ull << (B - 2)) : (1ull << (B - 1)));
         }
     }
 
@@ -252,6 +254,12 @@ HBS_HD void walk_block(const TileView& v, int32_t o, uint64_t g0, uint64_t n,
     s.known = known;
     s.carry = carry;
     s.last = last;
+}
+
+HBS_HD void walk_block(const TileView& v, int32_t o, uint64_t g0, uint64_t n,
+                       uint64_t pat, uint32_t pat_next, BlockMarks& m, BlockSum& s)
+{
+    walk_block_t<kBlockBytes, TileView>(v, o, g0, n, pat, pat_next, m, s);
 }
 
 /* summary of a block as an element of the tile algebra */
@@ -340,8 +348,9 @@ HBS_D void flag_error(RunHeader* hdr, uint32_t code)
  * mask.  nal_ord = number of NAL starts before this block (global ordinal of
  * the next NAL to open); rbsp_pos = arena offset of the block's first kept byte.
  */
-HBS_D uint64_t emit_block(const TileView& v, int32_t o, uint64_t g0, const BlockMarks& m, bool inside,
-                          uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
+template <int B, class View>
+HBS_D uint64_t emit_block_t(const View& v, int32_t o, uint64_t g0, const BlockMarks& m, bool inside,
+                            uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
 {
     uint64_t inside_mask = 0;
     uint32_t cur = 0;
@@ -377,7 +386,7 @@ HBS_D uint64_t emit_block(const TileView& v, int32_t o, uint64_t g0, const Block
         }
         cur = e + 1;
     }
-    if (inside) inside_mask |= ~below(cur);
+    if (inside) inside_mask |= below((uint32_t)B) & ~below(cur);
 
     for (uint64_t r = m.err & inside_mask; r != 0; r &= r - 1) {
         const uint32_t pos = ctz64(r);
@@ -385,6 +394,12 @@ HBS_D uint64_t emit_block(const TileView& v, int32_t o, uint64_t g0, const Block
         if (k < tgt.index_cap) atomic_or_status(&tgt.index[k], HBS_ST_ERROR);
     }
     return m.cand & inside_mask;
+}
+
+HBS_D uint64_t emit_block(const TileView& v, int32_t o, uint64_t g0, const BlockMarks& m, bool inside,
+                          uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
+{
+    return emit_block_t<kBlockBytes, TileView>(v, o, g0, m, inside, nal_ord, rbsp_pos, tgt);
 }
 
 /*

@@ -13,6 +13,8 @@ d1 = torch.from_numpy(base).cuda()
 d = d1.repeat(reps)
 n = d.numel()
 ctx = hbs.Context(0)
+import os
+if os.environ.get('HBS_KERNEL'): print('kernel variant', ctx.kernel())
 index, rbsp, summary, cap = ctx.alloc_outputs(n, index_cap=1600 * reps + 16)
 print("stream bytes", n, "grid", "cap", cap)
 for it in range(3):

@@ -25,6 +25,8 @@ def lib():
         _lib.sim_index_extract.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.sim_index_extract.restype = C.c_int
+        _lib.sim3_index_extract.argtypes = _lib.sim_index_extract.argtypes
+        _lib.sim3_index_extract.restype = C.c_int
         _lib.sim_emit_annexb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.sim_emit_annexb.restype = C.c_int64
         _lib.sim_synth_rbsp.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
@@ -32,7 +34,10 @@ def lib():
     return _lib
 
 
-def index_extract(stream, index_cap=None, want_rbsp=True):
+VARIANT = 2          # 2: LDS-image kernel logic (hbs_tile.h), 3: register-resident kernel logic (hbs_chunk.h)
+
+
+def index_extract(stream, index_cap=None, want_rbsp=True, variant=None):
     stream = np.ascontiguousarray(stream, dtype=np.uint8)
     n = len(stream)
     # the device code reads the stream with guarded loads only; give the sim an exact-size buffer
@@ -40,7 +45,8 @@ def index_extract(stream, index_cap=None, want_rbsp=True):
     idx = np.zeros(max(cap, 1), dtype=NAL_ENTRY)
     arena = np.full(n + 32, 0xAB, dtype=np.uint8)
     summ = np.zeros(1, dtype=SUMMARY)
-    rc = lib().sim_index_extract(stream.ctypes.data if n else None, n, idx.ctypes.data, cap,
+    fn = lib().sim3_index_extract if (variant or VARIANT) == 3 else lib().sim_index_extract
+    rc = fn(stream.ctypes.data if n else None, n, idx.ctypes.data, cap,
                                  arena.ctypes.data if want_rbsp else None, n + 16, summ.ctypes.data)
     assert rc == 0, rc
     s = summ[0]

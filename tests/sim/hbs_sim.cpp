@@ -13,6 +13,7 @@
 #include <cstring>
 #include <vector>
 #include "../../hevcbitstream_amd/csrc/hbs_tile.h"
+#include "../../hevcbitstream_amd/csrc/hbs_chunk.h"
 #include "../../hevcbitstream_amd/csrc/hbs_emit.h"
 #include "../../hevcbitstream_amd/csrc/hbs_parse.h"
 
@@ -226,4 +227,53 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
             parsed[k] = out;
         }
     return (int64_t)run;
+}
+
+/* register-resident variant (hbs_scan3.hip): the per-chunk logic of hbs_chunk.h in stream order */
+extern "C" int sim3_index_extract(const uint8_t* stream, uint64_t n,
+                                  hbs_nal_entry* index, uint64_t index_cap,
+                                  uint8_t* rbsp, uint64_t rbsp_cap, hbs_summary* sum)
+{
+    RunHeader hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.first_empty = ~0ull;
+    if (index_cap) memset(index, 0, index_cap * sizeof(hbs_nal_entry));
+    EmitTarget tgt{index, index_cap, &hdr};
+    Prefix run{0, 0, 0};
+    auto dword_at = [&](int64_t q) {
+        uint32_t v = 0;
+        for (int i = 0; i < 4; ++i) v |= (uint32_t)byte_at(stream, q + i, n) << (8 * i);
+        return v;
+    };
+    for (uint64_t g0 = 0; g0 < n; g0 += kChunk) {
+        RegView v;
+        v.xp = dword_at((int64_t)g0 - 4); v.x0 = dword_at((int64_t)g0); v.x1 = dword_at((int64_t)g0 + 4);
+        v.x2 = dword_at((int64_t)g0 + 8); v.x3 = dword_at((int64_t)g0 + 12); v.xn = dword_at((int64_t)g0 + 16);
+        v.stream = stream; v.g0 = g0; v.n = n;
+        const uint32_t pats = chunk_patterns(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn);
+        if (!chunk_maybe_pattern(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn) && pats != 0) return -200;   /* filter must be conservative */
+        BlockMarks m;
+        BlockSum s;
+        walk_block_t<kChunk, RegView>(v, 0, g0, n, pats & 0xFFFFu, pats >> 16, m, s);
+        const TileAgg a = as_agg(s);
+        const uint64_t keep = emit_block_t<kChunk, RegView>(v, 0, g0, m, run.inside != 0, run.nals, run.kept, tgt);
+        const Prefix next = fold(run, a);
+        if (popc64(keep) != next.kept - run.kept) return -201;
+        if (rbsp != nullptr && keep != 0) {
+            if (next.kept <= rbsp_cap) {
+                uint64_t lo, hi;
+                const uint32_t cnt = compact_chunk_regs(v.x0, v.x1, v.x2, v.x3, (uint32_t)keep, lo, hi);
+                for (uint32_t i = 0; i < cnt; ++i) rbsp[run.kept + i] = (uint8_t)(((i < 8) ? lo : hi) >> (8 * (i & 7)));
+            } else {
+                flag_error(&hdr, (uint32_t)(-HBS_E_CAPACITY));
+            }
+        }
+        run = next;
+    }
+    hdr.final_kept = run.kept; hdr.final_nals = run.nals; hdr.final_inside = run.inside;
+    uint8_t tail[8];
+    for (int i = 0; i < 8; ++i) tail[i] = byte_at(stream, (int64_t)n - 8 + i, n);
+    tail_fixup(&hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum);
+    for (uint64_t k = 0; k < hdr.final_nals; ++k) fill_rbsp_len(&hdr, index, index_cap, k);
+    return 0;
 }

@@ -9,6 +9,16 @@ from tests import _sim
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
+@pytest.fixture(autouse=True, params=[2, 3], ids=["lds-image", "registers"])
+def kernel_variant(request):
+    """both kernels' per-thread logic: hbs_tile.h (64-byte blocks over an LDS image) and
+    hbs_chunk.h (16-byte chunks in registers)"""
+    old = _sim.VARIANT
+    _sim.VARIANT = request.param
+    yield
+    _sim.VARIANT = old
+
+
 def check(orc, stream):
     stream = np.ascontiguousarray(stream, dtype=np.uint8)
     want_idx, want_arena, why = orc.index_extract(stream)
