@@ -439,7 +439,6 @@ void k_scan_extract3(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
          * emit pass without a second register set. */
         const bool more = tile + gridDim.x < num_tiles;
         const uint64_t next_seg = (tile + gridDim.x) * (uint64_t)k3TileBytes + (uint64_t)(wv * k3WaveBytes);
-        const bool next_whole = more && next_seg + k3WaveBytes + 4 <= n;
 
         /* ---- pass B: emit + copy, rows in order, running prefix in scalars ------------------- */
         const uint32_t tile_kept = tagg.known + (excl.inside ? tagg.sig : 0u);
@@ -478,15 +477,11 @@ void k_scan_extract3(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                     }
                 }
                 e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
-                if (next_whole) load_row(cur, r, reinterpret_cast<const u32x4*>(stream + next_seg + (uint64_t)(r * k3RowBytes)) + lane);
-                else if (more) set_row(cur, r, load_chunk_guarded(stream, next_seg + (uint64_t)(r * k3RowBytes + 16 * lane), n));
             }
         }
-        if (more) {
-            cur.after = next_whole ? *reinterpret_cast<const uint32_t*>(stream + next_seg + k3WaveBytes)
-                                   : load_dword_guarded(stream, (int64_t)(next_seg + k3WaveBytes), n);
-            cur.before = (next_seg >= 4) ? *reinterpret_cast<const uint32_t*>(stream + next_seg - 4) : 0xFFFFFFFFu;
-        }
+        /* next tile: all rows at once, with static register names (inside the rolled loop the
+         * compiler cannot tell which row a pending load targets and waits for all of them) */
+        if (more) fetch_rows(cur, stream, next_seg, n, lane);
         HBS3_T_MARK(3)
         __syncthreads();                                  /* wave_agg / lb slots are reused by the next tile */
         HBS3_T_MARK(4)
