@@ -119,7 +119,7 @@ class Context:
             raise HbsError("%s failed: %d (%s)" % (what, rc, self.lib.hbs_last_error(self.h).decode()))
 
     def set_kernel(self, variant):
-        """2 = LDS-image scan/extract kernel, 3 = register-resident one"""
+        """2 = LDS-image scan/extract kernel, 3 = register-resident one, 4 = event-sparse one"""
         self._check(self.lib.hbs_ctx_set_kernel(self.h, variant), "hbs_ctx_set_kernel")
 
     def kernel(self):

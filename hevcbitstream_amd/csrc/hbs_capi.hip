@@ -17,6 +17,7 @@
 
 #ifndef HBS_DEFAULT_KERNEL
 #define HBS_DEFAULT_KERNEL 2
+#define HBS_DEFAULT_SCHED 1
 #endif
 
 struct hbs_ctx {
@@ -26,7 +27,9 @@ struct hbs_ctx {
     int grid_blocks;
     int blocks_per_cu;
     int grid_blocks3, blocks_per_cu3;   /* register-resident kernel */
+    int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
     int variant;
+    int sched;
     unsigned long long* desc;
     uint64_t desc_tiles;
     hbs::RunHeader* hdr;
@@ -106,10 +109,15 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks3 = hbs::scan3_grid_blocks(device, &c->blocks_per_cu3);
     if (c->grid_blocks3 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    c->grid_blocks4 = hbs::scan4_grid_blocks(device, &c->blocks_per_cu4);
+    if (c->grid_blocks4 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) { c->grid_blocks = atoi(g); c->grid_blocks3 = atoi(g) < c->grid_blocks3 ? atoi(g) : c->grid_blocks3; }
+    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
     const char* kv = getenv("HBS_KERNEL");              /* 2 = LDS-image kernel, 3 = register-resident kernel */
-    c->variant = (kv && atoi(kv) == 2) ? 2 : ((kv && atoi(kv) == 3) ? 3 : HBS_DEFAULT_KERNEL);
+    const char* sv = getenv("HBS_SCHED");
+    c->sched = (sv && atoi(sv) >= 0 && atoi(sv) <= 2) ? atoi(sv) : HBS_DEFAULT_SCHED;
+    c->variant = (kv && atoi(kv) >= 2 && atoi(kv) <= 4) ? atoi(kv) : HBS_DEFAULT_KERNEL;
     *out = c;
     return 0;
 }
@@ -158,14 +166,14 @@ int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
 int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 {
     if (!c) return HBS_E_ARG;
-    if (blocks) *blocks = (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
-    if (blocks_per_cu) *blocks_per_cu = (c->variant == 3) ? c->blocks_per_cu3 : c->blocks_per_cu;
+    if (blocks) *blocks = (c->variant == 4) ? c->grid_blocks4 : (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
+    if (blocks_per_cu) *blocks_per_cu = (c->variant == 4) ? c->blocks_per_cu4 : (c->variant == 3) ? c->blocks_per_cu3 : c->blocks_per_cu;
     return 0;
 }
 
 int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 {
-    if (!c || (variant != 2 && variant != 3)) return HBS_E_ARG;
+    if (!c || variant < 2 || variant > 4) return HBS_E_ARG;
     c->variant = variant;
     return 0;
 }
@@ -214,7 +222,8 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
     a.desc = c->desc; a.hdr = c->hdr; a.summary = d_summary;
     a.variant = c->variant;
-    a.grid_blocks = (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
+    a.sched = c->sched;
+    a.grid_blocks = (c->variant == 4) ? c->grid_blocks4 : (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
     a.ev_begin = c->timing ? c->ev0 : nullptr;
     a.ev_end = c->timing ? c->ev1 : nullptr;
     c->ev_valid = (c->timing && n) ? 1 : 0;

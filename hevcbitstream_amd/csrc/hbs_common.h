@@ -73,8 +73,11 @@ struct RunHeader {
     uint32_t error;           /* HBS_E_* (positive magnitude) or 0               */
     unsigned long long first_empty;  /* ordinal of the first empty NAL (min), init ~0 */
     uint32_t abort_flag;      /* set when a look-back wait timed out             */
-    uint32_t pad;
+    uint32_t pad0[23];
+    uint32_t ticket;          /* next unclaimed tile (dynamic tile schedules); alone on its 128-byte line */
+    uint32_t pad1[31];
 };
+static_assert(sizeof(RunHeader) == 256, "RunHeader layout");
 
 HBS_HD uint32_t popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 HBS_HD uint32_t ctz64(uint64_t v)  { return (uint32_t)__builtin_ctzll(v); }

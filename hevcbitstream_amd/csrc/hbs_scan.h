@@ -19,7 +19,8 @@ struct ScanArgs {
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
-    int variant;                  /* 2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip) */
+    int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */
+    int variant;                  /* 2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip) */
 };
 
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
@@ -29,6 +30,10 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st);
 /* register-resident variant (hbs_scan3.hip) */
 int scan3_grid_blocks(int device, int* blocks_per_cu_out);
 void launch_scan_extract3_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st);
+
+/* event-sparse variant (hbs_scan4.hip) */
+int scan4_grid_blocks(int device, int* blocks_per_cu_out);
+void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st);
 
 } // namespace hbs
 #endif

@@ -37,7 +37,11 @@ __device__ unsigned long long g_phase_cycles[1024][8];
 #define HBS_T_MARK(i) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
 #define HBS_T_COUNT(i, v) { t_acc[i] += (v); }
 #define HBS_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles[blockIdx.x][i] = t_acc[i]; }
+/* instruction-count experiments: drop the rest of the tile after phase i (results are then wrong) */
+__device__ int g_stop_after = 99;
+#define HBS_T_STOP(i) if (g_stop_after == (i)) break;
 #else
+#define HBS_T_STOP(i)
 #define HBS_T_DECL
 #define HBS_T_MARK(i)
 #define HBS_T_COUNT(i, v)
@@ -66,6 +70,7 @@ struct TileLds {
     uint32_t wave_known[kWaves];
     uint32_t wave_sig[kWaves];
     WaveSlot lb[2][4];
+    uint32_t ticket;                           /* tile number handed to this workgroup (dynamic schedules) */
 };
 
 /* 16 stream bytes at offset g (may straddle or exceed [0,n)): 0xFF outside */
@@ -314,7 +319,8 @@ __device__ __forceinline__ bool look_back(TileLds& l, unsigned long long* desc, 
             if (lane == (lstar & 63) && wv < 4) {
                 WaveSlot& sl = l.lb[par][wv];
                 sl.status = win_ok ? (lstar < 64 ? 2u : 1u) : 0u;
-                sl.abort = (wv == 0) ? __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                /* the abort flag is one line shared by every workgroup: look at it only while stalled for long */
+                sl.abort = (wv == 0 && (spins & 63u) == 63u) ? __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 sl.win = win;
                 sl.pre_kept = p.kept; sl.pre_nals = p.nals; sl.pre_inside = p.inside;
             }
@@ -386,11 +392,21 @@ __device__ __forceinline__ void store_holes(const TileView& v, uint8_t* out, uin
     if (cnt & 1u) { *p = (uint8_t)lo; }
 }
 
+enum : int { kSchedStriped = 0, kSchedTicketTop = 1, kSchedTicketAfterPrefix = 2 };
+
+/* next unclaimed tile, the same value in every thread (contains a barrier) */
+__device__ __forceinline__ uint64_t take_ticket(TileLds& l, RunHeader* hdr, int tid)
+{
+    if (tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+    __syncthreads();
+    return (uint64_t)l.ticket;
+}
+
 __global__ __launch_bounds__(kThreads, 4)
 void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                     hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                     uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
-                    unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr)
+                    unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched)
 {
     __shared__ TileLds l;
     const int tid0 = threadIdx.x;
@@ -401,12 +417,18 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
 
     const uint64_t full_tiles = n / (uint64_t)kTileBytes;      /* tiles [0, full_tiles) are complete */
     TileRegs nxt;
-    uint64_t tile = blockIdx.x;
-    if (tile < full_tiles) fetch_tile(nxt, stream, tile * (uint64_t)kTileBytes, tid0);
+    /* sched 0: tile i belongs to workgroup i mod grid; 1: tiles are handed out in
+     * arrival order at the top of the loop; 2: the next tile is taken (and its
+     * loads issued) once the current one has its prefix */
+    uint64_t tile = (sched == kSchedStriped) ? (uint64_t)blockIdx.x : take_ticket(l, hdr, tid0);
+    if (sched != kSchedTicketTop && tile < full_tiles) fetch_tile(nxt, stream, tile * (uint64_t)kTileBytes, tid0);
     HBS_T_DECL
 
-    for (; tile < num_tiles; tile += gridDim.x) {
+    while (tile < num_tiles) {
         const uint64_t tile_base = tile * (uint64_t)kTileBytes;
+        if (sched == kSchedTicketTop && tile < full_tiles) fetch_tile(nxt, stream, tile_base, launder(tid0));
+        uint64_t next_tile = tile + gridDim.x;
+        do {
         {
             const int t0 = launder(tid0);
             if (tile < full_tiles) stage_tile(l, nxt, t0);
@@ -415,21 +437,25 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
         }
         __syncthreads();
         HBS_T_MARK(0)
+        HBS_T_STOP(0)
         const int tid = launder(tid0);
 
         const int32_t o0 = kThreadBytes * tid;
         const uint64_t g0 = tile_base + (uint64_t)o0;
         const TileAgg mine = classify_thread(view, o0, g0, n, l.keep, tid);
         HBS_T_MARK(1)
+        HBS_T_STOP(1)
 
         TileAgg agg;
         const ThreadPrefix tp = block_scan(l, mine, tid, agg);
         HBS_T_MARK(2)
+        HBS_T_STOP(2)
 
         Prefix excl;
         uint32_t lb_iters, lb_stalls;
         if (!look_back(l, desc, tile, agg, hdr, tid, excl, lb_iters, lb_stalls)) return;
         HBS_T_MARK(3)
+        HBS_T_STOP(3)
         HBS_T_COUNT(7, ((unsigned long long)lb_stalls << 32) | lb_iters)
         if (tid == 0 && tile == num_tiles - 1) {
             const Prefix incl = fold(excl, agg);
@@ -438,7 +464,8 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
         /* Next tile's HBM reads fly under the emit and the gather.  They are issued
          * behind the look-back because loads return in order: a descriptor read
          * queued behind 16 tile loads would wait for all of them. */
-        if (tile + gridDim.x < full_tiles) fetch_tile(nxt, stream, (tile + gridDim.x) * (uint64_t)kTileBytes, launder(tid0));
+        if (sched == kSchedTicketAfterPrefix) next_tile = take_ticket(l, hdr, launder(tid0));
+        if (sched != kSchedTicketTop && next_tile < full_tiles) fetch_tile(nxt, stream, next_tile * (uint64_t)kTileBytes, launder(tid0));
 
         const uint64_t ex_kept = excl.kept;
         const uint32_t tile_kept = agg.known + (excl.inside ? agg.sig : 0u);
@@ -451,6 +478,7 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
         if (tid == 0) l.slow_cnt = 0;
         __syncthreads();
         HBS_T_MARK(4)
+        HBS_T_STOP(4)
 
         if (rbsp != nullptr && tile_kept != 0) {
             if (ex_kept + tile_kept <= rbsp_cap) {
@@ -484,11 +512,18 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
         }
         __syncthreads();
         HBS_T_MARK(6)
+        } while (0);
+        if (sched == kSchedTicketTop) next_tile = take_ticket(l, hdr, launder(tid0));
+        tile = next_tile;
     }
     HBS_T_FLUSH
 }
 
 #ifdef HBS_PHASE_TIMING
+extern "C" int hbs_debug_set_stop(int phase)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stop_after), &phase, sizeof(int));
+}
 extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] */)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 1024 * 8);
@@ -498,7 +533,7 @@ extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] 
 __global__ void k_init_header(RunHeader* hdr)
 {
     hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
-    hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->pad = 0;
+    hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
 }
 
 __global__ void k_tail_fixup(const uint8_t* __restrict__ stream, uint64_t n,
@@ -554,9 +589,11 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
         if (a.variant == 3)
             launch_scan_extract3_kernel(a, num_tiles, st);
+        else if (a.variant == 4)
+            launch_scan_extract4_kernel(a, num_tiles, st);
         else
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
-                a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr);
+                a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched);
         if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
     }
     k_tail_fixup<<<1, 1, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);

@@ -24,7 +24,7 @@
  * No LDS image, no staging pass, no per-thread search; LDS holds ~1 KiB.
  */
 #include <hip/hip_runtime.h>
-#include "hbs_chunk.h"
+#include "hbs_wave.h"
 #include "hbs_scan.h"
 
 namespace hbs {
@@ -42,16 +42,6 @@ __device__ unsigned long long g_phase_cycles3[1024][8];
 #define HBS3_T_FLUSH
 #endif
 
-constexpr int k3Threads = 512;
-constexpr int k3Waves = k3Threads / 64;
-constexpr int k3Rows = 8;                                  /* rows of 1 KiB per wavefront per tile */
-constexpr int k3RowBytes = 1024;
-constexpr int k3WaveBytes = k3Rows * k3RowBytes;           /* 8 KiB  */
-constexpr int k3TileBytes = k3Waves * k3WaveBytes;         /* 64 KiB */
-static_assert(k3TileBytes == kTileBytes, "both kernels share the descriptor workspace sizing");
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 struct WaveSlot3 {
     uint32_t status, abort;
     TileAgg win;
@@ -63,83 +53,6 @@ struct Lds3 {
     TileAgg wave_agg[k3Waves];
     WaveSlot3 lb[2][4];
 };
-
-#define HBS_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-
-/* one wavefront's 8 KiB: 8 rows in named registers + the dwords just outside */
-struct Rows {
-#define HBS_DECL(r) u32x4 q##r;
-    HBS_REP8(HBS_DECL)
-#undef HBS_DECL
-    uint32_t before;          /* dword in front of the segment (0xFFFFFFFF before the stream) */
-    uint32_t after;           /* dword behind it (0xFF bytes past the end of the stream)      */
-};
-
-__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* __restrict__ s, int64_t g, uint64_t n)
-{
-    if (g >= 0 && (uint64_t)g + 4 <= n) return *reinterpret_cast<const uint32_t*>(s + g);
-    uint32_t v = 0xFFFFFFFFu;
-    for (int b = 0; b < 4; ++b) {
-        const int64_t q = g + b;
-        if (q >= 0 && (uint64_t)q < n) v = (v & ~(0xFFu << (8 * b))) | ((uint32_t)s[q] << (8 * b));
-    }
-    return v;
-}
-
-__device__ __forceinline__ u32x4 load_chunk_guarded(const uint8_t* __restrict__ s, uint64_t g, uint64_t n)
-{
-    if (g + 16 <= n) return *reinterpret_cast<const u32x4*>(s + g);
-    u32x4 v;
-    v.x = load_dword_guarded(s, (int64_t)g, n);
-    v.y = load_dword_guarded(s, (int64_t)g + 4, n);
-    v.z = load_dword_guarded(s, (int64_t)g + 8, n);
-    v.w = load_dword_guarded(s, (int64_t)g + 12, n);
-    return v;
-}
-
-/* fetch the segment that starts at stream offset seg (multiple of 8 KiB) */
-__device__ __forceinline__ void fetch_rows(Rows& R, const uint8_t* __restrict__ s, uint64_t seg, uint64_t n, int lane)
-{
-    if (seg + k3WaveBytes + 4 <= n) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(s + seg) + lane;
-#define HBS_LD(r) R.q##r = p[r * 64];
-        HBS_REP8(HBS_LD)
-#undef HBS_LD
-        R.after = *reinterpret_cast<const uint32_t*>(s + seg + k3WaveBytes);
-    } else {
-#define HBS_LD(r) R.q##r = load_chunk_guarded(s, seg + (uint64_t)(r * k3RowBytes + 16 * lane), n);
-        HBS_REP8(HBS_LD)
-#undef HBS_LD
-        R.after = load_dword_guarded(s, (int64_t)(seg + k3WaveBytes), n);
-    }
-    R.before = (seg >= 4) ? *reinterpret_cast<const uint32_t*>(s + seg - 4) : 0xFFFFFFFFu;
-}
-
-/* lane l <- value of lane l-1 (lane 0 <- edge) / lane l+1 (lane 63 <- edge) */
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, uint32_t edge)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t edge)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
 
 /* what a lane knows about its chunk inside a non-trivial row, after the row scan */
 struct LanePos {
@@ -198,47 +111,6 @@ __device__ __forceinline__ bool row_classify(const u32x4& q, uint32_t edge_prev,
     return true;
 }
 
-struct __attribute__((packed, aligned(1))) Unaligned16_3 { u32x4 v; };
-struct __attribute__((packed, aligned(1))) U8_3 { uint64_t v; };
-struct __attribute__((packed, aligned(1))) U4_3 { uint32_t v; };
-struct __attribute__((packed, aligned(1))) U2_3 { uint16_t v; };
-
-__device__ __forceinline__ void store_pieces(uint8_t* p, uint64_t lo, uint64_t hi, uint32_t cnt)
-{
-    if (cnt & 8u) { reinterpret_cast<U8_3*>(p)->v = lo; p += 8; lo = hi; }
-    if (cnt & 4u) { reinterpret_cast<U4_3*>(p)->v = (uint32_t)lo; p += 4; lo >>= 32; }
-    if (cnt & 2u) { reinterpret_cast<U2_3*>(p)->v = (uint16_t)lo; p += 2; lo >>= 16; }
-    if (cnt & 1u) { *p = (uint8_t)lo; }
-}
-
-/* decoupled look-back, 256 tiles per step (waves 0-3 inspect descriptors); as in hbs_scan.hip */
-__device__ __forceinline__ uint64_t ld_desc3(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_desc3(unsigned long long* p, uint64_t v) { __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ TileAgg window_fold3(const TileAgg& a, int lstar, int lane)
-{
-    const uint64_t need = (lstar >= 64) ? ~0ull : ((1ull << lstar) - 1ull);
-    const bool mine = lane < lstar;
-    const uint64_t m_ev = __ballot(mine && a.last != kKindNone) & need;
-    const uint64_t m_st = __ballot(mine && a.last == kKindStart) & need;
-    const uint64_t above = (lane >= 63) ? 0ull : (m_ev & ~((2ull << lane) - 1ull));
-    uint32_t st = 2u;
-    if (above != 0) st = (uint32_t)((m_st >> __builtin_ctzll(above)) & 1ull);
-    uint32_t k = 0, g = 0, c = 0;
-    if (mine) {
-        k = a.known + (st == 1u ? a.sig : 0u);
-        g = (st == 2u) ? a.sig : 0u;
-        c = a.cnt;
-    }
-    TileAgg w;
-    w.known = wave_sum32(k);
-    w.sig = wave_sum32(g);
-    w.cnt = wave_sum32(c);
-    w.last = kKindNone;
-    if (m_ev != 0) w.last = ((m_st >> __builtin_ctzll(m_ev)) & 1ull) ? kKindStart : kKindStop;
-    return w;
-}
-
 __device__ __forceinline__ bool look_back3(Lds3& l, unsigned long long* desc, uint64_t tile, const TileAgg& mine,
                                            RunHeader* hdr, int tid, Prefix& excl)
 {
@@ -275,7 +147,7 @@ __device__ __forceinline__ bool look_back3(Lds3& l, unsigned long long* desc, ui
                 if (lane == (lstar & 63)) {
                     WaveSlot3& sl = l.lb[par][wv];
                     sl.status = win_ok ? (lstar < 64 ? 2u : 1u) : 0u;
-                    sl.abort = (wv == 0) ? __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    sl.abort = (wv == 0 && (spins & 63u) == 63u) ? __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                     sl.win = win;
                     sl.pre_kept = p.kept; sl.pre_nals = p.nals; sl.pre_inside = p.inside;
                 }

@@ -1,0 +1,165 @@
+/*
+ * hbs_wave.h -- wavefront-level helpers shared by the register-resident kernels
+ * (hbs_scan3.hip, hbs_scan4.hip): the 8-row register image of one wavefront's
+ * 8 KiB, guarded loads at the stream edges, DPP neighbour access, wave scans,
+ * byte-aligned stores, and the look-back descriptor accessors.  Device only.
+ */
+#ifndef HBS_WAVE_H
+#define HBS_WAVE_H
+
+#include <hip/hip_runtime.h>
+#include "hbs_chunk.h"
+
+namespace hbs {
+
+constexpr int k3Threads = 512;
+constexpr int k3Waves = k3Threads / 64;
+constexpr int k3Rows = 8;                                  /* rows of 1 KiB per wavefront per tile */
+constexpr int k3RowBytes = 1024;
+constexpr int k3WaveBytes = k3Rows * k3RowBytes;           /* 8 KiB  */
+constexpr int k3TileBytes = k3Waves * k3WaveBytes;         /* 64 KiB */
+static_assert(k3TileBytes == kTileBytes, "both kernels share the descriptor workspace sizing");
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define HBS_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+/* one wavefront's 8 KiB: 8 rows in named registers + the dwords just outside */
+struct Rows {
+#define HBS_DECL(r) u32x4 q##r;
+    HBS_REP8(HBS_DECL)
+#undef HBS_DECL
+    uint32_t before;          /* dword in front of the segment (0xFFFFFFFF before the stream) */
+    uint32_t after;           /* dword behind it (0xFF bytes past the end of the stream)      */
+};
+
+/* Loads that may straddle either end of the stream (bytes outside read as 0xFF).  Rolled byte
+ * loops on purpose: these run for the one tile that holds the stream end and for elements next
+ * to it, and unrolled they would be most of the kernel's code. */
+__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* __restrict__ s, int64_t g, uint64_t n)
+{
+    if (g >= 0 && (uint64_t)g + 4 <= n) return *reinterpret_cast<const uint32_t*>(s + g);
+    uint32_t v = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+        const int64_t q = g + b;
+        if (q >= 0 && (uint64_t)q < n) v = (v & ~(0xFFu << (8 * b))) | ((uint32_t)s[q] << (8 * b));
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32x4 load_chunk_guarded(const uint8_t* __restrict__ s, uint64_t g, uint64_t n)
+{
+    if (g + 16 <= n) return *reinterpret_cast<const u32x4*>(s + g);
+    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu, w3 = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (uint32_t b = 0; b < 16; ++b) {
+        if (g + b < n) {
+            const uint32_t m = ~(0xFFu << (8u * (b & 3u)));
+            const uint32_t x = (uint32_t)s[g + b] << (8u * (b & 3u));
+            if ((b >> 2) == 0) w0 = (w0 & m) | x;
+            else if ((b >> 2) == 1) w1 = (w1 & m) | x;
+            else if ((b >> 2) == 2) w2 = (w2 & m) | x;
+            else w3 = (w3 & m) | x;
+        }
+    }
+    u32x4 v;
+    v.x = w0; v.y = w1; v.z = w2; v.w = w3;
+    return v;
+}
+
+/* fetch the segment that starts at stream offset seg (multiple of 8 KiB) */
+__device__ __forceinline__ void fetch_rows(Rows& R, const uint8_t* __restrict__ s, uint64_t seg, uint64_t n, int lane)
+{
+    if (seg + k3WaveBytes + 4 <= n) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(s + seg) + lane;
+#define HBS_LD(r) R.q##r = p[r * 64];
+        HBS_REP8(HBS_LD)
+#undef HBS_LD
+        R.after = *reinterpret_cast<const uint32_t*>(s + seg + k3WaveBytes);
+    } else {
+#define HBS_LD(r) R.q##r = load_chunk_guarded(s, seg + (uint64_t)(r * k3RowBytes + 16 * lane), n);
+        HBS_REP8(HBS_LD)
+#undef HBS_LD
+        R.after = load_dword_guarded(s, (int64_t)(seg + k3WaveBytes), n);
+    }
+    R.before = (seg >= 4) ? *reinterpret_cast<const uint32_t*>(s + seg - 4) : 0xFFFFFFFFu;
+}
+
+/* Opaque copy of a lane-constant value: hipcc otherwise hoists every address and predicate that
+ * only depends on the lane out of the tile loop and spills the lot around it. */
+__device__ __forceinline__ int launder_lane(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+/* lane l <- value of lane l-1 (lane 0 <- edge) / lane l+1 (lane 63 <- edge) */
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, uint32_t edge)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t edge)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct __attribute__((packed, aligned(1))) Unaligned16_3 { u32x4 v; };
+struct __attribute__((packed, aligned(1))) U8_3 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) U4_3 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U2_3 { uint16_t v; };
+
+__device__ __forceinline__ void store_pieces(uint8_t* p, uint64_t lo, uint64_t hi, uint32_t cnt)
+{
+    if (cnt & 8u) { reinterpret_cast<U8_3*>(p)->v = lo; p += 8; lo = hi; }
+    if (cnt & 4u) { reinterpret_cast<U4_3*>(p)->v = (uint32_t)lo; p += 4; lo >>= 32; }
+    if (cnt & 2u) { reinterpret_cast<U2_3*>(p)->v = (uint16_t)lo; p += 2; lo >>= 16; }
+    if (cnt & 1u) { *p = (uint8_t)lo; }
+}
+
+/* decoupled look-back, 256 tiles per step (waves 0-3 inspect descriptors); as in hbs_scan.hip */
+__device__ __forceinline__ uint64_t ld_desc3(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_desc3(unsigned long long* p, uint64_t v) { __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ TileAgg window_fold3(const TileAgg& a, int lstar, int lane)
+{
+    const uint64_t need = (lstar >= 64) ? ~0ull : ((1ull << lstar) - 1ull);
+    const bool mine = lane < lstar;
+    const uint64_t m_ev = __ballot(mine && a.last != kKindNone) & need;
+    const uint64_t m_st = __ballot(mine && a.last == kKindStart) & need;
+    const uint64_t above = (lane >= 63) ? 0ull : (m_ev & ~((2ull << lane) - 1ull));
+    uint32_t st = 2u;
+    if (above != 0) st = (uint32_t)((m_st >> __builtin_ctzll(above)) & 1ull);
+    uint32_t k = 0, g = 0, c = 0;
+    if (mine) {
+        k = a.known + (st == 1u ? a.sig : 0u);
+        g = (st == 2u) ? a.sig : 0u;
+        c = a.cnt;
+    }
+    TileAgg w;
+    w.known = wave_sum32(k);
+    w.sig = wave_sum32(g);
+    w.cnt = wave_sum32(c);
+    w.last = kKindNone;
+    if (m_ev != 0) w.last = ((m_st >> __builtin_ctzll(m_ev)) & 1ull) ? kKindStart : kKindStop;
+    return w;
+}
+
+} // namespace hbs
+#endif

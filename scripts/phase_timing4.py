@@ -1,0 +1,38 @@
+"""Diagnostic for the event-sparse kernel (hbs_scan4.hip): per-phase shader-clock sums per workgroup."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+so = "build/diag/libhbs_diag.so"      # built by `make diag` in the dev container
+assert os.path.exists(so), "run `make diag` first"
+import hevcbitstream_amd.api as api
+api.library_path = lambda: so
+import hevcbitstream_amd as hbs
+from tests import _orc
+orc = _orc.oracle()
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+want_rbsp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
+d = torch.from_numpy(base).cuda().repeat(64)
+ctx = hbs.Context(0)
+ctx.set_kernel(4)
+blocks, per_cu = ctx.grid()
+index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * 64 + 16)
+for _ in range(3):
+    ctx.index_extract_async(d, index, cap, rbsp if want_rbsp else None, summary)
+torch.cuda.synchronize()
+out = np.zeros((1024, 8), dtype=np.uint64)
+lib = api.load_library()
+lib.hbs_debug_phase_cycles4.argtypes = [C.c_void_p]
+assert lib.hbs_debug_phase_cycles4(out.ctypes.data) == 0
+names = ["ticket+fetch issue", "flags+list", "elements A", "lookback", "elements B", "copy"]
+nwg = min(blocks, 1024)
+act = out[:nwg, :6].astype(np.float64)
+tile_bytes = int(os.environ.get("HBS4_TILE", 65536))
+tiles = d.numel() / tile_bytes / blocks
+tot = act.sum(axis=1).mean()
+print("v4 mode", mode, "rbsp", want_rbsp, "grid", blocks, "per CU", per_cu, "tiles/WG %.1f -> cycles/tile %.0f" % (tiles, tot / tiles))
+lb = out[:nwg, 7]
+print("  look-back steps/tile %.2f, of which stalled %.2f" % ((lb & 0xFFFFFFFF).astype(np.float64).mean() / tiles, (lb >> 32).astype(np.float64).mean() / tiles))
+for i, nm in enumerate(names):
+    print("  %-18s %8.0f cyc/tile  %5.1f%%   (min WG %.0f, max WG %.0f)" % (nm, act[:, i].mean() / tiles, 100 * act[:, i].mean() / tot,
+                                                                   act[:, i].min() / tiles, act[:, i].max() / tiles))

@@ -27,6 +27,8 @@ def lib():
         _lib.sim_index_extract.restype = C.c_int
         _lib.sim3_index_extract.argtypes = _lib.sim_index_extract.argtypes
         _lib.sim3_index_extract.restype = C.c_int
+        _lib.sim4_index_extract.argtypes = _lib.sim_index_extract.argtypes
+        _lib.sim4_index_extract.restype = C.c_int
         _lib.sim_emit_annexb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.sim_emit_annexb.restype = C.c_int64
         _lib.sim_synth_rbsp.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
@@ -45,7 +47,7 @@ def index_extract(stream, index_cap=None, want_rbsp=True, variant=None):
     idx = np.zeros(max(cap, 1), dtype=NAL_ENTRY)
     arena = np.full(n + 32, 0xAB, dtype=np.uint8)
     summ = np.zeros(1, dtype=SUMMARY)
-    fn = lib().sim3_index_extract if (variant or VARIANT) == 3 else lib().sim_index_extract
+    fn = {2: lib().sim_index_extract, 3: lib().sim3_index_extract, 4: lib().sim4_index_extract}[variant or VARIANT]
     rc = fn(stream.ctypes.data if n else None, n, idx.ctypes.data, cap,
                                  arena.ctypes.data if want_rbsp else None, n + 16, summ.ctypes.data)
     assert rc == 0, rc

@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../hevcbitstream_amd/csrc/hbs_tile.h"
 #include "../../hevcbitstream_amd/csrc/hbs_chunk.h"
+#include "../../hevcbitstream_amd/csrc/hbs_sparse.h"
 #include "../../hevcbitstream_amd/csrc/hbs_emit.h"
 #include "../../hevcbitstream_amd/csrc/hbs_parse.h"
 
@@ -227,6 +228,106 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
             parsed[k] = out;
         }
     return (int64_t)run;
+}
+
+/* event-sparse variant (hbs_scan4.hip): flag test, elements with gaps, segment words -- tile by
+ * tile as the kernel does it, the look-back replaced by a running prefix */
+extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
+                                  hbs_nal_entry* index, uint64_t index_cap,
+                                  uint8_t* rbsp, uint64_t rbsp_cap, hbs_summary* sum)
+{
+    RunHeader hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.first_empty = ~0ull;
+    if (index_cap) memset(index, 0, index_cap * sizeof(hbs_nal_entry));
+    EmitTarget tgt{index, index_cap, &hdr};
+    Prefix run{0, 0, 0};
+    auto dword_at = [&](int64_t q) {
+        uint32_t v = 0;
+        for (int i = 0; i < 4; ++i) v |= (uint32_t)byte_at(stream, q + i, n) << (8 * i);
+        return v;
+    };
+    auto view_at = [&](uint64_t g0) {
+        RegView v;
+        v.xp = dword_at((int64_t)g0 - 4); v.x0 = dword_at((int64_t)g0); v.x1 = dword_at((int64_t)g0 + 4);
+        v.x2 = dword_at((int64_t)g0 + 8); v.x3 = dword_at((int64_t)g0 + 12); v.xn = dword_at((int64_t)g0 + 16);
+        v.stream = stream; v.g0 = g0; v.n = n;
+        return v;
+    };
+    const uint64_t num_tiles = (n + k4TileBytes - 1) / k4TileBytes;
+    std::vector<uint32_t> list, seg;
+    std::vector<uint8_t> flagged(k4ChunksPerTile);
+    for (uint64_t tile = 0; tile < num_tiles; ++tile) {
+        const uint64_t base = tile * (uint64_t)k4TileBytes, tile_end = base + k4TileBytes;
+        list.clear();
+        for (uint32_t c = 0; c < (uint32_t)k4ChunksPerTile; ++c) {
+            const uint64_t g = base + 16ull * c;
+            const RegView v = view_at(g);
+            bool f = chunk_flag(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn);
+            if (!f && g < n && chunk_patterns(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn) != 0) return -210;   /* the test must be conservative */
+            f = f || (g < n && n < g + 16);
+            flagged[c] = f;
+            if (f) list.push_back(c);
+        }
+        /* phase 0: tile aggregate */
+        TileAgg acc = agg_identity();
+        for (size_t i = 0; i < list.size(); ++i) {
+            const uint64_t prev_end = i ? base + 16ull * (list[i - 1] + 1u) : base;
+            const RegView v = view_at(base + 16ull * list[i]);
+            BlockMarks m; BlockSum s;
+            elem_walk(v, m, s);
+            acc = combine(acc, elem_agg(span_bytes(prev_end, v.g0, n), s));
+        }
+        const uint64_t last_end = list.empty() ? base : base + 16ull * (list.back() + 1u);
+        const TileAgg tagg = combine(acc, gap_agg(span_bytes(last_end, tile_end, n)));
+        const Prefix excl = run;
+        run = fold(run, tagg);
+        const uint32_t tile_kept = tagg.known + (excl.inside ? tagg.sig : 0u);
+        const bool can_store = rbsp != nullptr && excl.kept + tile_kept <= rbsp_cap;
+        if (rbsp != nullptr && !can_store) flag_error(&hdr, (uint32_t)(-HBS_E_CAPACITY));
+        uint8_t* out = rbsp + excl.kept;
+        /* phase 1: elements */
+        seg.assign(1, seg_pack(-1, 0u, excl.inside != 0u));
+        TileAgg accb = agg_identity();
+        for (size_t i = 0; i < list.size(); ++i) {
+            const uint64_t prev_end = i ? base + 16ull * (list[i - 1] + 1u) : base;
+            const RegView v = view_at(base + 16ull * list[i]);
+            BlockMarks m; BlockSum s;
+            elem_walk(v, m, s);
+            const uint32_t gap = span_bytes(prev_end, v.g0, n);
+            const ElemStart st = elem_start(accb, gap, excl.inside);
+            const uint32_t keep = (uint32_t)emit_block_t<kChunk, RegView>(v, 0, v.g0, m, st.inside, excl.nals + accb.cnt, excl.kept + st.kept, tgt);
+            const uint32_t nk = (uint32_t)__builtin_popcount(keep);
+            if (can_store && keep) {
+                uint64_t lo, hi;
+                const uint32_t cnt = compact_chunk_regs(v.x0, v.x1, v.x2, v.x3, keep, lo, hi);
+                for (uint32_t b = 0; b < cnt; ++b) out[st.kept + b] = (uint8_t)(((b < 8) ? lo : hi) >> (8 * (b & 7)));
+            }
+            const bool after = (s.last != kKindNone) ? (s.last == kKindStart) : st.inside;
+            seg.push_back(seg_pack((int32_t)list[i], st.kept + nk, after));
+            accb = combine(accb, elem_agg(gap, s));
+        }
+        /* copy of everything else */
+        uint32_t k = 0, copied_end = 0;
+        for (uint32_t c = 0; c < (uint32_t)k4ChunksPerTile; ++c) {
+            if (flagged[c]) { ++k; continue; }
+            const uint64_t g = base + 16ull * c;
+            if (g + 16 > n) continue;
+            const uint32_t w = seg[k];
+            if (!seg_inside(w)) continue;
+            const int64_t rank = (int64_t)seg_bias(w) + 16 * (int64_t)c;
+            if (rank < 0 || (uint64_t)rank + 16 > tile_kept) return -211;
+            if (can_store) memcpy(out + rank, stream + g, 16);
+            copied_end = (uint32_t)rank + 16;
+        }
+        (void)copied_end;
+    }
+    hdr.final_kept = run.kept; hdr.final_nals = run.nals; hdr.final_inside = run.inside;
+    uint8_t tail[8];
+    for (int i = 0; i < 8; ++i) tail[i] = byte_at(stream, (int64_t)n - 8 + i, n);
+    tail_fixup(&hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum);
+    for (uint64_t k = 0; k < hdr.final_nals; ++k) fill_rbsp_len(&hdr, index, index_cap, k);
+    return 0;
 }
 
 /* register-resident variant (hbs_scan3.hip): the per-chunk logic of hbs_chunk.h in stream order */

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
-@pytest.fixture(scope="module", params=[2, 3], ids=["lds-image-kernel", "register-kernel"])
+@pytest.fixture(scope="module", params=[2, 3, 4], ids=["lds-image-kernel", "register-kernel", "sparse-kernel"])
 def ctx(request):
     """both implementations of the fused kernel: hbs_scan.hip (2) and hbs_scan3.hip (3)"""
     import torch

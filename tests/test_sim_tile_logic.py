@@ -9,10 +9,10 @@ from tests import _sim
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
-@pytest.fixture(autouse=True, params=[2, 3], ids=["lds-image", "registers"])
+@pytest.fixture(autouse=True, params=[2, 3, 4], ids=["lds-image", "registers", "sparse"])
 def kernel_variant(request):
     """both kernels' per-thread logic: hbs_tile.h (64-byte blocks over an LDS image) and
-    hbs_chunk.h (16-byte chunks in registers)"""
+    hbs_chunk.h (16-byte chunks in registers), and hbs_sparse.h (flagged chunks as elements, gaps)"""
     old = _sim.VARIANT
     _sim.VARIANT = request.param
     yield
