@@ -33,6 +33,7 @@ struct hbs_ctx {
     unsigned long long* desc;
     uint64_t desc_tiles;
     hbs::RunHeader* hdr;
+    uint8_t* tail;                      /* padded copy of the stream's last tile (event-sparse kernel) */
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
     uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
@@ -105,6 +106,8 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     c->stream = c->own_stream;
     e = hipMalloc(reinterpret_cast<void**>(&c->hdr), sizeof(hbs::RunHeader));
     if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    c->tail = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&c->tail), (size_t)hbs::scan4_tail_bytes()) != hipSuccess) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks = hbs::scan_grid_blocks(device, &c->blocks_per_cu);
     if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks3 = hbs::scan3_grid_blocks(device, &c->blocks_per_cu3);
@@ -129,6 +132,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->desc) (void)hipFree(c->desc);
     if (c->hdr) (void)hipFree(c->hdr);
+    if (c->tail) (void)hipFree(c->tail);
     if (c->ws) (void)hipFree(c->ws);
     if (c->zeros) (void)hipFree(c->zeros);
     if (c->ev0) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
@@ -220,7 +224,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.stream = d_stream; a.n = n;
     a.index = d_index; a.index_cap = index_cap;
     a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
-    a.desc = c->desc; a.hdr = c->hdr; a.summary = d_summary;
+    a.desc = c->desc; a.hdr = c->hdr; a.tail = c->tail; a.summary = d_summary;
     a.variant = c->variant;
     a.sched = c->sched;
     a.grid_blocks = (c->variant == 4) ? c->grid_blocks4 : (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;

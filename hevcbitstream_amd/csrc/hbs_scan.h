@@ -16,6 +16,7 @@ struct ScanArgs {
     uint64_t rbsp_cap;
     unsigned long long* desc;     /* workspace: 2 words per 16 KiB tile           */
     RunHeader* hdr;               /* workspace                                    */
+    uint8_t* tail;                /* workspace of scan4_tail_bytes(): padded copy of the last tile (variant 4) */
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
@@ -33,6 +34,9 @@ void launch_scan_extract3_kernel(const ScanArgs& a, uint64_t num_tiles, hipStrea
 
 /* event-sparse variant (hbs_scan4.hip) */
 int scan4_grid_blocks(int device, int* blocks_per_cu_out);
+int scan4_tile_bytes();
+int scan4_tail_bytes();
+void launch_scan4_prepare_tail(const ScanArgs& a, hipStream_t st);
 void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st);
 
 } // namespace hbs

@@ -576,11 +576,13 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
 {
     hipError_t e;
     k_init_header<<<1, 1, 0, st>>>(a.hdr);
+    if (a.variant == 4) launch_scan4_prepare_tail(a, st);
     if (a.index_cap) {
         e = hipMemsetAsync(a.index, 0, a.index_cap * sizeof(hbs_nal_entry), st);
         if (e != hipSuccess) return e;
     }
-    const uint64_t num_tiles = (a.n + kTileBytes - 1) / kTileBytes;
+    const uint64_t tile_bytes = (a.variant == 4) ? (uint64_t)scan4_tile_bytes() : (uint64_t)kTileBytes;
+    const uint64_t num_tiles = (a.n + tile_bytes - 1) / tile_bytes;
     if (num_tiles) {
         e = hipMemsetAsync(a.desc, 0, num_tiles * 16, st);
         if (e != hipSuccess) return e;

@@ -43,20 +43,77 @@ __device__ unsigned long long g_phase_cycles4[1024][8];
 #define HBS4_T_MARK(i) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
 #define HBS4_T_COUNT(i, v) { t_acc[i] += (v); }
 #define HBS4_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles4[blockIdx.x][i] = t_acc[i]; }
+__device__ uint32_t g_dbg4[4096];
+#define HBS4_DBG(code) code
 #else
+#define HBS4_DBG(code)
 #define HBS4_T_DECL
 #define HBS4_T_MARK(i)
 #define HBS4_T_COUNT(i, v)
 #define HBS4_T_FLUSH
 #endif
 
-constexpr int k4TileRows = k4Waves * k3Rows;                /* rows of 1 KiB per tile */
+static_assert(k4Rows == 32, "the row lists below name every row register");
+#define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+#define HBS_ROW_PAIRS(X) X(0,1) X(1,2) X(2,3) X(3,4) X(4,5) X(5,6) X(6,7) X(7,8) X(8,9) X(9,10) X(10,11) X(11,12) X(12,13) X(13,14) X(14,15) X(15,16) X(16,17) X(17,18) X(18,19) X(19,20) X(20,21) X(21,22) X(22,23) X(23,24) X(24,25) X(25,26) X(26,27) X(27,28) X(28,29) X(29,30) X(30,31)   /* (row, next row) */
+#define HBS_ROWS_BUT_LAST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
+
+/* one wavefront's segment: k4Rows rows of 1 KiB in named registers + the dwords just outside */
+struct RowRegs {
+#define HBS_DECL(r) u32x4 q##r;
+    HBS_ROWS(HBS_DECL)
+#undef HBS_DECL
+    uint32_t before;          /* dword in front of the segment (0xFFFFFFFF before the stream) */
+    uint32_t after;           /* dword behind it (0xFF bytes past the end of the stream)      */
+};
+
+/* Row r of the register image, r wave-uniform: a scalar switch picks the registers, so that the
+ * per-row phases are one rolled loop body each (unrolled over 16 named rows the compiler hoists
+ * every row's addresses and constants out of the tile loop and runs out of registers). */
+__device__ __forceinline__ u32x4 get_row(const RowRegs& R, int r)
+{
+    switch (r) {
+#define HBS_CASE(i) case i: return R.q##i;
+    HBS_ROWS_BUT_LAST(HBS_CASE)
+#undef HBS_CASE
+    default: return R.q31;
+    }
+}
+__device__ __forceinline__ uint32_t row_first_dword(const RowRegs& R, int r)
+{
+    switch (r) {
+#define HBS_CASE(i) case i: return R.q##i.x;
+    HBS_ROWS_BUT_LAST(HBS_CASE)
+#undef HBS_CASE
+    default: return R.q31.x;
+    }
+}
+
+/* All of a wavefront's rows, unguarded: the last tile of a stream is read from a padded copy
+ * (k_prepare_tail4), so every address below exists.  `src` is the stream or that copy. */
+__device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __restrict__ src, uint64_t seg, int lane)
+{
+    const u32x4* p = reinterpret_cast<const u32x4*>(src + seg) + lane;
+#define HBS_LD(r) R.q##r = p[r * 64];
+    HBS_ROWS(HBS_LD)
+#undef HBS_LD
+}
+
+/* an element between the two phases (single-pass tiles): its bytes, marks, summary, and where
+ * it stands in the tile */
+struct ElemState {
+    uint32_t xpp, xp, x0, x1, x2, x3, xn;
+    uint32_t pa, pb, pc;                   /* ElemPacked                                      */
+    uint32_t gap;                          /* bytes of the gap in front of it                 */
+    uint32_t chunk;
+    TileAgg e;                             /* aggregate of the tile in front of that gap      */
+};
 
 struct Lds4 {
-    unsigned long long fm[k4TileRows];     /* flag mask of each row (bit l: chunk l of the row is an element) */
-    uint32_t row_cnt[64];                  /* flagged chunks per row (entries >= k4TileRows stay 0)          */
+    uint32_t row_cnt[k4TileRows];          /* flagged chunks per row                                          */
     uint16_t list[k4ChunksPerTile];        /* flagged chunks of the tile, in stream order  */
     uint32_t seg[k4ElemPass + 1];          /* segment words: [0] tile start, [i+1] element i of the pass */
+    ElemState est[k4ElemPass];
     TileAgg wtot[k4Waves];                 /* per-wavefront element aggregates of a pass   */
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
     uint32_t ex_inside, ex_ok;
@@ -178,99 +235,152 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
     return ok;
 }
 
-/* the six dwords around chunk g0 of the stream, for an element */
-__device__ __forceinline__ void elem_load(RegView& v, const uint8_t* __restrict__ stream, uint64_t g0, uint64_t n)
+__device__ __forceinline__ Prefix prefix_uniform4(const Prefix& p)
 {
-    const u32x4 q = load_chunk_guarded(stream, g0, n);
-    v.xp = load_dword_guarded(stream, (int64_t)g0 - 4, n);
-    v.xn = load_dword_guarded(stream, (int64_t)g0 + 16, n);
-    v.x0 = q.x; v.x1 = q.y; v.x2 = q.z; v.x3 = q.w;
+    Prefix r;
+    r.kept = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.kept >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p.kept);
+    r.nals = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.nals >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p.nals);
+    r.inside = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.inside);
+    return r;
+}
+
+/* the seven dwords around chunk g0 of the stream, for an element */
+__device__ __forceinline__ void elem_load(ElemView& v, const uint8_t* __restrict__ stream, uint64_t g0, uint64_t n, bool padded)
+{
+    if (g0 >= 8 && (padded || g0 + 20 <= n)) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(stream + g0);
+        const u32x4 q = *reinterpret_cast<const u32x4*>(p);
+        v.xpp = p[-2]; v.xp = p[-1]; v.xn = p[4];
+        v.x0 = q.x; v.x1 = q.y; v.x2 = q.z; v.x3 = q.w;
+    } else {
+        const u32x4 q = load_chunk_guarded(stream, g0, n);
+        v.xpp = load_dword_guarded(stream, (int64_t)g0 - 8, n);
+        v.xp = load_dword_guarded(stream, (int64_t)g0 - 4, n);
+        v.xn = load_dword_guarded(stream, (int64_t)g0 + 16, n);
+        v.x0 = q.x; v.x1 = q.y; v.x2 = q.z; v.x3 = q.w;
+    }
     v.stream = stream; v.g0 = g0; v.n = n;
 }
 
-__global__ __launch_bounds__(k4Threads, 4)
+/* lane `l` of v <- the wave-uniform value s.  The s_nop covers gfx950's wait states between a
+ * VALU instruction that writes an SGPR (the v_cmp of a ballot) and a VALU instruction reading
+ * it, which the compiler cannot insert across an asm statement. */
+#define write_lane(v, s, l) asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, " #l : "+v"(v) : "s"(s))
+
+/* flag mask of one row; e_prev / e_next = the dwords just outside the row */
+__device__ __forceinline__ uint64_t flag_row(const u32x4& q, uint32_t e_prev, uint32_t e_next, bool edge_tile,
+                                             uint64_t g, uint64_t n, bool& mine)
+{
+    const uint32_t xp = from_prev_lane(q.w, e_prev);
+    const uint32_t xn = from_next_lane(q.x, e_next);
+    bool f = chunk_flag(xp, q.x, q.y, q.z, q.w, xn);
+    if (edge_tile) f = f || (g < n && n < g + 16);          /* the chunk cut by the stream end is always an element */
+    mine = f;
+    return __ballot(f);
+}
+
+__global__ __launch_bounds__(k4Threads, 2)
 void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                      hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                      uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
-                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr)
+                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, const uint8_t* __restrict__ tail)
 {
     __shared__ Lds4 l;
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
-    if (tid0 < 64) l.row_cnt[tid0] = 0;
+    if (tid0 == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+    __syncthreads();
     HBS4_T_DECL
 
     for (;;) {
         int tid = launder_lane(tid0);
         int lane = tid & 63;
-        if (tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
-        __syncthreads();
-        const uint64_t tile = (uint64_t)l.ticket;
+        const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
         if (tile >= num_tiles) break;
         const uint64_t base = tile * (uint64_t)k4TileBytes;
         const uint64_t tile_end = base + (uint64_t)k4TileBytes;
-        const uint64_t wseg = base + (uint64_t)(wv * k3WaveBytes);
+        const uint64_t wseg = base + (uint64_t)(wv * k4WaveBytes);
         const bool edge_tile = tile_end + 4 > n;          /* some chunk of the tile may be cut by the stream end */
 
-        Rows R;
-        fetch_rows(R, stream, wseg, n, lane);
+        /* the last tile comes from its padded copy: tail[kTailLead + i] = stream[base + i] */
+        const uint8_t* const src = (tile == num_tiles - 1)
+            ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
+        RowRegs R;
+        fetch_row_regs(R, src, wseg, lane);
+        R.before = (wseg >= 4) ? *reinterpret_cast<const uint32_t*>(src + wseg - 4) : 0xFFFFFFFFu;
+        R.after = (tile == num_tiles - 1 || wv != k4Waves - 1) ? *reinterpret_cast<const uint32_t*>(src + wseg + k4WaveBytes)
+                                                               : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
         HBS4_T_MARK(0)
 
-        /* ---- 1. flag masks of my 8 rows ------------------------------------------------- */
+        /* ---- 1. flag masks of my rows --------------------------------------------------- */
+        /* Straight-line over the named rows; a row's 64-bit mask is stashed in lane r of
+         * fm_lo/fm_hi (v_writelane), so nothing per-row lives in SGPRs or LDS. */
         uint32_t myf = 0;                  /* bit r: my chunk of row r is an element */
+        uint32_t fm_lo = 0, fm_hi = 0;     /* lane r: flag mask of my row r          */
         {
             uint32_t e_prev = R.before;
-            const uint32_t next_x_0 = R.q1.x, next_x_1 = R.q2.x, next_x_2 = R.q3.x, next_x_3 = R.q4.x;
-            const uint32_t next_x_4 = R.q5.x, next_x_5 = R.q6.x, next_x_6 = R.q7.x, next_x_7 = 0u;
-#define HBS_FLAG(r) { \
-                const u32x4 q = R.q##r; \
-                const uint32_t e_next = (r == k3Rows - 1) ? R.after : (uint32_t)__builtin_amdgcn_readlane((int)next_x_##r, 0); \
-                const uint32_t xp = from_prev_lane(q.w, e_prev); \
-                const uint32_t xn = from_next_lane(q.x, e_next); \
-                bool f = chunk_flag(xp, q.x, q.y, q.z, q.w, xn); \
-                if (edge_tile) { \
-                    const uint64_t g = wseg + (uint64_t)(r * k3RowBytes + 16 * lane); \
-                    f = f || (g < n && n < g + 16); \
-                } \
+#define HBS_FLAG_BODY(r, e_next_expr) { \
+                const uint32_t xp = from_prev_lane(R.q##r.w, e_prev); \
+                const uint32_t xn = from_next_lane(R.q##r.x, (e_next_expr)); \
+                const bool f = chunk_flag(xp, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn); \
                 const uint64_t fmask = __ballot(f); \
                 myf |= f ? (1u << r) : 0u; \
-                if (lane == 0) { l.fm[k3Rows * wv + r] = fmask; l.row_cnt[k3Rows * wv + r] = (uint32_t)__builtin_popcountll(fmask); } \
-                e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63); }
-            HBS_REP8(HBS_FLAG)
+                write_lane(fm_lo, (uint32_t)fmask, r); \
+                write_lane(fm_hi, (uint32_t)(fmask >> 32), r); \
+                e_prev = (uint32_t)__builtin_amdgcn_readlane((int)R.q##r.w, 63); }
+#define HBS_FLAG(r, rn) HBS_FLAG_BODY(r, (uint32_t)__builtin_amdgcn_readlane((int)R.q##rn.x, 0))
+            HBS_ROW_PAIRS(HBS_FLAG)
+            HBS_FLAG_BODY(31, R.after)
 #undef HBS_FLAG
-            (void)next_x_7;
+#undef HBS_FLAG_BODY
         }
+        if (edge_tile && (n & 15ull) != 0 && n > wseg && n < wseg + (uint64_t)k4WaveBytes) {
+            /* the chunk cut by the stream end is always an element */
+            const uint32_t cut = (uint32_t)(n - wseg) >> 4;            /* its chunk number in my segment */
+            const int cr = (int)(cut >> 6), cl = (int)(cut & 63u);
+            if (lane == cl) myf |= 1u << cr;
+            if (lane == cr) { if (cl < 32) fm_lo |= 1u << cl; else fm_hi |= 1u << (cl - 32); }
+        }
+        if (lane < k4Rows) l.row_cnt[k4Rows * wv + lane] = (uint32_t)__builtin_popcount(fm_lo) + (uint32_t)__builtin_popcount(fm_hi);
+        uint32_t rowmask = (uint32_t)__ballot(lane < k4Rows && (fm_lo | fm_hi) != 0u);   /* my rows that hold an element */
         __syncthreads();
         tid = launder_lane(tid0); lane = tid & 63;
-        /* lane j: flagged chunks of the tile in front of row j */
-        uint32_t row_pre;
-        uint32_t nflag;
+        /* lane j: flagged chunks of the tile in front of rows 2j and 2j+1 */
+        uint32_t pre_even, pre_odd, nflag;
         {
-            const uint32_t cnt = l.row_cnt[lane];
-            const uint32_t inc = wave_incl_scan32(cnt, lane);
-            row_pre = inc - cnt;
+            const uint32_t c0 = l.row_cnt[2 * lane], c1 = l.row_cnt[2 * lane + 1];
+            const uint32_t inc = wave_incl_scan32(c0 + c1, lane);
+            pre_even = inc - (c0 + c1);
+            pre_odd = pre_even + c0;
             nflag = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
-        if (__ballot(myf != 0u) != 0ull) {
-#pragma unroll
-            for (int r = 0; r < k3Rows; ++r) {
-                const uint32_t rp = (uint32_t)__builtin_amdgcn_readlane((int)row_pre, k3Rows * wv + r);
-                if ((myf >> r) & 1u)
-                    l.list[rp + lanes_below(l.fm[k3Rows * wv + r])] = (uint16_t)(64 * (k3Rows * wv + r) + lane);
-            }
+        /* readlanes: only in wave-uniform control flow */
+#define HBS_ROW_PRE(r) ((uint32_t)__builtin_amdgcn_readlane((int)(((r) & 1) ? pre_odd : pre_even), (k4Rows * wv + (r)) >> 1))
+#define HBS_ROW_FM(r) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, (r)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, (r)))
+        for (uint32_t rm = rowmask; rm != 0u; rm &= rm - 1u) {
+            const int r = __builtin_ctz(rm);
+            const uint32_t rp = HBS_ROW_PRE(r);
+            const uint64_t f = HBS_ROW_FM(r);
+            if ((myf >> r) & 1u)
+                l.list[rp + lanes_below(f)] = (uint16_t)(64 * (k4Rows * wv + r) + lane);
         }
         __syncthreads();
+        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } if (tid < 128) g_dbg4[16 + tid] = l.row_cnt[tid]; for (int i = tid; i < 1024; i += k4Threads) g_dbg4[256 + i] = l.list[i]; g_dbg4[2048 + tid] = myf; })
         HBS4_T_MARK(1)
 
         /* ---- 2..4: phase 0 = aggregate + look-back, phase 1 = emit + copy ----------------- */
         const uint32_t npass = (nflag + (uint32_t)k4ElemPass - 1u) / (uint32_t)k4ElemPass;
+        const bool parked = npass == 1u;           /* elements survive the look-back in LDS */
         TileAgg tagg = agg_identity();
         Prefix excl;
         excl.kept = 0; excl.nals = 0; excl.inside = 0;
         bool can_store = false;
         uint8_t* out = rbsp;
+        uint32_t next_ticket = 0;
 #pragma unroll 1
         for (int phase = 0; phase < 2; ++phase) {
             TileAgg acc = agg_identity();
@@ -281,55 +391,75 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 const uint32_t pbase = p * (uint32_t)k4ElemPass;
                 const uint32_t i = pbase + (uint32_t)tid;
                 const bool wave_has = pbase + 64u * (uint32_t)wv < nflag;
-                TileAgg ea = agg_identity();
-                RegView v; BlockMarks m; BlockSum s;
+                const bool active = i < nflag;
+                ElemView v; ChunkMarks m; BlockSum s;
+                TileAgg e = agg_identity();        /* tile aggregate in front of my element's gap */
                 uint32_t gap = 0, c = 0;
-                if (wave_has) {
-                    if (i < nflag) {
-                        c = l.list[i];
-                        const uint64_t prev_end = (i > 0) ? base + 16ull * ((uint32_t)l.list[i - 1] + 1u) : base;
-                        elem_load(v, stream, base + 16ull * c, n);
-                        elem_walk(v, m, s);
-                        gap = span_bytes(prev_end, v.g0, n);
-                        ea = elem_agg(gap, s);
-                    }
-                    ea = wave_scan_combine(ea, lane);
-                }
-                if (lane == 63) l.wtot[wv] = ea;
-                __syncthreads();
-                TileAgg before = acc;
-#pragma unroll
-                for (int w = 0; w < k4Waves; ++w) {
-                    const TileAgg a = l.wtot[w];
-                    if (w < wv) before = combine(before, a);
-                    acc = combine(acc, a);
-                }
-                if (phase == 0) {
-                    if (npass > 1u) __syncthreads();
-                    continue;
-                }
-                if (wave_has) {
-                    TileAgg up = agg_shfl_up(ea, 1);
-                    if (lane == 0) up = agg_identity();
-                    if (i < nflag) {
-                        const TileAgg e = combine(before, up);
-                        const ElemStart st = elem_start(e, gap, excl.inside);
-                        const uint32_t keep = (uint32_t)emit_block_t<kChunk, RegView>(v, 0, v.g0, m, st.inside, excl.nals + e.cnt,
-                                                                                     excl.kept + st.kept, tgt);
-                        const uint32_t nk = (uint32_t)__builtin_popcount(keep);
-                        if (can_store && keep != 0u) {
-                            if (keep == 0xFFFFu) {
-                                u32x4 q; q.x = v.x0; q.y = v.x1; q.z = v.x2; q.w = v.x3;
-                                reinterpret_cast<Unaligned16_3*>(out + st.kept)->v = q;
-                            } else {
-                                uint64_t lo, hi;
-                                const uint32_t cn = compact_chunk_regs(v.x0, v.x1, v.x2, v.x3, keep, lo, hi);
-                                store_pieces(out + st.kept, lo, hi, cn);
-                            }
+                v.stream = stream; v.n = n;
+                if (phase == 0 || !parked) {
+                    TileAgg ea = agg_identity();
+                    if (wave_has) {
+                        if (active) {
+                            c = l.list[i];
+                            const uint64_t prev_end = (i > 0) ? base + 16ull * ((uint32_t)l.list[i - 1] + 1u) : base;
+                            elem_load(v, src, base + 16ull * c, n, tile == num_tiles - 1);
+                            elem_walk(v, m, s);
+                            gap = span_bytes(prev_end, v.g0, n);
+                            ea = elem_agg(gap, s);
                         }
-                        const bool after = (s.last != kKindNone) ? (s.last == kKindStart) : st.inside;
-                        l.seg[tid + 1] = seg_pack((int32_t)c, st.kept + nk, after);
+                        ea = wave_scan_combine(ea, lane);
                     }
+                    if (lane == 63) l.wtot[wv] = ea;
+                    __syncthreads();
+                    TileAgg before = acc;
+#pragma unroll
+                    for (int w = 0; w < k4Waves; ++w) {
+                        const TileAgg a = l.wtot[w];
+                        if (w < wv) before = combine(before, a);
+                        acc = combine(acc, a);
+                    }
+                    if (wave_has) {
+                        TileAgg up = agg_shfl_up(ea, 1);
+                        if (lane == 0) up = agg_identity();
+                        e = combine(before, up);
+                    }
+                    if (phase == 0) {
+                        if (parked && active) {
+                            ElemState st;
+                            const ElemPacked pk = elem_pack(m, s);
+                            st.xpp = v.xpp; st.xp = v.xp; st.x0 = v.x0; st.x1 = v.x1; st.x2 = v.x2; st.x3 = v.x3; st.xn = v.xn;
+                            st.pa = pk.a; st.pb = pk.b; st.pc = pk.c; st.gap = gap; st.chunk = c; st.e = e;
+                            l.est[tid] = st;
+                        }
+                        if (npass > 1u) __syncthreads();
+                        continue;
+                    }
+                } else if (active) {
+                    const ElemState st = l.est[tid];
+                    ElemPacked pk;
+                    pk.a = st.pa; pk.b = st.pb; pk.c = st.pc;
+                    elem_unpack(pk, m, s);
+                    v.xpp = st.xpp; v.xp = st.xp; v.x0 = st.x0; v.x1 = st.x1; v.x2 = st.x2; v.x3 = st.x3; v.xn = st.xn;
+                    gap = st.gap; c = st.chunk; e = st.e;
+                    v.g0 = base + 16ull * c;
+                }
+                if (active) {
+                    const ElemStart st = elem_start(e, gap, excl.inside);
+                    const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, m, st.inside, excl.nals + e.cnt,
+                                                                                  excl.kept + st.kept, tgt);
+                    const uint32_t nk = (uint32_t)__builtin_popcount(keep);
+                    if (can_store && keep != 0u) {
+                        if (keep == 0xFFFFu) {
+                            u32x4 q; q.x = v.x0; q.y = v.x1; q.z = v.x2; q.w = v.x3;
+                            reinterpret_cast<Unaligned16_3*>(out + st.kept)->v = q;
+                        } else {
+                            uint64_t lo, hi;
+                            const uint32_t cn = compact_chunk_regs(v.x0, v.x1, v.x2, v.x3, keep, lo, hi);
+                            store_pieces(out + st.kept, lo, hi, cn);
+                        }
+                    }
+                    const bool after = (s.last != kKindNone) ? (s.last == kKindStart) : st.inside;
+                    l.seg[tid + 1] = seg_pack((int32_t)c, st.kept + nk, after);
                 }
                 __syncthreads();
                 HBS4_T_MARK(4)
@@ -338,18 +468,22 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                  * element k-1 (k = 0: the tile start, pass 0) */
                 tid = launder_lane(tid0); lane = tid & 63;
                 if (can_store) {
+                    const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
+                    const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
+                    /* straight-line over the named rows: k from the stashed mask (two readlanes
+                     * and mbcnt), one LDS read, one store */
 #define HBS_COPY(r) { \
-                        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)row_pre, k3Rows * wv + r) + lanes_below(l.fm[k3Rows * wv + r]); \
-                        const uint32_t kp = k ? (k - 1u) / (uint32_t)k4ElemPass : 0u; \
-                        const uint32_t cc = (uint32_t)(64 * (k3Rows * wv + r) + lane); \
-                        const bool plain = !((myf >> r) & 1u) && kp == p && (!edge_tile || base + 16ull * cc + 16ull <= n); \
-                        if (plain) { \
+                        const uint32_t k = HBS_ROW_PRE(r) + lanes_below(HBS_ROW_FM(r)); \
+                        const uint32_t cc = cc0 + 64u * r; \
+                        const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
+                        if (!((myf >> r) & 1u) && served && cc < whole) { \
                             const uint32_t w = l.seg[k - pbase]; \
                             if (seg_inside(w)) reinterpret_cast<Unaligned16_3*>(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)))->v = R.q##r; \
                         } }
-                    HBS_REP8(HBS_COPY)
+                    HBS_ROWS(HBS_COPY)
 #undef HBS_COPY
                 }
+                if (p + 1 == np && tid == 0) l.ticket = next_ticket;
                 __syncthreads();
                 HBS4_T_MARK(5)
             }
@@ -372,7 +506,13 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             }
             __syncthreads();
             if (l.ex_ok == 0u) return;
-            excl.kept = l.ex_kept; excl.nals = l.ex_nals; excl.inside = l.ex_inside;
+            /* the next tile is claimed now; the answer is only needed at the end of this one */
+            if (tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
+            {
+                Prefix ex;
+                ex.kept = l.ex_kept; ex.nals = l.ex_nals; ex.inside = l.ex_inside;
+                excl = prefix_uniform4(ex);
+            }
             HBS4_T_MARK(3)
             if (tid == 0 && tile == num_tiles - 1) {
                 const Prefix incl = fold(excl, tagg);
@@ -383,16 +523,42 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             if (rbsp != nullptr && !can_store && tid == 0) atomicMax(&hdr->error, (uint32_t)(-HBS_E_CAPACITY));
             out = rbsp + excl.kept;
         }
+#undef HBS_ROW_PRE
+#undef HBS_ROW_FM
     }
     HBS4_T_FLUSH
 }
 
 #ifdef HBS_PHASE_TIMING
+extern "C" int hbs_debug_dump4(uint32_t* host_out /* [4096] */)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg4), sizeof(uint32_t) * 4096);
+}
 extern "C" int hbs_debug_phase_cycles4(unsigned long long* host_out /* [1024][8] */)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles4), sizeof(unsigned long long) * 1024 * 8);
 }
 #endif
+
+int scan4_tile_bytes() { return k4TileBytes; }
+int scan4_tail_bytes() { return k4TailBytes; }
+
+/* tail[k4TailLead + i] = stream[last_base + i] for i in [-k4TailLead, tile + pad), 0xFF where the
+ * stream has no byte: the main kernel reads the stream's last tile from here, unguarded */
+__global__ void k_prepare_tail4(const uint8_t* __restrict__ stream, uint64_t n, uint8_t* __restrict__ tail)
+{
+    if (n == 0) return;
+    const uint64_t last_base = ((n - 1) / (uint64_t)k4TileBytes) * (uint64_t)k4TileBytes;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)k4TailBytes; i += gridDim.x * blockDim.x) {
+        const int64_t q = (int64_t)last_base + (int64_t)i - k4TailLead;
+        tail[i] = (q >= 0 && (uint64_t)q < n) ? stream[q] : (uint8_t)0xFF;
+    }
+}
+
+void launch_scan4_prepare_tail(const ScanArgs& a, hipStream_t st)
+{
+    if (a.n) k_prepare_tail4<<<dim3(32), dim3(256), 0, st>>>(a.stream, a.n, a.tail);
+}
 
 int scan4_grid_blocks(int device, int* blocks_per_cu_out)
 {
@@ -410,7 +576,7 @@ void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, hipStrea
     uint64_t grid = (uint64_t)a.grid_blocks;
     if (grid > num_tiles) grid = num_tiles;
     k_scan_extract4<<<dim3((unsigned)grid), dim3(k4Threads), 0, st>>>(
-        a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr);
+        a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.tail);
 }
 
 } // namespace hbs

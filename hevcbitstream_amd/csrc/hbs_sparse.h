@@ -26,13 +26,23 @@
 
 namespace hbs {
 
-/* geometry of the event-sparse kernel: a workgroup of k4Waves wavefronts, 8 KiB each */
-constexpr int k4Waves         = 8;
+/* geometry of the event-sparse kernel: a workgroup of k4Waves wavefronts, each holding k4Rows
+ * rows of 1 KiB in registers.  Few wavefronts with many registers each: the ~100 registers the
+ * control code needs are paid per wavefront, so two fat wavefronts per SIMD keep twice the
+ * bytes in flight of four lean ones. */
+constexpr int k4Waves         = 4;
+constexpr int k4Rows          = 32;
 constexpr int k4Threads       = 64 * k4Waves;
-constexpr int k4TileBytes     = k4Waves * 8192;
-constexpr int k4ChunksPerTile = k4TileBytes / kChunk;
+constexpr int k4RowBytes      = 1024;
+constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 32 KiB  */
+constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 128 KiB */
+constexpr int k4TileRows      = k4Waves * k4Rows;            /* 128     */
+constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 8192    */
 constexpr int k4ElemPass      = k4Threads;                   /* elements handled per pass */
-static_assert(k4TileBytes <= kTileBytes && kTileBytes % k4TileBytes == 0, "descriptor workspace is sized for the smallest tile");
+constexpr int k4TailLead      = 16;                          /* bytes of the padded last-tile copy in front of the tile */
+constexpr int k4TailBytes     = k4TailLead + k4TileBytes + 64;
+static_assert(k4TileBytes % kTileBytes == 0, "the descriptor workspace is sized for kTileBytes tiles; larger tiles need less");
+static_assert(k4ChunksPerTile <= 65536, "chunk numbers are kept in 16 bits");
 
 /* per-halfword minimum of two dwords */
 HBS_HD uint32_t pk_min_u16(uint32_t a, uint32_t b)
@@ -89,11 +99,50 @@ HBS_HD TileAgg elem_agg(uint32_t gap_bytes, const BlockSum& s)
     return a;
 }
 
-/* exact classification of one chunk from its six dwords */
-HBS_HD void elem_walk(const RegView& v, BlockMarks& m, BlockSum& s)
+/* An element's bytes [-8, 20) around its chunk, in registers: everything the window rules and
+ * the index emission ever look at (pattern_kind reads back to o-5, emit_block_t to e-5), so an
+ * element costs one round of loads and no dependent ones. */
+struct ElemView {
+    uint32_t xpp, xp, x0, x1, x2, x3, xn;
+    const uint8_t* stream;
+    uint64_t g0;          /* stream offset of the chunk's first byte */
+    uint64_t n;
+
+    HBS_M uint32_t byte(int32_t o) const
+    {
+        if (o >= -8 && o < 20) {
+            const uint32_t k = (uint32_t)(o + 8) >> 2;
+            const uint32_t d = (k == 0) ? xpp : (k == 1) ? xp : (k == 2) ? x0 : (k == 3) ? x1 : (k == 4) ? x2 : (k == 5) ? x3 : xn;
+            return (d >> (8u * ((uint32_t)(o + 8) & 3u))) & 0xFFu;
+        }
+        const int64_t q = (int64_t)g0 + o;
+        return (q >= 0 && (uint64_t)q < n) ? stream[q] : 0xFFu;
+    }
+};
+
+typedef BlockMarksT<uint32_t> ChunkMarks;      /* 16 byte positions (+2 behind) fit 32 bits */
+
+/* exact classification of one chunk */
+HBS_HD void elem_walk(const ElemView& v, ChunkMarks& m, BlockSum& s)
 {
     const uint32_t pats = chunk_patterns(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn);
-    walk_block_t<kChunk, RegView>(v, 0, v.g0, v.n, pats & 0xFFFFu, pats >> 16, m, s);
+    walk_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, v.n, pats & 0xFFFFu, pats >> 16, m, s);
+}
+
+/* an element's marks and summary in three dwords (chunk-sized masks are 16 bits each) */
+struct ElemPacked { uint32_t a, b, c; };
+HBS_HD ElemPacked elem_pack(const ChunkMarks& m, const BlockSum& s)
+{
+    ElemPacked p;
+    p.a = (m.cand & 0xFFFFu) | (m.ev << 16);
+    p.b = (m.ev_start & 0xFFFFu) | (m.err << 16);
+    p.c = s.cnt | (s.known << 8) | (s.carry << 16) | (s.last << 24);
+    return p;
+}
+HBS_HD void elem_unpack(const ElemPacked& p, ChunkMarks& m, BlockSum& s)
+{
+    m.cand = p.a & 0xFFFFu; m.ev = p.a >> 16; m.ev_start = p.b & 0xFFFFu; m.err = p.b >> 16;
+    s.cnt = p.c & 0xFFu; s.known = (p.c >> 8) & 0xFFu; s.carry = (p.c >> 16) & 0xFFu; s.last = p.c >> 24;
 }
 
 /* Where an element stands once the tile's carried state is known: e = aggregate of

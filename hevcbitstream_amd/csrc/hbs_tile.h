@@ -35,13 +35,28 @@ struct TileGeom {
     uint64_t n;           /* stream length in bytes                 */
 };
 
-/* per-thread registers that live across the look-back wait */
-struct BlockMarks {
-    uint64_t cand;        /* bytes that are RBSP if their position is inside a NAL */
-    uint64_t ev;          /* terminator events (position of the pattern's last byte) */
-    uint64_t ev_start;    /* subset of ev that also starts a NAL                    */
-    uint64_t err;         /* positions that make nal_to_rbsp fail if inside a NAL   */
+/* per-thread registers that live across the look-back wait; Mask = one bit per byte of the
+ * block (uint64_t for 64-byte blocks, uint32_t is enough for 16-byte chunks) */
+template <class Mask>
+struct BlockMarksT {
+    Mask cand;            /* bytes that are RBSP if their position is inside a NAL */
+    Mask ev;              /* terminator events (position of the pattern's last byte) */
+    Mask ev_start;        /* subset of ev that also starts a NAL                    */
+    Mask err;             /* positions that make nal_to_rbsp fail if inside a NAL   */
 };
+typedef BlockMarksT<uint64_t> BlockMarks;
+
+/* bit helpers for either mask width */
+HBS_HD uint32_t mask_popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+HBS_HD uint32_t mask_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+HBS_HD uint32_t mask_ctz(uint64_t v)  { return (uint32_t)__builtin_ctzll(v); }
+HBS_HD uint32_t mask_ctz(uint32_t v)  { return (uint32_t)__builtin_ctz(v); }
+template <class T> struct type_id { typedef T type; };       /* keeps an argument out of template deduction */
+/* bits [0, n) set; n in [0, bits of Mask] */
+template <class Mask> HBS_HD Mask mask_below(uint32_t n)
+{
+    return n >= 8u * (uint32_t)sizeof(Mask) ? (Mask)~(Mask)0 : (Mask)(((Mask)1 << n) - (Mask)1);
+}
 
 /* what one block contributes to the scan */
 struct BlockSum {
@@ -199,17 +214,19 @@ HBS_HD uint64_t block_patterns(const TileView& v, int32_t o, uint32_t& aprev)
  * o = logical offset of the block in the tile image, g0 = its stream offset,
  * pat_next = patterns ending in the first two bytes of the next block.
  */
-template <int B, class View>
+template <int B, class View, class Mask = uint64_t>
 HBS_HD void walk_block_t(const View& v, int32_t o, uint64_t g0, uint64_t n,
-                         uint64_t pat, uint32_t pat_next, BlockMarks& m, BlockSum& s)
+                         typename type_id<Mask>::type pat, uint32_t pat_next, BlockMarksT<Mask>& m, BlockSum& s)
 {
+    static_assert(B <= (int)(8 * sizeof(Mask)), "mask too narrow for the block");
+    const Mask one = 1;
     const uint32_t nvalid = (g0 >= n) ? 0u : (n - g0 >= (uint64_t)B ? (uint32_t)B : (uint32_t)(n - g0));
-    m.cand = below(nvalid);
+    m.cand = mask_below<Mask>(nvalid);
     m.ev = m.ev_start = m.err = 0;
 
-    for (uint64_t r = pat; r != 0; r &= r - 1) {
-        const uint32_t j = ctz64(r);
-        const uint64_t bit = 1ull << j;
+    for (Mask r = pat; r != 0; r &= r - 1) {
+        const uint32_t j = mask_ctz(r);
+        const Mask bit = one << j;
         const int kind = pattern_kind(v, o + (int32_t)j, g0 + j, n);
         if (kind == kPatEpb) {
             m.cand &= ~bit;
@@ -231,26 +248,26 @@ HBS_HD void walk_block_t(const View& v, int32_t o, uint64_t g0, uint64_t n,
             const uint32_t j = (uint32_t)B + b;
             const int kind = pattern_kind(v, o + (int32_t)j, g0 + j, n);
             if (kind == kPatStart || kind == kPatStop)
-                m.cand &= ~((b == 0) ? (3ull << (B - 2)) : (1ull << (B - 1)));
+                m.cand &= ~((b == 0) ? ((Mask)3 << (B - 2)) : (one << (B - 1)));
         }
     }
 
     /* summary: bytes before the first event follow the carried state */
-    uint32_t carry = popc64(m.cand), known = 0, last = kKindNone;
+    uint32_t carry = mask_popc(m.cand), known = 0, last = kKindNone;
     if (m.ev != 0) {
-        uint32_t cur = ctz64(m.ev);
-        carry = popc64(m.cand & below(cur));
+        uint32_t cur = mask_ctz(m.ev);
+        carry = mask_popc((Mask)(m.cand & mask_below<Mask>(cur)));
         bool inside = false;
-        for (uint64_t r = m.ev; r != 0; r &= r - 1) {
-            const uint32_t e = ctz64(r);
-            if (inside) known += popc64(m.cand & below(e) & ~below(cur));
-            inside = (m.ev_start >> e) & 1ull;
+        for (Mask r = m.ev; r != 0; r &= r - 1) {
+            const uint32_t e = mask_ctz(r);
+            if (inside) known += mask_popc((Mask)(m.cand & mask_below<Mask>(e) & ~mask_below<Mask>(cur)));
+            inside = (m.ev_start >> e) & one;
             cur = e + 1;
         }
-        if (inside) known += popc64(m.cand & ~below(cur));
+        if (inside) known += mask_popc((Mask)(m.cand & ~mask_below<Mask>(cur)));
         last = inside ? kKindStart : kKindStop;
     }
-    s.cnt = popc64(m.ev_start);
+    s.cnt = mask_popc(m.ev_start);
     s.known = known;
     s.carry = carry;
     s.last = last;
@@ -348,18 +365,19 @@ HBS_D void flag_error(RunHeader* hdr, uint32_t code)
  * mask.  nal_ord = number of NAL starts before this block (global ordinal of
  * the next NAL to open); rbsp_pos = arena offset of the block's first kept byte.
  */
-template <int B, class View>
-HBS_D uint64_t emit_block_t(const View& v, int32_t o, uint64_t g0, const BlockMarks& m, bool inside,
-                            uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
+template <int B, class View, class Mask = uint64_t>
+HBS_D Mask emit_block_t(const View& v, int32_t o, uint64_t g0, const BlockMarksT<Mask>& m, bool inside,
+                        uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
 {
-    uint64_t inside_mask = 0;
+    const Mask one = 1;
+    Mask inside_mask = 0;
     uint32_t cur = 0;
     uint64_t ord = nal_ord;
 
-    for (uint64_t r = m.ev; r != 0; r &= r - 1) {
-        const uint32_t e = ctz64(r);
+    for (Mask r = m.ev; r != 0; r &= r - 1) {
+        const uint32_t e = mask_ctz(r);
         if (inside) {
-            inside_mask |= below(e) & ~below(cur);
+            inside_mask |= mask_below<Mask>(e) & ~mask_below<Mask>(cur);
             /* NAL ord-1 ends where the terminator begins (h264_nal.c:74) */
             const uint64_t k = ord - 1;
             const int32_t t = o + (int32_t)e - 2;             /* first byte of the terminator */
@@ -372,11 +390,11 @@ HBS_D uint64_t emit_block_t(const View& v, int32_t o, uint64_t g0, const BlockMa
             if (b3 == 0 && b2 == 0 && b1 == 1)                /* empty NAL: loop of hevc_analyze.c:135 stops */
                 atomic_min_u64(&tgt.hdr->first_empty, k);
         }
-        if ((m.ev_start >> e) & 1ull) {
+        if ((m.ev_start >> e) & one) {
             const uint64_t k = ord++;
             if (k < tgt.index_cap) {
                 tgt.index[k].start = g0 + e + 1;              /* h264_nal.c:61-62 */
-                tgt.index[k].rbsp_off = rbsp_pos + popc64(m.cand & inside_mask);
+                tgt.index[k].rbsp_off = rbsp_pos + mask_popc((Mask)(m.cand & inside_mask));
             } else {
                 flag_error(tgt.hdr, (uint32_t)(-HBS_E_CAPACITY));
             }
@@ -386,11 +404,11 @@ HBS_D uint64_t emit_block_t(const View& v, int32_t o, uint64_t g0, const BlockMa
         }
         cur = e + 1;
     }
-    if (inside) inside_mask |= below((uint32_t)B) & ~below(cur);
+    if (inside) inside_mask |= mask_below<Mask>((uint32_t)B) & ~mask_below<Mask>(cur);
 
-    for (uint64_t r = m.err & inside_mask; r != 0; r &= r - 1) {
-        const uint32_t pos = ctz64(r);
-        const uint64_t k = nal_ord + popc64(m.ev_start & below(pos)) - 1;
+    for (Mask r = m.err & inside_mask; r != 0; r &= r - 1) {
+        const uint32_t pos = mask_ctz(r);
+        const uint64_t k = nal_ord + mask_popc((Mask)(m.ev_start & mask_below<Mask>(pos))) - 1;
         if (k < tgt.index_cap) atomic_or_status(&tgt.index[k], HBS_ST_ERROR);
     }
     return m.cand & inside_mask;

@@ -248,7 +248,8 @@ extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
         return v;
     };
     auto view_at = [&](uint64_t g0) {
-        RegView v;
+        ElemView v;
+        v.xpp = dword_at((int64_t)g0 - 8);
         v.xp = dword_at((int64_t)g0 - 4); v.x0 = dword_at((int64_t)g0); v.x1 = dword_at((int64_t)g0 + 4);
         v.x2 = dword_at((int64_t)g0 + 8); v.x3 = dword_at((int64_t)g0 + 12); v.xn = dword_at((int64_t)g0 + 16);
         v.stream = stream; v.g0 = g0; v.n = n;
@@ -262,7 +263,7 @@ extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
         list.clear();
         for (uint32_t c = 0; c < (uint32_t)k4ChunksPerTile; ++c) {
             const uint64_t g = base + 16ull * c;
-            const RegView v = view_at(g);
+            const ElemView v = view_at(g);
             bool f = chunk_flag(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn);
             if (!f && g < n && chunk_patterns(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn) != 0) return -210;   /* the test must be conservative */
             f = f || (g < n && n < g + 16);
@@ -273,8 +274,8 @@ extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
         TileAgg acc = agg_identity();
         for (size_t i = 0; i < list.size(); ++i) {
             const uint64_t prev_end = i ? base + 16ull * (list[i - 1] + 1u) : base;
-            const RegView v = view_at(base + 16ull * list[i]);
-            BlockMarks m; BlockSum s;
+            const ElemView v = view_at(base + 16ull * list[i]);
+            ChunkMarks m; BlockSum s;
             elem_walk(v, m, s);
             acc = combine(acc, elem_agg(span_bytes(prev_end, v.g0, n), s));
         }
@@ -291,12 +292,18 @@ extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
         TileAgg accb = agg_identity();
         for (size_t i = 0; i < list.size(); ++i) {
             const uint64_t prev_end = i ? base + 16ull * (list[i - 1] + 1u) : base;
-            const RegView v = view_at(base + 16ull * list[i]);
-            BlockMarks m; BlockSum s;
-            elem_walk(v, m, s);
+            const ElemView v = view_at(base + 16ull * list[i]);
+            ChunkMarks m; BlockSum s;
+            {   /* the kernel parks marks and summary in LDS between the two phases */
+                ChunkMarks m0; BlockSum s0;
+                elem_walk(v, m0, s0);
+                elem_unpack(elem_pack(m0, s0), m, s);
+                if (m.cand != m0.cand || m.ev != m0.ev || m.ev_start != m0.ev_start || m.err != m0.err ||
+                    s.cnt != s0.cnt || s.known != s0.known || s.carry != s0.carry || s.last != s0.last) return -212;
+            }
             const uint32_t gap = span_bytes(prev_end, v.g0, n);
             const ElemStart st = elem_start(accb, gap, excl.inside);
-            const uint32_t keep = (uint32_t)emit_block_t<kChunk, RegView>(v, 0, v.g0, m, st.inside, excl.nals + accb.cnt, excl.kept + st.kept, tgt);
+            const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, m, st.inside, excl.nals + accb.cnt, excl.kept + st.kept, tgt);
             const uint32_t nk = (uint32_t)__builtin_popcount(keep);
             if (can_store && keep) {
                 uint64_t lo, hi;
