@@ -152,6 +152,10 @@ def main():
         algo_bytes = sb + rb + 32 * n
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         blocks, per_cu = ctx.grid()
+        variant = ctx.kernel()
+        kernel_name = {2: "hbs::k_scan_extract", 3: "hbs::k_scan_extract3", 4: "hbs::k_scan_extract4"}[variant]
+        geometry = {2: "512 threads, 64 KiB tiles (LDS image)", 3: "512 threads, 64 KiB tiles (registers)",
+                    4: "256 threads, 128 KiB tiles held in registers, tiles handed out by ticket"}[variant]
         out = {
             "metric": "Annex-B GB/s scanned + NAL units/s, 16 GiB synthetic stream, 1/2/4/8 MI355X",
             "value": round(total_bytes * args.steps / dt / 1e9, 2),
@@ -172,10 +176,10 @@ def main():
                                                           "; + RCCL all-gather of the NAL index" if world > 1 else ""),
                        "stream_bytes_per_gpu": sb, "nals_per_gpu": n,
                        "parallelism": "%d independent shard(s), one per GPU" % world,
-                       "grid": "%d persistent workgroups (%d per CU) x 512 threads, 64 KiB tiles" % (blocks, per_cu)},
+                       "grid": "%d persistent workgroups (%d per CU) x %s" % (blocks, per_cu, geometry)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "hbs::k_scan_extract", "kernel_ms": round(k_ms, 4),
+                         "kernel": kernel_name, "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": algo_bytes,
                          "note": "bytes = stream read once + RBSP written once + 32 B/NAL index; "
                                  "read-only fraction = %.4f" % (sb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},

@@ -16,7 +16,7 @@
 #include "hbs_parse.h"
 
 #ifndef HBS_DEFAULT_KERNEL
-#define HBS_DEFAULT_KERNEL 2
+#define HBS_DEFAULT_KERNEL 4
 #define HBS_DEFAULT_SCHED 1
 #endif
 
