@@ -56,6 +56,7 @@ __device__ uint32_t g_dbg4[4096];
 static_assert(k4Rows == 32, "the row lists below name every row register");
 #define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 #define HBS_ROW_PAIRS(X) X(0,1) X(1,2) X(2,3) X(3,4) X(4,5) X(5,6) X(6,7) X(7,8) X(8,9) X(9,10) X(10,11) X(11,12) X(12,13) X(13,14) X(14,15) X(15,16) X(16,17) X(17,18) X(18,19) X(19,20) X(20,21) X(21,22) X(22,23) X(23,24) X(24,25) X(25,26) X(26,27) X(27,28) X(28,29) X(29,30) X(30,31)   /* (row, next row) */
+#define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31)   /* (previous row, row, next row), inner rows */
 #define HBS_ROWS_BUT_LAST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
 
 /* one wavefront's segment: k4Rows rows of 1 KiB in named registers + the dwords just outside */
@@ -64,6 +65,7 @@ struct RowRegs {
     HBS_ROWS(HBS_DECL)
 #undef HBS_DECL
     uint32_t before;          /* dword in front of the segment (0xFFFFFFFF before the stream) */
+    uint32_t before2;         /* the dword in front of that one                               */
     uint32_t after;           /* dword behind it (0xFF bytes past the end of the stream)      */
 };
 
@@ -99,6 +101,10 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 #undef HBS_LD
 }
 
+/* what a flagged lane leaves for the thread that will handle its chunk as an element */
+constexpr int kDepCap = 64;
+struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
+
 /* an element between the two phases (single-pass tiles): its bytes, marks, summary, and where
  * it stands in the tile */
 struct ElemState {
@@ -114,6 +120,7 @@ struct Lds4 {
     uint16_t list[k4ChunksPerTile];        /* flagged chunks of the tile, in stream order  */
     uint32_t seg[k4ElemPass + 1];          /* segment words: [0] tile start, [i+1] element i of the pass */
     ElemState est[k4ElemPass];
+    Deposit dep[k4Waves][kDepCap];         /* bytes of the first elements of each wavefront, left by the flag pass */
     TileAgg wtot[k4Waves];                 /* per-wavefront element aggregates of a pass   */
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
     uint32_t ex_inside, ex_ok;
@@ -208,8 +215,7 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
                 if ((spins & 63u) == 63u)
                     aborted = __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                 if (++spins > (1u << 20) || aborted) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(2);
-                continue;
+                continue;               /* the round trip of the next poll is delay enough */
             }
             const TileAgg win = window_fold3(la, lstar < 64 ? lstar + 1 : 64, lane);
             const TileAgg total = combine(win, acc);
@@ -312,6 +318,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         RowRegs R;
         fetch_row_regs(R, src, wseg, lane);
         R.before = (wseg >= 4) ? *reinterpret_cast<const uint32_t*>(src + wseg - 4) : 0xFFFFFFFFu;
+        R.before2 = (wseg >= 8) ? *reinterpret_cast<const uint32_t*>(src + wseg - 8) : 0xFFFFFFFFu;
         R.after = (tile == num_tiles - 1 || wv != k4Waves - 1) ? *reinterpret_cast<const uint32_t*>(src + wseg + k4WaveBytes)
                                                                : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
         HBS4_T_MARK(0)
@@ -321,9 +328,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
          * fm_lo/fm_hi (v_writelane), so nothing per-row lives in SGPRs or LDS. */
         uint32_t myf = 0;                  /* bit r: my chunk of row r is an element */
         uint32_t fm_lo = 0, fm_hi = 0;     /* lane r: flag mask of my row r          */
+        uint32_t wslot = 0;                /* elements of this wavefront so far      */
         {
             uint32_t e_prev = R.before;
-#define HBS_FLAG_BODY(r, e_next_expr) { \
+#define HBS_FLAG_BODY(r, e_prev_z_expr, e_next_expr) { \
                 const uint32_t xp = from_prev_lane(R.q##r.w, e_prev); \
                 const uint32_t xn = from_next_lane(R.q##r.x, (e_next_expr)); \
                 const bool f = chunk_flag(xp, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn); \
@@ -331,10 +339,22 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 myf |= f ? (1u << r) : 0u; \
                 write_lane(fm_lo, (uint32_t)fmask, r); \
                 write_lane(fm_hi, (uint32_t)(fmask >> 32), r); \
+                if (fmask != 0) {        /* rare: leave the chunk's surroundings for its element thread */ \
+                    const uint32_t xpp = from_prev_lane(R.q##r.z, (e_prev_z_expr)); \
+                    const uint32_t slot = wslot + lanes_below(fmask); \
+                    if (f && slot < (uint32_t)kDepCap) { \
+                        Deposit d; \
+                        d.xpp = xpp; d.xp = xp; d.x0 = R.q##r.x; d.x1 = R.q##r.y; d.x2 = R.q##r.z; d.x3 = R.q##r.w; d.xn = xn; \
+                        d.chunk = (uint32_t)(64 * (k4Rows * wv + r) + lane); \
+                        l.dep[wv][slot] = d; \
+                    } \
+                    wslot += (uint32_t)__builtin_popcountll(fmask); \
+                } \
                 e_prev = (uint32_t)__builtin_amdgcn_readlane((int)R.q##r.w, 63); }
-#define HBS_FLAG(r, rn) HBS_FLAG_BODY(r, (uint32_t)__builtin_amdgcn_readlane((int)R.q##rn.x, 0))
-            HBS_ROW_PAIRS(HBS_FLAG)
-            HBS_FLAG_BODY(31, R.after)
+#define HBS_FLAG(rp, r, rn) HBS_FLAG_BODY(r, (uint32_t)__builtin_amdgcn_readlane((int)R.q##rp.z, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q##rn.x, 0))
+            HBS_FLAG_BODY(0, R.before2, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.x, 0))
+            HBS_ROW_TRIPLES(HBS_FLAG)
+            HBS_FLAG_BODY(31, (uint32_t)__builtin_amdgcn_readlane((int)R.q30.z, 63), R.after)
 #undef HBS_FLAG
 #undef HBS_FLAG_BODY
         }
@@ -342,7 +362,12 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             /* the chunk cut by the stream end is always an element */
             const uint32_t cut = (uint32_t)(n - wseg) >> 4;            /* its chunk number in my segment */
             const int cr = (int)(cut >> 6), cl = (int)(cut & 63u);
-            if (lane == cl) myf |= 1u << cr;
+            if (lane == cl && !((myf >> cr) & 1u)) {
+                /* not flagged by its bytes: nothing was deposited for it; it is the wavefront's last
+                 * element, and its thread must read the stream itself */
+                myf |= 1u << cr;
+                if (wslot < (uint32_t)kDepCap) l.dep[wv][wslot].chunk = 0xFFFFFFFFu;
+            }
             if (lane == cr) { if (cl < 32) fm_lo |= 1u << cl; else fm_hi |= 1u << (cl - 32); }
         }
         if (lane < k4Rows) l.row_cnt[k4Rows * wv + lane] = (uint32_t)__builtin_popcount(fm_lo) + (uint32_t)__builtin_popcount(fm_hi);
@@ -358,6 +383,11 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             pre_odd = pre_even + c0;
             nflag = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
+        /* elements in front of wavefronts 1..3 (their first rows are even: lane 16 w of pre_even) */
+        const uint32_t wb1 = (uint32_t)__builtin_amdgcn_readlane((int)pre_even, 1 * k4Rows / 2);
+        const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)pre_even, 2 * k4Rows / 2);
+        const uint32_t wb3 = (uint32_t)__builtin_amdgcn_readlane((int)pre_even, 3 * k4Rows / 2);
+        static_assert(k4Waves == 4 && k4Rows % 2 == 0, "wave bases are read from pre_even");
         /* readlanes: only in wave-uniform control flow */
 #define HBS_ROW_PRE(r) ((uint32_t)__builtin_amdgcn_readlane((int)(((r) & 1) ? pre_odd : pre_even), (k4Rows * wv + (r)) >> 1))
 #define HBS_ROW_FM(r) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, (r)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, (r)))
@@ -402,7 +432,18 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                         if (active) {
                             c = l.list[i];
                             const uint64_t prev_end = (i > 0) ? base + 16ull * ((uint32_t)l.list[i - 1] + 1u) : base;
-                            elem_load(v, src, base + 16ull * c, n, tile == num_tiles - 1);
+                            /* which wavefront flagged it, and as its how-manieth element */
+                            const uint32_t ew = (i >= wb1 ? 1u : 0u) + (i >= wb2 ? 1u : 0u) + (i >= wb3 ? 1u : 0u);
+                            const uint32_t ej = i - (ew == 0u ? 0u : ew == 1u ? wb1 : ew == 2u ? wb2 : wb3);
+                            Deposit d;
+                            d.chunk = 0xFFFFFFFFu;
+                            if (ej < (uint32_t)kDepCap) d = l.dep[ew][ej];
+                            if (d.chunk == c) {
+                                v.xpp = d.xpp; v.xp = d.xp; v.x0 = d.x0; v.x1 = d.x1; v.x2 = d.x2; v.x3 = d.x3; v.xn = d.xn;
+                                v.stream = src; v.g0 = base + 16ull * c; v.n = n;
+                            } else {
+                                elem_load(v, src, base + 16ull * c, n, tile == num_tiles - 1);
+                            }
                             elem_walk(v, m, s);
                             gap = span_bytes(prev_end, v.g0, n);
                             ea = elem_agg(gap, s);
@@ -467,6 +508,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 /* unflagged chunk with k elements in front of it: served by the pass that holds
                  * element k-1 (k = 0: the tile start, pass 0) */
                 tid = launder_lane(tid0); lane = tid & 63;
+                /* the next tile is claimed as late as its round trip can still hide behind the copy:
+                 * tiles are looked back in ticket order, and a ticket taken long before its tile
+                 * is started makes every successor wait */
+                if (p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
                 if (can_store) {
                     const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
                     const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
@@ -506,8 +551,6 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             }
             __syncthreads();
             if (l.ex_ok == 0u) return;
-            /* the next tile is claimed now; the answer is only needed at the end of this one */
-            if (tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
             {
                 Prefix ex;
                 ex.kept = l.ex_kept; ex.nals = l.ex_nals; ex.inside = l.ex_inside;
