@@ -315,6 +315,8 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         /* the last tile comes from its padded copy: tail[kTailLead + i] = stream[base + i] */
         const uint8_t* const src = (tile == num_tiles - 1)
             ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
+        /* until the tile's aggregate is out, this workgroup is what its successors wait for */
+        __builtin_amdgcn_s_setprio(3);
         RowRegs R;
         fetch_row_regs(R, src, wseg, lane);
         R.before = (wseg >= 4) ? *reinterpret_cast<const uint32_t*>(src + wseg - 4) : 0xFFFFFFFFu;
@@ -537,6 +539,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             const uint64_t last_end = (nflag > 0) ? base + 16ull * ((uint32_t)l.list[nflag - 1] + 1u) : base;
             tagg = combine(acc, gap_agg(span_bytes(last_end, tile_end, n)));
             HBS4_T_MARK(2)
+            if (wv != 0) __builtin_amdgcn_s_setprio(0);
 
             /* ---- 3. look-back (wavefront 0) ---------------------------------------------- */
             if (wv == 0) {
@@ -544,6 +547,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 uint32_t it, stl;
                 const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
                 HBS4_T_COUNT(7, ((unsigned long long)stl << 32) | it)
+                __builtin_amdgcn_s_setprio(0);
                 if (lane == 0) {
                     l.ex_kept = ex.kept; l.ex_nals = ex.nals; l.ex_inside = ex.inside; l.ex_ok = ok ? 1u : 0u;
                     l.seg[0] = seg_pack(-1, 0u, ex.inside != 0u);
