@@ -53,11 +53,13 @@ __device__ uint32_t g_dbg4[4096];
 #define HBS4_T_FLUSH
 #endif
 
-static_assert(k4Rows == 32, "the row lists below name every row register");
-#define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
-#define HBS_ROW_PAIRS(X) X(0,1) X(1,2) X(2,3) X(3,4) X(4,5) X(5,6) X(6,7) X(7,8) X(8,9) X(9,10) X(10,11) X(11,12) X(12,13) X(13,14) X(14,15) X(15,16) X(16,17) X(17,18) X(18,19) X(19,20) X(20,21) X(21,22) X(22,23) X(23,24) X(24,25) X(25,26) X(26,27) X(27,28) X(28,29) X(29,30) X(30,31)   /* (row, next row) */
-#define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31)   /* (previous row, row, next row), inner rows */
-#define HBS_ROWS_BUT_LAST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
+static_assert(k4Rows == 40, "the row lists below name every row register");
+#define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39)
+#define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31) X(30,31,32) X(31,32,33) X(32,33,34) X(33,34,35) X(34,35,36) X(35,36,37) X(36,37,38) X(37,38,39)   /* (previous row, row, next row), inner rows */
+#define HBS_ROWS_BUT_LAST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38)
+/* rows of wavefront 0 that wait in LDS while it handles elements and looks back: (slot, row) */
+constexpr int kParkRows = 16;
+#define HBS_PARKED(X) X(0,24) X(1,25) X(2,26) X(3,27) X(4,28) X(5,29) X(6,30) X(7,31) X(8,32) X(9,33) X(10,34) X(11,35) X(12,36) X(13,37) X(14,38) X(15,39)
 
 /* one wavefront's segment: k4Rows rows of 1 KiB in named registers + the dwords just outside */
 struct RowRegs {
@@ -78,7 +80,7 @@ __device__ __forceinline__ u32x4 get_row(const RowRegs& R, int r)
 #define HBS_CASE(i) case i: return R.q##i;
     HBS_ROWS_BUT_LAST(HBS_CASE)
 #undef HBS_CASE
-    default: return R.q31;
+    default: return R.q39;
     }
 }
 __device__ __forceinline__ uint32_t row_first_dword(const RowRegs& R, int r)
@@ -87,7 +89,7 @@ __device__ __forceinline__ uint32_t row_first_dword(const RowRegs& R, int r)
 #define HBS_CASE(i) case i: return R.q##i.x;
     HBS_ROWS_BUT_LAST(HBS_CASE)
 #undef HBS_CASE
-    default: return R.q31.x;
+    default: return R.q39.x;
     }
 }
 
@@ -105,23 +107,12 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 constexpr int kDepCap = 64;
 struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
 
-/* an element between the two phases (single-pass tiles): its bytes, marks, summary, and where
- * it stands in the tile */
-struct ElemState {
-    uint32_t xpp, xp, x0, x1, x2, x3, xn;
-    uint32_t pa, pb, pc;                   /* ElemPacked                                      */
-    uint32_t gap;                          /* bytes of the gap in front of it                 */
-    uint32_t chunk;
-    TileAgg e;                             /* aggregate of the tile in front of that gap      */
-};
-
 struct Lds4 {
-    uint32_t row_cnt[k4TileRows];          /* flagged chunks per row                                          */
-    uint16_t list[k4ChunksPerTile];        /* flagged chunks of the tile, in stream order  */
+    uint32_t wave_tot[k4Waves];            /* elements per wavefront                        */
+    uint16_t list[k4ChunksPerTile];        /* flagged chunks of the tile, in stream order   */
     uint32_t seg[k4ElemPass + 1];          /* segment words: [0] tile start, [i+1] element i of the pass */
-    ElemState est[k4ElemPass];
     Deposit dep[k4Waves][kDepCap];         /* bytes of the first elements of each wavefront, left by the flag pass */
-    TileAgg wtot[k4Waves];                 /* per-wavefront element aggregates of a pass   */
+    u32x4 park[kParkRows][64];             /* rows of wavefront 0 while it handles elements and looks back */
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
     uint32_t ex_inside, ex_ok;
     uint32_t ticket;
@@ -275,16 +266,69 @@ __device__ __forceinline__ void elem_load(ElemView& v, const uint8_t* __restrict
  * it, which the compiler cannot insert across an asm statement. */
 #define write_lane(v, s, l) asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, " #l : "+v"(v) : "s"(s))
 
-/* flag mask of one row; e_prev / e_next = the dwords just outside the row */
-__device__ __forceinline__ uint64_t flag_row(const u32x4& q, uint32_t e_prev, uint32_t e_next, bool edge_tile,
-                                             uint64_t g, uint64_t n, bool& mine)
+__device__ __forceinline__ TileAgg agg_readlane(const TileAgg& a, int l)
 {
-    const uint32_t xp = from_prev_lane(q.w, e_prev);
-    const uint32_t xn = from_next_lane(q.x, e_next);
-    bool f = chunk_flag(xp, q.x, q.y, q.z, q.w, xn);
-    if (edge_tile) f = f || (g < n && n < g + 16);          /* the chunk cut by the stream end is always an element */
-    mine = f;
-    return __ballot(f);
+    TileAgg r;
+    r.cnt = (uint32_t)__builtin_amdgcn_readlane((int)a.cnt, l); r.known = (uint32_t)__builtin_amdgcn_readlane((int)a.known, l);
+    r.sig = (uint32_t)__builtin_amdgcn_readlane((int)a.sig, l); r.last = (uint32_t)__builtin_amdgcn_readlane((int)a.last, l);
+    return r;
+}
+
+/* everything one lane of wavefront 0 knows about its element */
+struct Elem {
+    ElemView v;
+    ChunkMarks m;
+    BlockSum s;
+    uint32_t gap;          /* bytes of the gap in front of it            */
+    uint32_t chunk;        /* its chunk number in the tile               */
+};
+
+/* Element i of the tile (lane = i mod 64 of wavefront 0): its bytes come from the deposit its
+ * flagging lane left in LDS, or from the stream when there is none; then the exact window rules. */
+__device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i, uint32_t wb1, uint32_t wb2, uint32_t wb3,
+                                             const uint8_t* __restrict__ src, uint64_t base, uint64_t n, bool padded)
+{
+    const uint32_t c = l.list[i];
+    const uint64_t prev_end = (i > 0) ? base + 16ull * ((uint32_t)l.list[i - 1] + 1u) : base;
+    /* which wavefront flagged it, and as its how-manieth element */
+    const uint32_t ew = (i >= wb1 ? 1u : 0u) + (i >= wb2 ? 1u : 0u) + (i >= wb3 ? 1u : 0u);
+    const uint32_t ej = i - (ew == 0u ? 0u : ew == 1u ? wb1 : ew == 2u ? wb2 : wb3);
+    Deposit d;
+    d.chunk = 0xFFFFFFFFu;
+    if (ej < (uint32_t)kDepCap) d = l.dep[ew][ej];
+    if (d.chunk == c) {
+        el.v.xpp = d.xpp; el.v.xp = d.xp; el.v.x0 = d.x0; el.v.x1 = d.x1; el.v.x2 = d.x2; el.v.x3 = d.x3; el.v.xn = d.xn;
+        el.v.stream = src; el.v.g0 = base + 16ull * c; el.v.n = n;
+    } else {
+        elem_load(el.v, src, base + 16ull * c, n, padded);
+    }
+    elem_walk(el.v, el.m, el.s);
+    el.gap = span_bytes(prev_end, el.v.g0, n);
+    el.chunk = c;
+    return elem_agg(el.gap, el.s);
+}
+
+/* Second half for an element once the tile's carried state is known: index entries, its own kept
+ * bytes, and the segment word for the chunks behind it.  e = tile aggregate in front of its gap. */
+__device__ __forceinline__ void elem_emit(const Elem& el, const TileAgg& e, const Prefix& excl, bool can_store, uint8_t* out,
+                                          const EmitTarget& tgt, uint32_t* seg_slot)
+{
+    const ElemStart st = elem_start(e, el.gap, excl.inside);
+    const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(el.v, 0, el.v.g0, el.m, st.inside, excl.nals + e.cnt,
+                                                                          excl.kept + st.kept, tgt);
+    const uint32_t nk = (uint32_t)__builtin_popcount(keep);
+    if (can_store && keep != 0u) {
+        if (keep == 0xFFFFu) {
+            u32x4 q; q.x = el.v.x0; q.y = el.v.x1; q.z = el.v.x2; q.w = el.v.x3;
+            reinterpret_cast<Unaligned16_3*>(out + st.kept)->v = q;
+        } else {
+            uint64_t lo, hi;
+            const uint32_t cn = compact_chunk_regs(el.v.x0, el.v.x1, el.v.x2, el.v.x3, keep, lo, hi);
+            store_pieces(out + st.kept, lo, hi, cn);
+        }
+    }
+    const bool after = (el.s.last != kKindNone) ? (el.s.last == kKindStart) : st.inside;
+    *seg_slot = seg_pack((int32_t)el.chunk, st.kept + nk, after);
 }
 
 __global__ __launch_bounds__(k4Threads, 2)
@@ -310,10 +354,11 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         const uint64_t base = tile * (uint64_t)k4TileBytes;
         const uint64_t tile_end = base + (uint64_t)k4TileBytes;
         const uint64_t wseg = base + (uint64_t)(wv * k4WaveBytes);
+        const bool last_tile = tile == num_tiles - 1;
         const bool edge_tile = tile_end + 4 > n;          /* some chunk of the tile may be cut by the stream end */
 
         /* the last tile comes from its padded copy: tail[kTailLead + i] = stream[base + i] */
-        const uint8_t* const src = (tile == num_tiles - 1)
+        const uint8_t* const src = last_tile
             ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
         /* until the tile's aggregate is out, this workgroup is what its successors wait for */
         __builtin_amdgcn_s_setprio(3);
@@ -321,14 +366,14 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         fetch_row_regs(R, src, wseg, lane);
         R.before = (wseg >= 4) ? *reinterpret_cast<const uint32_t*>(src + wseg - 4) : 0xFFFFFFFFu;
         R.before2 = (wseg >= 8) ? *reinterpret_cast<const uint32_t*>(src + wseg - 8) : 0xFFFFFFFFu;
-        R.after = (tile == num_tiles - 1 || wv != k4Waves - 1) ? *reinterpret_cast<const uint32_t*>(src + wseg + k4WaveBytes)
-                                                               : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
+        R.after = (last_tile || wv != k4Waves - 1) ? *reinterpret_cast<const uint32_t*>(src + wseg + k4WaveBytes)
+                                                   : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
         HBS4_T_MARK(0)
 
         /* ---- 1. flag masks of my rows --------------------------------------------------- */
         /* Straight-line over the named rows; a row's 64-bit mask is stashed in lane r of
          * fm_lo/fm_hi (v_writelane), so nothing per-row lives in SGPRs or LDS. */
-        uint32_t myf = 0;                  /* bit r: my chunk of row r is an element */
+        uint64_t myf = 0;                  /* bit r: my chunk of row r is an element */
         uint32_t fm_lo = 0, fm_hi = 0;     /* lane r: flag mask of my row r          */
         uint32_t wslot = 0;                /* elements of this wavefront so far      */
         {
@@ -338,7 +383,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 const uint32_t xn = from_next_lane(R.q##r.x, (e_next_expr)); \
                 const bool f = chunk_flag(xp, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn); \
                 const uint64_t fmask = __ballot(f); \
-                myf |= f ? (1u << r) : 0u; \
+                myf |= f ? (1ull << r) : 0ull; \
                 write_lane(fm_lo, (uint32_t)fmask, r); \
                 write_lane(fm_hi, (uint32_t)(fmask >> 32), r); \
                 if (fmask != 0) {        /* rare: leave the chunk's surroundings for its element thread */ \
@@ -356,219 +401,174 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 #define HBS_FLAG(rp, r, rn) HBS_FLAG_BODY(r, (uint32_t)__builtin_amdgcn_readlane((int)R.q##rp.z, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q##rn.x, 0))
             HBS_FLAG_BODY(0, R.before2, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.x, 0))
             HBS_ROW_TRIPLES(HBS_FLAG)
-            HBS_FLAG_BODY(31, (uint32_t)__builtin_amdgcn_readlane((int)R.q30.z, 63), R.after)
+            HBS_FLAG_BODY(39, (uint32_t)__builtin_amdgcn_readlane((int)R.q38.z, 63), R.after)
 #undef HBS_FLAG
 #undef HBS_FLAG_BODY
+            static_assert(k4Rows == 40, "first and last row are named above");
         }
         if (edge_tile && (n & 15ull) != 0 && n > wseg && n < wseg + (uint64_t)k4WaveBytes) {
             /* the chunk cut by the stream end is always an element */
             const uint32_t cut = (uint32_t)(n - wseg) >> 4;            /* its chunk number in my segment */
             const int cr = (int)(cut >> 6), cl = (int)(cut & 63u);
-            if (lane == cl && !((myf >> cr) & 1u)) {
+            if (lane == cl && !((myf >> cr) & 1ull)) {
                 /* not flagged by its bytes: nothing was deposited for it; it is the wavefront's last
                  * element, and its thread must read the stream itself */
-                myf |= 1u << cr;
+                myf |= 1ull << cr;
                 if (wslot < (uint32_t)kDepCap) l.dep[wv][wslot].chunk = 0xFFFFFFFFu;
             }
             if (lane == cr) { if (cl < 32) fm_lo |= 1u << cl; else fm_hi |= 1u << (cl - 32); }
         }
-        if (lane < k4Rows) l.row_cnt[k4Rows * wv + lane] = (uint32_t)__builtin_popcount(fm_lo) + (uint32_t)__builtin_popcount(fm_hi);
-        uint32_t rowmask = (uint32_t)__ballot(lane < k4Rows && (fm_lo | fm_hi) != 0u);   /* my rows that hold an element */
+        /* lane r: elements of my rows in front of row r; then the same across wavefronts */
+        uint32_t local_pre;
+        uint64_t rowmask;                  /* my rows that hold an element */
+        {
+            const uint32_t cnt = (lane < k4Rows) ? (uint32_t)__builtin_popcount(fm_lo) + (uint32_t)__builtin_popcount(fm_hi) : 0u;
+            const uint32_t inc = wave_incl_scan32(cnt, lane);
+            local_pre = inc - cnt;
+            rowmask = __ballot(cnt != 0u);
+            if (lane == 63) l.wave_tot[wv] = inc;
+        }
         __syncthreads();
         tid = launder_lane(tid0); lane = tid & 63;
-        /* lane j: flagged chunks of the tile in front of rows 2j and 2j+1 */
-        uint32_t pre_even, pre_odd, nflag;
-        {
-            const uint32_t c0 = l.row_cnt[2 * lane], c1 = l.row_cnt[2 * lane + 1];
-            const uint32_t inc = wave_incl_scan32(c0 + c1, lane);
-            pre_even = inc - (c0 + c1);
-            pre_odd = pre_even + c0;
-            nflag = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        }
-        /* elements in front of wavefronts 1..3 (their first rows are even: lane 16 w of pre_even) */
-        const uint32_t wb1 = (uint32_t)__builtin_amdgcn_readlane((int)pre_even, 1 * k4Rows / 2);
-        const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)pre_even, 2 * k4Rows / 2);
-        const uint32_t wb3 = (uint32_t)__builtin_amdgcn_readlane((int)pre_even, 3 * k4Rows / 2);
-        static_assert(k4Waves == 4 && k4Rows % 2 == 0, "wave bases are read from pre_even");
+        const uint32_t wt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[0]);
+        const uint32_t wt1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[1]);
+        const uint32_t wt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[2]);
+        const uint32_t wt3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[3]);
+        static_assert(k4Waves == 4, "four wavefront totals");
+        const uint32_t wb1 = wt0, wb2 = wt0 + wt1, wb3 = wb2 + wt2, nflag = wb3 + wt3;
+        const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? wb1 : (wv == 2) ? wb2 : wb3;
         /* readlanes: only in wave-uniform control flow */
-#define HBS_ROW_PRE(r) ((uint32_t)__builtin_amdgcn_readlane((int)(((r) & 1) ? pre_odd : pre_even), (k4Rows * wv + (r)) >> 1))
+#define HBS_ROW_PRE(r) (wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, (r)))
 #define HBS_ROW_FM(r) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, (r)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, (r)))
-        for (uint32_t rm = rowmask; rm != 0u; rm &= rm - 1u) {
-            const int r = __builtin_ctz(rm);
+        for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
+            const int r = __builtin_ctzll(rm);
             const uint32_t rp = HBS_ROW_PRE(r);
             const uint64_t f = HBS_ROW_FM(r);
-            if ((myf >> r) & 1u)
+            if ((myf >> r) & 1ull)
                 l.list[rp + lanes_below(f)] = (uint16_t)(64 * (k4Rows * wv + r) + lane);
         }
         __syncthreads();
-        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } if (tid < 128) g_dbg4[16 + tid] = l.row_cnt[tid]; for (int i = tid; i < 1024; i += k4Threads) g_dbg4[256 + i] = l.list[i]; g_dbg4[2048 + tid] = myf; })
+        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < 1024; i += k4Threads) g_dbg4[256 + i] = l.list[i]; g_dbg4[2048 + tid] = (uint32_t)myf; })
         HBS4_T_MARK(1)
 
-        /* ---- 2..4: phase 0 = aggregate + look-back, phase 1 = emit + copy ----------------- */
+        /* ---- 2..4 on wavefront 0: elements -> tile aggregate -> look-back -> emit ----------- */
         const uint32_t npass = (nflag + (uint32_t)k4ElemPass - 1u) / (uint32_t)k4ElemPass;
-        const bool parked = npass == 1u;           /* elements survive the look-back in LDS */
-        TileAgg tagg = agg_identity();
-        Prefix excl;
-        excl.kept = 0; excl.nals = 0; excl.inside = 0;
-        bool can_store = false;
-        uint8_t* out = rbsp;
-        uint32_t next_ticket = 0;
+        if (wv == 0) {
+            /* this code needs ~100 registers of its own: part of this wavefront's rows wait in LDS */
+#define HBS_PARK(i, r) l.park[i][lane] = R.q##r;
+            HBS_PARKED(HBS_PARK)
+#undef HBS_PARK
+            Elem el;
+            TileAgg acc = agg_identity(), e = agg_identity();
+            el.gap = 0; el.chunk = 0;
 #pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase) {
-            TileAgg acc = agg_identity();
-            const uint32_t np = (phase == 1 && npass == 0u) ? 1u : npass;
-#pragma unroll 1
-            for (uint32_t p = 0; p < np; ++p) {
-                tid = launder_lane(tid0); lane = tid & 63;
-                const uint32_t pbase = p * (uint32_t)k4ElemPass;
-                const uint32_t i = pbase + (uint32_t)tid;
-                const bool wave_has = pbase + 64u * (uint32_t)wv < nflag;
-                const bool active = i < nflag;
-                ElemView v; ChunkMarks m; BlockSum s;
-                TileAgg e = agg_identity();        /* tile aggregate in front of my element's gap */
-                uint32_t gap = 0, c = 0;
-                v.stream = stream; v.n = n;
-                if (phase == 0 || !parked) {
-                    TileAgg ea = agg_identity();
-                    if (wave_has) {
-                        if (active) {
-                            c = l.list[i];
-                            const uint64_t prev_end = (i > 0) ? base + 16ull * ((uint32_t)l.list[i - 1] + 1u) : base;
-                            /* which wavefront flagged it, and as its how-manieth element */
-                            const uint32_t ew = (i >= wb1 ? 1u : 0u) + (i >= wb2 ? 1u : 0u) + (i >= wb3 ? 1u : 0u);
-                            const uint32_t ej = i - (ew == 0u ? 0u : ew == 1u ? wb1 : ew == 2u ? wb2 : wb3);
-                            Deposit d;
-                            d.chunk = 0xFFFFFFFFu;
-                            if (ej < (uint32_t)kDepCap) d = l.dep[ew][ej];
-                            if (d.chunk == c) {
-                                v.xpp = d.xpp; v.xp = d.xp; v.x0 = d.x0; v.x1 = d.x1; v.x2 = d.x2; v.x3 = d.x3; v.xn = d.xn;
-                                v.stream = src; v.g0 = base + 16ull * c; v.n = n;
-                            } else {
-                                elem_load(v, src, base + 16ull * c, n, tile == num_tiles - 1);
-                            }
-                            elem_walk(v, m, s);
-                            gap = span_bytes(prev_end, v.g0, n);
-                            ea = elem_agg(gap, s);
-                        }
-                        ea = wave_scan_combine(ea, lane);
-                    }
-                    if (lane == 63) l.wtot[wv] = ea;
-                    __syncthreads();
-                    TileAgg before = acc;
-#pragma unroll
-                    for (int w = 0; w < k4Waves; ++w) {
-                        const TileAgg a = l.wtot[w];
-                        if (w < wv) before = combine(before, a);
-                        acc = combine(acc, a);
-                    }
-                    if (wave_has) {
-                        TileAgg up = agg_shfl_up(ea, 1);
-                        if (lane == 0) up = agg_identity();
-                        e = combine(before, up);
-                    }
-                    if (phase == 0) {
-                        if (parked && active) {
-                            ElemState st;
-                            const ElemPacked pk = elem_pack(m, s);
-                            st.xpp = v.xpp; st.xp = v.xp; st.x0 = v.x0; st.x1 = v.x1; st.x2 = v.x2; st.x3 = v.x3; st.xn = v.xn;
-                            st.pa = pk.a; st.pb = pk.b; st.pc = pk.c; st.gap = gap; st.chunk = c; st.e = e;
-                            l.est[tid] = st;
-                        }
-                        if (npass > 1u) __syncthreads();
-                        continue;
-                    }
-                } else if (active) {
-                    const ElemState st = l.est[tid];
-                    ElemPacked pk;
-                    pk.a = st.pa; pk.b = st.pb; pk.c = st.pc;
-                    elem_unpack(pk, m, s);
-                    v.xpp = st.xpp; v.xp = st.xp; v.x0 = st.x0; v.x1 = st.x1; v.x2 = st.x2; v.x3 = st.x3; v.xn = st.xn;
-                    gap = st.gap; c = st.chunk; e = st.e;
-                    v.g0 = base + 16ull * c;
-                }
-                if (active) {
-                    const ElemStart st = elem_start(e, gap, excl.inside);
-                    const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, m, st.inside, excl.nals + e.cnt,
-                                                                                  excl.kept + st.kept, tgt);
-                    const uint32_t nk = (uint32_t)__builtin_popcount(keep);
-                    if (can_store && keep != 0u) {
-                        if (keep == 0xFFFFu) {
-                            u32x4 q; q.x = v.x0; q.y = v.x1; q.z = v.x2; q.w = v.x3;
-                            reinterpret_cast<Unaligned16_3*>(out + st.kept)->v = q;
-                        } else {
-                            uint64_t lo, hi;
-                            const uint32_t cn = compact_chunk_regs(v.x0, v.x1, v.x2, v.x3, keep, lo, hi);
-                            store_pieces(out + st.kept, lo, hi, cn);
-                        }
-                    }
-                    const bool after = (s.last != kKindNone) ? (s.last == kKindStart) : st.inside;
-                    l.seg[tid + 1] = seg_pack((int32_t)c, st.kept + nk, after);
-                }
-                __syncthreads();
-                HBS4_T_MARK(4)
-
-                /* unflagged chunk with k elements in front of it: served by the pass that holds
-                 * element k-1 (k = 0: the tile start, pass 0) */
-                tid = launder_lane(tid0); lane = tid & 63;
-                /* the next tile is claimed as late as its round trip can still hide behind the copy:
-                 * tiles are looked back in ticket order, and a ticket taken long before its tile
-                 * is started makes every successor wait */
-                if (p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
-                if (can_store) {
-                    const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
-                    const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
-                    /* straight-line over the named rows: k from the stashed mask (two readlanes
-                     * and mbcnt), one LDS read, one store */
-#define HBS_COPY(r) { \
-                        const uint32_t k = HBS_ROW_PRE(r) + lanes_below(HBS_ROW_FM(r)); \
-                        const uint32_t cc = cc0 + 64u * r; \
-                        const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
-                        if (!((myf >> r) & 1u) && served && cc < whole) { \
-                            const uint32_t w = l.seg[k - pbase]; \
-                            if (seg_inside(w)) reinterpret_cast<Unaligned16_3*>(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)))->v = R.q##r; \
-                        } }
-                    HBS_ROWS(HBS_COPY)
-#undef HBS_COPY
-                }
-                if (p + 1 == np && tid == 0) l.ticket = next_ticket;
-                __syncthreads();
-                HBS4_T_MARK(5)
+            for (uint32_t p = 0; p < npass; ++p) {
+                const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
+                TileAgg ea = agg_identity();
+                if (i < nflag) ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                ea = wave_scan_combine(ea, lane);
+                TileAgg up = agg_shfl_up(ea, 1);
+                if (lane == 0) up = agg_identity();
+                e = combine(acc, up);
+                acc = combine(acc, agg_readlane(ea, 63));
             }
-            if (phase == 1) break;
-
             const uint64_t last_end = (nflag > 0) ? base + 16ull * ((uint32_t)l.list[nflag - 1] + 1u) : base;
-            tagg = combine(acc, gap_agg(span_bytes(last_end, tile_end, n)));
+            const TileAgg tagg = combine(acc, gap_agg(span_bytes(last_end, tile_end, n)));
             HBS4_T_MARK(2)
-            if (wv != 0) __builtin_amdgcn_s_setprio(0);
 
-            /* ---- 3. look-back (wavefront 0) ---------------------------------------------- */
-            if (wv == 0) {
-                Prefix ex;
-                uint32_t it, stl;
-                const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
-                HBS4_T_COUNT(7, ((unsigned long long)stl << 32) | it)
-                __builtin_amdgcn_s_setprio(0);
-                if (lane == 0) {
-                    l.ex_kept = ex.kept; l.ex_nals = ex.nals; l.ex_inside = ex.inside; l.ex_ok = ok ? 1u : 0u;
-                    l.seg[0] = seg_pack(-1, 0u, ex.inside != 0u);
+            Prefix ex;
+            uint32_t it, stl;
+            const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
+            HBS4_T_COUNT(7, ((unsigned long long)stl << 32) | it)
+            __builtin_amdgcn_s_setprio(0);
+            const uint32_t tile_kept = tagg.known + (ex.inside ? tagg.sig : 0u);
+            const bool can = rbsp != nullptr && ex.kept + tile_kept <= rbsp_cap;
+            if (lane == 0) {
+                l.ex_kept = ex.kept; l.ex_nals = ex.nals; l.ex_inside = ex.inside;
+                l.ex_ok = !ok ? 0u : (rbsp != nullptr && !can) ? 2u : 1u;
+                l.seg[0] = seg_pack(-1, 0u, ex.inside != 0u);
+                if (ok && rbsp != nullptr && !can) atomicMax(&hdr->error, (uint32_t)(-HBS_E_CAPACITY));
+                if (ok && last_tile) {
+                    const Prefix incl = fold(ex, tagg);
+                    hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
                 }
-            }
-            __syncthreads();
-            if (l.ex_ok == 0u) return;
-            {
-                Prefix ex;
-                ex.kept = l.ex_kept; ex.nals = l.ex_nals; ex.inside = l.ex_inside;
-                excl = prefix_uniform4(ex);
             }
             HBS4_T_MARK(3)
-            if (tid == 0 && tile == num_tiles - 1) {
-                const Prefix incl = fold(excl, tagg);
-                hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
+            /* one pass (nearly always): the elements are still in registers */
+            if (ok && npass == 1u && (uint32_t)lane < nflag)
+                elem_emit(el, e, ex, can, rbsp + ex.kept, tgt, &l.seg[lane + 1]);
+#define HBS_UNPARK(i, r) R.q##r = l.park[i][lane];
+            HBS_PARKED(HBS_UNPARK)
+#undef HBS_UNPARK
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+        if (l.ex_ok == 0u) return;
+        Prefix excl;
+        {
+            Prefix ex;
+            ex.kept = l.ex_kept; ex.nals = l.ex_nals; ex.inside = l.ex_inside;
+            excl = prefix_uniform4(ex);
+        }
+        const bool can_store = rbsp != nullptr && l.ex_ok == 1u;
+        uint8_t* const out = rbsp + excl.kept;
+        HBS4_T_MARK(4)
+
+        /* ---- 5. copy everything that is not an element; tiles dense in elements take the
+         *         elements 64 at a time, wavefront 0 redoing each batch before its copy ------- */
+        TileAgg accb = agg_identity();     /* wavefront 0: aggregate of the batches done so far */
+        uint32_t next_ticket = 0;
+        const uint32_t np = npass ? npass : 1u;
+#pragma unroll 1
+        for (uint32_t p = 0; p < np; ++p) {
+            tid = launder_lane(tid0); lane = tid & 63;
+            const uint32_t pbase = p * (uint32_t)k4ElemPass;
+            if (npass > 1u) {
+                if (wv == 0) {
+#define HBS_PARK(i, r) l.park[i][lane] = R.q##r;
+                    HBS_PARKED(HBS_PARK)
+#undef HBS_PARK
+                    Elem el;
+                    const uint32_t i = pbase + (uint32_t)lane;
+                    TileAgg ea = agg_identity();
+                    if (i < nflag) ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                    ea = wave_scan_combine(ea, lane);
+                    TileAgg up = agg_shfl_up(ea, 1);
+                    if (lane == 0) up = agg_identity();
+                    const TileAgg e = combine(accb, up);
+                    accb = combine(accb, agg_readlane(ea, 63));
+                    if (i < nflag) elem_emit(el, e, excl, can_store, out, tgt, &l.seg[lane + 1]);
+#define HBS_UNPARK(i, r) R.q##r = l.park[i][lane];
+                    HBS_PARKED(HBS_UNPARK)
+#undef HBS_UNPARK
+                }
+                __syncthreads();
             }
-            const uint32_t tile_kept = tagg.known + (excl.inside ? tagg.sig : 0u);
-            can_store = rbsp != nullptr && excl.kept + tile_kept <= rbsp_cap;
-            if (rbsp != nullptr && !can_store && tid == 0) atomicMax(&hdr->error, (uint32_t)(-HBS_E_CAPACITY));
-            out = rbsp + excl.kept;
+            /* the next tile is claimed as late as its round trip can still hide behind the copy:
+             * tiles are looked back in ticket order, and a ticket taken long before its tile is
+             * started makes every successor wait */
+            if (p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
+            if (can_store) {
+                const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
+                const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
+                /* straight-line over the named rows: k from the stashed mask (two readlanes and
+                 * mbcnt), one LDS read, one store.  A chunk with k elements in front of it is
+                 * served by the batch that holds element k-1 (k = 0: the tile start, batch 0). */
+#define HBS_COPY(r) { \
+                    const uint32_t k = HBS_ROW_PRE(r) + lanes_below(HBS_ROW_FM(r)); \
+                    const uint32_t cc = cc0 + 64u * r; \
+                    const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
+                    if (!((myf >> r) & 1ull) && served && cc < whole) { \
+                        const uint32_t w = l.seg[k - pbase]; \
+                        if (seg_inside(w)) reinterpret_cast<Unaligned16_3*>(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)))->v = R.q##r; \
+                    } }
+                HBS_ROWS(HBS_COPY)
+#undef HBS_COPY
+            }
+            if (p + 1 == np && tid == 0) l.ticket = next_ticket;
+            __syncthreads();
+            HBS4_T_MARK(5)
         }
 #undef HBS_ROW_PRE
 #undef HBS_ROW_FM

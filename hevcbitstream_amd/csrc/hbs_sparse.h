@@ -31,17 +31,17 @@ namespace hbs {
  * control code needs are paid per wavefront, so two fat wavefronts per SIMD keep twice the
  * bytes in flight of four lean ones. */
 constexpr int k4Waves         = 4;
-constexpr int k4Rows          = 32;
+constexpr int k4Rows          = 40;
 constexpr int k4Threads       = 64 * k4Waves;
 constexpr int k4RowBytes      = 1024;
-constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 32 KiB  */
-constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 128 KiB */
-constexpr int k4TileRows      = k4Waves * k4Rows;            /* 128     */
-constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 8192    */
-constexpr int k4ElemPass      = k4Threads;                   /* elements handled per pass */
+constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 40 KiB  */
+constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 160 KiB */
+constexpr int k4TileRows      = k4Waves * k4Rows;            /* 160     */
+constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 10240   */
+constexpr int k4ElemPass      = 64;                          /* elements handled per pass: wavefront 0, one per lane */
 constexpr int k4TailLead      = 16;                          /* bytes of the padded last-tile copy in front of the tile */
 constexpr int k4TailBytes     = k4TailLead + k4TileBytes + 64;
-static_assert(k4TileBytes % kTileBytes == 0, "the descriptor workspace is sized for kTileBytes tiles; larger tiles need less");
+static_assert(k4TileBytes >= kTileBytes, "the descriptor workspace is sized for kTileBytes tiles; larger tiles need less");
 static_assert(k4ChunksPerTile <= 65536, "chunk numbers are kept in 16 bits");
 
 /* per-halfword minimum of two dwords */
