@@ -44,6 +44,7 @@ __device__ unsigned long long g_phase_cycles4[1024][8];
 #define HBS4_T_COUNT(i, v) { t_acc[i] += (v); }
 #define HBS4_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles4[blockIdx.x][i] = t_acc[i]; }
 __device__ uint32_t g_dbg4[4096];
+__device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all (wrong results, timing only) */
 #define HBS4_DBG(code) code
 #else
 #define HBS4_DBG(code)
@@ -104,6 +105,11 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 }
 
 /* what a flagged lane leaves for the thread that will handle its chunk as an element */
+/* take the next tile's ticket before (true) or after (false) the copy of the current one */
+#ifndef HBS4_TICKET_EARLY
+#define HBS4_TICKET_EARLY 0
+#endif
+constexpr bool kTicketEarly = HBS4_TICKET_EARLY != 0;
 constexpr int kDepCap = 64;
 struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
 
@@ -168,18 +174,29 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
         TileAgg acc = agg_identity();                 /* tiles between the window and `tile` */
         int64_t win_hi = (int64_t)tile - 1;
         uint32_t spins = 0;
+        uint64_t w0[4], w1[4];
+        bool fresh = true;                            /* the window moved: read all of it */
         for (;;) {
             ++dbg_iters;
-            uint64_t w0[4], w1[4];
+            /* A descriptor that has been seen ready stays usable (an aggregate can only turn into
+             * a prefix): while waiting, only the ones still missing are read again. */
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t t = win_hi - (4 * lane + j);
-                w0[j] = kDescPrefix; w1[j] = kDescPrefix;          /* virtual tile -1: empty prefix */
-                if (t >= 0) {
-                    w0[j] = ld_desc3(&desc[2 * t]);
-                    w1[j] = ld_desc3(&desc[2 * t + 1]);
+                bool need = fresh;
+                if (!fresh) {
+                    const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
+                    need = !((s0 == s1) && (s0 != kDescEmpty));
+                }
+                if (need) {
+                    w0[j] = kDescPrefix; w1[j] = kDescPrefix;          /* virtual tile -1: empty prefix */
+                    if (t >= 0) {
+                        w0[j] = ld_desc3(&desc[2 * t]);
+                        w1[j] = ld_desc3(&desc[2 * t + 1]);
+                    }
                 }
             }
+            fresh = false;
             int jp = 4;                     /* my nearest tile that already has its prefix */
             bool lane_ok = true;            /* every tile in front of it has its aggregate  */
             uint64_t pw0 = 0, pw1 = 0;
@@ -192,15 +209,11 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
                     else if (s0 == kDescPrefix) { jp = j; pw0 = w0[j]; pw1 = w1[j]; }
                 }
             }
-            TileAgg la = agg_identity();    /* earliest first: j = 3 is the earliest tile */
-#pragma unroll
-            for (int j = 3; j >= 0; --j)
-                if (j < jp) la = combine(la, unpack_agg(w0[j], w1[j]));
             const uint64_t m_pre = __ballot(jp < 4 && lane_ok);
             const uint64_t m_ok = __ballot(lane_ok);
             const int lstar = m_pre ? (int)__builtin_ctzll(m_pre) : 64;
-            const uint64_t need = (lstar >= 63) ? ~0ull : ((2ull << lstar) - 1ull);
-            if ((m_ok & need) != need) {
+            const uint64_t need_lanes = (lstar >= 63) ? ~0ull : ((2ull << lstar) - 1ull);
+            if ((m_ok & need_lanes) != need_lanes) {
                 ++dbg_stalls;
                 bool aborted = false;
                 if ((spins & 63u) == 63u)
@@ -208,6 +221,10 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
                 if (++spins > (1u << 20) || aborted) { ok = false; break; }
                 continue;               /* the round trip of the next poll is delay enough */
             }
+            TileAgg la = agg_identity();    /* earliest first: j = 3 is the earliest tile */
+#pragma unroll
+            for (int j = 3; j >= 0; --j)
+                if (j < jp) la = combine(la, unpack_agg(w0[j], w1[j]));
             const TileAgg win = window_fold3(la, lstar < 64 ? lstar + 1 : 64, lane);
             const TileAgg total = combine(win, acc);
             if (lstar < 64) {
@@ -217,6 +234,7 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
             }
             acc = total;
             win_hi -= 256;
+            fresh = true;
         }
     }
     if (lane == 0) {
@@ -373,8 +391,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         /* ---- 1. flag masks of my rows --------------------------------------------------- */
         /* Straight-line over the named rows; a row's 64-bit mask is stashed in lane r of
          * fm_lo/fm_hi (v_writelane), so nothing per-row lives in SGPRs or LDS. */
-        uint64_t myf = 0;                  /* bit r: my chunk of row r is an element */
-        uint32_t fm_lo = 0, fm_hi = 0;     /* lane r: flag mask of my row r          */
+        uint32_t fm_lo = 0, fm_hi = 0;     /* lane r: flag mask of my row r (rows without elements: 0) */
         uint32_t wslot = 0;                /* elements of this wavefront so far      */
         {
             uint32_t e_prev = R.before;
@@ -383,10 +400,9 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 const uint32_t xn = from_next_lane(R.q##r.x, (e_next_expr)); \
                 const bool f = chunk_flag(xp, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn); \
                 const uint64_t fmask = __ballot(f); \
-                myf |= f ? (1ull << r) : 0ull; \
-                write_lane(fm_lo, (uint32_t)fmask, r); \
-                write_lane(fm_hi, (uint32_t)(fmask >> 32), r); \
-                if (fmask != 0) {        /* rare: leave the chunk's surroundings for its element thread */ \
+                if (fmask != 0) {        /* rare: stash the mask, leave the chunk's surroundings for its element thread */ \
+                    write_lane(fm_lo, (uint32_t)fmask, r); \
+                    write_lane(fm_hi, (uint32_t)(fmask >> 32), r); \
                     const uint32_t xpp = from_prev_lane(R.q##r.z, (e_prev_z_expr)); \
                     const uint32_t slot = wslot + lanes_below(fmask); \
                     if (f && slot < (uint32_t)kDepCap) { \
@@ -410,13 +426,13 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             /* the chunk cut by the stream end is always an element */
             const uint32_t cut = (uint32_t)(n - wseg) >> 4;            /* its chunk number in my segment */
             const int cr = (int)(cut >> 6), cl = (int)(cut & 63u);
-            if (lane == cl && !((myf >> cr) & 1ull)) {
+            const uint64_t have = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, cr) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, cr);
+            if (!((have >> cl) & 1ull)) {
                 /* not flagged by its bytes: nothing was deposited for it; it is the wavefront's last
                  * element, and its thread must read the stream itself */
-                myf |= 1ull << cr;
-                if (wslot < (uint32_t)kDepCap) l.dep[wv][wslot].chunk = 0xFFFFFFFFu;
+                if (lane == 0 && wslot < (uint32_t)kDepCap) l.dep[wv][wslot].chunk = 0xFFFFFFFFu;
+                if (lane == cr) { if (cl < 32) fm_lo |= 1u << cl; else fm_hi |= 1u << (cl - 32); }
             }
-            if (lane == cr) { if (cl < 32) fm_lo |= 1u << cl; else fm_hi |= 1u << (cl - 32); }
         }
         /* lane r: elements of my rows in front of row r; then the same across wavefronts */
         uint32_t local_pre;
@@ -444,11 +460,11 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             const int r = __builtin_ctzll(rm);
             const uint32_t rp = HBS_ROW_PRE(r);
             const uint64_t f = HBS_ROW_FM(r);
-            if ((myf >> r) & 1ull)
+            if ((f >> lane) & 1ull)
                 l.list[rp + lanes_below(f)] = (uint16_t)(64 * (k4Rows * wv + r) + lane);
         }
         __syncthreads();
-        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < 1024; i += k4Threads) g_dbg4[256 + i] = l.list[i]; g_dbg4[2048 + tid] = (uint32_t)myf; })
+        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < 1024; i += k4Threads) g_dbg4[256 + i] = l.list[i]; })
         HBS4_T_MARK(1)
 
         /* ---- 2..4 on wavefront 0: elements -> tile aggregate -> look-back -> emit ----------- */
@@ -478,7 +494,9 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 
             Prefix ex;
             uint32_t it, stl;
-            const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
+            bool ok;
+            HBS4_DBG(if (g_fake_lb4) { ok = true; it = 0; stl = 0; ex.kept = tile * (uint64_t)(k4TileBytes - 4096); ex.nals = tile * 16; ex.inside = 1; } else)
+            ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
             HBS4_T_COUNT(7, ((unsigned long long)stl << 32) | it)
             __builtin_amdgcn_s_setprio(0);
             const uint32_t tile_kept = tagg.known + (ex.inside ? tagg.sig : 0u);
@@ -548,25 +566,40 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             /* the next tile is claimed as late as its round trip can still hide behind the copy:
              * tiles are looked back in ticket order, and a ticket taken long before its tile is
              * started makes every successor wait */
-            if (p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
+            if (kTicketEarly && p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
             if (can_store) {
-                const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
                 const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
-                /* straight-line over the named rows: k from the stashed mask (two readlanes and
-                 * mbcnt), one LDS read, one store.  A chunk with k elements in front of it is
+                const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
+                /* lane j: segment word j of this batch (j = 0..63), word 64 apart: a row without
+                 * elements needs one word, picked with a readlane instead of an LDS round trip */
+                const uint32_t segv = l.seg[lane];
+                const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[k4ElemPass]);
+                /* Straight-line over the named rows.  A chunk with k elements in front of it is
                  * served by the batch that holds element k-1 (k = 0: the tile start, batch 0). */
 #define HBS_COPY(r) { \
-                    const uint32_t k = HBS_ROW_PRE(r) + lanes_below(HBS_ROW_FM(r)); \
                     const uint32_t cc = cc0 + 64u * r; \
-                    const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
-                    if (!((myf >> r) & 1ull) && served && cc < whole) { \
-                        const uint32_t w = l.seg[k - pbase]; \
-                        if (seg_inside(w)) reinterpret_cast<Unaligned16_3*>(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)))->v = R.q##r; \
+                    if (!((rowmask >> r) & 1ull)) {          /* no element in this row: one k, one word for all lanes */ \
+                        const uint32_t k = HBS_ROW_PRE(r); \
+                        const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
+                        if (served) { \
+                            const uint32_t j = k - pbase; \
+                            const uint32_t w = (j == (uint32_t)k4ElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(j & 63u)); \
+                            if (seg_inside(w) && cc < whole) \
+                                reinterpret_cast<Unaligned16_3*>(out + (int64_t)seg_bias(w) + 16u * cc)->v = R.q##r; \
+                        } \
+                    } else { \
+                        const uint64_t f = HBS_ROW_FM(r); \
+                        const uint32_t k = HBS_ROW_PRE(r) + lanes_below(f); \
+                        const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
+                        if (!((f >> lane) & 1ull) && served && cc < whole) { \
+                            const uint32_t w = l.seg[k - pbase]; \
+                            if (seg_inside(w)) reinterpret_cast<Unaligned16_3*>(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)))->v = R.q##r; \
+                        } \
                     } }
                 HBS_ROWS(HBS_COPY)
 #undef HBS_COPY
             }
-            if (p + 1 == np && tid == 0) l.ticket = next_ticket;
+            if (p + 1 == np && tid == 0) l.ticket = kTicketEarly ? next_ticket : atomicAdd(&hdr->ticket, 1u);
             __syncthreads();
             HBS4_T_MARK(5)
         }
@@ -577,6 +610,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 }
 
 #ifdef HBS_PHASE_TIMING
+extern "C" int hbs_debug_fake_lb4(int on)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fake_lb4), &on, sizeof(int));
+}
 extern "C" int hbs_debug_dump4(uint32_t* host_out /* [4096] */)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg4), sizeof(uint32_t) * 4096);

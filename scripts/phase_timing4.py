@@ -17,9 +17,15 @@ ctx = hbs.Context(0)
 ctx.set_kernel(4)
 blocks, per_cu = ctx.grid()
 index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * 64 + 16)
+lib = api.load_library()
+if os.environ.get('HBS4_FAKE_LB'):
+    assert lib.hbs_debug_fake_lb4(C.c_int(1)) == 0
 for _ in range(3):
     ctx.index_extract_async(d, index, cap, rbsp if want_rbsp else None, summary)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ctx.index_extract_async(d, index, cap, rbsp if want_rbsp else None, summary); e1.record(); torch.cuda.synchronize()
+print('one call %.3f ms -> %.1f GB/s' % (e0.elapsed_time(e1), d.numel() / e0.elapsed_time(e1) / 1e6))
 out = np.zeros((1024, 8), dtype=np.uint64)
 lib = api.load_library()
 lib.hbs_debug_phase_cycles4.argtypes = [C.c_void_p]
