@@ -154,11 +154,29 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
 }
 
+/* Four 16-byte descriptor loads that bypass the non-coherent cache levels (sc1: the writer is on
+ * another XCD), issued together and awaited together.  A descriptor's two 8-byte words are each
+ * self-validating, so reading them with one 16-byte load is as good as two 8-byte atomics. */
+__device__ __forceinline__ void load_desc4(u32x4& d0, u32x4& d1, u32x4& d2, u32x4& d3,
+                                           const unsigned long long* p0, const unsigned long long* p1,
+                                           const unsigned long long* p2, const unsigned long long* p3)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+
 /*
- * Decoupled look-back by ONE wavefront, 256 predecessors per step: lane l reads the
- * descriptors of tiles win_hi - 4l - j (j = 0 nearest).  A lane folds the tiles in front of
- * its nearest prefix; the lanes up to the first one that holds a prefix are folded by
- * window_fold3().  Returns false on timeout/abort.  Called by every lane of wavefront 0.
+ * Decoupled look-back by ONE wavefront, 256 predecessors per step.  Lane l reads the descriptors
+ * of the tiles at distance l, 64 + l, 128 + l, 192 + l in front of win_hi: each of the four loads
+ * covers 64 consecutive descriptors, 1 KiB, eight cache lines.  The four groups are folded nearest
+ * first up to the nearest tile that already has its prefix.  Returns false on timeout/abort.
+ * Called by every lane of wavefront 0.
  */
 __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
                                            RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
@@ -179,41 +197,53 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
         for (;;) {
             ++dbg_iters;
             /* A descriptor that has been seen ready stays usable (an aggregate can only turn into
-             * a prefix): while waiting, only the ones still missing are read again. */
+             * a prefix): while waiting, only lanes that still miss one read again. */
+            bool need = fresh;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t t = win_hi - (4 * lane + j);
-                bool need = fresh;
-                if (!fresh) {
-                    const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
-                    need = !((s0 == s1) && (s0 != kDescEmpty));
+                const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
+                need = need || !((s0 == s1) && (s0 != kDescEmpty));
+            }
+            if (need) {
+                const int64_t t0 = win_hi - lane;
+                u32x4 d[4];
+                const unsigned long long* p[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t t = t0 - 64 * j;
+                    p[j] = &desc[2 * (t > 0 ? t : 0)];
                 }
-                if (need) {
-                    w0[j] = kDescPrefix; w1[j] = kDescPrefix;          /* virtual tile -1: empty prefix */
-                    if (t >= 0) {
-                        w0[j] = ld_desc3(&desc[2 * t]);
-                        w1[j] = ld_desc3(&desc[2 * t + 1]);
-                    }
+                load_desc4(d[0], d[1], d[2], d[3], p[0], p[1], p[2], p[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w0[j] = ((uint64_t)d[j].y << 32) | d[j].x;
+                    w1[j] = ((uint64_t)d[j].w << 32) | d[j].z;
+                    if (t0 - 64 * j < 0) { w0[j] = kDescPrefix; w1[j] = kDescPrefix; }   /* virtual tile -1: empty prefix */
                 }
             }
             fresh = false;
-            int jp = 4;                     /* my nearest tile that already has its prefix */
-            bool lane_ok = true;            /* every tile in front of it has its aggregate  */
+            /* nearest group that holds a prefix, with everything in front of it ready */
+            int j0 = -1, lstar = 64;
+            bool stall = false;
             uint64_t pw0 = 0, pw1 = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
                 const bool ready = (s0 == s1) && (s0 != kDescEmpty);
-                if (jp == 4) {
-                    if (!ready) lane_ok = false;
-                    else if (s0 == kDescPrefix) { jp = j; pw0 = w0[j]; pw1 = w1[j]; }
+                const uint64_t m_ready = __ballot(ready);
+                const uint64_t m_pre = __ballot(ready && s0 == kDescPrefix);
+                if (j0 < 0 && !stall) {
+                    if (m_pre != 0) {
+                        const int ls = (int)__builtin_ctzll(m_pre);
+                        const uint64_t front = (1ull << ls) - 1ull;
+                        if ((m_ready & front) != front) stall = true;
+                        else { j0 = j; lstar = ls; pw0 = w0[j]; pw1 = w1[j]; }
+                    } else if (m_ready != ~0ull) {
+                        stall = true;
+                    }
                 }
             }
-            const uint64_t m_pre = __ballot(jp < 4 && lane_ok);
-            const uint64_t m_ok = __ballot(lane_ok);
-            const int lstar = m_pre ? (int)__builtin_ctzll(m_pre) : 64;
-            const uint64_t need_lanes = (lstar >= 63) ? ~0ull : ((2ull << lstar) - 1ull);
-            if ((m_ok & need_lanes) != need_lanes) {
+            if (stall) {
                 ++dbg_stalls;
                 bool aborted = false;
                 if ((spins & 63u) == 63u)
@@ -221,13 +251,15 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
                 if (++spins > (1u << 20) || aborted) { ok = false; break; }
                 continue;               /* the round trip of the next poll is delay enough */
             }
-            TileAgg la = agg_identity();    /* earliest first: j = 3 is the earliest tile */
+            TileAgg total = acc;
 #pragma unroll
-            for (int j = 3; j >= 0; --j)
-                if (j < jp) la = combine(la, unpack_agg(w0[j], w1[j]));
-            const TileAgg win = window_fold3(la, lstar < 64 ? lstar + 1 : 64, lane);
-            const TileAgg total = combine(win, acc);
-            if (lstar < 64) {
+            for (int j = 0; j < 4; ++j) {
+                if (j0 < 0 || j <= j0) {
+                    const TileAgg win = window_fold3(unpack_agg(w0[j], w1[j]), (j == j0) ? lstar : 64, lane);
+                    total = combine(win, total);
+                }
+            }
+            if (j0 >= 0) {
                 const Prefix p = unpack_pre(readlane_u64(pw0, lstar), readlane_u64(pw1, lstar));
                 excl = fold(p, total);
                 break;
