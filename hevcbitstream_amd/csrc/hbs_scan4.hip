@@ -110,6 +110,11 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 #define HBS4_TICKET_EARLY 0
 #endif
 constexpr bool kTicketEarly = HBS4_TICKET_EARLY != 0;
+/* or in the middle of it: after this row's store (-1: never) */
+#ifndef HBS4_TICKET_ROW
+#define HBS4_TICKET_ROW (-1)
+#endif
+constexpr int kTicketRow = HBS4_TICKET_ROW;
 constexpr int kDepCap = 64;
 struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
 
@@ -609,6 +614,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 /* Straight-line over the named rows.  A chunk with k elements in front of it is
                  * served by the batch that holds element k-1 (k = 0: the tile start, batch 0). */
 #define HBS_COPY(r) { \
+                    if (kTicketRow == r && p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u); \
                     const uint32_t cc = cc0 + 64u * r; \
                     if (!((rowmask >> r) & 1ull)) {          /* no element in this row: one k, one word for all lanes */ \
                         const uint32_t k = HBS_ROW_PRE(r); \
@@ -631,7 +637,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 HBS_ROWS(HBS_COPY)
 #undef HBS_COPY
             }
-            if (p + 1 == np && tid == 0) l.ticket = kTicketEarly ? next_ticket : atomicAdd(&hdr->ticket, 1u);
+            if (p + 1 == np && tid == 0) l.ticket = (kTicketEarly || (kTicketRow >= 0 && can_store)) ? next_ticket : atomicAdd(&hdr->ticket, 1u);
             __syncthreads();
             HBS4_T_MARK(5)
         }

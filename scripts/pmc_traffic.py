@@ -1,0 +1,34 @@
+"""HBM traffic per launch of the fused kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+usage: pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <algorithmic_bytes> [out.json]
+Counters are in KiB; FETCH_SIZE is doubled per the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md."""
+import csv, glob, json, sys
+
+def rows(d, sub, name):
+    out = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"] and r["Counter_Name"] == name:
+                out.append(r)
+    by = {}
+    for r in out:
+        by.setdefault(r["Dispatch_Id"], 0.0)
+        by[r["Dispatch_Id"]] += float(r["Counter_Value"])
+    meta = out[0] if out else {}
+    return list(by.values()), meta
+
+fd, wd, sub, algo = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+f, fm = rows(fd, sub, "FETCH_SIZE")
+w, wm = rows(wd, sub, "WRITE_SIZE")
+fetch = sum(f) / len(f) * 1024 * 2
+write = sum(w) / len(w) * 1024
+res = {"kernel_substring": sub, "launches": {"fetch_pass": len(f), "write_pass": len(w)},
+       "fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write),
+       "traffic_bytes_per_launch": int(fetch + write), "algorithmic_bytes_per_launch": algo,
+       "ratio_traffic_over_algorithmic": round((fetch + write) / algo, 4),
+       "raw_KiB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
+       "dispatch": {k: fm.get(k) for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count")},
+       "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (no trace domains); KiB units; FETCH_SIZE x2 (gfx950)"}
+js = json.dumps(res, indent=1)
+print(js)
+if len(sys.argv) > 5:
+    open(sys.argv[5], "w").write(js + "\n")
