@@ -135,3 +135,15 @@ def test_repeatable(ctx, orc):
     for _ in range(3):
         got_idx, got_arena, s = run(ctx, stream)
         assert np.array_equal(got_idx, idx) and np.array_equal(got_arena, arena)
+
+
+@pytest.mark.parametrize("pattern", [b"\x00", b"\x00\x00\x03", b"\x00\x00\x01\x42", b"\x00\x00\x00\x01\x26\x01\xaf"],
+                         ids=["zeros", "epb-run", "start-codes", "tiny-nals"])
+def test_dense_patterns(ctx, orc, pattern):
+    """streams in which every 16-byte chunk is touched by a pattern: the event-sparse kernel takes the
+    elements of a tile in batches (and finds no plain chunk at all), the others run as usual."""
+    n = (1 << 20) + 12345
+    s = np.tile(np.frombuffer(pattern, dtype=np.uint8), n // len(pattern) + 1)[:n].copy()
+    check(ctx, orc, s)
+    s[n // 2:n // 2 + 4000] = 0x55          # a plain stretch in the middle of the dense stream
+    check(ctx, orc, s)
