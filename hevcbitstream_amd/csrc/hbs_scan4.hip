@@ -6,29 +6,29 @@
  * find_nal_unit + nal_to_rbsp, h264_nal.c:38-76 / :147-200, driven as in
  * hevc_analyze.c:135-177).  What differs is who does the exact work:
  *
- *   1. A tile is 64 KiB; wavefront w holds its 8 KiB as 8 rows of 1 KiB in
- *      VGPRs (hbs_wave.h).  Per 16-byte chunk, chunk_flag() (hbs_sparse.h)
- *      decides that no pattern 00 00 {<=3} can touch it; the row's ballot is its
- *      flag mask.  Flagged chunks -- a start code per NAL, a few emulation
- *      prevention bytes, a few false alarms: ~15 of 4096 -- are listed in LDS
- *      in stream order.
- *   2. Thread i takes the i-th listed chunk ("element"): exact window logic of
- *      hbs_tile.h on its six dwords, re-read from L2.  A wave scan with
- *      combine() over (gap, chunk) elements gives the tile aggregate; normally
- *      only wavefront 0 has any element.
- *   3. Wavefront 0 alone runs the decoupled look-back, 256 predecessors per
- *      step (4 per lane); the others wait at a barrier.
+ *   1. A workgroup is 4 wavefronts of 256 VGPRs; wavefront w holds 40 rows of
+ *      1 KiB in named registers (a tile = 160 KiB).  Per 16-byte chunk,
+ *      chunk_flag() (hbs_sparse.h) decides that no pattern 00 00 {<=3} can
+ *      touch it; the row's ballot is its flag mask.  Flagged chunks -- a start
+ *      code per NAL, a few emulation prevention bytes, a few false alarms: ~15
+ *      of 10240 -- are listed in LDS in stream order, and their lanes leave the
+ *      chunk's surroundings in LDS.
+ *   2. Wavefront 0 takes the listed chunks as "elements", one per lane: exact
+ *      window logic of hbs_tile.h on bytes [-8, 20) of the chunk.  A wave scan
+ *      with combine() over (gap, chunk) elements gives the tile aggregate.
+ *   3. Wavefront 0 runs the decoupled look-back, 256 predecessors per step;
+ *      the others wait at a barrier.  Part of wavefront 0's rows are parked in
+ *      LDS during 2 and 3, which need ~100 registers of their own.
  *   4. With the carried state known the elements emit index entries, write
  *      their own kept bytes, and leave one segment word each; every other chunk
- *      finds the word of the nearest element in front of it (row prefix +
- *      mbcnt of the flag mask) and, if inside a NAL, is one byte-aligned
- *      16-byte store straight from its registers.
+ *      finds the word of the nearest element in front of it and, if inside a
+ *      NAL, is one byte-aligned 16-byte store straight from its registers.
  *
  * Tiles are handed out by an atomic ticket in arrival order, so a workgroup
  * only ever waits for tiles that are already being worked on: no co-residency
  * requirement, and a slow workgroup delays its successors, not a whole round.
- * Streams dense in zero pairs (every chunk an element) stay exact: elements are
- * processed kThreads at a time.
+ * Tiles dense in zero pairs (every chunk an element) stay exact: elements are
+ * taken 64 at a time, each batch followed by the copy of the chunks behind it.
  */
 #include <hip/hip_runtime.h>
 #include "hbs_wave.h"
@@ -57,7 +57,6 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 static_assert(k4Rows == 40, "the row lists below name every row register");
 #define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39)
 #define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31) X(30,31,32) X(31,32,33) X(32,33,34) X(33,34,35) X(34,35,36) X(35,36,37) X(36,37,38) X(37,38,39)   /* (previous row, row, next row), inner rows */
-#define HBS_ROWS_BUT_LAST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38)
 /* rows of wavefront 0 that wait in LDS while it handles elements and looks back: (slot, row) */
 constexpr int kParkRows = 16;
 #define HBS_PARKED(X) X(0,24) X(1,25) X(2,26) X(3,27) X(4,28) X(5,29) X(6,30) X(7,31) X(8,32) X(9,33) X(10,34) X(11,35) X(12,36) X(13,37) X(14,38) X(15,39)
@@ -72,28 +71,6 @@ struct RowRegs {
     uint32_t after;           /* dword behind it (0xFF bytes past the end of the stream)      */
 };
 
-/* Row r of the register image, r wave-uniform: a scalar switch picks the registers, so that the
- * per-row phases are one rolled loop body each (unrolled over 16 named rows the compiler hoists
- * every row's addresses and constants out of the tile loop and runs out of registers). */
-__device__ __forceinline__ u32x4 get_row(const RowRegs& R, int r)
-{
-    switch (r) {
-#define HBS_CASE(i) case i: return R.q##i;
-    HBS_ROWS_BUT_LAST(HBS_CASE)
-#undef HBS_CASE
-    default: return R.q39;
-    }
-}
-__device__ __forceinline__ uint32_t row_first_dword(const RowRegs& R, int r)
-{
-    switch (r) {
-#define HBS_CASE(i) case i: return R.q##i.x;
-    HBS_ROWS_BUT_LAST(HBS_CASE)
-#undef HBS_CASE
-    default: return R.q39.x;
-    }
-}
-
 /* All of a wavefront's rows, unguarded: the last tile of a stream is read from a padded copy
  * (k_prepare_tail4), so every address below exists.  `src` is the stream or that copy. */
 __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __restrict__ src, uint64_t seg, int lane)
@@ -105,16 +82,6 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 }
 
 /* what a flagged lane leaves for the thread that will handle its chunk as an element */
-/* take the next tile's ticket before (true) or after (false) the copy of the current one */
-#ifndef HBS4_TICKET_EARLY
-#define HBS4_TICKET_EARLY 0
-#endif
-constexpr bool kTicketEarly = HBS4_TICKET_EARLY != 0;
-/* or in the middle of it: after this row's store (-1: never) */
-#ifndef HBS4_TICKET_ROW
-#define HBS4_TICKET_ROW (-1)
-#endif
-constexpr int kTicketRow = HBS4_TICKET_ROW;
 constexpr int kDepCap = 64;
 struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
 
@@ -573,7 +540,6 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         /* ---- 5. copy everything that is not an element; tiles dense in elements take the
          *         elements 64 at a time, wavefront 0 redoing each batch before its copy ------- */
         TileAgg accb = agg_identity();     /* wavefront 0: aggregate of the batches done so far */
-        uint32_t next_ticket = 0;
         const uint32_t np = npass ? npass : 1u;
 #pragma unroll 1
         for (uint32_t p = 0; p < np; ++p) {
@@ -600,10 +566,6 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 }
                 __syncthreads();
             }
-            /* the next tile is claimed as late as its round trip can still hide behind the copy:
-             * tiles are looked back in ticket order, and a ticket taken long before its tile is
-             * started makes every successor wait */
-            if (kTicketEarly && p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u);
             if (can_store) {
                 const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
                 const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
@@ -614,7 +576,6 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 /* Straight-line over the named rows.  A chunk with k elements in front of it is
                  * served by the batch that holds element k-1 (k = 0: the tile start, batch 0). */
 #define HBS_COPY(r) { \
-                    if (kTicketRow == r && p + 1 == np && tid == 0) next_ticket = atomicAdd(&hdr->ticket, 1u); \
                     const uint32_t cc = cc0 + 64u * r; \
                     if (!((rowmask >> r) & 1ull)) {          /* no element in this row: one k, one word for all lanes */ \
                         const uint32_t k = HBS_ROW_PRE(r); \
@@ -637,7 +598,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 HBS_ROWS(HBS_COPY)
 #undef HBS_COPY
             }
-            if (p + 1 == np && tid == 0) l.ticket = (kTicketEarly || (kTicketRow >= 0 && can_store)) ? next_ticket : atomicAdd(&hdr->ticket, 1u);
+            /* The next tile is claimed only now: tiles are looked back in ticket order, and a ticket
+             * taken before the copy (whose duration varies with memory load) makes successors wait for
+             * a tile that has not even been started (measured: 2.1 instead of 3.6 polls per tile). */
+            if (p + 1 == np && tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
             __syncthreads();
             HBS4_T_MARK(5)
         }

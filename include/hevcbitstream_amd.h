@@ -94,8 +94,10 @@ int  hbs_ctx_synchronize(hbs_ctx* ctx);
 int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
 int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
 int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
-/* Two implementations of the fused scan/extract kernel exist: 2 = tile staged in an LDS
- * image (hbs_scan.hip), 3 = tile held in registers (hbs_scan3.hip).  Same results. */
+/* Three implementations of the fused scan/extract kernel exist, with identical results:
+ * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the default and the fastest),
+ * 2 = tile staged in an LDS image (hbs_scan.hip), 3 = tile in registers, dense per-row
+ * classification (hbs_scan3.hip).  Environment HBS_KERNEL=2|3|4 sets the default. */
 int  hbs_ctx_set_kernel(hbs_ctx* ctx, int variant);
 int  hbs_ctx_get_kernel(hbs_ctx* ctx);
 /* Text of the last HIP/driver error seen by this context. */
