@@ -7,13 +7,18 @@
  * write_hevc_nal_unit, hevc_stream.c:1324-1327) plus the start-code bytes the
  * reference's callers put in front of each NAL.
  *
- * One wavefront per NAL; a lane owns 256-byte segments of that NAL's RBSP
- * (hbs_emit.h).  Pass 1 counts the bytes each segment inserts, a scan turns
- * NAL sizes into output offsets, pass 2 copies with insertion into byte-aligned
- * 16-byte stores.  Traffic: RBSP read twice, stream written once (3 B/B); the
- * round-1 kernel favours being obviously right over the last factor of speed.
+ * One wavefront per NAL, a row of 1 KiB at a time (lane l = 16 bytes at 16 l,
+ * the next row's load in flight).  A 03 is only ever inserted behind two zero
+ * bytes, so chunk_flag() (hbs_sparse.h: no two adjacent zeros start in bytes
+ * [-2, 16) of the chunk) clears nearly every chunk for a plain copy; flagged
+ * chunks run the byte-exact rbsp_to_nal rules of hbs_emit.h.  Pass 1 counts the
+ * inserted bytes per NAL, a scan turns NAL sizes into output offsets, pass 2
+ * copies into byte-aligned 16-byte stores.  Traffic: RBSP read twice, stream
+ * written once (3 B/B).
  */
 #include <hip/hip_runtime.h>
+#include "hbs_wave.h"
+#include "hbs_sparse.h"
 #include "hbs_emit.h"
 #include "hbs_emit_launch.h"
 
@@ -45,9 +50,46 @@ __device__ __forceinline__ uint64_t gap_of(const hbs_nal_entry* __restrict__ idx
     return idx[k].start - prev_end;
 }
 
+/* 16 bytes of a NAL's RBSP at offset off from its first byte; 0xFF behind its end */
+__device__ __forceinline__ u32x4 load_nal_chunk(const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, uint32_t off)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    if (off + 16u <= len) return reinterpret_cast<const U16*>(rbsp + begin + off)->v;
+    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu, w3 = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (uint32_t b = 0; b < 16; ++b) {
+        if (off + b < len) {
+            const uint32_t m = ~(0xFFu << (8u * (b & 3u)));
+            const uint32_t x = (uint32_t)rbsp[begin + off + b] << (8u * (b & 3u));
+            if ((b >> 2) == 0) w0 = (w0 & m) | x;
+            else if ((b >> 2) == 1) w1 = (w1 & m) | x;
+            else if ((b >> 2) == 2) w2 = (w2 & m) | x;
+            else w3 = (w3 & m) | x;
+        }
+    }
+    u32x4 v;
+    v.x = w0; v.y = w1; v.z = w2; v.w = w3;
+    return v;
+}
+
+/* One row of a NAL: which of its chunks may need a 03 (conservative), from the row's registers. */
+struct RowFlags {
+    bool mine;             /* my chunk */
+    uint64_t mask;         /* the row's  */
+};
+__device__ __forceinline__ RowFlags row_flags(const u32x4& q, uint32_t e_prev, uint32_t e_next, uint32_t off, uint32_t len)
+{
+    const uint32_t xp = from_prev_lane(q.w, e_prev);
+    const uint32_t xn = from_next_lane(q.x, e_next);
+    RowFlags r;
+    r.mine = off < len && chunk_flag(xp, q.x, q.y, q.z, q.w, xn);
+    r.mask = __ballot(r.mine);
+    return r;
+}
+
 __global__ __launch_bounds__(256)
 void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-              uint16_t* __restrict__ seg_cnt, unsigned long long* __restrict__ nal_total)
+              unsigned long long* __restrict__ nal_total)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -55,18 +97,23 @@ void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     for (uint64_t k = wave; k < n; k += nwaves) {
         const uint64_t begin = idx[k].rbsp_off;
         const uint32_t len = idx[k].rbsp_len;
-        const uint32_t nseg = (len + kSegBytes - 1) / kSegBytes;
-        const uint64_t slot0 = begin / kSegBytes + k;
-        uint32_t acc = 0;
-        for (uint32_t s = lane; s < nseg; s += 64) {
-            const uint64_t sb = begin + (uint64_t)s * kSegBytes;
-            const uint64_t se = (s + 1 == nseg) ? begin + len : sb + kSegBytes;
-            const uint32_t c = count_segment(rbsp, begin, sb, se);
-            seg_cnt[slot0 + s] = (uint16_t)c;
-            acc += c;
+        const uint32_t nrows = (len + 1023u) / 1024u;
+        uint32_t ins = 0;                                     /* wave-uniform */
+        uint32_t e_prev = 0xFFFFFFFFu;                        /* a NAL starts with count = 0 */
+        u32x4 qn = load_nal_chunk(rbsp, begin, len, 16u * (uint32_t)lane);
+        for (uint32_t r = 0; r < nrows; ++r) {
+            const u32x4 q = qn;
+            const uint32_t off = 1024u * r + 16u * (uint32_t)lane;
+            qn = load_nal_chunk(rbsp, begin, len, off + 1024u);
+            const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
+            if (f.mask != 0) {
+                uint32_t c = 0;
+                if (f.mine) c = count_segment(rbsp, begin, begin + off, begin + (off + 16u < len ? off + 16u : len));
+                ins += wave_sum_u32(c);
+            }
+            e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
         }
-        acc = wave_sum_u32(acc);
-        if (lane == 0) nal_total[k] = gap_of(idx, k, gap_mode) + len + acc;
+        if (lane == 0) nal_total[k] = gap_of(idx, k, gap_mode) + len + ins;
     }
 }
 
@@ -96,51 +143,69 @@ void k_scan_u64(const unsigned long long* __restrict__ v, unsigned long long* __
 
 __global__ __launch_bounds__(256)
 void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-             const uint16_t* __restrict__ seg_cnt, const unsigned long long* __restrict__ out_off,
+             const unsigned long long* __restrict__ nal_total, const unsigned long long* __restrict__ out_off,
              uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err)
 {
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t k = wave; k < n; k += nwaves) {
         const uint64_t begin = idx[k].rbsp_off;
         const uint32_t len = idx[k].rbsp_len;
-        const uint32_t nseg = (len + kSegBytes - 1) / kSegBytes;
-        const uint64_t slot0 = begin / kSegBytes + k;
+        const uint32_t nrows = (len + 1023u) / 1024u;
         const uint64_t gap = gap_of(idx, k, gap_mode);
         const uint64_t base = out_off[k];
         const uint64_t nal_start = base + gap;
-        uint32_t carry = 0;                                   /* inserted bytes before the current batch */
-        bool fits = true;
-        for (uint32_t s0 = 0; s0 < nseg; s0 += 64) {
-            const uint32_t s = s0 + lane;
-            const uint32_t c = (s < nseg) ? seg_cnt[slot0 + s] : 0u;
-            uint32_t tot;
-            const uint32_t before = wave_excl_scan_u32(c, lane, tot);
-            if (s < nseg) {
-                const uint64_t sb = begin + (uint64_t)s * kSegBytes;
-                const uint64_t se = (s + 1 == nseg) ? begin + len : sb + kSegBytes;
-                const uint64_t dst = nal_start + (uint64_t)s * kSegBytes + carry + before;
-                if (dst + (se - sb) + c <= out_cap) emit_segment(rbsp, begin, sb, se, out + dst);
-                else fits = false;
+        const uint64_t nal_end = base + nal_total[k];
+        const bool fits = nal_end <= out_cap;
+        if (fits) {
+            uint32_t ins = 0;                                 /* bytes inserted so far, wave-uniform */
+            uint32_t e_prev = 0xFFFFFFFFu;
+            u32x4 qn = load_nal_chunk(rbsp, begin, len, 16u * (uint32_t)lane);
+            for (uint32_t r = 0; r < nrows; ++r) {
+                const u32x4 q = qn;
+                const uint32_t off = 1024u * r + 16u * (uint32_t)lane;
+                qn = load_nal_chunk(rbsp, begin, len, off + 1024u);
+                const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
+                uint8_t* dst = out + nal_start + off + ins;
+                uint32_t c = 0;
+                if (f.mask != 0) {
+                    const uint64_t se = begin + (off + 16u < len ? off + 16u : len);
+                    if (f.mine) c = count_segment(rbsp, begin, begin + off, se);
+                    uint32_t tot;
+                    dst += wave_excl_scan_u32(c, lane, tot);
+                    ins += tot;
+                    if (f.mine) emit_segment(rbsp, begin, begin + off, se, dst);
+                }
+                if (!f.mine) {
+                    if (off + 16u <= len) {
+                        reinterpret_cast<U16*>(dst)->v = q;
+                    } else if (off < len) {                    /* the NAL's last, partial chunk */
+                        const uint32_t nb = len - off;
+#pragma unroll 1
+                        for (uint32_t b = 0; b < nb; ++b) {
+                            const uint32_t w = (b >> 2) == 0 ? q.x : (b >> 2) == 1 ? q.y : (b >> 2) == 2 ? q.z : q.w;
+                            dst[b] = (uint8_t)(w >> (8u * (b & 3u)));
+                        }
+                    }
+                }
+                e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
             }
-            carry += tot;
         }
         if (lane == 0) {
-            if (nal_start <= out_cap) {
+            if (fits) {
                 for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;      /* zero_byte / leading zeros */
                 if (gap) out[nal_start - 1] = 1;
-            } else {
-                fits = false;
             }
             if (idx_out) {
                 hbs_nal_entry e;
-                e.start = nal_start; e.end = nal_start + len + carry;
+                e.start = nal_start; e.end = nal_end;
                 e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
                 idx_out[k] = e;
             }
+            if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
         }
-        if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
     }
 }
 
@@ -193,11 +258,11 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    const unsigned grid = 256 * 8;
+    const unsigned grid = 256 * 16;
     if (a.n) {
-        k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.seg_cnt, a.nal_total);
+        k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total);
         k_scan_u64<<<1, 1024, 0, st>>>(a.nal_total, a.out_off, a.n, a.total);
-        k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.seg_cnt, a.out_off, a.out, a.out_cap, a.index_out, a.err);
+        k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err);
     } else {
         e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;

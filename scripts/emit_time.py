@@ -1,0 +1,23 @@
+"""Timing of K3 (hbs_emit_annexb) on a ~1 GiB synthetic arena (dev aid, not the bench)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+import hevcbitstream_amd as hbs
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ctx = hbs.Context(0)
+g = ctx.synth_stream(0x1234, 104858, mode)          # runs the generator + K3 once
+rb, sb = g["rbsp_bytes"], g["stream_bytes"]
+print("rbsp bytes", rb, "stream bytes", sb)
+out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
+idx_out = torch.empty(104858 * 32, dtype=torch.uint8, device="cuda")
+summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+for i in range(6):
+    ctx.emit_annexb_async(g["rbsp"], rb, g["index"], 104858, 1, out, idx_out, summary)
+    ev[i].record()
+torch.cuda.synchronize()
+ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+best = min(ts)
+print("ms per call", ["%.3f" % t for t in ts])
+print("best %.3f ms -> %.1f GB/s emitted, %.1f GB/s traffic (3 B/B)" % (best, sb / best / 1e6, (2 * rb + sb) / best / 1e6))
+assert torch.equal(out[:sb], g["stream"][:sb])

@@ -135,12 +135,27 @@ extern "C" int64_t sim_emit_annexb(const uint8_t* rbsp, const hbs_nal_entry* idx
         for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;
         if (gap) out[nal_start - 1] = 1;
         uint64_t dst = nal_start;
-        const uint32_t nseg = (len + kSegBytes - 1) / kSegBytes;
-        for (uint32_t s = 0; s < nseg; ++s) {
-            const uint64_t sb = begin + (uint64_t)s * kSegBytes;
-            const uint64_t se = (s + 1 == nseg) ? begin + len : sb + kSegBytes;
+        /* as the kernels do it: 16-byte chunks, the byte-exact rules only where chunk_flag() says
+         * two adjacent zeros may sit in front of one of the chunk's bytes */
+        auto nal_dword = [&](int64_t o) {          /* bytes of this NAL only; 0xFF outside */
+            uint32_t v = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int64_t q = o + i;
+                v |= (uint32_t)((q >= 0 && q < (int64_t)len) ? rbsp[begin + q] : 0xFF) << (8 * i);
+            }
+            return v;
+        };
+        for (uint32_t off = 0; off < len; off += 16) {
+            const uint64_t sb = begin + off, se = begin + (off + 16 < len ? off + 16 : len);
+            const bool f = chunk_flag(nal_dword((int64_t)off - 4), nal_dword(off), nal_dword(off + 4), nal_dword(off + 8),
+                                      nal_dword(off + 12), nal_dword(off + 16));
             const uint32_t c = count_segment(rbsp, begin, sb, se);
-            emit_segment(rbsp, begin, sb, se, out + dst);
+            if (!f) {
+                if (c != 0) return -2;             /* the test must be conservative */
+                memcpy(out + dst, rbsp + sb, se - sb);
+            } else {
+                emit_segment(rbsp, begin, sb, se, out + dst);
+            }
             dst += (se - sb) + c;
         }
         if (idx_out) { idx_out[k] = idx[k]; idx_out[k].start = nal_start; idx_out[k].end = dst; idx_out[k].status = 0; }
