@@ -241,15 +241,14 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
 {
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index_in || !d_out))) return HBS_E_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
-    const uint64_t nseg = rbsp_bytes / hbs::kSegBytes + n_nals + 2;
-    const uint64_t b_seg = round256(nseg * 2), b_n = round256((n_nals + 1) * 8);
+    const uint64_t b_seg = 8192, b_n = round256((n_nals + 1) * 8);       /* b_seg: the scan's 1024 partial sums */
     int rc = ensure_ws(c, b_seg + 2 * b_n + 512);
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::EmitArgs a;
     a.rbsp = d_rbsp; a.rbsp_bytes = rbsp_bytes; a.index_in = d_index_in; a.n = n_nals; a.gap_mode = gap_mode;
     a.out = d_out; a.out_cap = out_cap; a.index_out = d_index_out; a.summary = d_summary;
-    a.seg_cnt = reinterpret_cast<uint16_t*>(w);
+    a.scan_tmp = reinterpret_cast<unsigned long long*>(w);
     a.nal_total = reinterpret_cast<unsigned long long*>(w + b_seg);
     a.out_off = reinterpret_cast<unsigned long long*>(w + b_seg + b_n);
     a.total = reinterpret_cast<unsigned long long*>(w + b_seg + 2 * b_n);
@@ -264,7 +263,7 @@ int hbs_synth_rbsp(hbs_ctx* c, uint64_t seed, uint64_t n_nals, int mode,
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index)) || (mode != 0 && mode != 1)) return HBS_E_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
     const uint64_t b_n = round256((n_nals + 1) * 8);
-    int rc = ensure_ws(c, 2 * b_n + 512);
+    int rc = ensure_ws(c, 2 * b_n + 512 + 8192);
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::SynthArgs a;
@@ -273,6 +272,7 @@ int hbs_synth_rbsp(hbs_ctx* c, uint64_t seed, uint64_t n_nals, int mode,
     a.offs = reinterpret_cast<unsigned long long*>(w + b_n);
     a.total = reinterpret_cast<unsigned long long*>(w + 2 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + 2 * b_n + 256);
+    a.scan_tmp = reinterpret_cast<unsigned long long*>(w + 2 * b_n + 512);
     hipError_t e = hbs::launch_synth_rbsp(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_synth_rbsp");
 }

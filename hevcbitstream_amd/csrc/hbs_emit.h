@@ -19,7 +19,7 @@
 
 namespace hbs {
 
-constexpr uint32_t kSegBytes = 256;
+constexpr uint32_t kSegBytes = 256;       /* only the generator's segmenting of tests/sim still uses this */
 
 /* value of the reference's `count` on entering byte p of a NAL that begins at
  * nal_begin (arena offsets) */

@@ -117,28 +117,92 @@ void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     }
 }
 
-/* exclusive scan of v[0..n) into out[0..n), total to *total; one workgroup */
-__global__ __launch_bounds__(1024)
-void k_scan_u64(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
-                unsigned long long* __restrict__ total)
+/* ---- exclusive scan of v[0..n) into out[0..n), total to *total -----------------------------
+ * three small launches: per-block sums of contiguous slices, a scan of the 1024 sums, and the
+ * slices again with their offsets (coalesced 256-wide chunks, running carry). */
+constexpr int kScanBlocks = 1024;
+
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long x, int lane)
 {
-    __shared__ unsigned long long part[1024];
-    const int tid = threadIdx.x;
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t lo = (uint64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
-    unsigned long long s = 0;
-    for (uint64_t i = lo; i < hi; ++i) s += v[i];
-    part[tid] = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(x, d, 64);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+
+/* exclusive scan across the 256 threads of a workgroup; *total = sum (same in every thread) */
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long x, unsigned long long* wsum /* [4] LDS */,
+                                                                  unsigned long long& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long inc = wave_incl_scan_u64(x, lane);
+    __syncthreads();                       /* wsum may still be read from the previous round */
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        unsigned long long t = (tid >= d) ? part[tid - d] : 0ull;
+    unsigned long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wv) before += wsum[w]; tot += wsum[w]; }
+    total = tot;
+    return before + inc - x;
+}
+
+__global__ __launch_bounds__(256)
+void k_scan_reduce(const unsigned long long* __restrict__ v, uint64_t n, unsigned long long* __restrict__ part)
+{
+    __shared__ unsigned long long wsum[4];
+    const uint64_t per = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint64_t lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned long long s = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) s += v[i];
+    unsigned long long tot;
+    (void)block_excl_scan_u64(s, wsum, tot);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanBlocks)
+void k_scan_parts(unsigned long long* __restrict__ part, unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long sh[kScanBlocks];
+    const int tid = threadIdx.x;
+    const unsigned long long s = part[tid];
+    sh[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < kScanBlocks; d <<= 1) {
+        const unsigned long long t = (tid >= d) ? sh[tid - d] : 0ull;
         __syncthreads();
-        part[tid] += t;
+        sh[tid] += t;
         __syncthreads();
     }
-    unsigned long long run = part[tid] - s;
-    for (uint64_t i = lo; i < hi; ++i) { const unsigned long long x = v[i]; out[i] = run; run += x; }
-    if (tid == 1023) *total = part[1023];
+    part[tid] = sh[tid] - s;
+    if (tid == kScanBlocks - 1) *total = sh[tid];
+}
+
+__global__ __launch_bounds__(256)
+void k_scan_apply(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
+                  const unsigned long long* __restrict__ part)
+{
+    __shared__ unsigned long long wsum[4];
+    const uint64_t per = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint64_t lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned long long carry = part[blockIdx.x];
+    for (uint64_t base = lo; base < hi; base += 256) {
+        const uint64_t i = base + threadIdx.x;
+        const unsigned long long x = (i < hi) ? v[i] : 0ull;
+        unsigned long long tot;
+        const unsigned long long ex = block_excl_scan_u64(x, wsum, tot);
+        if (i < hi) out[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+static void launch_scan_u64(const unsigned long long* v, unsigned long long* out, uint64_t n, unsigned long long* total,
+                            unsigned long long* part /* kScanBlocks entries */, hipStream_t st)
+{
+    k_scan_reduce<<<kScanBlocks, 256, 0, st>>>(v, n, part);
+    k_scan_parts<<<1, kScanBlocks, 0, st>>>(part, total);
+    k_scan_apply<<<kScanBlocks, 256, 0, st>>>(v, out, n, part);
 }
 
 __global__ __launch_bounds__(256)
@@ -261,7 +325,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     const unsigned grid = 256 * 16;
     if (a.n) {
         k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total);
-        k_scan_u64<<<1, 1024, 0, st>>>(a.nal_total, a.out_off, a.n, a.total);
+        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total, a.scan_tmp, st);
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err);
     } else {
         e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
@@ -277,7 +341,7 @@ hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     if (a.n) {
         k_synth_len<<<1024, 256, 0, st>>>(a.seed, a.n, a.lens);
-        k_scan_u64<<<1, 1024, 0, st>>>(a.lens, a.offs, a.n, a.total);
+        launch_scan_u64(a.lens, a.offs, a.n, a.total, a.scan_tmp, st);
         k_synth_fill<<<256 * 8, 256, 0, st>>>(a.seed, a.n, a.mode, a.lens, a.offs, a.rbsp, a.rbsp_cap, a.index, a.err);
     } else {
         e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);

@@ -17,7 +17,7 @@ struct EmitArgs {
     hbs_nal_entry* index_out;         /* nullable                                  */
     hbs_summary* summary;
     /* workspace */
-    uint16_t* seg_cnt;                /* rbsp_bytes/256 + n + 1 entries            */
+    unsigned long long* scan_tmp;     /* 1024 entries                              */
     unsigned long long* nal_total;    /* n                                         */
     unsigned long long* out_off;      /* n                                         */
     unsigned long long* total;        /* 1                                         */
@@ -31,6 +31,7 @@ struct SynthArgs {
     hbs_summary* summary;
     unsigned long long* lens;         /* n */
     unsigned long long* offs;         /* n */
+    unsigned long long* scan_tmp;     /* 1024 entries */
     unsigned long long* total;
     uint32_t* err;
 };
