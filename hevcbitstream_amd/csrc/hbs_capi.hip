@@ -305,7 +305,7 @@ int hbs_parse_headers_ctx(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry
         if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(zero structs)");
     }
     const uint64_t b_n = round256((n_nals + 1) * 8);
-    int rc = ensure_ws(c, 3 * b_n + 512);
+    int rc = ensure_ws(c, 3 * b_n + 512 + 1024 * 24);
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::ParseArgs a;
@@ -320,6 +320,7 @@ int hbs_parse_headers_ctx(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry
     a.initial_pps = d_initial_pps;
     a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256);
+    a.scan_tmp = w + 3 * b_n + 512;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
 }

@@ -4,7 +4,7 @@
  *
  *   k4_plan    per NAL: type from RBSP bytes 0-1 (reference hevc_stream.c:176-179),
  *              bytes of the struct it parses into
- *   k4_scan    one workgroup: struct arena offsets; for every NAL the ordinal of
+ *   k4_scan_*  struct arena offsets; for every NAL the ordinal of
  *              the last SPS / PPS in front of it (the reference's "h->sps / h->pps
  *              as left by the last parse", hevc_stream.c:800-801)
  *   k4_parse   wave per NAL; pass 1 parameter sets, pass 2 slices against them
@@ -35,47 +35,126 @@ __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* _
     }
 }
 
-/* one workgroup: exclusive sum of slot sizes, and last SPS / PPS ordinal before each NAL */
-__global__ __launch_bounds__(1024)
-void k4_scan(const ParsedNal* parsed_in, ParsedNal* parsed, const unsigned long long* __restrict__ slot_size,
-             uint64_t n, long long* __restrict__ ctx_sps, long long* __restrict__ ctx_pps, unsigned long long* __restrict__ total)
+/* ---- exclusive sum of slot sizes, and last SPS / PPS ordinal before each NAL ----------------
+ * three small launches: per-block (sum, last SPS, last PPS) of contiguous slices, a scan of the
+ * 1024 block results, and the slices again with their carry-in (coalesced 256-wide chunks). */
+constexpr int kScan4Blocks = 1024;
+
+struct Scan3 { unsigned long long sum; long long sps, pps; };      /* sps/pps: ordinal of the last one seen, -1 = none */
+
+__device__ __forceinline__ Scan3 scan3_join(const Scan3& a, const Scan3& b)     /* a in front of b */
 {
-    __shared__ unsigned long long part[1024];
-    __shared__ long long lsps[1024], lpps[1024];
-    const int tid = threadIdx.x;
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t lo = (uint64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
-    unsigned long long s = 0;
-    long long ms = -1, mp = -1;
-    for (uint64_t i = lo; i < hi; ++i) {
-        s += slot_size[i];
-        const int t = parsed_in[i].nal_unit_type;
-        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) ms = (long long)i;
-        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) mp = (long long)i;
+    Scan3 r;
+    r.sum = a.sum + b.sum;
+    r.sps = b.sps > a.sps ? b.sps : a.sps;
+    r.pps = b.pps > a.pps ? b.pps : a.pps;
+    return r;
+}
+__device__ __forceinline__ Scan3 scan3_shfl_up(const Scan3& x, int d)
+{
+    Scan3 t;
+    t.sum = __shfl_up(x.sum, d, 64); t.sps = __shfl_up(x.sps, d, 64); t.pps = __shfl_up(x.pps, d, 64);
+    return t;
+}
+
+/* across the 256 threads of a workgroup: returns the join of everything in front of this thread
+ * (exclusive), *total = join of all (same in every thread) */
+__device__ __forceinline__ Scan3 block_excl_scan3(const Scan3& x, Scan3* wsum /* [4] LDS */, Scan3& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    Scan3 inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const Scan3 t = scan3_shfl_up(inc, d);
+        if (lane >= d) inc = scan3_join(t, inc);
     }
-    part[tid] = s; lsps[tid] = ms; lpps[tid] = mp;
+    Scan3 ex = scan3_shfl_up(inc, 1);
+    if (lane == 0) { ex.sum = 0; ex.sps = -1; ex.pps = -1; }
+    __syncthreads();                       /* wsum may still be read from the previous round */
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    Scan3 before, tot;
+    before.sum = 0; before.sps = -1; before.pps = -1;
+    tot = before;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wv) before = scan3_join(before, wsum[w]); tot = scan3_join(tot, wsum[w]); }
+    total = tot;
+    return scan3_join(before, ex);
+}
+
+__device__ __forceinline__ Scan3 scan3_of(const ParsedNal* parsed, const unsigned long long* slot_size, uint64_t i, bool valid)
+{
+    Scan3 x;
+    x.sum = 0; x.sps = -1; x.pps = -1;
+    if (valid) {
+        x.sum = slot_size[i];
+        const int t = parsed[i].nal_unit_type;
+        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) x.sps = (long long)i;
+        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) x.pps = (long long)i;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256)
+void k4_scan_reduce(const ParsedNal* __restrict__ parsed, const unsigned long long* __restrict__ slot_size, uint64_t n,
+                    Scan3* __restrict__ part)
+{
+    __shared__ Scan3 wsum[4];
+    const uint64_t per = (n + kScan4Blocks - 1) / kScan4Blocks;
+    const uint64_t lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    Scan3 acc;
+    acc.sum = 0; acc.sps = -1; acc.pps = -1;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) acc = scan3_join(acc, scan3_of(parsed, slot_size, i, true));
+    Scan3 tot;
+    (void)block_excl_scan3(acc, wsum, tot);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScan4Blocks)
+void k4_scan_parts(Scan3* __restrict__ part, unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long ssum[kScan4Blocks];
+    __shared__ long long ssps[kScan4Blocks], spps[kScan4Blocks];
+    const int tid = threadIdx.x;
+    const Scan3 mine = part[tid];
+    ssum[tid] = mine.sum; ssps[tid] = mine.sps; spps[tid] = mine.pps;
+    __syncthreads();
+    for (int d = 1; d < kScan4Blocks; d <<= 1) {
         unsigned long long t = 0; long long a = -1, b = -1;
-        if (tid >= d) { t = part[tid - d]; a = lsps[tid - d]; b = lpps[tid - d]; }
+        if (tid >= d) { t = ssum[tid - d]; a = ssps[tid - d]; b = spps[tid - d]; }
         __syncthreads();
-        part[tid] += t;
-        if (a > lsps[tid]) lsps[tid] = a;
-        if (b > lpps[tid]) lpps[tid] = b;
+        ssum[tid] += t;
+        if (a > ssps[tid]) ssps[tid] = a;
+        if (b > spps[tid]) spps[tid] = b;
         __syncthreads();
     }
-    unsigned long long run = part[tid] - s;
-    long long cs = (tid > 0) ? lsps[tid - 1] : -1, cp = (tid > 0) ? lpps[tid - 1] : -1;
-    for (uint64_t i = lo; i < hi; ++i) {
-        const unsigned long long sz = slot_size[i];
-        parsed[i].struct_off = sz ? run : ~0ull;
-        run += sz;
-        ctx_sps[i] = cs; ctx_pps[i] = cp;
-        const int t = parsed_in[i].nal_unit_type;
-        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) cs = (long long)i;
-        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) cp = (long long)i;
+    Scan3 ex;                                   /* everything in front of block tid */
+    ex.sum = ssum[tid] - mine.sum;
+    ex.sps = tid ? ssps[tid - 1] : -1;
+    ex.pps = tid ? spps[tid - 1] : -1;
+    part[tid] = ex;
+    if (tid == kScan4Blocks - 1) *total = ssum[tid];
+}
+
+__global__ __launch_bounds__(256)
+void k4_scan_apply(ParsedNal* __restrict__ parsed, const unsigned long long* __restrict__ slot_size, uint64_t n,
+                   const Scan3* __restrict__ part, long long* __restrict__ ctx_sps, long long* __restrict__ ctx_pps)
+{
+    __shared__ Scan3 wsum[4];
+    const uint64_t per = (n + kScan4Blocks - 1) / kScan4Blocks;
+    const uint64_t lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    Scan3 carry = part[blockIdx.x];
+    for (uint64_t base = lo; base < hi; base += 256) {
+        const uint64_t i = base + threadIdx.x;
+        const Scan3 x = scan3_of(parsed, slot_size, i, i < hi);
+        Scan3 tot;
+        const Scan3 ex = scan3_join(carry, block_excl_scan3(x, wsum, tot));
+        if (i < hi) {
+            parsed[i].struct_off = x.sum ? ex.sum : ~0ull;
+            ctx_sps[i] = ex.sps; ctx_pps[i] = ex.pps;
+        }
+        carry = scan3_join(carry, tot);
     }
-    if (tid == 1023) *total = part[1023];
 }
 
 /* pass 0: parameter sets; pass 1: slices */
@@ -176,7 +255,10 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     if (a.n) {
         k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size);
-        k4_scan<<<1, 1024, 0, st>>>(a.parsed, a.parsed, a.slot_size, a.n, a.ctx_sps, a.ctx_pps, a.total);
+        Scan3* part = reinterpret_cast<Scan3*>(a.scan_tmp);
+        k4_scan_reduce<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part);
+        k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
+        k4_scan_apply<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
             k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err);
             k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err);

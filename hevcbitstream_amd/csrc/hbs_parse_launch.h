@@ -26,6 +26,7 @@ struct ParseArgs {
     const uint8_t* initial_pps;      /* optional: hevc_pps_t in force before NAL 0 */
     unsigned long long* total;
     uint32_t* err;
+    void* scan_tmp;                  /* 1024 x 24 bytes */
 };
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);

@@ -1,0 +1,27 @@
+"""Timing of K4 (hbs_parse_headers) on config 3: synthetic 4K30 stream, ~100k NALs (dev aid)."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+import hevcbitstream_amd as hbs
+from hevcbitstream_amd.api import PARSED, SUMMARY
+from tests.hevc_synth import stream_4k30
+stream, n = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
+s = np.frombuffer(stream, dtype=np.uint8).copy()
+ctx = hbs.Context(0)
+d = torch.from_numpy(s).cuda()
+index, rbsp, summary, cap = ctx.alloc_outputs(d.numel())
+ctx.index_extract_async(d, index, cap, rbsp, summary)
+n = int(ctx.read_summary(summary)["nal_count"])
+parsed, structs = ctx.parse_headers(rbsp, index, n)
+pt = torch.empty(n * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+sm = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+for i in range(6):
+    ctx.parse_headers_async(rbsp, index, n, pt, structs, sm)
+    ev[i].record()
+torch.cuda.synchronize()
+ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+best = min(ts)
+print("stream bytes", len(s), "nals", n, "struct arena bytes", structs.numel())
+print("ms per call", ["%.3f" % t for t in ts])
+print("best %.3f ms -> %.2f M NAL/s; struct arena written at %.1f GB/s" % (best, n / best / 1e3, structs.numel() / best / 1e6))
