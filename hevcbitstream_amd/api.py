@@ -19,7 +19,7 @@ PARSED = np.dtype([("rc", "<i4"), ("nal_unit_type", "<i4"), ("nal_layer_id", "<i
 
 EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stream", "hbs_ctx_use_own_stream",
            "hbs_ctx_get_stream",
-           "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_read_summary",
+           "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_index_extract_host", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel"]
@@ -64,6 +64,8 @@ def load_library():
     lib.hbs_last_error.restype = C.c_char_p
     lib.hbs_index_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                       C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.hbs_index_extract_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_uint64, C.c_void_p]
     lib.hbs_read_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hbs_workspace_bytes.argtypes = [C.c_uint64]
     lib.hbs_workspace_bytes.restype = C.c_uint64
@@ -178,6 +180,36 @@ class Context:
         return ent, arena, s
 
     # ---- K3 and the synthetic workload -------------------------------------------------
+
+    def index_extract_host(self, stream, window_bytes=256 << 20, index_cap=None, want_rbsp=True, pinned=True):
+        """Windowed ingest of a HOST stream of any length (hbs_index_extract_host): `stream` is a numpy
+        uint8 array (or anything np.asarray accepts).  Returns (entries ndarray[NAL_ENTRY], arena ndarray
+        or None, summary record).  pinned=True stages the stream and the outputs in page-locked memory so
+        that uploads, scans and downloads overlap."""
+        t = self.torch
+        a = np.ascontiguousarray(np.asarray(stream, dtype=np.uint8))
+        n = int(a.size)
+        cap = (n // 3 + 2) if index_cap is None else int(index_cap)
+
+        def host(nbytes):
+            buf = t.empty(max(nbytes, 16), dtype=t.uint8)
+            return buf.pin_memory() if pinned else buf
+        h_stream = host(n)
+        if n:
+            h_stream[:n].copy_(t.from_numpy(a))
+        h_index = host(max(cap, 1) * NAL_ENTRY.itemsize)
+        h_rbsp = host(n + 16) if want_rbsp else None
+        summ = np.zeros(1, dtype=SUMMARY)
+        rc = self.lib.hbs_index_extract_host(self.h, C.c_void_p(h_stream.data_ptr()), n, int(window_bytes),
+                                             C.c_void_p(h_index.data_ptr()), cap,
+                                             C.c_void_p(h_rbsp.data_ptr()) if h_rbsp is not None else None, n + 16,
+                                             summ.ctypes.data_as(C.c_void_p))
+        self._check(rc, "hbs_index_extract_host")
+        s = summ[0]
+        cnt = int(s["nal_count"])
+        ent = h_index.numpy()[: cnt * NAL_ENTRY.itemsize].view(NAL_ENTRY).copy()
+        arena = h_rbsp.numpy()[: int(s["rbsp_bytes"])].copy() if h_rbsp is not None else None
+        return ent, arena, s
 
     def emit_annexb_async(self, rbsp, rbsp_bytes, index, n_nals, gap_mode, out, index_out, summary):
         """Enqueue K3.  rbsp/index/out/index_out/summary are device tensors (index_out may be None)."""

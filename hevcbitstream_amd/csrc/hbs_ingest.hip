@@ -1,0 +1,125 @@
+/*
+ * hbs_ingest.hip -- HIP backend of the windowed ingest (hbs_ingest.h) and its C entry point
+ * hbs_index_extract_host: host stream in, host index + RBSP out, any length.
+ *
+ * Two device window buffers and two HIP streams: while the compute stream scans window w
+ * (hbs_index_extract) and downloads its index and RBSP, the copy stream uploads the fresh bytes
+ * of window w+1; the bytes window w+1 scans again are moved device-to-device behind the scan.
+ * Host buffers that are page-locked (hipHostMalloc / hipHostRegister / torch pin_memory) make the
+ * transfers truly asynchronous; pageable ones work, staged by the driver.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "hbs_ingest.h"
+
+extern "C" {
+int hbs_ctx_set_stream(hbs_ctx* ctx, void* hip_stream);
+void* hbs_ctx_get_stream(hbs_ctx* ctx);
+}
+
+namespace {
+
+struct HipBackend {
+    hbs_ctx* ctx;
+    const uint8_t* h_stream;
+    uint8_t* h_rbsp;                   /* nullable */
+    uint64_t lead, window;
+    uint64_t idx_cap;
+    uint8_t* d_buf[2] = {nullptr, nullptr};
+    uint64_t fresh[2] = {0, 0};
+    uint8_t* d_rbsp = nullptr;
+    hbs_nal_entry* d_index = nullptr;
+    hbs_summary* d_summary = nullptr;
+    hipStream_t s_in = nullptr, s_cmp = nullptr;
+    hipEvent_t up_done[2] = {nullptr, nullptr}, buf_free[2] = {nullptr, nullptr};
+    void* saved_stream = nullptr;
+    hipError_t err = hipSuccess;
+
+    uint64_t lead_capacity() const { return lead; }
+    uint64_t index_capacity() const { return idx_cap; }
+    uint64_t fresh_len(int b) const { return fresh[b]; }
+
+    int ok(hipError_t e) { if (e != hipSuccess) { err = e; return HBS_E_HIP; } return 0; }
+
+    int begin(uint64_t)
+    {
+        const uint64_t cap = lead + window + 256;
+        for (int b = 0; b < 2; ++b) {
+            if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_buf[b]), cap))) return rc;
+            if (int rc = ok(hipEventCreateWithFlags(&up_done[b], hipEventDisableTiming))) return rc;
+            if (int rc = ok(hipEventCreateWithFlags(&buf_free[b], hipEventDisableTiming))) return rc;
+        }
+        if (h_rbsp) if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_rbsp), cap))) return rc;
+        if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_index), (idx_cap ? idx_cap : 1) * sizeof(hbs_nal_entry)))) return rc;
+        if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_summary), sizeof(hbs_summary)))) return rc;
+        if (int rc = ok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking))) return rc;
+        if (int rc = ok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking))) return rc;
+        saved_stream = hbs_ctx_get_stream(ctx);
+        return hbs_ctx_set_stream(ctx, s_cmp);
+    }
+    void end()
+    {
+        if (s_cmp) { (void)hipStreamSynchronize(s_cmp); (void)hbs_ctx_set_stream(ctx, saved_stream); }
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        for (int b = 0; b < 2; ++b) {
+            if (d_buf[b]) (void)hipFree(d_buf[b]);
+            if (up_done[b]) (void)hipEventDestroy(up_done[b]);
+            if (buf_free[b]) (void)hipEventDestroy(buf_free[b]);
+        }
+        if (d_rbsp) (void)hipFree(d_rbsp);
+        if (d_index) (void)hipFree(d_index);
+        if (d_summary) (void)hipFree(d_summary);
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_cmp) (void)hipStreamDestroy(s_cmp);
+    }
+    int upload(int b, uint64_t dst_off, uint64_t src_lo, uint64_t len)
+    {
+        fresh[b] = len;
+        /* the buffer's previous window must have been scanned and carried out of */
+        if (int rc = ok(hipStreamWaitEvent(s_in, buf_free[b], 0))) return rc;
+        if (len) if (int rc = ok(hipMemcpyAsync(d_buf[b] + dst_off, h_stream + src_lo, len, hipMemcpyHostToDevice, s_in))) return rc;
+        return ok(hipEventRecord(up_done[b], s_in));
+    }
+    int carry(int from, uint64_t from_off, int to, uint64_t to_off, uint64_t len)
+    {
+        if (len) if (int rc = ok(hipMemcpyAsync(d_buf[to] + to_off, d_buf[from] + from_off, len, hipMemcpyDeviceToDevice, s_cmp))) return rc;
+        return ok(hipEventRecord(buf_free[from], s_cmp));
+    }
+    int scan(int b, uint64_t off, uint64_t len, hbs_summary* out)
+    {
+        if (int rc = ok(hipStreamWaitEvent(s_cmp, up_done[b], 0))) return rc;
+        int rc = hbs_index_extract(ctx, d_buf[b] + off, len, d_index, idx_cap, d_rbsp, d_rbsp ? lead + window + 256 : 0, d_summary);
+        if (rc) return rc;
+        return hbs_read_summary(ctx, d_summary, out);
+    }
+    int fetch_index(uint64_t first, uint64_t count, hbs_nal_entry* dst)
+    {
+        if (int rc = ok(hipMemcpyAsync(dst, d_index + first, count * sizeof(hbs_nal_entry), hipMemcpyDeviceToHost, s_cmp))) return rc;
+        return ok(hipStreamSynchronize(s_cmp));
+    }
+    int fetch_rbsp(uint64_t off, uint64_t len, uint64_t dst_off)
+    {
+        if (!len) return 0;
+        return ok(hipMemcpyAsync(h_rbsp + dst_off, d_rbsp + off, len, hipMemcpyDeviceToHost, s_cmp));
+    }
+};
+
+} // namespace
+
+extern "C" int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t stream_bytes, uint64_t window_bytes,
+                                      hbs_nal_entry* h_index, uint64_t index_cap,
+                                      uint8_t* h_rbsp, uint64_t rbsp_cap, hbs_summary* h_summary)
+{
+    if (!ctx || !h_summary || (stream_bytes && !h_stream) || (index_cap && !h_index)) return HBS_E_ARG;
+    window_bytes &= ~15ull;
+    if (window_bytes < 4096) return HBS_E_ARG;
+    HipBackend be;
+    be.ctx = ctx; be.h_stream = h_stream; be.h_rbsp = h_rbsp;
+    be.window = window_bytes; be.lead = window_bytes;
+    /* entries one window can produce: a window (with what it scans again) of 2 x window_bytes, one NAL per 32 bytes */
+    const uint64_t per_window = (2 * window_bytes) / 32 + 64;
+    be.idx_cap = per_window;
+    const int rc = hbs::ingest_windowed(be, stream_bytes, window_bytes, h_index, index_cap, h_rbsp != nullptr, rbsp_cap, h_summary);
+    be.end();
+    return rc;
+}

@@ -133,6 +133,21 @@ int hbs_index_extract(hbs_ctx* ctx,
                       hbs_summary* d_summary);
 
 /*
+ * The same for a stream in HOST memory of any length (larger than device memory is fine): the
+ * stream is uploaded window by window (window_bytes each, >= 4096, rounded down to 16), the
+ * upload of one window overlapping the scan and the download of the previous one; index and RBSP
+ * arrive in host memory with offsets relative to h_stream / h_rbsp, identical to what
+ * hbs_index_extract returns for the whole stream.  Replaces the windowed reader of
+ * hevc_analyze.c:124-210 (and gets a NAL that straddles two reads right).
+ * Limits: a NAL (with the zeros in front of it) must fit in one window, and a window must not
+ * hold more than window_bytes/16 NALs; HBS_E_CAPACITY in h_summary->error otherwise.
+ * Page-locked host buffers make the transfers asynchronous; pageable ones work.
+ */
+int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t stream_bytes, uint64_t window_bytes,
+                           hbs_nal_entry* h_index, uint64_t index_cap,
+                           uint8_t* h_rbsp, uint64_t rbsp_cap, hbs_summary* h_summary);
+
+/*
  * K3: re-emit Annex-B from an RBSP arena: for every NAL, the bytes between the
  * previous NAL and this one (zeros and the 01 of the start code) followed by
  * rbsp_to_nal() of its RBSP (h264_nal.c:92-132: a 03 is inserted in front of

@@ -29,6 +29,9 @@ def lib():
         _lib.sim3_index_extract.restype = C.c_int
         _lib.sim4_index_extract.argtypes = _lib.sim_index_extract.argtypes
         _lib.sim4_index_extract.restype = C.c_int
+        _lib.sim_index_extract_host.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                C.c_void_p, C.c_uint64, C.c_void_p]
+        _lib.sim_index_extract_host.restype = C.c_int
         _lib.sim_emit_annexb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.sim_emit_annexb.restype = C.c_int64
         _lib.sim_synth_rbsp.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
@@ -54,6 +57,20 @@ def index_extract(stream, index_cap=None, want_rbsp=True, variant=None):
     s = summ[0]
     assert (arena[n + 16:] == 0xAB).all()
     return idx[:int(s["nal_count"])].copy(), arena[:int(s["rbsp_bytes"])].copy(), s
+
+
+def index_extract_windowed(stream, window_bytes, index_cap=None, want_rbsp=True):
+    """hbs_ingest.h's driver over the CPU single-stepper (event-sparse tile logic per window)"""
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    n = len(stream)
+    cap = (n // 3 + 2) if index_cap is None else index_cap
+    idx = np.zeros(max(cap, 1), dtype=NAL_ENTRY)
+    arena = np.full(n + 32, 0xAB, dtype=np.uint8)
+    summ = np.zeros(1, dtype=SUMMARY)
+    rc = lib().sim_index_extract_host(stream.ctypes.data if n else None, n, window_bytes, idx.ctypes.data, cap,
+                                      arena.ctypes.data if want_rbsp else None, n + 16, summ.ctypes.data)
+    s = summ[0]
+    return rc, idx[:int(s["nal_count"])].copy(), arena[:int(s["rbsp_bytes"])].copy(), s
 
 
 def emit_annexb(arena, idx, gap_mode=0):

@@ -17,6 +17,7 @@
 #include "../../hevcbitstream_amd/csrc/hbs_sparse.h"
 #include "../../hevcbitstream_amd/csrc/hbs_emit.h"
 #include "../../hevcbitstream_amd/csrc/hbs_parse.h"
+#include "../../hevcbitstream_amd/csrc/hbs_ingest.h"
 
 using namespace hbs;
 
@@ -399,4 +400,57 @@ extern "C" int sim3_index_extract(const uint8_t* stream, uint64_t n,
     tail_fixup(&hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum);
     for (uint64_t k = 0; k < hdr.final_nals; ++k) fill_rbsp_len(&hdr, index, index_cap, k);
     return 0;
+}
+
+/* ---- windowed ingest (hbs_ingest.h) over the CPU single-stepper ----------------------------- */
+extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n, hbs_nal_entry* index, uint64_t index_cap,
+                                  uint8_t* rbsp, uint64_t rbsp_cap, hbs_summary* sum);
+namespace {
+struct SimBackend {
+    const uint8_t* h_stream;
+    uint8_t* h_rbsp;
+    uint64_t lead, window, idx_cap;
+    std::vector<uint8_t> buf[2], rbsp;
+    std::vector<hbs_nal_entry> index;
+    uint64_t fresh[2] = {0, 0};
+    uint64_t lead_capacity() const { return lead; }
+    uint64_t index_capacity() const { return idx_cap; }
+    uint64_t fresh_len(int b) const { return fresh[b]; }
+    int begin(uint64_t)
+    {
+        for (int b = 0; b < 2; ++b) buf[b].assign(lead + window + 256, 0xEE);
+        rbsp.assign(lead + window + 256, 0);
+        index.resize(idx_cap ? idx_cap : 1);
+        return 0;
+    }
+    int upload(int b, uint64_t dst_off, uint64_t src_lo, uint64_t len)
+    {
+        fresh[b] = len;
+        if (len) memcpy(buf[b].data() + dst_off, h_stream + src_lo, len);
+        return 0;
+    }
+    int carry(int from, uint64_t from_off, int to, uint64_t to_off, uint64_t len)
+    {
+        if (len) memcpy(buf[to].data() + to_off, buf[from].data() + from_off, len);
+        return 0;
+    }
+    int scan(int b, uint64_t off, uint64_t len, hbs_summary* out)
+    {
+        /* an exact-size copy: the device code must not look past the window */
+        std::vector<uint8_t> w(buf[b].begin() + off, buf[b].begin() + off + len);
+        return sim4_index_extract(w.data(), len, index.data(), idx_cap, h_rbsp ? rbsp.data() : nullptr, rbsp.size(), out);
+    }
+    int fetch_index(uint64_t first, uint64_t count, hbs_nal_entry* dst) { memcpy(dst, index.data() + first, count * sizeof(hbs_nal_entry)); return 0; }
+    int fetch_rbsp(uint64_t off, uint64_t len, uint64_t dst_off) { if (len) memcpy(h_rbsp + dst_off, rbsp.data() + off, len); return 0; }
+};
+}
+
+extern "C" int sim_index_extract_host(const uint8_t* stream, uint64_t n, uint64_t window_bytes, hbs_nal_entry* index, uint64_t index_cap,
+                                      uint8_t* rbsp, uint64_t rbsp_cap, hbs_summary* sum)
+{
+    SimBackend be;
+    window_bytes &= ~15ull;
+    be.h_stream = stream; be.h_rbsp = rbsp; be.window = window_bytes; be.lead = window_bytes;
+    be.idx_cap = (2 * window_bytes) / 32 + 64;
+    return hbs::ingest_windowed(be, n, window_bytes, index, index_cap, rbsp != nullptr, rbsp_cap, sum);
 }
