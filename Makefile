@@ -22,7 +22,7 @@ lib: $(LIB)
 LEGACY_OBJ := build/obj/hbs_legacy_c.o
 $(LEGACY_OBJ): $(CSRC)/hbs_legacy.c $(HDRS)
 	@mkdir -p build/obj
-	$(CC) -std=c99 -O2 -fPIC -Wall -Wextra -Iinclude -c -o $@ $<
+	$(CC) -std=c99 -O2 -fPIC -Wall -Wextra -Iinclude -I$(CSRC) -c -o $@ $<
 
 HIP_OBJS := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(HIP_SRCS))
 build/obj/%.o: $(CSRC)/%.hip $(HDRS)

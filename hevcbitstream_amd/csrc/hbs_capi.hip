@@ -293,6 +293,16 @@ int hbs_parse_headers_ctx(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry
                           hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
                           const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary)
 {
+    return hbs_parse_headers_trace(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, d_initial_sps_slot, d_initial_pps,
+                                   nullptr, 0, nullptr, d_summary);
+}
+
+int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                            hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                            const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                            hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary)
+{
+    static_assert(sizeof(hbs_trace_rec) == sizeof(hbs::TraceRec), "public record == kernel record");
     static_assert(sizeof(hbs_parsed_nal) == sizeof(hbs::ParsedNal), "public record == kernel record");
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index || !d_parsed))) return HBS_E_ARG;
     if (reinterpret_cast<uintptr_t>(d_structs) & 15) return HBS_E_ARG;
@@ -321,6 +331,7 @@ int hbs_parse_headers_ctx(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry
     a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256);
     a.scan_tmp = w + 3 * b_n + 512;
+    a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
 }

@@ -13,7 +13,7 @@
  *   hevc_new / hevc_free        hevc_nal.c:34-57, :64-91
  *   peek_hevc_nal_unit          hevc_nal.c:97-114
  *   read_hevc_nal_unit          hevc_stream.c:155-240
- *   read_debug_hevc_nal_unit    hevc_stream.c:2343-2428 (NAL-header lines only, see below)
+ *   read_debug_hevc_nal_unit    hevc_stream.c:2343-3434 (per-field trace from the GPU parser's log)
  *   write_hevc_nal_unit         hevc_stream.c:1249-1333 (syntax writers: not in this round)
  *   debug_bytes, h264_dbgfile   h264_stream.c:33, :117-126
  *
@@ -232,10 +232,54 @@ int peek_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     return h->nal->nal_unit_type;
 }
 
+/* ---- per-field trace (read_debug_hevc_nal_unit) ------------------------------------------- */
+#include "hbs_trace_names.h"
+
+#define TRACE_CAP 65536u
+static hbs_trace_rec* g_dtrace = NULL;
+static uint32_t* g_dtrace_count = NULL;
+static hbs_trace_rec* g_htrace = NULL;
+
+static void need_trace(void)
+{
+    int rc;
+    if (g_dtrace) return;
+    if ((rc = hbs_dev_alloc(g_ctx, (uint64_t)TRACE_CAP * sizeof(hbs_trace_rec), (void**)&g_dtrace))) die("hbs_dev_alloc", rc);
+    if ((rc = hbs_dev_alloc(g_ctx, 16, (void**)&g_dtrace_count))) die("hbs_dev_alloc", rc);
+    g_htrace = (hbs_trace_rec*)malloc((size_t)TRACE_CAP * sizeof(hbs_trace_rec));
+}
+
+static const char* trace_name(unsigned site)
+{
+    int lo = 0, hi = (int)(sizeof(hbs_trace_names) / sizeof(hbs_trace_names[0])) - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        if (hbs_trace_names[mid].site == site) return hbs_trace_names[mid].name;
+        if (hbs_trace_names[mid].site < site) lo = mid + 1; else hi = mid - 1;
+    }
+    return NULL;
+}
+
+static void print_trace(void)
+{
+    uint32_t n = 0, i;
+    int rc;
+    if ((rc = hbs_copy_to_host(g_ctx, &n, g_dtrace_count, sizeof(n)))) die("hbs_copy_to_host", rc);
+    if (n > TRACE_CAP) n = TRACE_CAP;
+    if (n && (rc = hbs_copy_to_host(g_ctx, g_htrace, g_dtrace, (uint64_t)n * sizeof(hbs_trace_rec)))) die("hbs_copy_to_host", rc);
+    for (i = 0; i < n; i++) {
+        const char* name = trace_name(g_htrace[i].site);
+        printf("%ld.%d: ", (long)(g_htrace[i].pos >> 3), (int)(8 - (g_htrace[i].pos & 7)));     /* b->p - b->start, b->bits_left */
+        if (!name) printf("site_%u: %d \n", g_htrace[i].site, g_htrace[i].value);                /* table out of date */
+        else if (name[0]) printf("%s: %d \n", name, g_htrace[i].value);
+        /* an empty name: the reference prints the cursor and nothing else there (hevc_stream.c:3147) */
+    }
+}
+
 static int is_slice(int t) { return (t >= 0 && t <= 9) || (t >= 16 && t <= 21); }
 
 /* *stripped = 0 when nal_to_rbsp already rejected the NAL (nothing of *h is touched then) */
-static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped)
+static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int trace)
 {
     static const uint8_t sc[3] = {0, 0, 1};
     hbs_summary s;
@@ -256,8 +300,18 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped)
      * the derived RPS tables live on the device next to the SPS */
     if ((rc = hbs_copy_to_device(g_ctx, g_dsps_slot, h->sps, sizeof(hevc_sps_t)))) die("hbs_copy_to_device", rc);
     if ((rc = hbs_copy_to_device(g_ctx, g_dpps, h->pps, sizeof(hevc_pps_t)))) die("hbs_copy_to_device", rc);
-    if ((rc = hbs_parse_headers_ctx(g_ctx, g_dout, g_dindex, 1, g_dparsed, g_dstruct, sizeof(hevc_vps_t) + 64,
-                                    g_dsps_slot, g_dpps, g_dsummary))) die("hbs_parse_headers", rc);
+    if (trace) need_trace();
+    if ((rc = hbs_parse_headers_trace(g_ctx, g_dout, g_dindex, 1, g_dparsed, g_dstruct, sizeof(hevc_vps_t) + 64,
+                                      g_dsps_slot, g_dpps, trace ? g_dtrace : NULL, trace ? TRACE_CAP : 0,
+                                      trace ? g_dtrace_count : NULL, g_dsummary))) die("hbs_parse_headers", rc);
+    if (trace) {
+        /* hevc_stream.c:2363-2367: the header lines, then one line per syntax element the parser read */
+        printf("0.8: forbidden_zero_bit: %d \n", (buf[0] >> 7) & 1);
+        printf("0.7: nal->nal_unit_type: %d \n", (buf[0] >> 1) & 0x3F);
+        printf("0.1: nal->nal_layer_id: %d \n", ((buf[0] & 1) << 5) | ((size > 1 ? buf[1] : 0) >> 3));
+        printf("1.3: nal->nal_temporal_id_plus1: %d \n", (size > 1 ? buf[1] : 0) & 7);
+        print_trace();
+    }
     if ((rc = hbs_copy_to_host(g_ctx, &p, g_dparsed, sizeof(p)))) die("hbs_copy_to_host", rc);
     t = p.nal_unit_type;
     h->nal->nal_unit_type = t;
@@ -300,25 +354,20 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped)
 int read_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
     int stripped;
-    return read_nal(h, buf, size, &stripped);
+    return read_nal(h, buf, size, &stripped, 0);
 }
 
 /*
- * hevc_stream.c:2343-2428.  The reference prints one line per syntax element
- * while it reads; this round prints the four NAL-header lines (:2363-2367,
- * positions are fixed) and parses the rest silently on the GPU.  The per-field
- * trace is SURVEY.md 8(f) rank 2.
+ * hevc_stream.c:2343-3434: the same parse, printing "<byte>.<bits left>: <name>: <value>" per syntax
+ * element to stdout while it reads.  The GPU parser logs (site, cursor, value) per element
+ * (hbs_parse_headers_trace); the names come from hbs_trace_names.h.  As in the reference, the debug
+ * reader is not the plain reader: it takes ONE bit for sub_layer_level_idc (hevc_stream.c:2939 against
+ * :751), so streams with sub-layer levels parse differently from read_hevc_nal_unit -- kept.
  */
 int read_debug_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
     int stripped;
-    const int rc = read_nal(h, buf, size, &stripped);
-    if (!stripped) return rc;          /* the reference returns before the header when nal_to_rbsp fails (:2355) */
-    printf("0.8: forbidden_zero_bit: 0 \n");
-    printf("0.7: nal->nal_unit_type: %d \n", h->nal->nal_unit_type);
-    printf("0.1: nal->nal_layer_id: %d \n", h->nal->nal_layer_id);
-    printf("1.3: nal->nal_temporal_id_plus1: %d \n", h->nal->nal_temporal_id_plus1);
-    return rc;
+    return read_nal(h, buf, size, &stripped, 1);
 }
 
 /* hevc_stream.c:1249-1333: needs the syntax writers, not built yet */

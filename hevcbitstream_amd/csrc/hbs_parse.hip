@@ -163,7 +163,8 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               ParsedNal* __restrict__ parsed, uint8_t* __restrict__ structs, uint64_t structs_cap,
               const long long* __restrict__ ctx_sps, const long long* __restrict__ ctx_pps,
               const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot,
-              const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err)
+              const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
+              TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count)
 {
     __shared__ uint8_t win[4][kWinBytes];
     __shared__ RpsRow own_rows[4];
@@ -203,6 +204,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         if (lane == 0) {
             Parser ps;
             ps.b.win = win[wv]; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
+            ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
@@ -234,6 +236,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             ParsedNal out = parsed[k];
             parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
             parsed[k] = out;
+            if (trace_count) trace_count[k] = ps.b.tr_n;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -253,6 +256,10 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
+    if (a.n && a.trace_count) {
+        e = hipMemsetAsync(a.trace_count, 0, a.n * sizeof(uint32_t), st);      /* NALs that are not parsed have no trace */
+        if (e != hipSuccess) return e;
+    }
     if (a.n) {
         k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size);
         Scan3* part = reinterpret_cast<Scan3*>(a.scan_tmp);
@@ -260,8 +267,8 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
         k4_scan_apply<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
-            k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err);
-            k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err);
+            k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
+            k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
         }
     }
     k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);

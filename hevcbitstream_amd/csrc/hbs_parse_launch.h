@@ -8,6 +8,7 @@
 namespace hbs {
 
 struct ParsedNal;
+struct TraceRec;
 
 struct ParseArgs {
     const uint8_t* rbsp;
@@ -27,6 +28,9 @@ struct ParseArgs {
     unsigned long long* total;
     uint32_t* err;
     void* scan_tmp;                  /* 1024 x 24 bytes */
+    TraceRec* trace;                 /* optional: trace_cap records per NAL (device) */
+    uint32_t trace_cap;
+    uint32_t* trace_count;           /* optional: records each NAL produced (may exceed trace_cap) */
 };
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);

@@ -212,6 +212,18 @@ int hbs_parse_headers(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* 
 int hbs_parse_headers_ctx(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                           hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
                           const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary);
+
+/* Same, and additionally the per-field trace the reference's read_debug_* readers print
+ * (hevc_stream.c:2343-3434): for NAL k, d_trace[k * trace_cap ...] receives one record per syntax
+ * element read behind the NAL header, in reading order; d_trace_count[k] = how many it produced
+ * (records beyond trace_cap are counted, not stored).  `site` identifies the syntax element (the key
+ * of the name table the legacy read_debug_hevc_nal_unit prints with), `pos` the bit position of
+ * the RBSP cursor before the read, `value` what was read. */
+typedef struct hbs_trace_rec { uint32_t site; uint32_t pos; int32_t value; } hbs_trace_rec;
+int hbs_parse_headers_trace(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                            hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                            const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                            hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary);
 uint64_t hbs_sps_slot_bytes(void);
 uint64_t hbs_sps_tables_offset(void);
 

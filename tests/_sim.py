@@ -108,3 +108,28 @@ def parse_headers(rbsp, idx):
     got = L.sim_parse_headers(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, structs.ctypes.data, need)
     assert got == need
     return parsed[:n], structs[:need]
+
+
+TRACE = np.dtype([("site", "<u4"), ("pos", "<u4"), ("value", "<i4")])
+
+
+def parse_trace(rbsp, idx, cap=65536):
+    """K4 single-stepped with the per-field trace: (parsed, structs, [records ndarray[TRACE] per NAL])"""
+    from tests._parsecmp import PARSED
+    L = lib()
+    L.sim_parse_headers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.sim_parse_headers.restype = C.c_int64
+    L.sim_parse_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                  C.c_void_p, C.c_uint32, C.c_void_p]
+    L.sim_parse_trace.restype = C.c_int64
+    rbsp = np.ascontiguousarray(np.concatenate([rbsp, np.zeros(16, dtype=np.uint8)]))
+    idx = np.ascontiguousarray(idx)
+    n = len(idx)
+    parsed = np.zeros(max(n, 1), dtype=PARSED)
+    need = L.sim_parse_headers(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, None, 0)
+    structs = np.zeros(need + 64, dtype=np.uint8)
+    trace = np.zeros(max(n, 1) * cap, dtype=TRACE)
+    count = np.zeros(max(n, 1), dtype=np.uint32)
+    L.sim_parse_trace(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, structs.ctypes.data, need,
+                      trace.ctypes.data, cap, count.ctypes.data)
+    return parsed[:n], structs[:need], [trace[k * cap:k * cap + min(int(count[k]), cap)].copy() for k in range(n)]

@@ -181,6 +181,10 @@ extern "C" int64_t sim_synth_rbsp(uint64_t seed, uint64_t n, int mode, uint8_t* 
 }
 
 /* K4 in stream order: plan, context resolution and the per-NAL parse of hbs_parse.hip */
+static TraceRec* g_sim_trace = nullptr;       /* set by sim_parse_trace around sim_parse_headers */
+static uint32_t g_sim_trace_cap = 0;
+static uint32_t* g_sim_trace_count = nullptr;
+
 extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n,
                                      ParsedNal* parsed, uint8_t* structs, uint64_t structs_cap)
 {
@@ -219,6 +223,7 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
             const uint8_t* src = rbsp + idx[k].rbsp_off;
             ps.b.win = src; ps.b.full = src; ps.b.win_bytes = idx[k].rbsp_len < 512u ? idx[k].rbsp_len : 512u;
             ps.b.size = idx[k].rbsp_len; ps.b.pos = 16;
+            ps.b.tr = g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr; ps.b.tr_cap = g_sim_trace_cap; ps.b.tr_n = 0;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
@@ -242,8 +247,19 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
             ParsedNal out = parsed[k];
             parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
             parsed[k] = out;
+            if (g_sim_trace_count) g_sim_trace_count[k] = ps.b.tr_n;
         }
     return (int64_t)run;
+}
+
+extern "C" int64_t sim_parse_trace(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n, ParsedNal* parsed, uint8_t* structs,
+                                   uint64_t structs_cap, TraceRec* trace, uint32_t trace_cap, uint32_t* trace_count)
+{
+    g_sim_trace = trace; g_sim_trace_cap = trace_cap; g_sim_trace_count = trace_count;
+    for (uint64_t k = 0; k < n; ++k) trace_count[k] = 0;
+    const int64_t r = sim_parse_headers(rbsp, idx, n, parsed, structs, structs_cap);
+    g_sim_trace = nullptr; g_sim_trace_cap = 0; g_sim_trace_count = nullptr;
+    return r;
 }
 
 /* event-sparse variant (hbs_scan4.hip): flag test, elements with gaps, segment words -- tile by

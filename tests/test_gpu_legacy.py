@@ -112,3 +112,35 @@ def test_reference_hevc_analyze_links_and_runs():
 
     assert keep(out) == keep(want)
     assert len(keep(out)) == 10 * 6
+
+
+def test_reference_cli_full_stdout():
+    """the reference's CLI (unmodified hevc_analyze.c) on this library prints, line for line, what it prints
+    on its own library: NAL walk on the GPU, header parse + per-field trace on the GPU, names from
+    hbs_trace_names.h.  Golden outputs: tests/golden/make_trace_names.py."""
+    import gzip
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "hevc_analyze_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hevc_analyze_amd not built (needs /root/reference at build time)")
+    vectors = json.load(gzip.open(os.path.join(HERE, "golden", "trace_vectors.json.gz"), "rt"))
+
+    def norm(text):
+        lines = text.splitlines()
+        # the first hex dump starts 4 bytes in front of the file buffer (heap bytes): drop those 4
+        for i, l in enumerate(lines):
+            if l.startswith("!! Found NAL"):
+                lines[i + 1] = lines[i + 1][12:]
+                break
+        return lines
+
+    for v in vectors:
+        with tempfile.NamedTemporaryFile(suffix=".hevc", delete=False) as f:
+            f.write(bytes.fromhex(v["stream"]))
+            path = f.name
+        try:
+            out = subprocess.run([exe, path], stdout=subprocess.PIPE, check=True).stdout.decode("latin-1")
+        finally:
+            os.unlink(path)
+        got, want = norm(out), norm(v["stdout"])
+        assert got == want, (v["tag"], [(a, b) for a, b in zip(got, want) if a != b][:3], len(got), len(want))
