@@ -155,7 +155,7 @@ def main():
         variant = ctx.kernel()
         kernel_name = {2: "hbs::k_scan_extract", 3: "hbs::k_scan_extract3", 4: "hbs::k_scan_extract4"}[variant]
         geometry = {2: "512 threads, 64 KiB tiles (LDS image)", 3: "512 threads, 64 KiB tiles (registers)",
-                    4: "256 threads, 128 KiB tiles held in registers, tiles handed out by ticket"}[variant]
+                    4: "256 threads, 192 KiB tiles held in registers, tiles handed out by ticket"}[variant]
         out = {
             "metric": "Annex-B GB/s scanned + NAL units/s, 16 GiB synthetic stream, 1/2/4/8 MI355X",
             "value": round(total_bytes * args.steps / dt / 1e9, 2),

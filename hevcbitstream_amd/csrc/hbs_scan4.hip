@@ -6,12 +6,12 @@
  * find_nal_unit + nal_to_rbsp, h264_nal.c:38-76 / :147-200, driven as in
  * hevc_analyze.c:135-177).  What differs is who does the exact work:
  *
- *   1. A workgroup is 4 wavefronts of 256 VGPRs; wavefront w holds 40 rows of
- *      1 KiB in named registers (a tile = 160 KiB).  Per 16-byte chunk,
+ *   1. A workgroup is 4 wavefronts of 256 VGPRs; wavefront w holds 48 rows of
+ *      1 KiB in named registers (a tile = 192 KiB).  Per 16-byte chunk,
  *      chunk_flag() (hbs_sparse.h) decides that no pattern 00 00 {<=3} can
  *      touch it; the row's ballot is its flag mask.  Flagged chunks -- a start
  *      code per NAL, a few emulation prevention bytes, a few false alarms: ~15
- *      of 10240 -- are listed in LDS in stream order, and their lanes leave the
+ *      of 12288 -- are listed in LDS in stream order, and their lanes leave the
  *      chunk's surroundings in LDS.
  *   2. Wavefront 0 takes the listed chunks as "elements", one per lane: exact
  *      window logic of hbs_tile.h on bytes [-8, 20) of the chunk.  A wave scan
@@ -54,12 +54,12 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #define HBS4_T_FLUSH
 #endif
 
-static_assert(k4Rows == 40, "the row lists below name every row register");
-#define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39)
-#define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31) X(30,31,32) X(31,32,33) X(32,33,34) X(33,34,35) X(34,35,36) X(35,36,37) X(36,37,38) X(37,38,39)   /* (previous row, row, next row), inner rows */
+static_assert(k4Rows == 48, "the row lists below name every row register");
+#define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47)
+#define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31) X(30,31,32) X(31,32,33) X(32,33,34) X(33,34,35) X(34,35,36) X(35,36,37) X(36,37,38) X(37,38,39) X(38,39,40) X(39,40,41) X(40,41,42) X(41,42,43) X(42,43,44) X(43,44,45) X(44,45,46) X(45,46,47)   /* (previous row, row, next row), inner rows */
 /* rows of wavefront 0 that wait in LDS while it handles elements and looks back: (slot, row) */
-constexpr int kParkRows = 16;
-#define HBS_PARKED(X) X(0,24) X(1,25) X(2,26) X(3,27) X(4,28) X(5,29) X(6,30) X(7,31) X(8,32) X(9,33) X(10,34) X(11,35) X(12,36) X(13,37) X(14,38) X(15,39)
+constexpr int kParkRows = 20;
+#define HBS_PARKED(X) X(0,28) X(1,29) X(2,30) X(3,31) X(4,32) X(5,33) X(6,34) X(7,35) X(8,36) X(9,37) X(10,38) X(11,39) X(12,40) X(13,41) X(14,42) X(15,43) X(16,44) X(17,45) X(18,46) X(19,47)
 
 /* one wavefront's segment: k4Rows rows of 1 KiB in named registers + the dwords just outside */
 struct RowRegs {
@@ -421,10 +421,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 #define HBS_FLAG(rp, r, rn) HBS_FLAG_BODY(r, (uint32_t)__builtin_amdgcn_readlane((int)R.q##rp.z, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q##rn.x, 0))
             HBS_FLAG_BODY(0, R.before2, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.x, 0))
             HBS_ROW_TRIPLES(HBS_FLAG)
-            HBS_FLAG_BODY(39, (uint32_t)__builtin_amdgcn_readlane((int)R.q38.z, 63), R.after)
+            HBS_FLAG_BODY(47, (uint32_t)__builtin_amdgcn_readlane((int)R.q46.z, 63), R.after)
 #undef HBS_FLAG
 #undef HBS_FLAG_BODY
-            static_assert(k4Rows == 40, "first and last row are named above");
+            static_assert(k4Rows == 48, "first and last row are named above");
         }
         if (edge_tile && (n & 15ull) != 0 && n > wseg && n < wseg + (uint64_t)k4WaveBytes) {
             /* the chunk cut by the stream end is always an element */

@@ -31,13 +31,13 @@ namespace hbs {
  * control code needs are paid per wavefront, so two fat wavefronts per SIMD keep twice the
  * bytes in flight of four lean ones. */
 constexpr int k4Waves         = 4;
-constexpr int k4Rows          = 40;
+constexpr int k4Rows          = 48;
 constexpr int k4Threads       = 64 * k4Waves;
 constexpr int k4RowBytes      = 1024;
-constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 40 KiB  */
-constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 160 KiB */
-constexpr int k4TileRows      = k4Waves * k4Rows;            /* 160     */
-constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 10240   */
+constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 48 KiB  */
+constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 192 KiB */
+constexpr int k4TileRows      = k4Waves * k4Rows;            /* 192     */
+constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 12288   */
 constexpr int k4ElemPass      = 64;                          /* elements handled per pass: wavefront 0, one per lane */
 constexpr int k4TailLead      = 16;                          /* bytes of the padded last-tile copy in front of the tile */
 constexpr int k4TailBytes     = k4TailLead + k4TileBytes + 64;

@@ -1,0 +1,19 @@
+"""Regenerate the row lists of hbs_scan4.hip / hbs_sparse.h for N rows per wavefront (dev aid).
+usage: set_rows4.py N [park_first]"""
+import re, sys
+rows = int(sys.argv[1]); park_first = int(sys.argv[2]) if len(sys.argv) > 2 else rows - 16
+p = 'hevcbitstream_amd/csrc/hbs_scan4.hip'
+s = open(p).read()
+s = re.sub(r'static_assert\(k4Rows == \d+, "the row lists below name every row register"\);', 'static_assert(k4Rows == %d, "the row lists below name every row register");' % rows, s)
+s = re.sub(r'#define HBS_ROWS\(X\) .*', '#define HBS_ROWS(X) ' + ' '.join('X(%d)' % i for i in range(rows)), s)
+s = re.sub(r'#define HBS_ROW_TRIPLES\(X\) .*', '#define HBS_ROW_TRIPLES(X) ' + ' '.join('X(%d,%d,%d)' % (i - 1, i, i + 1) for i in range(1, rows - 1)) + '   /* (previous row, row, next row), inner rows */', s)
+s = re.sub(r'constexpr int kParkRows = \d+;', 'constexpr int kParkRows = %d;' % (rows - park_first), s)
+s = re.sub(r'#define HBS_PARKED\(X\) .*', '#define HBS_PARKED(X) ' + ' '.join('X(%d,%d)' % (i, park_first + i) for i in range(rows - park_first)), s)
+s = re.sub(r'HBS_FLAG_BODY\(\d+, \(uint32_t\)__builtin_amdgcn_readlane\(\(int\)R\.q\d+\.z, 63\), R\.after\)', 'HBS_FLAG_BODY(%d, (uint32_t)__builtin_amdgcn_readlane((int)R.q%d.z, 63), R.after)' % (rows - 1, rows - 2), s)
+s = re.sub(r'static_assert\(k4Rows == \d+, "first and last row are named above"\);', 'static_assert(k4Rows == %d, "first and last row are named above");' % rows, s)
+open(p, 'w').write(s)
+p = 'hevcbitstream_amd/csrc/hbs_sparse.h'
+s = open(p).read()
+s = re.sub(r'constexpr int k4Rows          = \d+;', 'constexpr int k4Rows          = %d;' % rows, s)
+open(p, 'w').write(s)
+print("rows", rows, "parked", rows - park_first)
