@@ -336,6 +336,37 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
 }
 
+int hbs_write_headers(hbs_ctx* c, const hbs_parsed_nal* d_parsed, uint64_t n_nals, uint8_t* d_structs,
+                      const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                      uint8_t* d_rbsp_out, uint32_t rbsp_cap, hbs_written_nal* d_written)
+{
+    static_assert(sizeof(hbs_written_nal) == sizeof(hbs::WrittenNal), "public record == kernel record");
+    if (!c || (n_nals && (!d_parsed || !d_structs || !d_rbsp_out || !d_written))) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    if (!c->zeros) {
+        const size_t zb = (sizeof(hevc_sps_t) + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->zeros), zb);
+        if (e != hipSuccess) return fail(c, e, "hipMalloc(zero structs)");
+        e = hipMemsetAsync(c->zeros, 0, zb, c->stream);
+        if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(zero structs)");
+    }
+    const uint64_t b_n = round256((n_nals + 1) * 8);
+    int rc = ensure_ws(c, 3 * b_n + 512 + 1024 * 24);
+    if (rc) return rc;
+    uint8_t* w = static_cast<uint8_t*>(c->ws);
+    hbs::WriteArgs a;
+    a.parsed = reinterpret_cast<const hbs::ParsedNal*>(d_parsed); a.n = n_nals; a.structs = d_structs;
+    a.rbsp_out = d_rbsp_out; a.rbsp_cap = rbsp_cap; a.written = reinterpret_cast<hbs::WrittenNal*>(d_written);
+    a.slot_size = reinterpret_cast<unsigned long long*>(w);
+    a.ctx_sps = reinterpret_cast<long long*>(w + b_n);
+    a.ctx_pps = reinterpret_cast<long long*>(w + 2 * b_n);
+    a.zeros = c->zeros; a.initial_sps_slot = d_initial_sps_slot; a.initial_pps = d_initial_pps;
+    a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
+    a.scan_tmp = w + 3 * b_n + 512;
+    hipError_t e = hbs::launch_write_headers(a, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "launch_write_headers");
+}
+
 /* plain device-memory helpers so that C callers (hbs_legacy.c) need no HIP headers */
 int hbs_dev_alloc(hbs_ctx* c, uint64_t bytes, void** out)
 {

@@ -370,15 +370,62 @@ int read_debug_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     return read_nal(h, buf, size, &stripped, 1);
 }
 
-/* hevc_stream.c:1249-1333: needs the syntax writers, not built yet */
+/*
+ * hevc_stream.c:1249-1327: serialise the struct *h holds for h->nal's type into buf.  The syntax
+ * writers run on the GPU (hbs_write_headers) into an RBSP buffer of size * 3 / 4 bytes (:1265), then
+ * rbsp_to_nal.  As in the reference: slices are written against h->pps / h->sps as they stand and
+ * the derived RPS tables of the last SPS read or written; a slice write replaces h->slice_data's
+ * payload by the zeros behind the header in the RBSP buffer (:1699-1706).
+ */
 int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
-    static int warned = 0;
-    (void)h; (void)buf; (void)size;
-    if (!warned) {
-        fprintf(stderr, "libhevcbitstream (MI355X build): write_hevc_nal_unit is not implemented in this round "
-                        "(the RBSP->NAL step is: rbsp_to_nal / hbs_emit_annexb)\n");
-        warned = 1;
+    hbs_parsed_nal p;
+    hbs_written_nal w;
+    const void* src = NULL;
+    uint64_t src_bytes = 0;
+    uint32_t cap;
+    int rc, t, rbsp_size, nal_size;
+    uint8_t* rbsp;
+    static hbs_written_nal* d_written = NULL;
+    if (size < 0) return -1;
+    need_ctx();
+    cap = (uint32_t)((long)size * 3 / 4);
+    need_bufs(16, (uint64_t)cap + 16);
+    if (!d_written && (rc = hbs_dev_alloc(g_ctx, sizeof(hbs_written_nal), (void**)&d_written))) die("hbs_dev_alloc", rc);
+    t = h->nal->nal_unit_type;
+    if (t == HEVC_NAL_UNIT_TYPE_VPS_NUT) { src = h->vps; src_bytes = sizeof(hevc_vps_t); }
+    else if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) { src = h->sps; src_bytes = sizeof(hevc_sps_t); }
+    else if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) { src = h->pps; src_bytes = sizeof(hevc_pps_t); }
+    else if (is_slice(t)) { src = h->sh; src_bytes = sizeof(hevc_slice_header_t); }
+    else return -1;                                                      /* :1306 */
+    /* parameter sets in force: what the object holds (the SPS's derived tables stay on the device) */
+    if ((rc = hbs_copy_to_device(g_ctx, g_dsps_slot, h->sps, sizeof(hevc_sps_t)))) die("hbs_copy_to_device", rc);
+    if ((rc = hbs_copy_to_device(g_ctx, g_dpps, h->pps, sizeof(hevc_pps_t)))) die("hbs_copy_to_device", rc);
+    if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+        /* written in place in its slot so that the tables it derives replace the ones in force */
+        p.struct_off = 0;
+    } else {
+        if ((rc = hbs_copy_to_device(g_ctx, g_dstruct, src, src_bytes))) die("hbs_copy_to_device", rc);
+        p.struct_off = 0;
     }
-    return -1;
+    p.rc = 0; p.nal_unit_type = t; p.nal_layer_id = h->nal->nal_layer_id; p.nal_temporal_id_plus1 = h->nal->nal_temporal_id_plus1;
+    p.slice_data_size = 0; p.slice_data_off = 0;
+    if ((rc = hbs_copy_to_device(g_ctx, g_dparsed, &p, sizeof(p)))) die("hbs_copy_to_device", rc);
+    if ((rc = hbs_write_headers(g_ctx, g_dparsed, 1, t == HEVC_NAL_UNIT_TYPE_SPS_NUT ? g_dsps_slot : g_dstruct,
+                                g_dsps_slot, g_dpps, g_dout, cap, d_written))) die("hbs_write_headers", rc);
+    if ((rc = hbs_copy_to_host(g_ctx, &w, d_written, sizeof(w)))) die("hbs_copy_to_host", rc);
+    if (is_slice(t) && h->slice_data) {                                  /* :1699-1706 */
+        free(h->slice_data->rbsp_buf);
+        h->slice_data->rbsp_size = w.slice_data_size;
+        h->slice_data->rbsp_buf = w.slice_data_size > 0 ? (uint8_t*)calloc(1, (size_t)w.slice_data_size) : NULL;
+    }
+    if (w.rc < 0) return -1;                                             /* :1312 */
+    rbsp_size = (int)w.rbsp_size;
+    rbsp = (uint8_t*)malloc((size_t)rbsp_size + 16);
+    if (rbsp_size && (rc = hbs_copy_to_host(g_ctx, rbsp, g_dout, (uint64_t)rbsp_size))) die("hbs_copy_to_host", rc);
+    nal_size = size;
+    rc = rbsp_to_nal(rbsp, &rbsp_size, buf, &nal_size);                  /* :1319 */
+    free(rbsp);
+    if (rc < 0) return -1;
+    return nal_size;
 }

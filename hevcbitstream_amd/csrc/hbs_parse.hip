@@ -136,6 +136,7 @@ void k4_scan_parts(Scan3* __restrict__ part, unsigned long long* __restrict__ to
     if (tid == kScan4Blocks - 1) *total = ssum[tid];
 }
 
+template <bool kAssignSlots>
 __global__ __launch_bounds__(256)
 void k4_scan_apply(ParsedNal* __restrict__ parsed, const unsigned long long* __restrict__ slot_size, uint64_t n,
                    const Scan3* __restrict__ part, long long* __restrict__ ctx_sps, long long* __restrict__ ctx_pps)
@@ -150,7 +151,7 @@ void k4_scan_apply(ParsedNal* __restrict__ parsed, const unsigned long long* __r
         Scan3 tot;
         const Scan3 ex = scan3_join(carry, block_excl_scan3(x, wsum, tot));
         if (i < hi) {
-            parsed[i].struct_off = x.sum ? ex.sum : ~0ull;
+            if (kAssignSlots) parsed[i].struct_off = x.sum ? ex.sum : ~0ull;
             ctx_sps[i] = ex.sps; ctx_pps[i] = ex.pps;
         }
         carry = scan3_join(carry, tot);
@@ -204,7 +205,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         if (lane == 0) {
             Parser ps;
             ps.b.win = win[wv]; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
-            ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0;
+            ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wr = false; ps.b.wbuf = nullptr;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
@@ -242,6 +243,79 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     }
 }
 
+/* ---- K5: syntax writers (write_hevc_nal_unit, hevc_stream.c:1249-1327, up to rbsp_to_nal) ---- */
+
+__global__ void k5_slot_sizes(const ParsedNal* __restrict__ parsed, uint64_t n, unsigned long long* __restrict__ slot_size)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        slot_size[k] = (parsed[k].struct_off != ~0ull) ? slot_bytes_of(parsed[k].nal_unit_type) : 0ull;
+}
+
+/* one NAL per wavefront: the wave clears the NAL's RBSP buffer (the reference callocs it), lane 0 walks
+ * the syntax in write mode.  pass 0: parameter sets (an SPS re-derives the RPS tables behind it, as
+ * the reference's writer refreshes its file-static ones); pass 1: slices against them. */
+__global__ __launch_bounds__(256)
+void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_t* __restrict__ structs,
+              const long long* __restrict__ ctx_sps, const long long* __restrict__ ctx_pps,
+              const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot, const uint8_t* __restrict__ init_pps,
+              uint8_t* __restrict__ rbsp_out, uint32_t rbsp_cap, WrittenNal* __restrict__ written)
+{
+    __shared__ RpsRow own_rows[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t k = wave; k < n; k += nwaves) {
+        const int type = parsed[k].nal_unit_type;
+        const bool slice = is_slice_type_nal(type);
+        const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
+        if ((slice || pset) && (pass == 0) != pset) continue;
+        if (!(slice || pset) && pass != 0) continue;
+        uint8_t* out = rbsp_out + k * (uint64_t)rbsp_cap;
+        for (uint32_t i = lane; i < rbsp_cap; i += 64) out[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            WrittenNal res;
+            res.rc = -1; res.rbsp_size = 0; res.slice_data_size = 0; res.pad = 0;
+            if ((slice || pset) && parsed[k].struct_off != ~0ull) {
+                uint8_t* slot = structs + parsed[k].struct_off;
+                Parser ps;
+                ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = rbsp_cap; ps.b.pos = 0;
+                ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wr = true; ps.b.wbuf = out;
+                ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+                const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
+                const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
+                const hevc_sps_t* last_sps = zero_sps;
+                const hevc_pps_t* last_pps = zero_pps;
+                if (slice) {
+                    const long long cs = ctx_sps[k], cp = ctx_pps[k];
+                    if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
+                        last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[cs].struct_off);
+                        ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[cs].struct_off + round16(sizeof(hevc_sps_t)));
+                    } else if (cs < 0 && init_sps_slot) {
+                        last_sps = reinterpret_cast<const hevc_sps_t*>(init_sps_slot);
+                        ps.sps_rps = reinterpret_cast<const RpsTables*>(init_sps_slot + round16(sizeof(hevc_sps_t)));
+                    }
+                    if (cp >= 0 && parsed[cp].struct_off != ~0ull)
+                        last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
+                    else if (cp < 0 && init_pps)
+                        last_pps = reinterpret_cast<const hevc_pps_t*>(init_pps);
+                    RpsRow* row = &own_rows[wv];
+                    row->NumDeltaPocs = row->NumNegativePics = row->NumPositivePics = 0;
+                    for (int i = 0; i < 32; ++i) { row->DeltaPocS0[i] = row->UsedByCurrPicS0[i] = row->DeltaPocS1[i] = row->UsedByCurrPicS1[i] = 0; }
+                    ps.own = row;
+                } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+                    ps.out_rps = reinterpret_cast<RpsTables*>(slot + round16(sizeof(hevc_sps_t)));
+                }
+                write_one_nal(ps, type, parsed[k].nal_layer_id, parsed[k].nal_temporal_id_plus1, slot,
+                              last_pps, last_sps, zero_pps, zero_sps, &res);
+            }
+            written[k] = res;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ void k4_summary(uint64_t n, const unsigned long long* total, const uint32_t* err, hbs_summary* sum)
 {
     sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = 0; sum->stream_bytes = 0;
@@ -265,13 +339,28 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         Scan3* part = reinterpret_cast<Scan3*>(a.scan_tmp);
         k4_scan_reduce<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part);
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
-        k4_scan_apply<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
+        k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
             k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
             k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
         }
     }
     k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);
+    return hipGetLastError();
+}
+
+hipError_t launch_write_headers(const WriteArgs& a, hipStream_t st)
+{
+    if (a.n) {
+        Scan3* part = reinterpret_cast<Scan3*>(a.scan_tmp);
+        k5_slot_sizes<<<1024, 256, 0, st>>>(a.parsed, a.n, a.slot_size);
+        k4_scan_reduce<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part);
+        k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
+        k4_scan_apply<false><<<kScan4Blocks, 256, 0, st>>>(const_cast<ParsedNal*>(a.parsed), a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
+        for (int pass = 0; pass < 2; ++pass)
+            k5_write<<<256 * 4, 256, 0, st>>>(a.parsed, a.n, pass, a.structs, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot,
+                                              a.initial_pps, a.rbsp_out, a.rbsp_cap, a.written);
+    }
     return hipGetLastError();
 }
 

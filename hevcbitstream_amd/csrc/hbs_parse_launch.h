@@ -35,5 +35,27 @@ struct ParseArgs {
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);
 
+struct WrittenNal;
+
+struct WriteArgs {
+    const ParsedNal* parsed;         /* n records: type, layer, temporal id, struct_off            */
+    uint64_t n;
+    uint8_t* structs;                /* struct arena (an SPS's derived tables are refreshed)        */
+    uint8_t* rbsp_out;               /* n x rbsp_cap bytes                                          */
+    uint32_t rbsp_cap;
+    WrittenNal* written;             /* n records                                                   */
+    /* workspace */
+    unsigned long long* slot_size;   /* n */
+    long long* ctx_sps;              /* n */
+    long long* ctx_pps;              /* n */
+    const uint8_t* zeros;
+    const uint8_t* initial_sps_slot;
+    const uint8_t* initial_pps;
+    unsigned long long* total;
+    void* scan_tmp;
+};
+
+hipError_t launch_write_headers(const WriteArgs& a, hipStream_t st);
+
 } // namespace hbs
 #endif

@@ -239,6 +239,21 @@ int hbs_synth_rbsp(hbs_ctx* ctx, uint64_t seed, uint64_t n_nals, int mode,
                    uint8_t* d_rbsp, uint64_t rbsp_cap, hbs_nal_entry* d_index, hbs_summary* d_summary);
 uint64_t hbs_synth_rbsp_bound(uint64_t n_nals);
 
+/*
+ * K5: the syntax writers behind write_hevc_nal_unit (hevc_stream.c:1249-1327): NAL k's struct
+ * (at d_structs + d_parsed[k].struct_off, of the type d_parsed[k] names; layout as hbs_parse_headers
+ * leaves it, an SPS followed by its derived tables) is serialised into d_rbsp_out + k * rbsp_cap
+ * (rbsp_cap bytes per NAL, zero-filled first; the reference uses size * 3 / 4 of the caller's buffer).
+ * Slices are written against the last SPS / PPS in front of them in the batch (or the initial ones).
+ * d_written[k]: rc 0 / -1 (unsupported type, or wrote past rbsp_cap), the whole bytes written, and
+ * what the reference's writer leaves in h->slice_data->rbsp_size.  hbs_emit_annexb turns the RBSP
+ * into NAL bytes (rbsp_to_nal).  Quirks of the reference's writers are kept: see hbs_parse.h.
+ */
+typedef struct hbs_written_nal { int32_t rc; uint32_t rbsp_size; int32_t slice_data_size; uint32_t pad; } hbs_written_nal;
+int hbs_write_headers(hbs_ctx* ctx, const hbs_parsed_nal* d_parsed, uint64_t n_nals, uint8_t* d_structs,
+                      const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                      uint8_t* d_rbsp_out, uint32_t rbsp_cap, hbs_written_nal* d_written);
+
 /* Device-memory helpers for callers without HIP headers (the legacy C layer):
  * allocate / free on the context's GPU, synchronising copies, async fill. */
 int hbs_dev_alloc(hbs_ctx* ctx, uint64_t bytes, void** out);

@@ -133,3 +133,21 @@ def parse_trace(rbsp, idx, cap=65536):
     L.sim_parse_trace(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, structs.ctypes.data, need,
                       trace.ctypes.data, cap, count.ctypes.data)
     return parsed[:n], structs[:need], [trace[k * cap:k * cap + min(int(count[k]), cap)].copy() for k in range(n)]
+
+
+WRITTEN = np.dtype([("rc", "<i4"), ("rbsp_size", "<u4"), ("slice_data_size", "<i4"), ("pad", "<u4")])
+
+
+def write_nal(nal_type, layer, tid, slot, sps_slot, pps, cap):
+    """write_one_nal single-stepped: (result record, RBSP bytes written)"""
+    L = lib()
+    L.sim_write_nal.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.sim_write_nal.restype = C.c_int
+    slot = np.ascontiguousarray(slot)
+    out = np.zeros(cap + 16, dtype=np.uint8)
+    res = np.zeros(1, dtype=WRITTEN)
+    L.sim_write_nal(nal_type, layer, tid, slot.ctypes.data,
+                    sps_slot.ctypes.data if sps_slot is not None else None, pps.ctypes.data if pps is not None else None,
+                    out.ctypes.data, cap, res.ctypes.data)
+    r = res[0]
+    return r, out[:int(r["rbsp_size"])].copy()

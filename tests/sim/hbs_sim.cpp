@@ -223,7 +223,7 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
             const uint8_t* src = rbsp + idx[k].rbsp_off;
             ps.b.win = src; ps.b.full = src; ps.b.win_bytes = idx[k].rbsp_len < 512u ? idx[k].rbsp_len : 512u;
             ps.b.size = idx[k].rbsp_len; ps.b.pos = 16;
-            ps.b.tr = g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr; ps.b.tr_cap = g_sim_trace_cap; ps.b.tr_n = 0;
+            ps.b.tr = g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr; ps.b.tr_cap = g_sim_trace_cap; ps.b.tr_n = 0; ps.b.wr = false; ps.b.wbuf = nullptr;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
@@ -469,4 +469,31 @@ extern "C" int sim_index_extract_host(const uint8_t* stream, uint64_t n, uint64_
     be.h_stream = stream; be.h_rbsp = rbsp; be.window = window_bytes; be.lead = window_bytes;
     be.idx_cap = (2 * window_bytes) / 32 + 64;
     return hbs::ingest_windowed(be, n, window_bytes, index, index_cap, rbsp != nullptr, rbsp_cap, sum);
+}
+
+/* ---- syntax writers (write_one_nal) single-stepped: one NAL from its struct --------------------- */
+extern "C" int sim_write_nal(int type, int layer, int tid, uint8_t* slot /* struct; an SPS is followed by its RpsTables */,
+                             const uint8_t* sps_slot /* SPS + tables in force, or null */, const uint8_t* pps /* or null */,
+                             uint8_t* out, uint32_t cap, WrittenNal* res)
+{
+    static std::vector<uint8_t> zeros(sizeof(hevc_sps_t) + 64, 0);
+    memset(out, 0, cap);
+    Parser ps;
+    ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = cap; ps.b.pos = 0;
+    ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wr = true; ps.b.wbuf = out;
+    ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+    const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
+    const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
+    const hevc_sps_t* last_sps = sps_slot ? reinterpret_cast<const hevc_sps_t*>(sps_slot) : zero_sps;
+    const hevc_pps_t* last_pps = pps ? reinterpret_cast<const hevc_pps_t*>(pps) : zero_pps;
+    RpsRow row;
+    if (is_slice_type_nal(type)) {
+        if (sps_slot) ps.sps_rps = reinterpret_cast<const RpsTables*>(sps_slot + round16(sizeof(hevc_sps_t)));
+        memset(&row, 0, sizeof(row));
+        ps.own = &row;
+    } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+        ps.out_rps = reinterpret_cast<RpsTables*>(slot + round16(sizeof(hevc_sps_t)));
+    }
+    write_one_nal(ps, type, layer, tid, slot, last_pps, last_sps, zero_pps, zero_sps, res);
+    return 0;
 }

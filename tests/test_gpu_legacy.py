@@ -144,3 +144,40 @@ def test_reference_cli_full_stdout():
             os.unlink(path)
         got, want = norm(out), norm(v["stdout"])
         assert got == want, (v["tag"], [(a, b) for a, b in zip(got, want) if a != b][:3], len(got), len(want))
+
+
+def test_write_hevc_nal_unit_golden():
+    """hevc_new + read_hevc_nal_unit + (edit) + write_hevc_nal_unit per NAL against the reference's writer
+    (tests/golden/make_golden_write.py): bytes, return value and the slice_data side effect."""
+    import gzip
+    import hevcbitstream_amd as hbs
+    from tests._parsecmp import which_struct
+    vectors = json.load(gzip.open(os.path.join(HERE, "golden", "write_vectors.json.gz"), "rt"))
+
+    def field_index(kind, name):
+        for n, i, c in _orc.flat_fields(_orc.STRUCT_TYPES[kind]):
+            if n == name:
+                return i
+        raise KeyError(name)
+
+    lib = hbs.load_library()
+    lib.write_hevc_nal_unit.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+    for v in vectors:
+        p = LegacyHevc(lib)
+        for k, st in enumerate(v["steps"]):
+            nal = bytes.fromhex(st["nal"])
+            assert p.read(nal) == st["read_rc"], (v["seed"], k)
+            if "write_rc" not in st:
+                continue
+            kind = which_struct(int(p.v["nal"][1]))
+            saved = p.v[kind].copy()
+            for name, value in st["edits"]:
+                p.v[kind][field_index(kind, name)] = value
+            out = np.zeros(st["size"] + 16, dtype=np.uint8)
+            rc = lib.write_hevc_nal_unit(p.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), st["size"])
+            p.v[kind][:] = saved
+            assert rc == st["write_rc"], (v["seed"], k, kind, rc, st["write_rc"])
+            if rc > 0:
+                assert bytes(out[:rc]).hex() == st["out"], (v["seed"], k, kind, st["edits"])
+            if kind == "sh":
+                assert p.slice_data()[0] == st["slice_data_size"], (v["seed"], k)
