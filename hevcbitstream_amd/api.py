@@ -14,13 +14,14 @@ SUMMARY = np.dtype([("nal_count", "<u8"), ("nal_found", "<u8"), ("rbsp_bytes", "
                     ("reserved", "<u8", (3,))])
 ST_ERROR, ST_TRAILING03, ST_UNTERMINATED = 1, 2, 4
 # layout of hbs_parsed_nal
+WRITTEN = np.dtype([("rc", "<i4"), ("rbsp_size", "<u4"), ("slice_data_size", "<i4"), ("pad", "<u4")])
 PARSED = np.dtype([("rc", "<i4"), ("nal_unit_type", "<i4"), ("nal_layer_id", "<i4"), ("nal_temporal_id_plus1", "<i4"),
                    ("struct_off", "<u8"), ("slice_data_size", "<i4"), ("slice_data_off", "<u4")])
 
 EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stream", "hbs_ctx_use_own_stream",
            "hbs_ctx_get_stream",
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_index_extract_host", "hbs_read_summary",
-           "hbs_workspace_bytes", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
+           "hbs_workspace_bytes", "hbs_write_headers", "hbs_parse_headers_trace", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel"]
 
@@ -66,6 +67,8 @@ def load_library():
                                       C.c_void_p, C.c_uint64, C.c_void_p]
     lib.hbs_index_extract_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.hbs_write_headers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_uint32, C.c_void_p]
     lib.hbs_read_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hbs_workspace_bytes.argtypes = [C.c_uint64]
     lib.hbs_workspace_bytes.restype = C.c_uint64
@@ -210,6 +213,22 @@ class Context:
         ent = h_index.numpy()[: cnt * NAL_ENTRY.itemsize].view(NAL_ENTRY).copy()
         arena = h_rbsp.numpy()[: int(s["rbsp_bytes"])].copy() if h_rbsp is not None else None
         return ent, arena, s
+
+    def write_headers(self, parsed, structs, n_nals, rbsp_cap):
+        """K5: serialise the structs of a parsed batch back to RBSP.  parsed: ndarray[PARSED] (host) or a device
+        uint8 tensor of n records; structs: the device struct arena hbs_parse_headers filled.  Returns
+        (written ndarray[WRITTEN], rbsp device tensor of n_nals * rbsp_cap bytes)."""
+        t = self.torch
+        dev = t.device("cuda", self.device)
+        if isinstance(parsed, np.ndarray):
+            parsed = t.from_numpy(np.ascontiguousarray(parsed).view(np.uint8).copy()).to(dev)
+        out = t.empty(max(n_nals, 1) * rbsp_cap, dtype=t.uint8, device=dev)
+        written = t.empty(max(n_nals, 1) * WRITTEN.itemsize, dtype=t.uint8, device=dev)
+        self._bind_stream()
+        rc = self.lib.hbs_write_headers(self.h, C.c_void_p(parsed.data_ptr()), n_nals, C.c_void_p(structs.data_ptr()),
+                                        None, None, C.c_void_p(out.data_ptr()), rbsp_cap, C.c_void_p(written.data_ptr()))
+        self._check(rc, "hbs_write_headers")
+        return written[: n_nals * WRITTEN.itemsize].cpu().numpy().view(WRITTEN).copy(), out
 
     def emit_annexb_async(self, rbsp, rbsp_bytes, index, n_nals, gap_mode, out, index_out, summary):
         """Enqueue K3.  rbsp/index/out/index_out/summary are device tensors (index_out may be None)."""

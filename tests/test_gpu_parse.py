@@ -109,3 +109,33 @@ def test_config3_4k30_100k_nals(ctx):
     # whole stream: slice_data_size + header bytes + 1 == rbsp_len for every slice
     sl = (parsed["nal_unit_type"] == 1) | (parsed["nal_unit_type"] == 19)
     assert (parsed["slice_data_size"][sl] + parsed["slice_data_off"][sl].astype(np.int64) == idx["rbsp_len"][sl]).all()
+
+
+def test_write_headers_batch_roundtrip(ctx):
+    """K5 over a whole parsed batch (config-3 style stream, ~8k NALs): VPS and PPS come back bit for bit
+    (SURVEY: "round-trips VPS/PPS exactly"), an SPS comes back without its trailing bits and unfinished
+    last byte: a prefix of the RBSP it was parsed from.  (Slices: byte parity with the reference's writer,
+    which re-codes some fields, is in the golden tests; here only that every one is written.)"""
+    stream, n = stream_4k30(17, n_pictures=1000, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
+    s, idx, arena, parsed, structs = gpu_parse(ctx, stream)
+    assert (parsed["rc"] >= 0).all()
+    import torch
+    cap = 256
+    written, out = ctx.write_headers(parsed, torch.from_numpy(structs).cuda(), len(parsed), cap)
+    out = out.cpu().numpy()
+    assert (written["rc"] == 0).all()
+    kinds = {32: 0, 33: 0, 34: 0, "slice": 0}
+    for k in range(len(parsed)):
+        t = int(parsed["nal_unit_type"][k])
+        got = bytes(out[k * cap:k * cap + int(written["rbsp_size"][k])])
+        rb = bytes(arena[int(idx["rbsp_off"][k]):int(idx["rbsp_off"][k]) + int(idx["rbsp_len"][k])])
+        if t in (32, 34):
+            assert got == rb, (k, t)
+            kinds[t] += 1
+        elif t == 33:
+            assert len(got) >= len(rb) - 2 and rb.startswith(got), (k, got.hex(), rb.hex())
+            kinds[t] += 1
+        else:
+            assert 3 <= len(got) < cap and got[:2] == rb[:2], (k, len(got))
+            kinds["slice"] += 1
+    assert min(kinds.values()) > 0, kinds
