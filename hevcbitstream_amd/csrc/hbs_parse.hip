@@ -158,7 +158,9 @@ void k4_scan_apply(ParsedNal* __restrict__ parsed, const unsigned long long* __r
     }
 }
 
-/* pass 0: parameter sets; pass 1: slices */
+/* pass 0: parameter sets; pass 1: slices.  kMode: plain parse, or parse + per-field trace (the debug
+ * reader's variant of the syntax, see hbs_parse.h) */
+template <int kMode>
 __global__ __launch_bounds__(256)
 void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int pass,
               ParsedNal* __restrict__ parsed, uint8_t* __restrict__ structs, uint64_t structs_cap,
@@ -203,9 +205,9 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
         if (lane == 0) {
-            Parser ps;
+            ParserT<kMode> ps;
             ps.b.win = win[wv]; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
-            ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wr = false; ps.b.wbuf = nullptr;
+            ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
@@ -279,9 +281,9 @@ void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_
             res.rc = -1; res.rbsp_size = 0; res.slice_data_size = 0; res.pad = 0;
             if ((slice || pset) && parsed[k].struct_off != ~0ull) {
                 uint8_t* slot = structs + parsed[k].struct_off;
-                Parser ps;
+                ParserT<kModeWrite> ps;
                 ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = rbsp_cap; ps.b.pos = 0;
-                ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wr = true; ps.b.wbuf = out;
+                ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = out;
                 ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
                 const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
                 const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
@@ -341,8 +343,13 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
         k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
-            k4_parse<<<256 * 4, 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
-            k4_parse<<<256 * 8, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
+            for (int pass = 0; pass < 2; ++pass) {
+                const unsigned grid = pass == 0 ? 256 * 4 : 256 * 8;
+                if (a.trace)
+                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
+                else
+                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr);
+            }
         }
     }
     k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);

@@ -25,3 +25,20 @@ best = min(ts)
 print("stream bytes", len(s), "nals", n, "struct arena bytes", structs.numel())
 print("ms per call", ["%.3f" % t for t in ts])
 print("best %.3f ms -> %.2f M NAL/s; struct arena written at %.1f GB/s" % (best, n / best / 1e3, structs.numel() / best / 1e6))
+
+# K5: write the whole batch back (RBSP only)
+cap = 256
+parsed_dev = torch.from_numpy(parsed.view(np.uint8).copy()).cuda()
+written, out = ctx.write_headers(parsed_dev, structs, n, cap)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+wr = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+import ctypes as C
+for i in range(4):
+    ctx._bind_stream()
+    rc = ctx.lib.hbs_write_headers(ctx.h, C.c_void_p(parsed_dev.data_ptr()), n, C.c_void_p(structs.data_ptr()), None, None,
+                                   C.c_void_p(out.data_ptr()), cap, C.c_void_p(wr.data_ptr()))
+    assert rc == 0
+    ev[i].record()
+torch.cuda.synchronize()
+tw = min(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
+print("K5 write_headers: best %.3f ms -> %.2f M NAL/s (rc<0: %d)" % (tw, n / tw / 1e3, int((written["rc"] < 0).sum())))

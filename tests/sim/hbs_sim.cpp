@@ -185,8 +185,9 @@ static TraceRec* g_sim_trace = nullptr;       /* set by sim_parse_trace around s
 static uint32_t g_sim_trace_cap = 0;
 static uint32_t* g_sim_trace_count = nullptr;
 
-extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n,
-                                     ParsedNal* parsed, uint8_t* structs, uint64_t structs_cap)
+template <int kMode>
+static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n,
+                              ParsedNal* parsed, uint8_t* structs, uint64_t structs_cap)
 {
     static std::vector<uint8_t> zeros(sizeof(hevc_sps_t) + 64, 0);
     uint64_t run = 0;
@@ -219,11 +220,11 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
             if (off + slot > structs_cap) { parsed[k].struct_off = ~0ull; continue; }
             uint8_t* dst = structs + off;
             memset(dst, 0, slot);
-            Parser ps;
+            ParserT<kMode> ps;
             const uint8_t* src = rbsp + idx[k].rbsp_off;
             ps.b.win = src; ps.b.full = src; ps.b.win_bytes = idx[k].rbsp_len < 512u ? idx[k].rbsp_len : 512u;
             ps.b.size = idx[k].rbsp_len; ps.b.pos = 16;
-            ps.b.tr = g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr; ps.b.tr_cap = g_sim_trace_cap; ps.b.tr_n = 0; ps.b.wr = false; ps.b.wbuf = nullptr;
+            ps.b.tr = g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr; ps.b.tr_cap = g_sim_trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
@@ -252,12 +253,18 @@ extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* i
     return (int64_t)run;
 }
 
+extern "C" int64_t sim_parse_headers(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n,
+                                     ParsedNal* parsed, uint8_t* structs, uint64_t structs_cap)
+{
+    return sim_parse_impl<kModeRead>(rbsp, idx, n, parsed, structs, structs_cap);
+}
+
 extern "C" int64_t sim_parse_trace(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n, ParsedNal* parsed, uint8_t* structs,
                                    uint64_t structs_cap, TraceRec* trace, uint32_t trace_cap, uint32_t* trace_count)
 {
     g_sim_trace = trace; g_sim_trace_cap = trace_cap; g_sim_trace_count = trace_count;
     for (uint64_t k = 0; k < n; ++k) trace_count[k] = 0;
-    const int64_t r = sim_parse_headers(rbsp, idx, n, parsed, structs, structs_cap);
+    const int64_t r = sim_parse_impl<kModeTrace>(rbsp, idx, n, parsed, structs, structs_cap);
     g_sim_trace = nullptr; g_sim_trace_cap = 0; g_sim_trace_count = nullptr;
     return r;
 }
@@ -478,9 +485,9 @@ extern "C" int sim_write_nal(int type, int layer, int tid, uint8_t* slot /* stru
 {
     static std::vector<uint8_t> zeros(sizeof(hevc_sps_t) + 64, 0);
     memset(out, 0, cap);
-    Parser ps;
+    ParserT<kModeWrite> ps;
     ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = cap; ps.b.pos = 0;
-    ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wr = true; ps.b.wbuf = out;
+    ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = out;
     ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
     const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
     const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
