@@ -152,7 +152,7 @@ def main():
         algo_bytes = sb + rb + 32 * n
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         blocks, per_cu = ctx.grid()
-        variant = ctx.kernel()
+        variant = ctx.last_kernel()          # automatic mode: the kernel the density probe picked
         kernel_name = {2: "hbs::k_scan_extract", 3: "hbs::k_scan_extract3", 4: "hbs::k_scan_extract4"}[variant]
         geometry = {2: "512 threads, 64 KiB tiles (LDS image)", 3: "512 threads, 64 KiB tiles (registers)",
                     4: "256 threads, 192 KiB tiles held in registers, tiles handed out by ticket"}[variant]

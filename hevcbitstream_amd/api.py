@@ -23,7 +23,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_index_extract_host", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_write_headers", "hbs_parse_headers_trace", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
-           "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel"]
+           "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel"]
 
 
 class HbsError(RuntimeError):
@@ -61,6 +61,7 @@ def load_library():
     lib.hbs_ctx_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hbs_ctx_set_kernel.argtypes = [C.c_void_p, C.c_int]
     lib.hbs_ctx_get_kernel.argtypes = [C.c_void_p]
+    lib.hbs_ctx_last_kernel.argtypes = [C.c_void_p]
     lib.hbs_last_error.argtypes = [C.c_void_p]
     lib.hbs_last_error.restype = C.c_char_p
     lib.hbs_index_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -124,11 +125,16 @@ class Context:
             raise HbsError("%s failed: %d (%s)" % (what, rc, self.lib.hbs_last_error(self.h).decode()))
 
     def set_kernel(self, variant):
-        """2 = LDS-image scan/extract kernel, 3 = register-resident one, 4 = event-sparse one"""
+        """0 = automatic (density probe picks 4 or 2 on the device; the default), 2 = LDS-image
+        scan/extract kernel, 3 = register-resident one, 4 = event-sparse one"""
         self._check(self.lib.hbs_ctx_set_kernel(self.h, variant), "hbs_ctx_set_kernel")
 
     def kernel(self):
         return self.lib.hbs_ctx_get_kernel(self.h)
+
+    def last_kernel(self):
+        """the kernel that ran the last index_extract (waits for it)"""
+        return self.lib.hbs_ctx_last_kernel(self.h)
 
     def enable_timing(self, on=True):
         self._check(self.lib.hbs_ctx_enable_timing(self.h, 1 if on else 0), "hbs_ctx_enable_timing")

@@ -16,7 +16,7 @@
 #include "hbs_parse.h"
 
 #ifndef HBS_DEFAULT_KERNEL
-#define HBS_DEFAULT_KERNEL 4
+#define HBS_DEFAULT_KERNEL 0
 #define HBS_DEFAULT_SCHED 1
 #endif
 
@@ -28,7 +28,9 @@ struct hbs_ctx {
     int blocks_per_cu;
     int grid_blocks3, blocks_per_cu3;   /* register-resident kernel */
     int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
-    int variant;
+    int variant;                  /* 0 = automatic */
+    int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
+    int probe_pending;
     int sched;
     unsigned long long* desc;
     uint64_t desc_tiles;
@@ -117,10 +119,11 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) { c->grid_blocks = atoi(g); c->grid_blocks3 = atoi(g) < c->grid_blocks3 ? atoi(g) : c->grid_blocks3; }
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
-    const char* kv = getenv("HBS_KERNEL");              /* 2 = LDS-image kernel, 3 = register-resident kernel */
+    const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 3 register-resident, 4 event-sparse */
     const char* sv = getenv("HBS_SCHED");
     c->sched = (sv && atoi(sv) >= 0 && atoi(sv) <= 2) ? atoi(sv) : HBS_DEFAULT_SCHED;
-    c->variant = (kv && atoi(kv) >= 2 && atoi(kv) <= 4) ? atoi(kv) : HBS_DEFAULT_KERNEL;
+    c->variant = (kv && (atoi(kv) == 0 || (atoi(kv) >= 2 && atoi(kv) <= 4))) ? atoi(kv) : HBS_DEFAULT_KERNEL;
+    c->last_variant = c->variant ? c->variant : 4;
     *out = c;
     return 0;
 }
@@ -170,19 +173,37 @@ int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
 int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 {
     if (!c) return HBS_E_ARG;
-    if (blocks) *blocks = (c->variant == 4) ? c->grid_blocks4 : (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
-    if (blocks_per_cu) *blocks_per_cu = (c->variant == 4) ? c->blocks_per_cu4 : (c->variant == 3) ? c->blocks_per_cu3 : c->blocks_per_cu;
+    const int v = c->variant ? c->variant : c->last_variant;
+    if (blocks) *blocks = (v == 4) ? c->grid_blocks4 : (v == 3) ? c->grid_blocks3 : c->grid_blocks;
+    if (blocks_per_cu) *blocks_per_cu = (v == 4) ? c->blocks_per_cu4 : (v == 3) ? c->blocks_per_cu3 : c->blocks_per_cu;
     return 0;
 }
 
 int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 {
-    if (!c || variant < 2 || variant > 4) return HBS_E_ARG;
+    if (!c || variant < 0 || variant == 1 || variant > 4) return HBS_E_ARG;
     c->variant = variant;
+    if (variant) c->last_variant = variant;
     return 0;
 }
 
 int hbs_ctx_get_kernel(hbs_ctx* c) { return c ? c->variant : HBS_E_ARG; }
+
+int hbs_ctx_last_kernel(hbs_ctx* c)
+{
+    if (!c) return HBS_E_ARG;
+    if (c->variant) return c->variant;
+    if (!c->probe_pending) return c->last_variant;
+    /* automatic mode: the choice was made on the device; read the probe's counts back */
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    hbs::RunHeader h;
+    hipError_t e = hipMemcpyAsync(&h, c->hdr, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, e, "read-back of the density probe");
+    c->last_variant = hbs::probe_says_dense(h.probe_chunks, h.probe_flagged) ? 2 : 4;
+    c->probe_pending = 0;
+    return c->last_variant;
+}
 
 int hbs_ctx_use_own_stream(hbs_ctx* c)
 {
@@ -227,7 +248,8 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.desc = c->desc; a.hdr = c->hdr; a.tail = c->tail; a.summary = d_summary;
     a.variant = c->variant;
     a.sched = c->sched;
-    a.grid_blocks = (c->variant == 4) ? c->grid_blocks4 : (c->variant == 3) ? c->grid_blocks3 : c->grid_blocks;
+    a.grid_blocks = c->grid_blocks; a.grid_blocks3 = c->grid_blocks3; a.grid_blocks4 = c->grid_blocks4;
+    c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
     a.ev_begin = c->timing ? c->ev0 : nullptr;
     a.ev_end = c->timing ? c->ev1 : nullptr;
     c->ev_valid = (c->timing && n) ? 1 : 0;

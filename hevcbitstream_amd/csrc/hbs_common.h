@@ -73,11 +73,21 @@ struct RunHeader {
     uint32_t error;           /* HBS_E_* (positive magnitude) or 0               */
     unsigned long long first_empty;  /* ordinal of the first empty NAL (min), init ~0 */
     uint32_t abort_flag;      /* set when a look-back wait timed out             */
-    uint32_t pad0[23];
+    uint32_t probe_chunks;    /* density probe: 16-byte chunks sampled ...                      */
+    uint32_t probe_flagged;   /* ... and how many of them may hold a 00 00 pair (hbs_sparse.h)  */
+    uint32_t pad0[21];
     uint32_t ticket;          /* next unclaimed tile (dynamic tile schedules); alone on its 128-byte line */
     uint32_t pad1[31];
 };
 static_assert(sizeof(RunHeader) == 256, "RunHeader layout");
+
+/* The kernel-choice rule of the automatic mode (hbs_scan.hip launch_scan_extract): the event-sparse
+ * kernel handles flagged chunks 64 at a time on one wavefront, so once more than one chunk in
+ * kDenseOneIn may hold a zero pair the LDS-image kernel, whose cost does not depend on the data,
+ * is the faster of the two. */
+constexpr uint32_t kDenseOneIn = 100;   /* measured crossover: ~1.1 % of chunks flagged (scripts/density_sweep.py) */
+HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged) { return (uint64_t)flagged * kDenseOneIn > (uint64_t)chunks; }
+enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2 };
 
 HBS_HD uint32_t popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 HBS_HD uint32_t ctz64(uint64_t v)  { return (uint32_t)__builtin_ctzll(v); }

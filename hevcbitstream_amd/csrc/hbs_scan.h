@@ -18,10 +18,12 @@ struct ScanArgs {
     RunHeader* hdr;               /* workspace                                    */
     uint8_t* tail;                /* workspace of scan4_tail_bytes(): padded copy of the last tile (variant 4) */
     hbs_summary* summary;         /* device                                       */
-    int grid_blocks;              /* persistent workgroups (<= resident capacity) */
+    int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
+    int grid_blocks3, grid_blocks4;   /* ... of the register-resident and of the event-sparse kernel          */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
     int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */
-    int variant;                  /* 2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip) */
+    int variant;                  /* 0: automatic (density probe, then event-sparse or LDS-image kernel, decided on the device),
+                                     2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip) */
 };
 
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
@@ -37,7 +39,8 @@ int scan4_grid_blocks(int device, int* blocks_per_cu_out);
 int scan4_tile_bytes();
 int scan4_tail_bytes();
 void launch_scan4_prepare_tail(const ScanArgs& a, hipStream_t st);
-void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st);
+void launch_scan4_probe(const ScanArgs& a, hipStream_t st);
+void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 } // namespace hbs
 #endif

@@ -406,8 +406,9 @@ __global__ __launch_bounds__(kThreads, 4)
 void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                     hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                     uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
-                    unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched)
+                    unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched, int gate)
 {
+    if (gate == kGateIfDense && !probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
     __shared__ TileLds l;
     const int tid0 = threadIdx.x;
     EmitTarget tgt;
@@ -534,6 +535,7 @@ __global__ void k_init_header(RunHeader* hdr)
 {
     hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
     hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
+    hdr->probe_chunks = 0; hdr->probe_flagged = 0;
 }
 
 __global__ void k_tail_fixup(const uint8_t* __restrict__ stream, uint64_t n,
@@ -575,27 +577,38 @@ int scan_grid_blocks(int device, int* blocks_per_cu_out)
 hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
 {
     hipError_t e;
+    const bool automatic = a.variant == 0;
     k_init_header<<<1, 1, 0, st>>>(a.hdr);
-    if (a.variant == 4) launch_scan4_prepare_tail(a, st);
+    if (automatic && a.n) launch_scan4_probe(a, st);
+    if (automatic || a.variant == 4) launch_scan4_prepare_tail(a, st);
     if (a.index_cap) {
         e = hipMemsetAsync(a.index, 0, a.index_cap * sizeof(hbs_nal_entry), st);
         if (e != hipSuccess) return e;
     }
-    const uint64_t tile_bytes = (a.variant == 4) ? (uint64_t)scan4_tile_bytes() : (uint64_t)kTileBytes;
-    const uint64_t num_tiles = (a.n + tile_bytes - 1) / tile_bytes;
+    const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
+    const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;
+    const uint64_t num_tiles = (a.variant == 4) ? tiles4 : tiles2;      /* automatic: the finer of the two tilings sizes the memset */
     if (num_tiles) {
         e = hipMemsetAsync(a.desc, 0, num_tiles * 16, st);
         if (e != hipSuccess) return e;
         uint64_t grid = (uint64_t)a.grid_blocks;
-        if (grid > num_tiles) grid = num_tiles;
+        if (grid > tiles2) grid = tiles2;
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
-        if (a.variant == 3)
+        if (a.variant == 3) {
             launch_scan_extract3_kernel(a, num_tiles, st);
-        else if (a.variant == 4)
-            launch_scan_extract4_kernel(a, num_tiles, st);
-        else
+        } else if (a.variant == 4) {
+            launch_scan_extract4_kernel(a, tiles4, kGateNone, st);
+        } else if (automatic) {
+            /* Both kernels are enqueued; each reads the probe's verdict from the run header and the
+             * one it rules out returns at once (no host round trip, the call stays asynchronous).
+             * They share the descriptor array and the ticket: whichever runs finds both untouched. */
+            launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
-                a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched);
+                a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateIfDense);
+        } else {
+            k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
+                a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateNone);
+        }
         if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
     }
     k_tail_fixup<<<1, 1, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);

@@ -384,7 +384,7 @@ int scan3_grid_blocks(int device, int* blocks_per_cu_out)
 
 void launch_scan_extract3_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st)
 {
-    uint64_t grid = (uint64_t)a.grid_blocks;
+    uint64_t grid = (uint64_t)a.grid_blocks3;
     if (grid > num_tiles) grid = num_tiles;
     k_scan_extract3<<<dim3((unsigned)grid), dim3(k3Threads), 0, st>>>(
         a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr);

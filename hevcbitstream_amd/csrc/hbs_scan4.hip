@@ -357,8 +357,10 @@ __global__ __launch_bounds__(k4Threads, 2)
 void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                      hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                      uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
-                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, const uint8_t* __restrict__ tail)
+                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, const uint8_t* __restrict__ tail,
+                     int gate)
 {
+    if (gate == kGateIfSparse && probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
     __shared__ Lds4 l;
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -657,12 +659,44 @@ int scan4_grid_blocks(int device, int* blocks_per_cu_out)
     return prop.multiProcessorCount * per_cu;
 }
 
-void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st)
+void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st)
 {
-    uint64_t grid = (uint64_t)a.grid_blocks;
+    uint64_t grid = (uint64_t)a.grid_blocks4;
     if (grid > num_tiles) grid = num_tiles;
     k_scan_extract4<<<dim3((unsigned)grid), dim3(k4Threads), 0, st>>>(
-        a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.tail);
+        a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.tail, gate);
+}
+
+/* Density probe of the automatic mode: kProbeBlocks windows of 16 KiB spread evenly over the
+ * stream; counts the chunks that chunk_flag() would hand to the element path (neighbouring
+ * chunks ignored: an estimate is all the choice needs). */
+constexpr int kProbeBlocks = 64;
+__global__ __launch_bounds__(256)
+void k_probe_density(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr)
+{
+    const uint64_t stride = (n / kProbeBlocks) & ~15ull;
+    const uint64_t base = (uint64_t)blockIdx.x * stride;
+    uint32_t chunks = 0, flagged = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t off = base + (uint64_t)(k * 256 + (int)threadIdx.x) * 16u;
+        const bool in = off + 16 <= n;
+        bool f = false;
+        if (in) {
+            const Quad q = *reinterpret_cast<const Quad*>(stream + off);
+            f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+        }
+        chunks += (uint32_t)__builtin_popcountll(__ballot(in));
+        flagged += (uint32_t)__builtin_popcountll(__ballot(f));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&hdr->probe_chunks, chunks);
+        atomicAdd(&hdr->probe_flagged, flagged);
+    }
+}
+
+void launch_scan4_probe(const ScanArgs& a, hipStream_t st)
+{
+    k_probe_density<<<dim3(kProbeBlocks), dim3(256), 0, st>>>(a.stream, a.n, a.hdr);
 }
 
 } // namespace hbs

@@ -95,11 +95,17 @@ int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
 int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
 int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
 /* Three implementations of the fused scan/extract kernel exist, with identical results:
- * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the default and the fastest),
- * 2 = tile staged in an LDS image (hbs_scan.hip), 3 = tile in registers, dense per-row
- * classification (hbs_scan3.hip).  Environment HBS_KERNEL=2|3|4 sets the default. */
+ * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
+ *     pairs are rare, and the slowest on zero-heavy data),
+ * 2 = tile staged in an LDS image (hbs_scan.hip; same speed on any data),
+ * 3 = tile in registers, dense per-row classification (hbs_scan3.hip).
+ * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and kernel 4 or
+ *     kernel 2 is picked from it on the device, without a host round trip.
+ * Environment HBS_KERNEL=0|2|3|4 sets the default.  hbs_ctx_last_kernel waits for the last
+ * hbs_index_extract and says which kernel ran it. */
 int  hbs_ctx_set_kernel(hbs_ctx* ctx, int variant);
 int  hbs_ctx_get_kernel(hbs_ctx* ctx);
+int  hbs_ctx_last_kernel(hbs_ctx* ctx);
 /* Text of the last HIP/driver error seen by this context. */
 const char* hbs_last_error(hbs_ctx* ctx);
 /* Library/self description: "hevcbitstream_amd <ver> gfx950 ..." */

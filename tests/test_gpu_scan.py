@@ -12,9 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
-@pytest.fixture(scope="module", params=[2, 3, 4], ids=["lds-image-kernel", "register-kernel", "sparse-kernel"])
+@pytest.fixture(scope="module", params=[0, 2, 3, 4], ids=["automatic", "lds-image-kernel", "register-kernel", "sparse-kernel"])
 def ctx(request):
-    """both implementations of the fused kernel: hbs_scan.hip (2) and hbs_scan3.hip (3)"""
+    """the three implementations of the fused kernel (hbs_scan.hip 2, hbs_scan3.hip 3, hbs_scan4.hip 4) and the
+    automatic choice between 4 and 2 (the default)"""
     import torch
     import hevcbitstream_amd as hbs
     assert torch.cuda.is_available()
@@ -147,3 +148,23 @@ def test_dense_patterns(ctx, orc, pattern):
     check(ctx, orc, s)
     s[n // 2:n // 2 + 4000] = 0x55          # a plain stretch in the middle of the dense stream
     check(ctx, orc, s)
+
+
+def test_automatic_choice_follows_density(orc):
+    """the default mode picks the event-sparse kernel for coded-video-like bytes and the LDS-image kernel for
+    zero-heavy ones, on the device; the answer is the oracle's either way"""
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    try:
+        assert c.kernel() == 0
+        rng = np.random.default_rng(77)
+        n = 3 << 20
+        sparse = rng.integers(1, 256, size=n, dtype=np.uint8)
+        for p in range(5000, n - 8, 9973):
+            sparse[p:p + 4] = (0, 0, 1, 0x40)
+        dense = ALPHA[rng.integers(0, len(ALPHA), size=n)]
+        for stream, want in ((sparse, 4), (dense, 2), (sparse, 4)):
+            check(c, orc, stream)
+            assert c.last_kernel() == want
+    finally:
+        c.close()
