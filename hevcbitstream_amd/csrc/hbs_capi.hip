@@ -31,6 +31,7 @@ struct hbs_ctx {
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
+    int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
     int sched;
     unsigned long long* desc;
     uint64_t desc_tiles;
@@ -264,8 +265,16 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index_in || !d_out))) return HBS_E_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
     const uint64_t b_seg = 8192, b_n = round256((n_nals + 1) * 8);       /* b_seg: the scan's 1024 partial sums */
-    int rc = ensure_ws(c, b_seg + 2 * b_n + 512);
+    int rc = ensure_ws(c, b_seg + 2 * b_n + 768);
     if (rc) return rc;
+    if (c->emit_blocks <= 0) {
+        c->emit_blocks = hbs::emit_grid_blocks(c->device);
+        if (c->emit_blocks <= 0) return fail(c, hipErrorUnknown, "occupancy query of the emit kernel");
+        const char* eb = getenv("HBS_EMIT_BLOCKS");         /* debugging aid */
+        if (eb && atoi(eb) > 0 && atoi(eb) < c->emit_blocks) c->emit_blocks = atoi(eb);
+        const char* tp = getenv("HBS_EMIT_TWO_PASS");
+        c->emit_two_pass = (tp && atoi(tp) == 1) ? 1 : 0;
+    }
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::EmitArgs a;
     a.rbsp = d_rbsp; a.rbsp_bytes = rbsp_bytes; a.index_in = d_index_in; a.n = n_nals; a.gap_mode = gap_mode;
@@ -275,6 +284,8 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.out_off = reinterpret_cast<unsigned long long*>(w + b_seg + b_n);
     a.total = reinterpret_cast<unsigned long long*>(w + b_seg + 2 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + b_seg + 2 * b_n + 256);
+    a.ticket = reinterpret_cast<uint32_t*>(w + b_seg + 2 * b_n + 512);
+    a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_emit_annexb");
 }

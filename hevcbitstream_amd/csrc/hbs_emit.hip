@@ -7,14 +7,12 @@
  * write_hevc_nal_unit, hevc_stream.c:1324-1327) plus the start-code bytes the
  * reference's callers put in front of each NAL.
  *
- * One wavefront per NAL, a row of 1 KiB at a time (lane l = 16 bytes at 16 l,
- * the next row's load in flight).  A 03 is only ever inserted behind two zero
- * bytes, so chunk_flag() (hbs_sparse.h: no two adjacent zeros start in bytes
- * [-2, 16) of the chunk) clears nearly every chunk for a plain copy; flagged
- * chunks run the byte-exact rbsp_to_nal rules of hbs_emit.h.  Pass 1 counts the
- * inserted bytes per NAL, a scan turns NAL sizes into output offsets, pass 2
- * copies into byte-aligned 16-byte stores.  Traffic: RBSP read twice, stream
- * written once (3 B/B).
+ * A 03 is only ever inserted behind two zero bytes, so chunk_flag() (hbs_sparse.h:
+ * no two adjacent zeros start in bytes [-2, 16) of the chunk) clears nearly every
+ * 16-byte chunk for a plain copy; flagged chunks run the byte-exact rbsp_to_nal
+ * rules of hbs_emit.h.  k3_fused does it in one pass (RBSP read once, stream
+ * written once; see the comment in front of it); k3_count / scan / k3_emit is the
+ * older three-step version (RBSP read twice), kept for comparison.
  */
 #include <hip/hip_runtime.h>
 #include "hbs_wave.h"
@@ -273,6 +271,408 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
     }
 }
 
+/* ---- single pass: count, look-back, emit ---------------------------------------------------
+ * A workgroup takes a group of kEmitGroup consecutive NALs by ticket, kEmitSlots per wavefront
+ * (fat wavefronts, 2 workgroups per CU, as in K12).  A wavefront loads up to kEmitRows rows of
+ * 1 KiB of each of its NALs into registers in one burst (lane l = 16 bytes at 16 l of each row)
+ * and counts the bytes rbsp_to_nal would insert; wavefront 0 publishes the group's output size
+ * and looks back over the groups in front of it (decoupled look-back: one 64-bit word per group,
+ * value << 2 | status, status 1 = size of the group, 2 = size of everything up to and including
+ * it; 256 groups per step); then every wavefront writes its NALs from the registers it still
+ * holds (a NAL longer than kEmitRows KiB is read a second time, batch by batch).  HBM
+ * traffic: RBSP read once, stream written once.  Tickets are taken by running workgroups only and
+ * a workgroup finishes its groups in ticket order, so every group a look-back waits for is being
+ * worked on.  (Look-back units as small as one wavefront's share were tried: with 2048 of them in
+ * flight the prefix frontier cannot advance fast enough, 3x slower.)
+ *
+ * Rows that chunk_flag() clears are copied straight from registers; a row with a flagged chunk
+ * (or with the NAL's partial last chunk) goes through a rolled loop that runs the byte-exact
+ * rules of hbs_emit.h on memory, so the unrolled code stays small. */
+#ifdef HBS_PHASE_TIMING
+/* diagnostic build only (make diag, scripts/emit_phase.py): bit 0 skips the stores, bit 1 the look-back wait, bit 2 the count */
+__device__ int g_k3_exp = 0;
+extern "C" int hbs_debug_k3_exp(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k3_exp), &v, sizeof(int)); }
+#define HBS_K3_EXP(bit) ((g_k3_exp >> (bit)) & 1)
+__device__ unsigned long long g_phase_cycles_emit[1024][8];
+extern "C" int hbs_debug_phase_cycles_emit(unsigned long long* host_out /* [1024][8] */)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles_emit), sizeof(unsigned long long) * 1024 * 8);
+}
+#define HBS3_T_DECL unsigned long long t_prev = __builtin_amdgcn_s_memtime(), t_acc[8] = {0,0,0,0,0,0,0,0};
+#define HBS3_T_MARK(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; }
+#define HBS3_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles_emit[blockIdx.x][i] = t_acc[i]; }
+#else
+#define HBS_K3_EXP(bit) 0
+#define HBS3_T_DECL
+#define HBS3_T_MARK(i)
+#define HBS3_T_FLUSH
+#endif
+
+#ifndef HBS_EMIT_SLOTS
+#define HBS_EMIT_SLOTS 3
+#define HBS_EMIT_ROWS 12
+#endif
+constexpr int kEmitSlots = HBS_EMIT_SLOTS;        /* NALs a wavefront works on at a time */
+constexpr int kEmitRows = HBS_EMIT_ROWS;          /* rows of 1 KiB per slot held in registers */
+constexpr int kEmitGroup = 4 * kEmitSlots;        /* NALs per workgroup and ticket */
+constexpr uint32_t kEmitSpinLimit = 1u << 26;
+
+struct __attribute__((packed, aligned(1))) Chunk16 { u32x4 v; };
+
+/* rows [r0, r0 + kEmitRows) of a NAL.  Unpredicated loads: a lane whose chunk starts behind the
+ * NAL's last chunk reads that last chunk again (and never uses it), and the last chunk may reach up
+ * to 15 bytes past the NAL -- harmless (flags are conservative, exact code is bounded by len) as
+ * long as the bytes exist: reads stay below `arena`. */
+__device__ __forceinline__ void load_rows(u32x4 (&R)[kEmitRows], const uint8_t* __restrict__ rbsp, uint64_t arena,
+                                          uint64_t begin, uint32_t len, uint32_t r0, int lane)
+{
+    if (len == 0) return;                                                                  /* wave-uniform */
+    const uint32_t last_off = (len - 1u) & ~15u;
+    const uint64_t room = arena - begin;                                                   /* bytes readable from the NAL's first byte on */
+    const uint8_t* const base = rbsp + begin;
+    if (room >= 16u) {
+        const uint64_t safe = room - 16u;
+        const uint32_t lim = safe < (uint64_t)last_off ? (uint32_t)safe : last_off;        /* wave-uniform */
+#pragma unroll
+        for (int r = 0; r < kEmitRows; ++r) {
+            if (1024u * (r0 + (uint32_t)r) <= last_off) {                                  /* wave-uniform: the row exists */
+                /* launder_lane: every row computes its offset where it needs it; kept across the slots
+                 * and phases (they are all the same expression) they would fill the register file */
+                const uint32_t off = 1024u * (r0 + (uint32_t)r) + 16u * (uint32_t)launder_lane(lane);
+                R[r] = reinterpret_cast<const Chunk16*>(base + (off < lim ? off : lim))->v;
+            }
+        }
+    }
+    if (begin + last_off + 16u > arena && (last_off >> 10) >= r0 && (last_off >> 10) < r0 + kEmitRows) {   /* wave-uniform, rare */
+        const u32x4 t = load_nal_chunk(rbsp, begin, len, last_off);
+#pragma unroll
+        for (int r = 0; r < kEmitRows; ++r)
+            if ((last_off >> 10) == r0 + (uint32_t)r && (uint32_t)lane == ((last_off >> 4) & 63u)) R[r] = t;
+    }
+}
+
+/* flags of one batch of rows held in R: rowmask = rows with a flagged chunk (they take the exact
+ * path; wave-uniform), myflags bit r = my chunk of row r is flagged */
+__device__ __forceinline__ void flag_batch(const u32x4 (&R)[kEmitRows], uint32_t len, uint32_t r0, int lane,
+                                           uint32_t& e_prev, uint32_t& rowmask, uint32_t& myflags)
+{
+    rowmask = 0; myflags = 0;
+#pragma unroll
+    for (int r = 0; r < kEmitRows; ++r) {
+        const uint32_t row_lo = 1024u * (r0 + (uint32_t)r);
+        if (row_lo < len) {                                    /* wave-uniform */
+            const uint32_t off = row_lo + 16u * (uint32_t)launder_lane(lane);
+            /* a 03 goes in front of byte i only if bytes i-2, i-1 are zero: the chunk behind does not matter */
+            const uint32_t xp = from_prev_lane(R[r].w, e_prev);
+            const bool mine = off < len && chunk_flag(xp, R[r].x, R[r].y, R[r].z, R[r].w, 0xFFFFFFFFu);
+            if (__ballot(mine) != 0) rowmask |= 1u << r;
+            myflags |= (mine ? 1u : 0u) << r;
+            e_prev = (uint32_t)__builtin_amdgcn_readlane((int)R[r].w, 63);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+/* bytes rbsp_to_nal inserts into the batch (its flagged chunks, byte-exact, on memory) */
+__device__ __forceinline__ uint32_t count_batch(const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, uint32_t r0, int lane,
+                                                uint32_t rowmask, uint32_t myflags)
+{
+    uint32_t ins = 0;
+#pragma unroll 1
+    for (uint32_t rm = rowmask; rm != 0; rm &= rm - 1u) {
+        const uint32_t r = (uint32_t)__builtin_ctz(rm);
+        const uint32_t off = 1024u * (r0 + r) + 16u * (uint32_t)lane;
+        uint32_t c = 0;
+        if ((myflags >> r) & 1u) c = count_segment(rbsp, begin, begin + off, begin + (off + 16u < len ? off + 16u : len));
+        ins += wave_sum_u32(c);
+    }
+    return ins;
+}
+
+__device__ __forceinline__ void store_bytes(uint8_t* dst, const u32x4& q, uint32_t nb)
+{
+#pragma unroll 1
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t w = (i >> 2) == 0 ? q.x : (i >> 2) == 1 ? q.y : (i >> 2) == 2 ? q.z : q.w;
+        dst[i] = (uint8_t)(w >> (8u * (i & 3u)));
+    }
+}
+
+/* writes the batch at dst0 + (offset in the NAL) + (bytes inserted in front); ins = bytes inserted so far */
+__device__ __forceinline__ void emit_batch(const u32x4 (&R)[kEmitRows], const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len,
+                                           uint32_t r0, int lane, uint32_t rowmask, uint32_t myflags, uint32_t& ins, uint8_t* dst0)
+{
+    uint32_t rowins = ins;                /* lane r: bytes inserted in front of row r */
+#pragma unroll 1
+    for (uint32_t rm = rowmask; rm != 0; rm &= rm - 1u) {      /* rows with flagged chunks: exact rules, from memory */
+        const uint32_t r = (uint32_t)__builtin_ctz(rm);
+        const uint32_t off = 1024u * (r0 + r) + 16u * (uint32_t)lane;
+        const bool mine = ((myflags >> r) & 1u) != 0;
+        const uint64_t se = begin + (off + 16u < len ? off + 16u : len);
+        uint32_t c = 0, tot;
+        if (mine) c = count_segment(rbsp, begin, begin + off, se);
+        uint8_t* dst = dst0 + off + ins + wave_excl_scan_u32(c, lane, tot);
+        if (mine) {
+            emit_segment(rbsp, begin, begin + off, se, dst);
+        } else if (off < len) {
+            const u32x4 q = load_nal_chunk(rbsp, begin, len, off);
+            if (off + 16u <= len) reinterpret_cast<Chunk16*>(dst)->v = q;
+            else store_bytes(dst, q, len - off);               /* the NAL's last, partial chunk */
+        }
+        if ((uint32_t)lane > r) rowins += tot;
+        ins += tot;
+    }
+    const uint32_t last_off = len ? ((len - 1u) & ~15u) : 0u;
+    const bool partial = (len & 15u) != 0;
+#pragma unroll
+    for (int r = 0; r < kEmitRows; ++r) {
+        const uint32_t row_lo = 1024u * (r0 + (uint32_t)r);
+        if (row_lo < len && !((rowmask >> r) & 1u)) {          /* wave-uniform: no flagged chunk in the row */
+            const uint32_t off = row_lo + 16u * (uint32_t)launder_lane(lane);
+            uint8_t* dst = dst0 + off + (uint32_t)__builtin_amdgcn_readlane((int)rowins, r);
+            if (off + 16u <= len) reinterpret_cast<Chunk16*>(dst)->v = R[r];
+            if (partial && (last_off >> 10) == r0 + (uint32_t)r) {                    /* wave-uniform: the NAL's last row */
+                if (off == last_off) store_bytes(dst, R[r], len - last_off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                     /* one row at a time: interleaving rows only costs registers */
+    }
+}
+
+/* bytes of the output in front of group g (wavefront 0, all lanes); 256 groups per step:
+ * lane l looks at the groups at distance l, 64 + l, 128 + l, 192 + l */
+__device__ __forceinline__ unsigned long long k3_look_back(const unsigned long long* __restrict__ desc, uint64_t g, int lane, uint32_t* err)
+{
+    unsigned long long prefix = 0;
+    uint64_t pos = g;                                         /* groups [0, pos) are still to be accounted for */
+    while (pos > 0) {
+        unsigned long long v[4] = {0, 0, 0, 0};
+        uint32_t spins = 0;
+        int stop_q = 4, stop_l = 0;                           /* nearest group with an inclusive prefix: quarter, lane */
+        for (;;) {
+            bool all = true;
+            stop_q = 4;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const uint64_t dist = (uint64_t)(64 * q + lane);
+                const bool valid = dist < pos;
+                if (valid && (v[q] & 3ull) == 0) v[q] = ld_desc3(desc + (pos - 1 - dist));
+                const uint64_t full = __ballot(valid && (v[q] & 3ull) == 2ull);
+                if (full) { stop_q = q; stop_l = (int)__builtin_ctzll(full); }
+            }
+            /* everything nearer than the stop (or the whole window) must be there */
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t dist = (uint64_t)(64 * q + lane);
+                const bool needed = dist < pos && (q < stop_q || (q == stop_q && lane <= stop_l));
+                if (__ballot(needed && (v[q] & 3ull) == 0) != 0) all = false;
+            }
+            if (all) break;
+            if (++spins > kEmitSpinLimit) { if (lane == 0) atomicMax(err, (uint32_t)(-HBS_E_TIMEOUT)); return prefix; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        unsigned long long x = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t dist = (uint64_t)(64 * q + lane);
+            if (dist < pos && (q < stop_q || (q == stop_q && lane <= stop_l))) x += v[q] >> 2;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        prefix += x;
+        if (stop_q < 4) break;
+        pos = pos > 256 ? pos - 256 : 0;
+    }
+    return prefix;
+}
+
+/* what lane 0 adds to a NAL: the zero bytes and the 01 in front of it, its entry of the output index */
+__device__ __forceinline__ void finish_nal(uint8_t* __restrict__ out, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
+                                           uint64_t k, uint64_t base, uint64_t nal_start, uint64_t nal_end,
+                                           uint64_t begin, uint32_t len, bool fits, int lane)
+{
+    if (lane != 0) return;
+    if (fits) {
+        for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;      /* zero_byte / leading zeros */
+        if (nal_start != base) out[nal_start - 1] = 1;
+    }
+    if (idx_out) {
+        hbs_nal_entry e;
+        e.start = nal_start; e.end = nal_end;
+        e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
+        idx_out[k] = e;
+    }
+    if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+}
+
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+/* what lane j knows about slot j of a wavefront's share of a group */
+struct SlotEntry { uint64_t begin, gap; uint32_t len; };
+__device__ __forceinline__ SlotEntry fetch_entries(const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode, uint64_t k0, int lane)
+{
+    SlotEntry e; e.begin = 0; e.gap = 0; e.len = 0;
+    if (lane < kEmitSlots && k0 + (uint64_t)lane < n) {
+        e.begin = idx[k0 + lane].rbsp_off; e.len = idx[k0 + lane].rbsp_len; e.gap = gap_of(idx, k0 + lane, gap_mode);
+    }
+    return e;
+}
+
+struct Lds3 {
+    unsigned long long tot[kEmitGroup];      /* bytes NAL j of the group takes in the output: gap + payload + inserted */
+    unsigned long long off[kEmitGroup];      /* where it starts */
+    uint32_t ticket;
+};
+
+__global__ __launch_bounds__(256, 2)
+void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+              unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
+              uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
+              unsigned long long* __restrict__ total, uint32_t* __restrict__ err)
+{
+    __shared__ Lds3 l;
+    const int lane0 = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t ngroups = (n + kEmitGroup - 1) / kEmitGroup;
+    HBS3_T_DECL
+    for (;;) {
+        const int lane = launder_lane(lane0);                 /* keeps lane-constant values from being hoisted out of the loop (and spilled) */
+        /* The ticket is taken as late as possible -- when the previous group's stores have been issued.
+         * A workgroup that sits on a ticket it has not started yet is what the look-backs of everybody
+         * behind it wait for: fetching the next ticket while the current group is written was 15 %
+         * slower, fetching it before the look-back 50 %. */
+        __syncthreads();                                      /* the previous group is done with l */
+        if (threadIdx.x == 0) l.ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint64_t g = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
+        if (g >= ngroups) break;
+        HBS3_T_MARK(0)
+        const uint64_t k0 = g * kEmitGroup + (uint64_t)(kEmitSlots * wv);
+        const SlotEntry ent = fetch_entries(idx, n, gap_mode, k0, lane);
+        const uint64_t e_begin = ent.begin, e_gap = ent.gap;
+        const uint32_t e_len = ent.len;
+        HBS3_T_MARK(1)
+        u32x4 R[kEmitSlots][kEmitRows];
+
+        /* 1. sizes.  NALs longer than a slot are streamed through slot 0's registers, now and again in step 3 */
+#pragma unroll 1
+        for (int j = 0; j < kEmitSlots; ++j) {
+            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)e_len, j);
+            if (ln <= (uint32_t)kEmitRows * 1024u) continue;
+            const uint64_t bg = bcast64(e_begin, j);
+            uint32_t e_prev = 0xFFFFFFFFu, ins_long = 0;      /* a NAL starts with count = 0 */
+#pragma unroll 1
+            for (uint32_t r0 = 0; r0 < ((ln + 1023u) >> 10); r0 += kEmitRows) {
+                uint32_t rmask, mflags;
+                load_rows(R[0], rbsp, arena, bg, ln, r0, lane);
+                flag_batch(R[0], ln, r0, lane, e_prev, rmask, mflags);
+                ins_long += count_batch(rbsp, bg, ln, r0, lane, rmask, mflags);
+            }
+            if (lane == 0) l.tot[kEmitSlots * wv + j] = bcast64(e_gap, j) + ln + ins_long;
+        }
+
+        uint64_t begin[kEmitSlots], gap[kEmitSlots];
+        uint32_t len[kEmitSlots], ins[kEmitSlots], rowmask[kEmitSlots], myflags[kEmitSlots];
+        bool resident[kEmitSlots];
+#pragma unroll
+        for (int j = 0; j < kEmitSlots; ++j) {
+            begin[j] = bcast64(e_begin, j); gap[j] = bcast64(e_gap, j);
+            len[j] = (uint32_t)__builtin_amdgcn_readlane((int)e_len, j);
+            resident[j] = k0 + (uint64_t)j < n && len[j] <= (uint32_t)kEmitRows * 1024u;
+            if (resident[j]) load_rows(R[j], rbsp, arena, begin[j], len[j], 0, lane);
+        }
+        HBS3_T_MARK(2)
+#pragma unroll
+        for (int j = 0; j < kEmitSlots; ++j) {
+            ins[j] = 0; rowmask[j] = 0; myflags[j] = 0;
+            if (resident[j]) {
+                uint32_t e_prev = 0xFFFFFFFFu;
+                if (!HBS_K3_EXP(2)) {
+                    flag_batch(R[j], len[j], 0, lane, e_prev, rowmask[j], myflags[j]);
+                    ins[j] = count_batch(rbsp, begin[j], len[j], 0, lane, rowmask[j], myflags[j]);
+                }
+                if (lane == 0) l.tot[kEmitSlots * wv + j] = gap[j] + len[j] + ins[j];
+            } else if (k0 + (uint64_t)j >= n) {
+                if (lane == 0) l.tot[kEmitSlots * wv + j] = 0ull;
+            }
+        }
+        HBS3_T_MARK(3)
+        __syncthreads();
+        HBS3_T_MARK(4)
+
+        /* 2. where the group starts */
+        if (wv == 0) {
+            const unsigned long long x = lane < kEmitGroup ? l.tot[lane] : 0ull;
+            const unsigned long long inc = wave_incl_scan_u64(x, lane);
+            const unsigned long long agg = __shfl(inc, kEmitGroup - 1, 64);
+            if (lane == 0 && g != 0) st_desc3(desc + g, (agg << 2) | 1ull);
+            const unsigned long long before = HBS_K3_EXP(1) ? g * 123000ull : k3_look_back(desc, g, lane, err);
+            if (lane == 0) {
+                st_desc3(desc + g, ((before + agg) << 2) | 2ull);
+                if (g == ngroups - 1) *total = before + agg;
+            }
+            if (lane < kEmitGroup) l.off[lane] = before + inc - x;
+        }
+        __syncthreads();
+        HBS3_T_MARK(5)
+
+        /* 3. the bytes: resident NALs straight from their registers (no load in this code, so the
+         * stores are not made to wait for one another) ... */
+#pragma unroll
+        for (int j = 0; j < kEmitSlots; ++j) {
+            if (resident[j]) {                                /* wave-uniform */
+                const uint64_t base = l.off[kEmitSlots * wv + j];
+                const uint64_t nal_start = base + gap[j];
+                const uint64_t nal_end = nal_start + len[j] + ins[j];
+                const bool fits = nal_end <= out_cap;
+                if (fits && !HBS_K3_EXP(0)) {
+                    uint32_t ins2 = 0;
+                    emit_batch(R[j], rbsp, begin[j], len[j], 0, lane, rowmask[j], myflags[j], ins2, out + nal_start);
+                }
+                finish_nal(out, idx_out, err, k0 + (uint64_t)j, base, nal_start, nal_end, begin[j], len[j], fits, lane);
+            }
+        }
+        /* ... long ones read a second time */
+#pragma unroll 1
+        for (int j = 0; j < kEmitSlots; ++j) {
+            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)e_len, j);
+            if (ln <= (uint32_t)kEmitRows * 1024u) continue;
+            const uint64_t bg = bcast64(e_begin, j);
+            const uint64_t base = l.off[kEmitSlots * wv + j];
+            const uint64_t nal_start = base + bcast64(e_gap, j);
+            const uint64_t nal_end = base + l.tot[kEmitSlots * wv + j];
+            const bool fits = nal_end <= out_cap;
+            if (fits) {
+                uint32_t e_prev = 0xFFFFFFFFu, ins2 = 0;
+#pragma unroll 1
+                for (uint32_t r0 = 0; r0 < ((ln + 1023u) >> 10); r0 += kEmitRows) {
+                    uint32_t rmask, mflags;
+                    load_rows(R[0], rbsp, arena, bg, ln, r0, lane);
+                    flag_batch(R[0], ln, r0, lane, e_prev, rmask, mflags);
+                    emit_batch(R[0], rbsp, bg, ln, r0, lane, rmask, mflags, ins2, out + nal_start);
+                }
+            }
+            finish_nal(out, idx_out, err, k0 + (uint64_t)j, base, nal_start, nal_end, bg, ln, fits, lane);
+        }
+        HBS3_T_MARK(6)
+    }
+    HBS3_T_FLUSH
+}
+
+int emit_grid_blocks(int device)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_fused, 256, 0) != hipSuccess || per_cu < 1) return -1;
+    return prop.multiProcessorCount * per_cu;
+}
+
 __global__ void k3_summary(const unsigned long long* total, uint64_t n, uint64_t rbsp_bytes, const uint32_t* err, hbs_summary* sum)
 {
     sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes; sum->stream_bytes = *total;
@@ -323,10 +723,20 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     const unsigned grid = 256 * 16;
-    if (a.n) {
+    if (a.n && a.two_pass) {
         k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.total, a.scan_tmp, st);
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err);
+    } else if (a.n) {
+        const uint64_t ngroups = (a.n + kEmitGroup - 1) / kEmitGroup;
+        e = hipMemsetAsync(a.nal_total, 0, ngroups * sizeof(unsigned long long), st);       /* the look-back words */
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(a.ticket, 0, sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+        uint64_t blocks = (uint64_t)a.grid_blocks;
+        if (blocks > ngroups) blocks = ngroups;
+        k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.ticket,
+                                                         a.out, a.out_cap, a.index_out, a.total, a.err);
     } else {
         e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;

@@ -22,6 +22,9 @@ struct EmitArgs {
     unsigned long long* out_off;      /* n                                         */
     unsigned long long* total;        /* 1                                         */
     uint32_t* err;                    /* 1                                         */
+    uint32_t* ticket;                 /* 1, on a cache line of its own             */
+    int grid_blocks;                  /* resident workgroups of the single-pass kernel (emit_grid_blocks) */
+    int two_pass;                     /* 1: count / scan / emit as three steps (kept for comparison)      */
 };
 
 struct SynthArgs {
@@ -36,6 +39,7 @@ struct SynthArgs {
     uint32_t* err;
 };
 
+int emit_grid_blocks(int device);
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st);
 hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st);
 

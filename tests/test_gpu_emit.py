@@ -49,6 +49,25 @@ def test_emit_random_rbsp(ctx, orc):
         assert np.array_equal(got, orc.emit_annexb(arena, idx))
 
 
+def test_emit_row_and_batch_edges(ctx, orc):
+    """NAL lengths around the kernel's row (1 KiB) and register batch (16 KiB) sizes, mostly-plain bytes with a few
+    zero runs (the register copy path), the arena ending exactly at the last NAL's last byte"""
+    rng = np.random.RandomState(32)
+    edge = [1, 15, 16, 17, 1023, 1024, 1025, 1039, 1040, 16383, 16384, 16385, 16400, 32768, 32769, 40000, 70001]
+    for rep in range(6):
+        lens = [int(edge[i]) for i in rng.permutation(len(edge))[:rng.randint(3, len(edge))]]
+        gaps = [int(rng.randint(3, 6)) for _ in lens]
+        arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+        for p in rng.randint(0, len(arena), size=len(arena) // 700 + 2):
+            arena[p:p + rng.randint(2, 5)] = 0
+            if rng.rand() < 0.5 and p + 5 < len(arena):
+                arena[p + 4] = rng.randint(0, 5)
+        idx = fake_index(lens, gaps)
+        got, _ = ctx.emit_annexb(dev(arena), idx)
+        want = orc.emit_annexb(arena, idx)
+        assert np.array_equal(got, want), (rep, lens)
+
+
 def test_emit_zero_runs(ctx, orc):
     for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
         for tail in ([], [1], [4], [0, 0, 1]):
