@@ -348,7 +348,8 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
         if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(zero structs)");
     }
     const uint64_t b_n = round256((n_nals + 1) * 8);
-    int rc = ensure_ws(c, 3 * b_n + 512 + 1024 * 24);
+    const uint64_t b_rows = round256(hbs::parse_own_rows_bytes(n_nals));
+    int rc = ensure_ws(c, 3 * b_n + 512 + round256(1024 * 24) + b_rows);
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::ParseArgs a;
@@ -364,6 +365,7 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256);
     a.scan_tmp = w + 3 * b_n + 512;
+    a.own_rows = reinterpret_cast<hbs::RpsRow*>(w + 3 * b_n + 512 + round256(1024 * 24));
     a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
@@ -384,7 +386,7 @@ int hbs_write_headers(hbs_ctx* c, const hbs_parsed_nal* d_parsed, uint64_t n_nal
         if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(zero structs)");
     }
     const uint64_t b_n = round256((n_nals + 1) * 8);
-    int rc = ensure_ws(c, 3 * b_n + 512 + 1024 * 24);
+    int rc = ensure_ws(c, 3 * b_n + 512 + round256(1024 * 24) + round256(hbs::parse_own_rows_bytes(n_nals)));
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::WriteArgs a;
@@ -396,6 +398,7 @@ int hbs_write_headers(hbs_ctx* c, const hbs_parsed_nal* d_parsed, uint64_t n_nal
     a.zeros = c->zeros; a.initial_sps_slot = d_initial_sps_slot; a.initial_pps = d_initial_pps;
     a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
     a.scan_tmp = w + 3 * b_n + 512;
+    a.own_rows = reinterpret_cast<hbs::RpsRow*>(w + 3 * b_n + 512 + round256(1024 * 24));
     hipError_t e = hbs::launch_write_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_write_headers");
 }

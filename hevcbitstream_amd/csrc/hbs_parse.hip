@@ -15,7 +15,7 @@
 
 namespace hbs {
 
-constexpr uint32_t kWinBytes = 512;                 /* RBSP bytes staged in LDS per NAL */
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
                         ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size)
@@ -158,8 +158,28 @@ void k4_scan_apply(ParsedNal* __restrict__ parsed, const unsigned long long* __r
     }
 }
 
-/* pass 0: parameter sets; pass 1: slices.  kMode: plain parse, or parse + per-field trace (the debug
- * reader's variant of the syntax, see hbs_parse.h) */
+/* the memset of every struct a parse fills (hevc_stream.c:250, :310, :425, init_slice_hevc :19-24):
+ * the struct arena is one contiguous run of slots, zeroed in one streaming pass */
+__global__ __launch_bounds__(256)
+void k4_zero(uint8_t* __restrict__ structs, uint64_t structs_cap, const unsigned long long* __restrict__ total)
+{
+    const uint64_t bytes = *total < structs_cap ? *total : structs_cap;       /* slots are multiples of 16 */
+    uint4* q = reinterpret_cast<uint4*>(structs);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < bytes / 16; i += (uint64_t)gridDim.x * blockDim.x) q[i] = z;
+}
+
+/* One NAL per LANE: a wavefront walks 64 consecutive NALs at once.  The walk is a long chain of
+ * dependent scalar steps (a bit at a time, as bs.h does), so one parser per wavefront left the
+ * machine with ~4000 parsers in flight; the slices of a stream mostly take the same path through
+ * the syntax, so 64 of them in lock step diverge little.  Each lane stages the first kLaneWin
+ * bytes of its RBSP in LDS (stride kLaneWinStride bytes: lanes reading the same offset hit
+ * different banks) and owns one RpsRow of a global scratch for its slice's own short-term RPS.
+ * pass 0: parameter sets; pass 1: slices against them.  kMode: plain parse, or parse + per-field
+ * trace (the debug reader's variant of the syntax, see hbs_parse.h). */
+constexpr uint32_t kLaneWin = 64;
+constexpr uint32_t kLaneWinStride = kLaneWin + 4;
+
 template <int kMode>
 __global__ __launch_bounds__(256)
 void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int pass,
@@ -167,46 +187,64 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               const long long* __restrict__ ctx_sps, const long long* __restrict__ ctx_pps,
               const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot,
               const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
-              TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count)
+              TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
+              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */)
 {
-    __shared__ uint8_t win[4][kWinBytes];
-    __shared__ RpsRow own_rows[4];
+    __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
+    struct __attribute__((packed, aligned(1))) U16 { u32x4_t v; };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    RpsRow* const my_rows = own_rows + wave * 64;
+    uint8_t* const my_win = win[wv] + (uint32_t)lane * kLaneWinStride;
 
-    for (uint64_t k = wave; k < n; k += nwaves) {
-        const int type = parsed[k].nal_unit_type;
+    for (uint64_t chunk = wave; chunk * 64 < n; chunk += nwaves) {
+        const uint64_t k = chunk * 64 + (uint64_t)lane;
+        int type = -1;
+        if (k < n) type = parsed[k].nal_unit_type;
         const bool slice = is_slice_type_nal(type);
         const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
-        if (type < 0) continue;                                  /* nal_to_rbsp failed: rc stays -1 */
-        if (!slice && !pset) continue;                            /* unsupported type: rc -1, header fields kept (:221) */
-        if ((pass == 0) != pset) continue;
-
-        const hbs_nal_entry e = idx[k];
-        const uint64_t off = parsed[k].struct_off;
-        const uint64_t slot = slot_bytes_of(type);
-        if (off + slot > structs_cap) {
-            if (lane == 0) { atomicMax(err, (uint32_t)(-HBS_E_CAPACITY)); parsed[k].struct_off = ~0ull; }
-            continue;
+        /* type < 0: nal_to_rbsp failed, rc stays -1; other types: rc -1, header fields kept (:221) */
+        bool active = type >= 0 && (slice || pset) && ((pass == 0) == pset);
+        hbs_nal_entry e;
+        e.start = e.end = e.rbsp_off = 0; e.rbsp_len = 0; e.status = 0;
+        uint64_t off = 0;
+        if (active) {
+            e = idx[k];
+            off = parsed[k].struct_off;
+            if (off + slot_bytes_of(type) > structs_cap) {
+                atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+                parsed[k].struct_off = ~0ull;
+                active = false;
+            }
         }
-        uint8_t* dst = structs + off;
-        /* memset (hevc_stream.c:250, :310, :425, init_slice_hevc :19-24) by the whole wave */
-        {
-            uint4* q = reinterpret_cast<uint4*>(dst);
+        if (pass == 1) {                                       /* fresh rows for the slices' own short-term RPS, by the whole wave */
+            uint4* q = reinterpret_cast<uint4*>(my_rows);
             const uint4 z = make_uint4(0, 0, 0, 0);
-            for (uint64_t i = lane; i < slot / 16; i += 64) q[i] = z;
+            for (uint32_t i = (uint32_t)lane; i < (uint32_t)(64 * sizeof(RpsRow) / 16); i += 64) q[i] = z;
         }
-        /* first bytes of the RBSP into LDS */
+        /* first bytes of my RBSP into my LDS window */
         const uint8_t* src = rbsp + e.rbsp_off;
-        const uint32_t wb = e.rbsp_len < kWinBytes ? e.rbsp_len : kWinBytes;
-        for (uint32_t i = lane; i < wb; i += 64) win[wv][i] = src[i];
+        const uint32_t wb = e.rbsp_len < kLaneWin ? e.rbsp_len : kLaneWin;
+        if (active) {
+#pragma unroll
+            for (uint32_t i = 0; i < kLaneWin; i += 16) {
+                if (i + 16 <= wb) {
+                    const u32x4_t v = reinterpret_cast<const U16*>(src + i)->v;
+                    uint32_t* d = reinterpret_cast<uint32_t*>(my_win + i);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                } else {
+                    for (uint32_t b = i; b < wb; ++b) my_win[b] = src[b];
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-        if (lane == 0) {
+        if (active) {
+            uint8_t* dst = structs + off;
             ParserT<kMode> ps;
-            ps.b.win = win[wv]; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
+            ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
             ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
             ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
@@ -214,7 +252,6 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             const hevc_sps_t* last_sps = zero_sps;
             const hevc_pps_t* last_pps = zero_pps;
             if (slice) {
-                static_cast<void>(0);
                 reinterpret_cast<hevc_slice_header_t*>(dst)->collocated_from_l0_flag = 1;
                 const long long cs = ctx_sps[k], cp = ctx_pps[k];
                 if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
@@ -228,10 +265,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                     last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
                 else if (cp < 0 && init_pps)
                     last_pps = reinterpret_cast<const hevc_pps_t*>(init_pps);
-                RpsRow* row = &own_rows[wv];
-                row->NumDeltaPocs = row->NumNegativePics = row->NumPositivePics = 0;
-                for (int i = 0; i < 32; ++i) { row->DeltaPocS0[i] = row->UsedByCurrPicS0[i] = row->DeltaPocS1[i] = row->UsedByCurrPicS1[i] = 0; }
-                ps.own = row;
+                ps.own = &my_rows[lane];
             } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
                 ps.out_rps = reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
             }
@@ -253,68 +287,70 @@ __global__ void k5_slot_sizes(const ParsedNal* __restrict__ parsed, uint64_t n, 
         slot_size[k] = (parsed[k].struct_off != ~0ull) ? slot_bytes_of(parsed[k].nal_unit_type) : 0ull;
 }
 
-/* one NAL per wavefront: the wave clears the NAL's RBSP buffer (the reference callocs it), lane 0 walks
- * the syntax in write mode.  pass 0: parameter sets (an SPS re-derives the RPS tables behind it, as
- * the reference's writer refreshes its file-static ones); pass 1: slices against them. */
+/* one NAL per lane, as in k4_parse: lane l of a wavefront walks the syntax of NAL 64 c + l in write
+ * mode into its own RBSP buffer (cleared beforehand in one go: the reference callocs it).
+ * pass 0: parameter sets (an SPS re-derives the RPS tables behind it, as the reference's writer
+ * refreshes its file-static ones) and the types that are not written at all; pass 1: slices. */
 __global__ __launch_bounds__(256)
 void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_t* __restrict__ structs,
               const long long* __restrict__ ctx_sps, const long long* __restrict__ ctx_pps,
               const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot, const uint8_t* __restrict__ init_pps,
-              uint8_t* __restrict__ rbsp_out, uint32_t rbsp_cap, WrittenNal* __restrict__ written)
+              uint8_t* __restrict__ rbsp_out, uint32_t rbsp_cap, WrittenNal* __restrict__ written,
+              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */)
 {
-    __shared__ RpsRow own_rows[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t k = wave; k < n; k += nwaves) {
+    RpsRow* const my_rows = own_rows + wave * 64;
+    for (uint64_t chunk = wave; chunk * 64 < n; chunk += nwaves) {
+        const uint64_t k = chunk * 64 + (uint64_t)lane;
+        if (pass == 1) {                                       /* fresh rows for the slices' own short-term RPS, by the whole wave */
+            uint4* q = reinterpret_cast<uint4*>(my_rows);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = (uint32_t)lane; i < (uint32_t)(64 * sizeof(RpsRow) / 16); i += 64) q[i] = z;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (k >= n) continue;
         const int type = parsed[k].nal_unit_type;
         const bool slice = is_slice_type_nal(type);
         const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
         if ((slice || pset) && (pass == 0) != pset) continue;
         if (!(slice || pset) && pass != 0) continue;
         uint8_t* out = rbsp_out + k * (uint64_t)rbsp_cap;
-        for (uint32_t i = lane; i < rbsp_cap; i += 64) out[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            WrittenNal res;
-            res.rc = -1; res.rbsp_size = 0; res.slice_data_size = 0; res.pad = 0;
-            if ((slice || pset) && parsed[k].struct_off != ~0ull) {
-                uint8_t* slot = structs + parsed[k].struct_off;
-                ParserT<kModeWrite> ps;
-                ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = rbsp_cap; ps.b.pos = 0;
-                ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = out;
-                ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
-                const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
-                const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
-                const hevc_sps_t* last_sps = zero_sps;
-                const hevc_pps_t* last_pps = zero_pps;
-                if (slice) {
-                    const long long cs = ctx_sps[k], cp = ctx_pps[k];
-                    if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
-                        last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[cs].struct_off);
-                        ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[cs].struct_off + round16(sizeof(hevc_sps_t)));
-                    } else if (cs < 0 && init_sps_slot) {
-                        last_sps = reinterpret_cast<const hevc_sps_t*>(init_sps_slot);
-                        ps.sps_rps = reinterpret_cast<const RpsTables*>(init_sps_slot + round16(sizeof(hevc_sps_t)));
-                    }
-                    if (cp >= 0 && parsed[cp].struct_off != ~0ull)
-                        last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
-                    else if (cp < 0 && init_pps)
-                        last_pps = reinterpret_cast<const hevc_pps_t*>(init_pps);
-                    RpsRow* row = &own_rows[wv];
-                    row->NumDeltaPocs = row->NumNegativePics = row->NumPositivePics = 0;
-                    for (int i = 0; i < 32; ++i) { row->DeltaPocS0[i] = row->UsedByCurrPicS0[i] = row->DeltaPocS1[i] = row->UsedByCurrPicS1[i] = 0; }
-                    ps.own = row;
-                } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
-                    ps.out_rps = reinterpret_cast<RpsTables*>(slot + round16(sizeof(hevc_sps_t)));
+        WrittenNal res;
+        res.rc = -1; res.rbsp_size = 0; res.slice_data_size = 0; res.pad = 0;
+        if ((slice || pset) && parsed[k].struct_off != ~0ull) {
+            uint8_t* slot = structs + parsed[k].struct_off;
+            ParserT<kModeWrite> ps;
+            ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = rbsp_cap; ps.b.pos = 0;
+            ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = out;
+            ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+            const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
+            const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
+            const hevc_sps_t* last_sps = zero_sps;
+            const hevc_pps_t* last_pps = zero_pps;
+            if (slice) {
+                const long long cs = ctx_sps[k], cp = ctx_pps[k];
+                if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
+                    last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[cs].struct_off);
+                    ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[cs].struct_off + round16(sizeof(hevc_sps_t)));
+                } else if (cs < 0 && init_sps_slot) {
+                    last_sps = reinterpret_cast<const hevc_sps_t*>(init_sps_slot);
+                    ps.sps_rps = reinterpret_cast<const RpsTables*>(init_sps_slot + round16(sizeof(hevc_sps_t)));
                 }
-                write_one_nal(ps, type, parsed[k].nal_layer_id, parsed[k].nal_temporal_id_plus1, slot,
-                              last_pps, last_sps, zero_pps, zero_sps, &res);
+                if (cp >= 0 && parsed[cp].struct_off != ~0ull)
+                    last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
+                else if (cp < 0 && init_pps)
+                    last_pps = reinterpret_cast<const hevc_pps_t*>(init_pps);
+                ps.own = &my_rows[lane];
+            } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+                ps.out_rps = reinterpret_cast<RpsTables*>(slot + round16(sizeof(hevc_sps_t)));
             }
-            written[k] = res;
+            write_one_nal(ps, type, parsed[k].nal_layer_id, parsed[k].nal_temporal_id_plus1, slot,
+                          last_pps, last_sps, zero_pps, zero_sps, &res);
         }
-        __builtin_amdgcn_wave_barrier();
+        written[k] = res;
     }
 }
 
@@ -325,6 +361,14 @@ __global__ void k4_summary(uint64_t n, const unsigned long long* total, const ui
     sum->reserved[0] = *total;                       /* struct arena bytes needed */
     sum->reserved[1] = sum->reserved[2] = 0;
 }
+
+/* workgroups of the parse kernel: a wavefront per 64 NALs, at most kParseMaxBlocks workgroups */
+unsigned parse_grid_blocks(uint64_t n)
+{
+    const uint64_t want = (n + 255) / 256;
+    return (unsigned)(want < 1 ? 1 : want > kParseMaxBlocks ? kParseMaxBlocks : want);
+}
+uint64_t parse_own_rows_bytes(uint64_t n) { return (uint64_t)parse_grid_blocks(n) * 4u * 64u * sizeof(RpsRow); }
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
 {
@@ -343,12 +387,13 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
         k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
+            k4_zero<<<2048, 256, 0, st>>>(a.structs, a.structs_cap, a.total);
+            const unsigned grid = parse_grid_blocks(a.n);
             for (int pass = 0; pass < 2; ++pass) {
-                const unsigned grid = pass == 0 ? 256 * 4 : 256 * 8;
                 if (a.trace)
-                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count);
+                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows);
                 else
-                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr);
+                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows);
             }
         }
     }
@@ -364,9 +409,11 @@ hipError_t launch_write_headers(const WriteArgs& a, hipStream_t st)
         k4_scan_reduce<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part);
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
         k4_scan_apply<false><<<kScan4Blocks, 256, 0, st>>>(const_cast<ParsedNal*>(a.parsed), a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
+        hipError_t e = hipMemsetAsync(a.rbsp_out, 0, a.n * (uint64_t)a.rbsp_cap, st);
+        if (e != hipSuccess) return e;
         for (int pass = 0; pass < 2; ++pass)
-            k5_write<<<256 * 4, 256, 0, st>>>(a.parsed, a.n, pass, a.structs, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot,
-                                              a.initial_pps, a.rbsp_out, a.rbsp_cap, a.written);
+            k5_write<<<parse_grid_blocks(a.n), 256, 0, st>>>(a.parsed, a.n, pass, a.structs, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot,
+                                                             a.initial_pps, a.rbsp_out, a.rbsp_cap, a.written, a.own_rows);
     }
     return hipGetLastError();
 }

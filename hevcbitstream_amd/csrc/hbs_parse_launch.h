@@ -9,6 +9,8 @@ namespace hbs {
 
 struct ParsedNal;
 struct TraceRec;
+struct RpsRow;
+constexpr unsigned kParseMaxBlocks = 512;
 
 struct ParseArgs {
     const uint8_t* rbsp;
@@ -31,8 +33,11 @@ struct ParseArgs {
     TraceRec* trace;                 /* optional: trace_cap records per NAL (device) */
     uint32_t trace_cap;
     uint32_t* trace_count;           /* optional: records each NAL produced (may exceed trace_cap) */
+    RpsRow* own_rows;                /* parse_own_rows_bytes(n): one row per lane of the parse grid */
 };
 
+unsigned parse_grid_blocks(uint64_t n);
+uint64_t parse_own_rows_bytes(uint64_t n);
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);
 
 struct WrittenNal;
@@ -53,6 +58,7 @@ struct WriteArgs {
     const uint8_t* initial_pps;
     unsigned long long* total;
     void* scan_tmp;
+    RpsRow* own_rows;                /* parse_own_rows_bytes(n) */
 };
 
 hipError_t launch_write_headers(const WriteArgs& a, hipStream_t st);
