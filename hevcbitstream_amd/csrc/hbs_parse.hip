@@ -177,6 +177,10 @@ void k4_zero(uint8_t* __restrict__ structs, uint64_t structs_cap, const unsigned
  * different banks) and owns one RpsRow of a global scratch for its slice's own short-term RPS.
  * pass 0: parameter sets; pass 1: slices against them.  kMode: plain parse, or parse + per-field
  * trace (the debug reader's variant of the syntax, see hbs_parse.h). */
+#ifndef HBS_PARSE_LANES
+#define HBS_PARSE_LANES 64
+#endif
+constexpr int kParseLanes = HBS_PARSE_LANES;          /* NALs a wavefront walks at once (lanes 0 .. kParseLanes-1) */
 constexpr uint32_t kLaneWin = 64;
 constexpr uint32_t kLaneWinStride = kLaneWin + 4;
 
@@ -198,10 +202,10 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     RpsRow* const my_rows = own_rows + wave * 64;
     uint8_t* const my_win = win[wv] + (uint32_t)lane * kLaneWinStride;
 
-    for (uint64_t chunk = wave; chunk * 64 < n; chunk += nwaves) {
-        const uint64_t k = chunk * 64 + (uint64_t)lane;
+    for (uint64_t chunk = wave; chunk * kParseLanes < n; chunk += nwaves) {
+        const uint64_t k = chunk * kParseLanes + (uint64_t)lane;
         int type = -1;
-        if (k < n) type = parsed[k].nal_unit_type;
+        if (k < n && lane < kParseLanes) type = parsed[k].nal_unit_type;
         const bool slice = is_slice_type_nal(type);
         const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
         /* type < 0: nal_to_rbsp failed, rc stays -1; other types: rc -1, header fields kept (:221) */
@@ -302,8 +306,8 @@ void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     RpsRow* const my_rows = own_rows + wave * 64;
-    for (uint64_t chunk = wave; chunk * 64 < n; chunk += nwaves) {
-        const uint64_t k = chunk * 64 + (uint64_t)lane;
+    for (uint64_t chunk = wave; chunk * kParseLanes < n; chunk += nwaves) {
+        const uint64_t k = chunk * kParseLanes + (uint64_t)lane;
         if (pass == 1) {                                       /* fresh rows for the slices' own short-term RPS, by the whole wave */
             uint4* q = reinterpret_cast<uint4*>(my_rows);
             const uint4 z = make_uint4(0, 0, 0, 0);
@@ -311,7 +315,7 @@ void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (k >= n) continue;
+        if (k >= n || lane >= kParseLanes) continue;
         const int type = parsed[k].nal_unit_type;
         const bool slice = is_slice_type_nal(type);
         const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
@@ -365,7 +369,7 @@ __global__ void k4_summary(uint64_t n, const unsigned long long* total, const ui
 /* workgroups of the parse kernel: a wavefront per 64 NALs, at most kParseMaxBlocks workgroups */
 unsigned parse_grid_blocks(uint64_t n)
 {
-    const uint64_t want = (n + 255) / 256;
+    const uint64_t want = (n + 4 * kParseLanes - 1) / (4 * kParseLanes);
     return (unsigned)(want < 1 ? 1 : want > kParseMaxBlocks ? kParseMaxBlocks : want);
 }
 uint64_t parse_own_rows_bytes(uint64_t n) { return (uint64_t)parse_grid_blocks(n) * 4u * 64u * sizeof(RpsRow); }

@@ -10,7 +10,7 @@ namespace hbs {
 struct ParsedNal;
 struct TraceRec;
 struct RpsRow;
-constexpr unsigned kParseMaxBlocks = 512;
+constexpr unsigned kParseMaxBlocks = 2048;
 
 struct ParseArgs {
     const uint8_t* rbsp;
