@@ -303,8 +303,9 @@ class Context:
                                         structs.numel() if structs is not None else 0, C.c_void_p(summary.data_ptr()))
         self._check(rc, "hbs_parse_headers")
 
-    def parse_headers(self, rbsp, index, n_nals):
-        """Plan, allocate the struct arena, parse.  Returns (parsed ndarray[PARSED], structs device tensor)."""
+    def parse_headers(self, rbsp, index, n_nals, poison=None):
+        """Plan, allocate the struct arena, parse.  Returns (parsed ndarray[PARSED], structs device tensor).
+        poison: byte the arena is filled with beforehand (tests: the parse has to clear what it fills)."""
         t = self.torch
         dev = t.device("cuda", self.device)
         parsed = t.empty(max(n_nals, 1) * PARSED.itemsize, dtype=t.uint8, device=dev)
@@ -312,6 +313,8 @@ class Context:
         self.parse_headers_async(rbsp, index, n_nals, parsed, None, summary)
         need = int(self.read_summary(summary)["reserved"][0])
         structs = t.empty(need + 16, dtype=t.uint8, device=dev)
+        if poison is not None:
+            structs.fill_(poison)
         self.parse_headers_async(rbsp, index, n_nals, parsed, structs, summary)
         s = self.read_summary(summary)
         if int(s["error"]) != 0:

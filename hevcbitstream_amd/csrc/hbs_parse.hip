@@ -158,15 +158,35 @@ void k4_scan_apply(ParsedNal* __restrict__ parsed, const unsigned long long* __r
     }
 }
 
-/* the memset of every struct a parse fills (hevc_stream.c:250, :310, :425, init_slice_hevc :19-24):
- * the struct arena is one contiguous run of slots, zeroed in one streaming pass */
-__global__ __launch_bounds__(256)
-void k4_zero(uint8_t* __restrict__ structs, uint64_t structs_cap, const unsigned long long* __restrict__ total)
+/* the memset of every struct a parse fills (hevc_stream.c:250, :310, :425, init_slice_hevc :19-24).
+ * Slice slots are cleared by spare workgroups of the parameter-set launch (the parameter sets
+ * themselves are few and their parse is one long dependent chain: the clearing hides behind it);
+ * a parameter set's slot is cleared by the wavefront that parses it. */
+__device__ __forceinline__ void zero_slot(uint8_t* __restrict__ dst, uint64_t bytes, int lane)
 {
-    const uint64_t bytes = *total < structs_cap ? *total : structs_cap;       /* slots are multiples of 16 */
-    uint4* q = reinterpret_cast<uint4*>(structs);
+    uint4* q = reinterpret_cast<uint4*>(dst);
     const uint4 z = make_uint4(0, 0, 0, 0);
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < bytes / 16; i += (uint64_t)gridDim.x * blockDim.x) q[i] = z;
+    for (uint64_t i = (uint64_t)lane; i < bytes / 16; i += 64) q[i] = z;       /* slots are multiples of 16 */
+}
+
+__device__ __forceinline__ void zero_slice_slots(const ParsedNal* __restrict__ parsed, uint64_t n, uint8_t* __restrict__ structs,
+                                                 uint64_t structs_cap, uint64_t wave, uint64_t nwaves, int lane)
+{
+    const uint64_t slot = slot_bytes_of(HEVC_NAL_UNIT_TYPE_TRAIL_R);             /* every slice type has the same struct */
+    for (uint64_t chunk = wave; chunk * 64 < n; chunk += nwaves) {
+        const uint64_t k = chunk * 64 + (uint64_t)lane;
+        uint64_t off = ~0ull;
+        if (k < n && is_slice_type_nal(parsed[k].nal_unit_type)) off = parsed[k].struct_off;
+        if (off != ~0ull && off + slot > structs_cap) off = ~0ull;
+        uint64_t todo = __ballot(off != ~0ull);
+        while (todo) {                                                           /* wave-uniform */
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint64_t oj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), j) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, j);
+            zero_slot(structs + oj, slot, lane);
+        }
+    }
 }
 
 /* One NAL per LANE: a wavefront walks 64 consecutive NALs at once.  The walk is a long chain of
@@ -175,12 +195,14 @@ void k4_zero(uint8_t* __restrict__ structs, uint64_t structs_cap, const unsigned
  * the syntax, so 64 of them in lock step diverge little.  Each lane stages the first kLaneWin
  * bytes of its RBSP in LDS (stride kLaneWinStride bytes: lanes reading the same offset hit
  * different banks) and owns one RpsRow of a global scratch for its slice's own short-term RPS.
- * pass 0: parameter sets; pass 1: slices against them.  kMode: plain parse, or parse + per-field
- * trace (the debug reader's variant of the syntax, see hbs_parse.h). */
+ * pass 0: parameter sets (workgroups [0, parse_blocks)) while the workgroups behind them clear the
+ * slice slots; pass 1: slices against them.  kMode: plain parse, or parse + per-field trace (the
+ * debug reader's variant of the syntax, see hbs_parse.h). */
 #ifndef HBS_PARSE_LANES
 #define HBS_PARSE_LANES 64
 #endif
 constexpr int kParseLanes = HBS_PARSE_LANES;          /* NALs a wavefront walks at once (lanes 0 .. kParseLanes-1) */
+constexpr unsigned kZeroBlocks = 1024;                /* spare workgroups of the parameter-set launch that clear slice slots */
 constexpr uint32_t kLaneWin = 64;
 constexpr uint32_t kLaneWinStride = kLaneWin + 4;
 
@@ -192,13 +214,18 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot,
               const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
-              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */)
+              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
     struct __attribute__((packed, aligned(1))) U16 { u32x4_t v; };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    if (blockIdx.x >= parse_blocks) {                          /* pass 0 only: the spare workgroups */
+        zero_slice_slots(parsed, n, structs, structs_cap, (uint64_t)(blockIdx.x - parse_blocks) * 4u + (uint64_t)wv,
+                         (uint64_t)(gridDim.x - parse_blocks) * 4u, lane);
+        return;
+    }
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (uint64_t)wv;
+    const uint64_t nwaves = (uint64_t)parse_blocks * 4u;
     RpsRow* const my_rows = own_rows + wave * 64;
     uint8_t* const my_win = win[wv] + (uint32_t)lane * kLaneWinStride;
 
@@ -226,6 +253,15 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             uint4* q = reinterpret_cast<uint4*>(my_rows);
             const uint4 z = make_uint4(0, 0, 0, 0);
             for (uint32_t i = (uint32_t)lane; i < (uint32_t)(64 * sizeof(RpsRow) / 16); i += 64) q[i] = z;
+        } else {                                               /* the slots of my parameter sets, by the whole wave */
+            uint64_t todo = __ballot(active);
+            while (todo) {
+                const int j = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint64_t oj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), j) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, j);
+                zero_slot(structs + oj, slot_bytes_of(__builtin_amdgcn_readlane(type, j)), lane);
+            }
         }
         /* first bytes of my RBSP into my LDS window */
         const uint8_t* src = rbsp + e.rbsp_off;
@@ -391,13 +427,13 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
         k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
-            k4_zero<<<2048, 256, 0, st>>>(a.structs, a.structs_cap, a.total);
-            const unsigned grid = parse_grid_blocks(a.n);
+            const unsigned pblocks = parse_grid_blocks(a.n);
             for (int pass = 0; pass < 2; ++pass) {
+                const unsigned grid = pblocks + (pass == 0 ? kZeroBlocks : 0u);
                 if (a.trace)
-                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows);
+                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks);
                 else
-                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows);
+                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks);
             }
         }
     }

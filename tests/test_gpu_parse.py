@@ -1,4 +1,4 @@
-"""Parity tests for K4 (one-NAL-per-wavefront header parse) through the C ABI:
+"""Parity tests for K4 (header parse, one NAL per lane) through the C ABI:
 NAL header, VPS/SPS/PPS/slice-segment-header structs and slice payload location
 against the oracle parser, on streams from tests/hevc_synth.py."""
 import json
@@ -32,7 +32,7 @@ def gpu_parse(ctx, stream_bytes):
     ctx.index_extract_async(d, index, cap, rbsp, summary)
     sm = ctx.read_summary(summary)
     n = int(sm["nal_count"])
-    parsed, structs = ctx.parse_headers(rbsp, index, n)
+    parsed, structs = ctx.parse_headers(rbsp, index, n, poison=0xA5)      # the parse has to clear every struct it fills
     import hevcbitstream_amd as hbs
     idx = index[: n * 32].cpu().numpy().view(hbs.NAL_ENTRY)
     return s, idx, rbsp[: int(sm["rbsp_bytes"])].cpu().numpy(), parsed, structs.cpu().numpy()
