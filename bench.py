@@ -102,13 +102,22 @@ def main():
     index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
 
     from hevcbitstream_amd import shard
+    # N > 1: the one exchange of the path is the all-gather of the NAL index (counts, then the padded entry
+    # arrays; RCCL).  It runs on the collective's stream while the next step's scan fills the other index buffer.
+    indexes = [index, torch.empty_like(index)] if world > 1 else [index]
+    gatherer = shard.IndexGatherer(torch, dist, cap, index.device, depth=2) if world > 1 else None
+    counter = [0]
 
     def step():
-        ctx.index_extract_async(stream, index, cap, rbsp, summary)
-        if world > 1:       # the one exchange of the path: counts, then the padded index arrays (RCCL all-gather)
-            shard.gather_index(torch, dist, index, n, sb, rb, cap)
+        buf = indexes[counter[0] % len(indexes)]
+        counter[0] += 1
+        ctx.index_extract_async(stream, buf, cap, rbsp, summary)
+        if gatherer is not None:
+            gatherer.submit(buf, n, sb, rb)
 
     def fence():
+        if gatherer is not None:
+            gatherer.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -32,6 +32,50 @@ def gather_index(torch, dist, local_index, local_count, local_stream_bytes, loca
     return all_index.view(world, capacity * ENTRY_BYTES), meta.view(world, 3)
 
 
+class IndexGatherer:
+    """The same exchange, pipelined: the gather of one step's index runs on the collective's own
+    stream while the next step's scan is already writing the other index buffer.  `depth` results
+    are kept in flight (preallocated receive buffers); submit() hands back the slot to pass to
+    result() later.  The caller alternates its OWN index buffers likewise: a buffer handed to
+    submit() may be written again once the submit() `depth` steps later has returned."""
+
+    def __init__(self, torch, dist, capacity, device, depth=2, group=None):
+        self.torch, self.dist, self.group = torch, dist, group
+        self.capacity, self.depth = capacity, depth
+        self.world = dist.get_world_size(group)
+        self.recv = [torch.empty(self.world * capacity * ENTRY_BYTES, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.meta = [torch.empty(self.world * 3, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.meta_local = [torch.empty(3, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+        self.step = 0
+
+    def submit(self, local_index, local_count, local_stream_bytes, local_rbsp_bytes):
+        slot = self.step % self.depth
+        self.step += 1
+        self._wait(slot)                                     # the result that used this slot is overwritten now
+        t = self.torch
+        self.meta_local[slot].copy_(t.tensor([local_count, local_stream_bytes, local_rbsp_bytes], dtype=t.int64), non_blocking=True)
+        w0 = self.dist.all_gather_into_tensor(self.meta[slot], self.meta_local[slot], group=self.group, async_op=True)
+        w1 = self.dist.all_gather_into_tensor(self.recv[slot], local_index[: self.capacity * ENTRY_BYTES], group=self.group, async_op=True)
+        self.work[slot] = (w0, w1)
+        return slot
+
+    def _wait(self, slot):
+        if self.work[slot] is not None:
+            for w in self.work[slot]:
+                w.wait()
+            self.work[slot] = None
+
+    def result(self, slot):
+        """(all_index [world, capacity*32], meta [world, 3]) of a submitted step; waits for it"""
+        self._wait(slot)
+        return self.recv[slot].view(self.world, self.capacity * ENTRY_BYTES), self.meta[slot].view(self.world, 3)
+
+    def drain(self):
+        for slot in range(self.depth):
+            self._wait(slot)
+
+
 def global_entries(all_index, meta):
     """Host-side view of a gathered index as ONE entry array over the concatenation of the
     shards: start/end shifted by the bytes of the shards in front, rbsp_off by their RBSP bytes."""

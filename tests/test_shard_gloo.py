@@ -31,6 +31,22 @@ def _worker(rank, world, port, ret):
     t = torch.from_numpy(local.view(np.uint8).copy())
     all_index, meta = shard.gather_index(torch, dist, t, n, len(stream), len(arena), cap)
     glob = shard.global_entries(all_index, meta)
+    # the pipelined form of the same exchange: three steps in flight over two slots, each with its own local buffer
+    gat = shard.IndexGatherer(torch, dist, cap, torch.device("cpu"), depth=2)
+    bufs, slots = [], []
+    for step in range(3):
+        b = t.clone()
+        if step == 1:
+            b[:32] = 0xEE                                  # a different payload per step: results must not mix
+        bufs.append(b)
+        slots.append(gat.submit(b, n, len(stream), len(arena)))
+        if step == 1:
+            got1, meta1 = gat.result(slots[1])
+            mine = got1[rank]
+            assert bytes(mine[:32].tolist()) == b"\xEE" * 32 and torch.equal(mine[32:], t[32:])
+    got2, meta2 = gat.result(slots[2])
+    gat.drain()
+    assert torch.equal(got2, all_index) and torch.equal(meta2, meta)
     # every rank got the same thing; rank 0 checks it against the concatenated stream
     streams = [None] * world
     dist.all_gather_object(streams, stream.tobytes())
