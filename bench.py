@@ -21,6 +21,9 @@ Extra objects on that line:
   cpu_baseline  the oracle's byte-at-a-time restatement of the reference loop
                 (find_nal_unit + nal_to_rbsp per NAL, oracle/hbs_oracle_nal.c) timed
                 on ONE host core over a bounded prefix of rank 0's stream.
+  other_kernels (N = 1 only, outside the timed region) the other rows of the path on the same
+                GPU: RBSP -> Annex-B (hbs_emit_annexb) over the 16 GiB arena, header parse and
+                header writers (hbs_parse_headers / hbs_write_headers) on a 100 k-NAL 4K30 stream.
 """
 import argparse
 import json
@@ -65,6 +68,64 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
                       "oracle/hbs_oracle_nal.c, gcc -O2, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, dt)}
 
 
+def other_kernels(torch, hbs, ctx, g, n):
+    """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
+    import ctypes as C
+    import numpy as np
+    from hevcbitstream_amd.api import PARSED, SUMMARY
+    from tests.hevc_synth import stream_4k30
+    res = {}
+    sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
+    idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ctx.emit_annexb_async(g["rbsp"], rb, g["index"], n, 1, out, idx_out, summary)
+    for i in range(4):
+        ev[i].record()
+        if i < 3:
+            ctx.emit_annexb_async(g["rbsp"], rb, g["index"], n, 1, out, idx_out, summary)
+    torch.cuda.synchronize()
+    ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
+    assert torch.equal(out[:sb], g["stream"][:sb]), "emitted stream != generated stream"
+    res["emit_annexb"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s emitted", "ms": round(ms, 3),
+                          "hbm_traffic_GBs": round((rb + sb) / ms / 1e6, 1), "workload": "the bench arena: %d NALs, %.2f GiB" % (n, rb / 2**30)}
+    del out, idx_out
+    stream, _ = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
+    d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+    index, rbsp, summ, cap = ctx.alloc_outputs(d.numel())
+    ctx.index_extract_async(d, index, cap, rbsp, summ)
+    m = int(ctx.read_summary(summ)["nal_count"])
+    parsed, structs = ctx.parse_headers(rbsp, index, m)
+    assert int((parsed["rc"] < 0).sum()) == 0
+    pt = torch.empty(m * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+    sm = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    for i in range(6):
+        ctx.parse_headers_async(rbsp, index, m, pt, structs, sm)
+        ev[i].record()
+    torch.cuda.synchronize()
+    ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(5))
+    res["parse_headers"] = {"value": round(m / ms / 1e3, 1), "unit": "M NAL/s", "ms": round(ms, 3),
+                            "workload": "synthetic 4K30 stream, %d NALs (VPS/SPS/PPS every 60 pictures, 8 slices per picture)" % m}
+    parsed_dev = torch.from_numpy(parsed.view(np.uint8).copy()).cuda()
+    wcap = 256
+    written, wout = ctx.write_headers(parsed_dev, structs, m, wcap)
+    assert int((written["rc"] < 0).sum()) == 0
+    wr = torch.empty(m * 16, dtype=torch.uint8, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    for i in range(5):
+        ctx._bind_stream()
+        rc = ctx.lib.hbs_write_headers(ctx.h, C.c_void_p(parsed_dev.data_ptr()), m, C.c_void_p(structs.data_ptr()), None, None,
+                                       C.c_void_p(wout.data_ptr()), wcap, C.c_void_p(wr.data_ptr()))
+        assert rc == 0
+        ev[i].record()
+    torch.cuda.synchronize()
+    ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(4))
+    res["write_headers"] = {"value": round(m / ms / 1e3, 1), "unit": "M NAL/s", "ms": round(ms, 3), "workload": "the structs of that parse"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nals", type=int, default=N_NALS_16GIB, help="NALs per GPU (default: 16 GiB of stream)")
     ap.add_argument("--mode", type=int, default=0, help="0 uniform payload (headline), 1 zero-heavy")
-    ap.add_argument("--cpu-sample-nals", type=int, default=400_000, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-sample-nals", type=int, default=1_000_000, help="0 disables the CPU baseline leg")
+    ap.add_argument("--other-kernels", type=int, default=1, help="0 skips the emit / parse / write measurements (N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +257,9 @@ def main():
         }
         if args.cpu_sample_nals > 0:
             out["cpu_baseline"] = cpu_baseline(stream, gen_index, n, min(args.cpu_sample_nals, n))
+        if world == 1 and args.other_kernels:
+            del rbsp, index
+            out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
