@@ -265,7 +265,9 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index_in || !d_out))) return HBS_E_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
     const uint64_t b_seg = 8192, b_n = round256((n_nals + 1) * 8);       /* b_seg: the scan's 1024 partial sums */
-    int rc = ensure_ws(c, b_seg + 2 * b_n + 768);
+    const uint64_t items_cap = hbs::emit_items_bound(n_nals, out_cap);
+    const uint64_t b_items = round256(items_cap * 8), b_desc = round256(hbs::emit_desc_words(items_cap) * 8);
+    int rc = ensure_ws(c, b_seg + 2 * b_n + b_items + b_desc + 1024);
     if (rc) return rc;
     if (c->emit_blocks <= 0) {
         c->emit_blocks = hbs::emit_grid_blocks(c->device);
@@ -282,9 +284,13 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.scan_tmp = reinterpret_cast<unsigned long long*>(w);
     a.nal_total = reinterpret_cast<unsigned long long*>(w + b_seg);
     a.out_off = reinterpret_cast<unsigned long long*>(w + b_seg + b_n);
-    a.total = reinterpret_cast<unsigned long long*>(w + b_seg + 2 * b_n);
-    a.err = reinterpret_cast<uint32_t*>(w + b_seg + 2 * b_n + 256);
-    a.ticket = reinterpret_cast<uint32_t*>(w + b_seg + 2 * b_n + 512);
+    a.items = reinterpret_cast<unsigned long long*>(w + b_seg + 2 * b_n); a.items_cap = items_cap;
+    a.desc = reinterpret_cast<unsigned long long*>(w + b_seg + 2 * b_n + b_items);
+    uint8_t* tail = w + b_seg + 2 * b_n + b_items + b_desc;
+    a.total = reinterpret_cast<unsigned long long*>(tail);
+    a.err = reinterpret_cast<uint32_t*>(tail + 256);
+    a.ticket = reinterpret_cast<uint32_t*>(tail + 512);
+    a.n_items = reinterpret_cast<unsigned long long*>(tail + 768);
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_emit_annexb");

@@ -486,25 +486,6 @@ __device__ __forceinline__ unsigned long long k3_look_back(const unsigned long l
     return prefix;
 }
 
-/* what lane 0 adds to a NAL: the zero bytes and the 01 in front of it, its entry of the output index */
-__device__ __forceinline__ void finish_nal(uint8_t* __restrict__ out, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
-                                           uint64_t k, uint64_t base, uint64_t nal_start, uint64_t nal_end,
-                                           uint64_t begin, uint32_t len, bool fits, int lane)
-{
-    if (lane != 0) return;
-    if (fits) {
-        for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;      /* zero_byte / leading zeros */
-        if (nal_start != base) out[nal_start - 1] = 1;
-    }
-    if (idx_out) {
-        hbs_nal_entry e;
-        e.start = nal_start; e.end = nal_end;
-        e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
-        idx_out[k] = e;
-    }
-    if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
-}
-
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
@@ -512,25 +493,60 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)
     return ((uint64_t)hi << 32) | lo;
 }
 
-/* what lane j knows about slot j of a wavefront's share of a group */
-struct SlotEntry { uint64_t begin, gap; uint32_t len; };
-__device__ __forceinline__ SlotEntry fetch_entries(const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode, uint64_t k0, int lane)
+/* ---- work items --------------------------------------------------------------------------
+ * A slot holds at most kEmitRows KiB, so the unit of work is a SEGMENT: rows [12 s, 12 s + 12) of a
+ * NAL.  A NAL of any length is ceil(len / 12 KiB) consecutive items, spread over wavefronts and
+ * workgroups like any other items; the look-back that places NALs also carries the bytes inserted
+ * into the segments in front.  (A coded picture is routinely 50-500 KiB: without this one
+ * wavefront would stream it alone while everything behind it waits for its size.)
+ * When every NAL fits a slot -- items == NALs -- the item list is not built at all. */
+constexpr uint32_t kEmitSegBytes = (uint32_t)kEmitRows * 1024u;
+constexpr int kItemSegBits = 20;                             /* rbsp_len < 2^32: fewer than 2^19 segments */
+
+__global__ void k3_seg_count(const hbs_nal_entry* __restrict__ idx, uint64_t n, unsigned long long* __restrict__ segs)
 {
-    SlotEntry e; e.begin = 0; e.gap = 0; e.len = 0;
-    if (lane < kEmitSlots && k0 + (uint64_t)lane < n) {
-        e.begin = idx[k0 + lane].rbsp_off; e.len = idx[k0 + lane].rbsp_len; e.gap = gap_of(idx, k0 + lane, gap_mode);
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t len = idx[k].rbsp_len;
+        segs[k] = len <= kEmitSegBytes ? 1ull : (unsigned long long)((len + kEmitSegBytes - 1u) / kEmitSegBytes);
+    }
+}
+
+__global__ void k3_expand(const unsigned long long* __restrict__ segs, const unsigned long long* __restrict__ item_base, uint64_t n,
+                          const unsigned long long* __restrict__ n_items, unsigned long long* __restrict__ items, uint64_t items_cap)
+{
+    if (*n_items == n || *n_items > items_cap) return;       /* identity: nothing to build; too many: the main kernel reports it */
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long base = item_base[k], m = segs[k];
+        for (unsigned long long sgm = 0; sgm < m; ++sgm) items[base + sgm] = (k << kItemSegBits) | sgm;
+    }
+}
+
+/* what lane j knows about slot j of a wavefront's share of a group */
+struct SlotEntry { uint64_t k, begin, gap; uint32_t len, r0; };
+__device__ __forceinline__ SlotEntry fetch_entries(const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+                                                   const unsigned long long* __restrict__ items, uint64_t n_items,
+                                                   uint64_t i0, int lane)
+{
+    SlotEntry e; e.k = ~0ull; e.begin = 0; e.gap = 0; e.len = 0; e.r0 = 0;
+    const uint64_t i = i0 + (uint64_t)lane;
+    if (lane < kEmitSlots && i < n_items) {
+        uint64_t k = i, sgm = 0;
+        if (n_items != n) { const unsigned long long it = items[i]; k = it >> kItemSegBits; sgm = it & ((1ull << kItemSegBits) - 1ull); }
+        e.k = k; e.begin = idx[k].rbsp_off; e.len = idx[k].rbsp_len; e.r0 = (uint32_t)sgm * (uint32_t)kEmitRows;
+        e.gap = sgm == 0 ? gap_of(idx, k, gap_mode) : 0ull;
     }
     return e;
 }
 
 struct Lds3 {
-    unsigned long long tot[kEmitGroup];      /* bytes NAL j of the group takes in the output: gap + payload + inserted */
+    unsigned long long tot[kEmitGroup];      /* bytes item j of the group takes in the output: gap + payload + inserted */
     unsigned long long off[kEmitGroup];      /* where it starts */
     uint32_t ticket;
 };
 
 __global__ __launch_bounds__(256, 2)
 void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+              const unsigned long long* __restrict__ items, const unsigned long long* __restrict__ n_items_ptr, uint64_t items_cap,
               unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
               uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err)
@@ -538,7 +554,12 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
     __shared__ Lds3 l;
     const int lane0 = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t ngroups = (n + kEmitGroup - 1) / kEmitGroup;
+    const uint64_t n_items = *n_items_ptr;
+    if (n_items > items_cap) {                                /* only when the NALs add up to more than the output holds */
+        if (blockIdx.x == 0 && threadIdx.x == 0) { atomicMax(err, (uint32_t)(-HBS_E_CAPACITY)); *total = 0; }
+        return;
+    }
+    const uint64_t ngroups = (n_items + kEmitGroup - 1) / kEmitGroup;
     HBS3_T_DECL
     for (;;) {
         const int lane = launder_lane(lane0);                 /* keeps lane-constant values from being hoisted out of the loop (and spilled) */
@@ -552,54 +573,37 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
         const uint64_t g = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
         if (g >= ngroups) break;
         HBS3_T_MARK(0)
-        const uint64_t k0 = g * kEmitGroup + (uint64_t)(kEmitSlots * wv);
-        const SlotEntry ent = fetch_entries(idx, n, gap_mode, k0, lane);
-        const uint64_t e_begin = ent.begin, e_gap = ent.gap;
-        const uint32_t e_len = ent.len;
+        const SlotEntry ent = fetch_entries(idx, n, gap_mode, items, n_items, g * kEmitGroup + (uint64_t)(kEmitSlots * wv), lane);
         HBS3_T_MARK(1)
+
+        /* 1. my items: load, count */
         u32x4 R[kEmitSlots][kEmitRows];
-
-        /* 1. sizes.  NALs longer than a slot are streamed through slot 0's registers, now and again in step 3 */
-#pragma unroll 1
-        for (int j = 0; j < kEmitSlots; ++j) {
-            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)e_len, j);
-            if (ln <= (uint32_t)kEmitRows * 1024u) continue;
-            const uint64_t bg = bcast64(e_begin, j);
-            uint32_t e_prev = 0xFFFFFFFFu, ins_long = 0;      /* a NAL starts with count = 0 */
-#pragma unroll 1
-            for (uint32_t r0 = 0; r0 < ((ln + 1023u) >> 10); r0 += kEmitRows) {
-                uint32_t rmask, mflags;
-                load_rows(R[0], rbsp, arena, bg, ln, r0, lane);
-                flag_batch(R[0], ln, r0, lane, e_prev, rmask, mflags);
-                ins_long += count_batch(rbsp, bg, ln, r0, lane, rmask, mflags);
-            }
-            if (lane == 0) l.tot[kEmitSlots * wv + j] = bcast64(e_gap, j) + ln + ins_long;
-        }
-
-        uint64_t begin[kEmitSlots], gap[kEmitSlots];
-        uint32_t len[kEmitSlots], ins[kEmitSlots], rowmask[kEmitSlots], myflags[kEmitSlots];
-        bool resident[kEmitSlots];
+        uint64_t nal[kEmitSlots], begin[kEmitSlots], gap[kEmitSlots];
+        uint32_t len[kEmitSlots], r0[kEmitSlots], ins[kEmitSlots], rowmask[kEmitSlots], myflags[kEmitSlots];
 #pragma unroll
         for (int j = 0; j < kEmitSlots; ++j) {
-            begin[j] = bcast64(e_begin, j); gap[j] = bcast64(e_gap, j);
-            len[j] = (uint32_t)__builtin_amdgcn_readlane((int)e_len, j);
-            resident[j] = k0 + (uint64_t)j < n && len[j] <= (uint32_t)kEmitRows * 1024u;
-            if (resident[j]) load_rows(R[j], rbsp, arena, begin[j], len[j], 0, lane);
+            nal[j] = bcast64(ent.k, j); begin[j] = bcast64(ent.begin, j); gap[j] = bcast64(ent.gap, j);
+            len[j] = (uint32_t)__builtin_amdgcn_readlane((int)ent.len, j);
+            r0[j] = (uint32_t)__builtin_amdgcn_readlane((int)ent.r0, j);
+            if (nal[j] != ~0ull) load_rows(R[j], rbsp, arena, begin[j], len[j], r0[j], lane);
         }
         HBS3_T_MARK(2)
 #pragma unroll
         for (int j = 0; j < kEmitSlots; ++j) {
             ins[j] = 0; rowmask[j] = 0; myflags[j] = 0;
-            if (resident[j]) {
+            unsigned long long tot = 0;
+            if (nal[j] != ~0ull) {
+                /* a NAL starts with count = 0; a later segment continues behind the dword in front of it */
                 uint32_t e_prev = 0xFFFFFFFFu;
+                if (r0[j] != 0) e_prev = reinterpret_cast<const Chunk16*>(rbsp + begin[j] + 1024ull * r0[j] - 16u)->v.w;
                 if (!HBS_K3_EXP(2)) {
-                    flag_batch(R[j], len[j], 0, lane, e_prev, rowmask[j], myflags[j]);
-                    ins[j] = count_batch(rbsp, begin[j], len[j], 0, lane, rowmask[j], myflags[j]);
+                    flag_batch(R[j], len[j], r0[j], lane, e_prev, rowmask[j], myflags[j]);
+                    ins[j] = count_batch(rbsp, begin[j], len[j], r0[j], lane, rowmask[j], myflags[j]);
                 }
-                if (lane == 0) l.tot[kEmitSlots * wv + j] = gap[j] + len[j] + ins[j];
-            } else if (k0 + (uint64_t)j >= n) {
-                if (lane == 0) l.tot[kEmitSlots * wv + j] = 0ull;
+                const uint32_t left = len[j] - 1024u * r0[j];         /* the first segment of an empty NAL: 0 */
+                tot = gap[j] + (left < kEmitSegBytes ? left : kEmitSegBytes) + ins[j];
             }
+            if (lane == 0) l.tot[kEmitSlots * wv + j] = tot;
         }
         HBS3_T_MARK(3)
         __syncthreads();
@@ -621,48 +625,42 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
         __syncthreads();
         HBS3_T_MARK(5)
 
-        /* 3. the bytes: resident NALs straight from their registers (no load in this code, so the
-         * stores are not made to wait for one another) ... */
+        /* 3. the bytes, straight from the registers (no load in this code, so the stores are not made
+         * to wait for one another) */
 #pragma unroll
         for (int j = 0; j < kEmitSlots; ++j) {
-            if (resident[j]) {                                /* wave-uniform */
+            if (nal[j] != ~0ull) {                            /* wave-uniform */
                 const uint64_t base = l.off[kEmitSlots * wv + j];
-                const uint64_t nal_start = base + gap[j];
-                const uint64_t nal_end = nal_start + len[j] + ins[j];
-                const bool fits = nal_end <= out_cap;
+                const uint64_t first_byte = base + gap[j];            /* where this segment's first RBSP byte lands */
+                const uint64_t item_end = base + l.tot[kEmitSlots * wv + j];
+                const bool fits = item_end <= out_cap;
                 if (fits && !HBS_K3_EXP(0)) {
                     uint32_t ins2 = 0;
-                    emit_batch(R[j], rbsp, begin[j], len[j], 0, lane, rowmask[j], myflags[j], ins2, out + nal_start);
+                    /* emit_batch places byte `off` of the NAL at dst0 + off + (inserted since r0) */
+                    emit_batch(R[j], rbsp, begin[j], len[j], r0[j], lane, rowmask[j], myflags[j], ins2, out + first_byte - 1024ull * r0[j]);
                 }
-                finish_nal(out, idx_out, err, k0 + (uint64_t)j, base, nal_start, nal_end, begin[j], len[j], fits, lane);
-            }
-        }
-        /* ... long ones read a second time */
-#pragma unroll 1
-        for (int j = 0; j < kEmitSlots; ++j) {
-            const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)e_len, j);
-            if (ln <= (uint32_t)kEmitRows * 1024u) continue;
-            const uint64_t bg = bcast64(e_begin, j);
-            const uint64_t base = l.off[kEmitSlots * wv + j];
-            const uint64_t nal_start = base + bcast64(e_gap, j);
-            const uint64_t nal_end = base + l.tot[kEmitSlots * wv + j];
-            const bool fits = nal_end <= out_cap;
-            if (fits) {
-                uint32_t e_prev = 0xFFFFFFFFu, ins2 = 0;
-#pragma unroll 1
-                for (uint32_t r0 = 0; r0 < ((ln + 1023u) >> 10); r0 += kEmitRows) {
-                    uint32_t rmask, mflags;
-                    load_rows(R[0], rbsp, arena, bg, ln, r0, lane);
-                    flag_batch(R[0], ln, r0, lane, e_prev, rmask, mflags);
-                    emit_batch(R[0], rbsp, bg, ln, r0, lane, rmask, mflags, ins2, out + nal_start);
+                if (lane == 0) {
+                    const bool first = r0[j] == 0, last = 1024ull * r0[j] + kEmitSegBytes >= len[j];
+                    if (fits && first) {
+                        for (uint64_t i = base; i + 1 < first_byte; ++i) out[i] = 0;      /* zero_byte / leading zeros */
+                        if (first_byte != base) out[first_byte - 1] = 1;
+                    }
+                    if (idx_out) {
+                        if (first) { idx_out[nal[j]].start = first_byte; idx_out[nal[j]].rbsp_off = begin[j]; idx_out[nal[j]].rbsp_len = len[j]; idx_out[nal[j]].status = 0; }
+                        if (last) idx_out[nal[j]].end = item_end;
+                    }
+                    if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
                 }
             }
-            finish_nal(out, idx_out, err, k0 + (uint64_t)j, base, nal_start, nal_end, bg, ln, fits, lane);
         }
         HBS3_T_MARK(6)
     }
     HBS3_T_FLUSH
 }
+
+/* items never outnumber this: one per NAL plus one per started 12 KiB of output (the payload fits the output or the call fails) */
+uint64_t emit_items_bound(uint64_t n, uint64_t out_cap) { return n + out_cap / kEmitSegBytes + 1; }
+uint64_t emit_desc_words(uint64_t items_cap) { return (items_cap + kEmitGroup - 1) / kEmitGroup + 1; }
 
 int emit_grid_blocks(int device)
 {
@@ -728,15 +726,19 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.total, a.scan_tmp, st);
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err);
     } else if (a.n) {
-        const uint64_t ngroups = (a.n + kEmitGroup - 1) / kEmitGroup;
-        e = hipMemsetAsync(a.nal_total, 0, ngroups * sizeof(unsigned long long), st);       /* the look-back words */
+        /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
+        k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total);
+        launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st);
+        k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap);
+        const uint64_t ngroups = (a.items_cap + kEmitGroup - 1) / kEmitGroup;       /* upper bound */
+        e = hipMemsetAsync(a.desc, 0, ngroups * sizeof(unsigned long long), st);    /* the look-back words */
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(a.ticket, 0, sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
         uint64_t blocks = (uint64_t)a.grid_blocks;
         if (blocks > ngroups) blocks = ngroups;
-        k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.ticket,
-                                                         a.out, a.out_cap, a.index_out, a.total, a.err);
+        k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.items, a.n_items, a.items_cap,
+                                                         a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err);
     } else {
         e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;

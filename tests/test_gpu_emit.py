@@ -68,6 +68,33 @@ def test_emit_row_and_batch_edges(ctx, orc):
         assert np.array_equal(got, want), (rep, lens)
 
 
+def test_emit_long_nals(ctx, orc):
+    """coded pictures of 50 KiB .. 3 MiB between small NALs: a long NAL is split into 12 KiB segments that different
+    wavefronts and workgroups write; zero runs straddle the segment borders"""
+    rng = np.random.RandomState(33)
+    for rep in range(3):
+        lens = [int(x) for x in rng.permutation([7, 300, 12288, 12289, 24576, 24577, 50_000, 123_457, 500_001, 3_000_000 if rep == 0 else 200_000, 40, 9000])]
+        gaps = [int(rng.randint(3, 6)) for _ in lens]
+        arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+        pos = 0
+        for n in lens:                                       # zeros across every 12 KiB border of every NAL
+            for b in range(12288, n, 12288):
+                arena[pos + b - rng.randint(1, 4): pos + b + rng.randint(0, 3)] = 0
+            pos += n
+        for p in rng.randint(0, len(arena), size=len(arena) // 5000 + 2):
+            arena[p:p + rng.randint(2, 6)] = 0
+        idx = fake_index(lens, gaps)
+        got, got_idx = ctx.emit_annexb(dev(arena), idx)
+        want = orc.emit_annexb(arena, idx)
+        assert np.array_equal(got, want), (rep, lens)
+        pos = 0
+        for k, (n, g) in enumerate(zip(lens, gaps)):         # the output index: where each NAL went
+            start = pos + g
+            assert int(got_idx["start"][k]) == start and bytes(want[start - 3:start]) == b"\x00\x00\x01"
+            pos = int(got_idx["end"][k])
+        assert pos == len(want)
+
+
 def test_emit_zero_runs(ctx, orc):
     for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
         for tail in ([], [1], [4], [0, 0, 1]):
