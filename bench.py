@@ -68,6 +68,22 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
                       "oracle/hbs_oracle_nal.c, gcc -O2, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, dt)}
 
 
+def pmc_traffic(kernel_name, algo_bytes):
+    """profiles/r*/traffic_<kernel>.json of the newest round, if it is about this kernel and this workload"""
+    import glob
+    short = kernel_name.split("::")[-1]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s.json" % short)), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("algorithmic_bytes_per_launch") == algo_bytes:
+            return {"traffic_bytes_per_launch": d["traffic_bytes_per_launch"],
+                    "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per the gfx950 note): "
+                              "fetch %d + write %d B per launch" % (os.path.relpath(f, ROOT), d["fetch_bytes_per_launch"], d["write_bytes_per_launch"])}
+    return None
+
+
 def other_kernels(torch, hbs, ctx, g, n):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
@@ -255,6 +271,12 @@ def main():
                          "note": "bytes = stream read once + RBSP written once + 32 B/NAL index; "
                                  "read-only fraction = %.4f" % (sb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
         }
+        # HBM bytes per launch by PMC (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes): counters cannot be read from
+        # inside this process, so the figure of the committed profile of this very workload and kernel is quoted
+        tr = pmc_traffic(kernel_name, algo_bytes)
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
         if args.cpu_sample_nals > 0:
             out["cpu_baseline"] = cpu_baseline(stream, gen_index, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:
