@@ -265,7 +265,8 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index_in || !d_out))) return HBS_E_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
     const uint64_t b_seg = 8192, b_n = round256((n_nals + 1) * 8);       /* b_seg: the scan's 1024 partial sums */
-    const uint64_t items_cap = hbs::emit_items_bound(n_nals, out_cap);
+    /* NALs that do not overlap add up to at most rbsp_bytes; an index whose NALs add up to more gets HBS_E_CAPACITY */
+    const uint64_t items_cap = hbs::emit_items_bound(n_nals, out_cap < rbsp_bytes ? out_cap : rbsp_bytes);
     const uint64_t b_items = round256(items_cap * 8), b_desc = round256(hbs::emit_desc_words(items_cap) * 8);
     int rc = ensure_ws(c, b_seg + 2 * b_n + b_items + b_desc + 1024);
     if (rc) return rc;

@@ -658,8 +658,8 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
     HBS3_T_FLUSH
 }
 
-/* items never outnumber this: one per NAL plus one per started 12 KiB of output (the payload fits the output or the call fails) */
-uint64_t emit_items_bound(uint64_t n, uint64_t out_cap) { return n + out_cap / kEmitSegBytes + 1; }
+/* items never outnumber this: one per NAL plus one per started 12 KiB of payload */
+uint64_t emit_items_bound(uint64_t n, uint64_t payload_bytes) { return n + payload_bytes / kEmitSegBytes + 1; }
 uint64_t emit_desc_words(uint64_t items_cap) { return (items_cap + kEmitGroup - 1) / kEmitGroup + 1; }
 
 int emit_grid_blocks(int device)

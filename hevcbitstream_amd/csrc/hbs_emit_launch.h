@@ -25,7 +25,7 @@ struct EmitArgs {
     uint32_t* ticket;                 /* 1, on a cache line of its own             */
     unsigned long long* n_items;      /* 1: work items of the single-pass kernel (segments of <= 12 KiB)  */
     unsigned long long* items;        /* items_cap entries                                                */
-    uint64_t items_cap;               /* emit_items_bound(n, out_cap)                                     */
+    uint64_t items_cap;               /* emit_items_bound(n, payload bytes)                               */
     unsigned long long* desc;         /* items_cap / 12 + 1 look-back words                               */
     int grid_blocks;                  /* resident workgroups of the single-pass kernel (emit_grid_blocks) */
     int two_pass;                     /* 1: count / scan / emit as three steps (kept for comparison)      */
@@ -44,7 +44,7 @@ struct SynthArgs {
 };
 
 int emit_grid_blocks(int device);
-uint64_t emit_items_bound(uint64_t n, uint64_t out_cap);
+uint64_t emit_items_bound(uint64_t n, uint64_t payload_bytes);
 uint64_t emit_desc_words(uint64_t items_cap);
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st);
 hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st);

@@ -160,6 +160,9 @@ int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t strea
  * any byte <= 3 that follows two zeros; nothing is appended after a trailing
  * 00 00).
  *
+ *   d_rbsp, rbsp_bytes                the arena and its size: nothing at or behind d_rbsp + rbsp_bytes
+ *                                     is read, and the NALs must add up to at most rbsp_bytes
+ *                                     (they do unless entries overlap; else HBS_E_CAPACITY)
  *   d_index_in[k].rbsp_off/rbsp_len   where NAL k's RBSP lives in d_rbsp
  *   gap_mode 0   gap of NAL k = d_index_in[k].start - d_index_in[k-1].end
  *                (start of NAL 0 for k = 0): what hbs_index_extract recorded
@@ -179,7 +182,7 @@ int hbs_emit_annexb(hbs_ctx* ctx, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
 uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals);
 
 /*
- * K4: header parse, one NAL per wavefront, over the RBSP arena and index that
+ * K4: header parse, one NAL per lane (64 per wavefront), over the RBSP arena and index that
  * hbs_index_extract produced.  For NAL k it does what read_hevc_nal_unit()
  * does after nal_to_rbsp (hevc_stream.c:175-239): NAL header, then by type the
  * VPS / SPS / PPS / slice-segment-header reader, into structs laid out exactly
