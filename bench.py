@@ -18,9 +18,10 @@ Extra objects on that line:
                 per launch (stream read + RBSP written + 32 B/NAL index) divided by
                 its mean duration, measured here with HIP events recorded around
                 that kernel on the stream it runs on (hbs_ctx_enable_timing).
-  cpu_baseline  the oracle's byte-at-a-time restatement of the reference loop
-                (find_nal_unit + nal_to_rbsp per NAL, oracle/hbs_oracle_nal.c) timed
-                on ONE host core over a bounded prefix of rank 0's stream.
+  cpu_baseline  the reference's loop (find_nal_unit + nal_to_rbsp per NAL) timed on ONE host
+                core over a bounded prefix of rank 0's stream: the real reference library when
+                its prebuilt copy is there (oracle/_ref, "reference"), else the oracle's
+                byte-at-a-time restatement (oracle/hbs_oracle_nal.c, "port").
   other_kernels (N = 1 only, outside the timed region) the other rows of the path on the same
                 GPU: RBSP -> Annex-B (hbs_emit_annexb) over the 16 GiB arena, header parse and
                 header writers (hbs_parse_headers / hbs_write_headers) on a 100 k-NAL 4K30 stream.
@@ -41,31 +42,48 @@ SEED = 0x1234
 
 
 def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
-    """Oracle ("port") on one host core over the first `sample_nals` NALs of the stream."""
+    """The reference's own loop (find_nal_unit + nal_to_rbsp per NAL) on one host core over the first `sample_nals`
+    NALs of the stream: through the REAL reference library when its prebuilt copy travelled with the tree
+    (oracle/_ref, kind "reference"), else through the oracle's restatement (kind "port")."""
+    import ctypes as C
     import numpy as np
     from tests import _orc
-    orc = _orc.oracle()
     ent = index_dev[: sample_nals * 32].cpu().numpy().view(_orc.NAL_ENTRY)
     nbytes = int(ent["end"][-1])
-    # keep the following start code so that the sampled prefix ends like the full stream does not:
-    # the last sampled NAL is then terminated exactly as in the full stream
+    # keep the following start code: the last sampled NAL is then terminated exactly as in the full stream
     host = stream_dev[: nbytes + 4].cpu().numpy()
     arena = np.zeros(nbytes + 64, dtype=np.uint8)          # pre-faulted output
-    idx = np.zeros(sample_nals + 8, dtype=_orc.NAL_ENTRY)
     arena[:] = 1
-    import ctypes as C
-    why = C.c_int(0)
-    t0 = time.perf_counter()
-    n = orc.lib.orc_index_stream(host.ctypes.data_as(C.POINTER(C.c_uint8)), len(host), idx.ctypes.data, len(idx), C.byref(why))
-    tot = orc.lib.orc_extract_rbsp(host.ctypes.data_as(C.POINTER(C.c_uint8)), idx.ctypes.data, n,
-                                   arena.ctypes.data_as(C.POINTER(C.c_uint8)), len(arena))
-    dt = time.perf_counter() - t0
-    assert n >= sample_nals and tot > 0
-    assert np.array_equal(idx["start"][:sample_nals], ent["start"]) and np.array_equal(idx["rbsp_off"][:sample_nals], ent["rbsp_off"])
-    return {"value": round(len(host) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+    u8p = C.POINTER(C.c_uint8)
+    drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+    if os.path.exists(drv):
+        lib = C.CDLL(drv)
+        lib.ref_walk.restype = C.c_int64
+        lib.ref_walk.argtypes = [u8p, C.c_int64, u8p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.c_int64]
+        starts = np.zeros(sample_nals + 8, dtype=np.uint64)
+        tot = C.c_int64(0)
+        t0 = time.perf_counter()
+        n = lib.ref_walk(host.ctypes.data_as(u8p), len(host), arena.ctypes.data_as(u8p), len(arena), C.byref(tot),
+                         starts.ctypes.data_as(C.POINTER(C.c_uint64)), len(starts))
+        dt = time.perf_counter() - t0
+        # the 4 bytes kept behind the sample are a start code: the reference finds one more, empty-handed NAL there or stops
+        assert n >= sample_nals and np.array_equal(starts[:sample_nals], ent["start"])
+        assert tot.value >= int(ent["rbsp_off"][-1]) + int(ent["rbsp_len"][-1])
+        kind, what = "reference", "the reference's find_nal_unit + nal_to_rbsp (oracle/_ref/libhevcref.so, gcc -O2) driven by oracle/ref_driver.c"
+    else:
+        orc = _orc.oracle()
+        idx = np.zeros(sample_nals + 8, dtype=_orc.NAL_ENTRY)
+        why = C.c_int(0)
+        t0 = time.perf_counter()
+        n = orc.lib.orc_index_stream(host.ctypes.data_as(u8p), len(host), idx.ctypes.data, len(idx), C.byref(why))
+        tot = orc.lib.orc_extract_rbsp(host.ctypes.data_as(u8p), idx.ctypes.data, n, arena.ctypes.data_as(u8p), len(arena))
+        dt = time.perf_counter() - t0
+        assert n >= sample_nals and tot > 0
+        assert np.array_equal(idx["start"][:sample_nals], ent["start"]) and np.array_equal(idx["rbsp_off"][:sample_nals], ent["rbsp_off"])
+        kind, what = "port", "find_nal_unit loop + nal_to_rbsp per NAL, oracle/hbs_oracle_nal.c, gcc -O2"
+    return {"value": round(len(host) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
             "nal_per_s": round(n / dt, 1),
-            "sample": "first %d NALs (%.2f GiB) of rank 0's stream: find_nal_unit loop + nal_to_rbsp per NAL, "
-                      "oracle/hbs_oracle_nal.c, gcc -O2, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, dt)}
+            "sample": "first %d NALs (%.2f GiB) of rank 0's stream: %s, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, what, dt)}
 
 
 def pmc_traffic(kernel_name, algo_bytes):

@@ -77,6 +77,31 @@ def test_stream_loop_vs_reference(orc, ref):
         assert [(int(a), int(b)) for a, b in zip(idx["start"], idx["end"])] == want, data.hex()
 
 
+@pytest.mark.ref
+def test_reference_baseline_driver(orc, ref):
+    """oracle/ref_driver.c (what bench.py times as the "reference" CPU baseline) walks a stream like the oracle does:
+    same NAL starts, same RBSP bytes"""
+    import ctypes as C
+    import os
+    drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_driver.so")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref/libref_driver.so not built")
+    lib = C.CDLL(drv)
+    u8p = C.POINTER(C.c_uint8)
+    lib.ref_walk.restype = C.c_int64
+    lib.ref_walk.argtypes = [u8p, C.c_int64, u8p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.c_int64]
+    for mode in (0, 1):
+        stream, idx, arena = orc.gen_stream(0x77 + mode, 150, mode)
+        buf = stream.copy()
+        out = np.zeros(len(buf) + 64, dtype=np.uint8)
+        starts = np.zeros(len(idx) + 8, dtype=np.uint64)
+        tot = C.c_int64(0)
+        n = lib.ref_walk(buf.ctypes.data_as(u8p), len(buf), out.ctypes.data_as(u8p), len(out), C.byref(tot),
+                         starts.ctypes.data_as(C.POINTER(C.c_uint64)), len(starts))
+        assert n == len(idx) and np.array_equal(starts[:n], idx["start"])
+        assert tot.value == len(arena) and np.array_equal(out[:tot.value], arena)
+
+
 def test_roundtrip_property(orc):
     """rbsp_to_nal(nal_to_rbsp(x)) == x for accepted x not ending in 00 00 03
     (SURVEY.md App. B); and the synthetic generator's arena/index are what the
