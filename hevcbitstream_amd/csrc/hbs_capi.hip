@@ -251,6 +251,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.sched = c->sched;
     a.grid_blocks = c->grid_blocks; a.grid_blocks3 = c->grid_blocks3; a.grid_blocks4 = c->grid_blocks4;
     c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
+    if (hbs::scan_takes_small_path(n, index_cap, c->variant)) { c->probe_pending = 0; c->last_variant = 2; }
     a.ev_begin = c->timing ? c->ev0 : nullptr;
     a.ev_end = c->timing ? c->ev1 : nullptr;
     c->ev_valid = (c->timing && n) ? 1 : 0;

@@ -29,6 +29,8 @@ struct ScanArgs {
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
 int scan_grid_blocks(int device, int* blocks_per_cu_out);
 hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st);
+/* automatic mode, at most one 64 KiB tile and a small index: one launch of one workgroup does the whole call */
+bool scan_takes_small_path(uint64_t n, uint64_t index_cap, int variant);
 
 /* register-resident variant (hbs_scan3.hip) */
 int scan3_grid_blocks(int device, int* blocks_per_cu_out);

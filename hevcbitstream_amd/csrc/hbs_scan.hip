@@ -402,14 +402,13 @@ __device__ __forceinline__ uint64_t take_ticket(TileLds& l, RunHeader* hdr, int 
     return (uint64_t)l.ticket;
 }
 
-__global__ __launch_bounds__(kThreads, 4)
-void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
-                    hbs_nal_entry* __restrict__ index, uint64_t index_cap,
-                    uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
-                    unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched, int gate)
+/* the tile loop of the LDS-image kernel; `first` = the workgroup's first tile under the striped schedule */
+__device__ __forceinline__
+void scan_tiles(TileLds& l, const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
+                hbs_nal_entry* __restrict__ index, uint64_t index_cap,
+                uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
+                unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched)
 {
-    if (gate == kGateIfDense && !probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
-    __shared__ TileLds l;
     const int tid0 = threadIdx.x;
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
@@ -520,6 +519,17 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
     HBS_T_FLUSH
 }
 
+__global__ __launch_bounds__(kThreads, 4)
+void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
+                    hbs_nal_entry* __restrict__ index, uint64_t index_cap,
+                    uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
+                    unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched, int gate)
+{
+    if (gate == kGateIfDense && !probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
+    __shared__ TileLds l;
+    scan_tiles(l, stream, n, num_tiles, index, index_cap, rbsp, rbsp_cap, desc, hdr, sched);
+}
+
 #ifdef HBS_PHASE_TIMING
 extern "C" int hbs_debug_set_stop(int phase)
 {
@@ -537,6 +547,7 @@ __global__ void k_init_header(RunHeader* hdr)
     hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
     hdr->probe_chunks = 0; hdr->probe_flagged = 0;
 }
+/* (k_scan_small below does the same in front of its tile) */
 
 __global__ void k_tail_fixup(const uint8_t* __restrict__ stream, uint64_t n,
                              hbs_nal_entry* index, uint64_t index_cap,
@@ -555,6 +566,52 @@ __global__ void k_fill_rbsp_len(const RunHeader* hdr, hbs_nal_entry* index, uint
     const uint64_t found = hdr->final_nals;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < found; k += (uint64_t)gridDim.x * blockDim.x)
         fill_rbsp_len(hdr, index, index_cap, k);
+}
+
+/* A stream of at most one tile (the legacy single-NAL symbols call with a few KiB): everything the
+ * call does -- header, index clear, the tile, the end-of-stream fix-up, rbsp_len -- in ONE launch
+ * of one workgroup instead of nine launches. */
+__device__ __forceinline__ void init_header(RunHeader* hdr)
+{
+    hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
+    hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
+    hdr->probe_chunks = 0; hdr->probe_flagged = 0;
+}
+
+__global__ __launch_bounds__(kThreads, 4)
+void k_scan_small(const uint8_t* __restrict__ stream, uint64_t n,
+                  hbs_nal_entry* index, uint64_t index_cap, uint8_t* rbsp, uint64_t rbsp_cap,
+                  unsigned long long* __restrict__ desc, RunHeader* hdr, hbs_summary* sum)
+{
+    __shared__ TileLds l;
+    const int tid = threadIdx.x;
+    if (tid == 0) init_header(hdr);
+    {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(index);
+        for (uint64_t i = (uint64_t)tid; i < index_cap * (sizeof(hbs_nal_entry) / 8); i += kThreads) q[i] = 0ull;
+    }
+    __threadfence();
+    __syncthreads();
+    if (n) scan_tiles(l, stream, n, 1, index, index_cap, rbsp, rbsp_cap, desc, hdr, kSchedStriped);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        uint8_t tail[8];
+        for (int i = 0; i < 8; ++i) {
+            const int64_t q = (int64_t)n - 8 + i;
+            tail[i] = (q >= 0) ? stream[q] : (uint8_t)0xFF;
+        }
+        tail_fixup(hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum);
+    }
+    __threadfence();
+    __syncthreads();
+    const uint64_t found = *reinterpret_cast<volatile uint64_t*>(&hdr->final_nals);
+    for (uint64_t k = (uint64_t)tid; k < found; k += kThreads) fill_rbsp_len(hdr, index, index_cap, k);
+}
+
+bool scan_takes_small_path(uint64_t n, uint64_t index_cap, int variant)
+{
+    return variant == 0 && n <= (uint64_t)kTileBytes && index_cap <= 16384;
 }
 
 /* ---- host side ------------------------------------------------------------ */
@@ -578,6 +635,12 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
 {
     hipError_t e;
     const bool automatic = a.variant == 0;
+    if (scan_takes_small_path(a.n, a.index_cap, a.variant)) {
+        if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
+        k_scan_small<<<1, dim3(kThreads), 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.summary);
+        if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
+        return hipGetLastError();
+    }
     k_init_header<<<1, 1, 0, st>>>(a.hdr);
     if (automatic && a.n) launch_scan4_probe(a, st);
     if (automatic || a.variant == 4) launch_scan4_prepare_tail(a, st);
