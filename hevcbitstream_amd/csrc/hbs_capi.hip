@@ -446,6 +446,41 @@ int hbs_copy_to_host(hbs_ctx* c, void* h_dst, const void* d_src, uint64_t bytes)
     return e == hipSuccess ? 0 : fail(c, e, "hipMemcpy(D2H)");
 }
 
+/* the same without the wait: h_src must be page-locked (hbs_host_alloc) and stay untouched until the stream
+ * has passed the copy; the legacy wrappers use it to put a whole call behind ONE synchronisation */
+int hbs_copy_to_device_async(hbs_ctx* c, void* d_dst, const void* h_src, uint64_t bytes)
+{
+    if (!c) return HBS_E_ARG;
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hipMemcpyAsync(H2D)");
+}
+
+int hbs_copy_device(hbs_ctx* c, void* d_dst, const void* d_src, uint64_t bytes)
+{
+    if (!c) return HBS_E_ARG;
+    if (!bytes) return 0;
+    hipError_t e = hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hipMemcpyAsync(D2D)");
+}
+
+int hbs_host_alloc(hbs_ctx* c, uint64_t bytes, void** out)
+{
+    if (!c || !out) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault);
+    return e == hipSuccess ? 0 : fail(c, e, "hipHostMalloc");
+}
+
+int hbs_host_free(hbs_ctx* c, void* p)
+{
+    if (!c) return HBS_E_ARG;
+    if (!p) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    hipError_t e = hipHostFree(p);
+    return e == hipSuccess ? 0 : fail(c, e, "hipHostFree");
+}
+
 int hbs_fill_device(hbs_ctx* c, void* d_dst, int value, uint64_t bytes)
 {
     if (!c) return HBS_E_ARG;

@@ -38,13 +38,33 @@ static uint8_t* g_dbuf = NULL;       /* input bytes                       */
 static uint64_t g_dbuf_cap = 0;
 static uint8_t* g_dout = NULL;       /* RBSP arena / emitted stream       */
 static uint64_t g_dout_cap = 0;
-static hbs_nal_entry* g_dindex = NULL;   /* 4 entries                     */
+/* one device block, so that a call's small results come back in ONE copy:
+ *   [0, 64) summary | [64, 192) 4 index entries | [192, 320) 4 parsed records | [384, 448) the parse's summary |
+ *   [512, ...) one struct slot (VPS-sized) */
+static uint8_t* g_dblock = NULL;
+static hbs_nal_entry* g_dindex = NULL;
 static hbs_summary* g_dsummary = NULL;
-static hbs_parsed_nal* g_dparsed = NULL; /* 4 records                     */
-static uint8_t* g_dstruct = NULL;    /* one struct slot (VPS-sized)       */
+static hbs_parsed_nal* g_dparsed = NULL;
+static uint8_t* g_dstruct = NULL;
 static uint8_t* g_dsps_slot = NULL;  /* SPS in force + its RPS tables     */
 static uint8_t* g_dpps = NULL;       /* PPS in force                      */
 #define LEGACY_INDEX_CAP 4
+#define RES_SUMMARY 0
+#define RES_INDEX 64
+#define RES_PARSED 192
+#define RES_STRUCT 512
+#define RES_SMALL 320                                      /* summary + index + parsed */
+#define RES_SUMMARY2 384                                   /* the parse's own summary: the scan's stays readable */
+#define RES_SLICE (RES_STRUCT + ((sizeof(hevc_slice_header_t) + 15) & ~(size_t)15))
+static uint8_t g_hres[RES_STRUCT + 8192];                  /* host mirror of the front of the block */
+/* page-locked staging for uploads: [00 00 01 | NAL bytes] goes up in one copy that nobody waits for */
+static uint8_t* g_hstage = NULL;
+static uint64_t g_hstage_cap = 0;
+/* what the device copies of the parameter sets in force were last loaded from (h->sps / h->pps are the
+ * caller's to edit between calls: they are compared, and uploaded again only when they differ) */
+static uint8_t* g_sps_shadow = NULL;
+static uint8_t* g_pps_shadow = NULL;
+static int g_sps_shadow_ok = 0, g_pps_shadow_ok = 0;
 
 static void die(const char* what, int rc)
 {
@@ -60,14 +80,49 @@ static void need_ctx(void)
     if (g_ctx) return;
     rc = hbs_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
     if (rc) { g_ctx = NULL; die("hbs_ctx_create", rc); }
-    if ((rc = hbs_dev_alloc(g_ctx, LEGACY_INDEX_CAP * sizeof(hbs_nal_entry), (void**)&g_dindex))) die("hbs_dev_alloc", rc);
-    if ((rc = hbs_dev_alloc(g_ctx, sizeof(hbs_summary), (void**)&g_dsummary))) die("hbs_dev_alloc", rc);
-    if ((rc = hbs_dev_alloc(g_ctx, LEGACY_INDEX_CAP * sizeof(hbs_parsed_nal), (void**)&g_dparsed))) die("hbs_dev_alloc", rc);
-    if ((rc = hbs_dev_alloc(g_ctx, sizeof(hevc_vps_t) + 64, (void**)&g_dstruct))) die("hbs_dev_alloc", rc);
+    if ((rc = hbs_dev_alloc(g_ctx, RES_STRUCT + sizeof(hevc_vps_t) + 64, (void**)&g_dblock))) die("hbs_dev_alloc", rc);
+    g_dsummary = (hbs_summary*)(g_dblock + RES_SUMMARY);
+    g_dindex = (hbs_nal_entry*)(g_dblock + RES_INDEX);
+    g_dparsed = (hbs_parsed_nal*)(g_dblock + RES_PARSED);
+    g_dstruct = g_dblock + RES_STRUCT;
     if ((rc = hbs_dev_alloc(g_ctx, hbs_sps_slot_bytes(), (void**)&g_dsps_slot))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_dev_alloc(g_ctx, sizeof(hevc_pps_t) + 64, (void**)&g_dpps))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
     if ((rc = hbs_fill_device(g_ctx, g_dpps, 0, sizeof(hevc_pps_t)))) die("hbs_fill_device", rc);
+    g_sps_shadow = (uint8_t*)malloc(sizeof(hevc_sps_t));
+    g_pps_shadow = (uint8_t*)malloc(sizeof(hevc_pps_t));
+}
+
+/* [prefix | bytes] into the device input buffer at offset 0; returns without waiting */
+static void upload_input(const uint8_t* prefix, uint64_t prefix_len, const uint8_t* bytes, uint64_t len)
+{
+    int rc;
+    if (prefix_len + len + 64 > g_hstage_cap) {
+        if (g_hstage) hbs_host_free(g_ctx, g_hstage);
+        g_hstage_cap = (prefix_len + len) * 2 + 65536;
+        if ((rc = hbs_host_alloc(g_ctx, g_hstage_cap, (void**)&g_hstage))) die("hbs_host_alloc", rc);
+    } else {
+        /* the previous call's upload has long been consumed: every wrapper ends with a synchronising copy */
+    }
+    if (prefix_len) memcpy(g_hstage, prefix, prefix_len);
+    if (len) memcpy(g_hstage + prefix_len, bytes, len);
+    if ((rc = hbs_copy_to_device_async(g_ctx, g_dbuf, g_hstage, prefix_len + len))) die("hbs_copy_to_device_async", rc);
+}
+
+/* the device copies of the parameter sets in force follow the caller's object */
+static void sync_context(const hevc_stream_t* h)
+{
+    int rc;
+    if (!g_sps_shadow_ok || memcmp(g_sps_shadow, h->sps, sizeof(hevc_sps_t)) != 0) {
+        if ((rc = hbs_copy_to_device(g_ctx, g_dsps_slot, h->sps, sizeof(hevc_sps_t)))) die("hbs_copy_to_device", rc);
+        memcpy(g_sps_shadow, h->sps, sizeof(hevc_sps_t));
+        g_sps_shadow_ok = 1;
+    }
+    if (!g_pps_shadow_ok || memcmp(g_pps_shadow, h->pps, sizeof(hevc_pps_t)) != 0) {
+        if ((rc = hbs_copy_to_device(g_ctx, g_dpps, h->pps, sizeof(hevc_pps_t)))) die("hbs_copy_to_device", rc);
+        memcpy(g_pps_shadow, h->pps, sizeof(hevc_pps_t));
+        g_pps_shadow_ok = 1;
+    }
 }
 
 static void need_bufs(uint64_t in_bytes, uint64_t out_bytes)
@@ -85,14 +140,21 @@ static void need_bufs(uint64_t in_bytes, uint64_t out_bytes)
     }
 }
 
-/* scan + extract the first `bytes` of the device input buffer; results to the host */
-static void run_index(uint64_t bytes, int want_rbsp, hbs_summary* sum, hbs_nal_entry* ent)
+/* scan + extract the first `bytes` of the device input buffer (no wait) */
+static void launch_index(uint64_t bytes, int want_rbsp)
 {
     int rc = hbs_index_extract(g_ctx, g_dbuf, bytes, g_dindex, LEGACY_INDEX_CAP,
                                want_rbsp ? g_dout : NULL, want_rbsp ? g_dout_cap : 0, g_dsummary);
     if (rc) die("hbs_index_extract", rc);
-    if ((rc = hbs_read_summary(g_ctx, g_dsummary, sum))) die("hbs_read_summary", rc);
-    if ((rc = hbs_copy_to_host(g_ctx, ent, g_dindex, LEGACY_INDEX_CAP * sizeof(hbs_nal_entry)))) die("hbs_copy_to_host", rc);
+}
+
+/* the front `bytes` of the result block to the host (waits for everything enqueued so far) */
+static void fetch_results(uint64_t bytes, hbs_summary* sum, hbs_nal_entry* ent)
+{
+    int rc;
+    if ((rc = hbs_copy_to_host(g_ctx, g_hres, g_dblock, bytes))) die("hbs_copy_to_host", rc);
+    memcpy(sum, g_hres + RES_SUMMARY, sizeof(*sum));
+    memcpy(ent, g_hres + RES_INDEX, LEGACY_INDEX_CAP * sizeof(hbs_nal_entry));
 }
 
 /* ---- byte layer ------------------------------------------------------------------------- */
@@ -112,8 +174,9 @@ int find_nal_unit(uint8_t* buf, int size, int* nal_start, int* nal_end)
         hbs_nal_entry e[LEGACY_INDEX_CAP];
         if (len > (uint64_t)size) len = (uint64_t)size;
         need_bufs(len, 0);
-        { int rc = hbs_copy_to_device(g_ctx, g_dbuf, buf, len); if (rc) die("hbs_copy_to_device", rc); }
-        run_index(len, 0, &s, e);
+        upload_input(NULL, 0, buf, len);
+        launch_index(len, 0);
+        fetch_results(RES_SMALL, &s, e);
         if (s.nal_found >= 1 && !(e[0].status & HBS_ST_UNTERMINATED)) {
             /* first NAL terminated inside the prefix (possibly empty: the loop of the callers stops) */
             *nal_start = (int)e[0].start;
@@ -142,9 +205,9 @@ int nal_to_rbsp(const uint8_t* nal_buf, int* nal_size, uint8_t* rbsp_buf, int* r
     need_ctx();
     need_bufs((uint64_t)n + 16, (uint64_t)n + 16);
     /* the kernel works on Annex-B: put a start code in front of the NAL */
-    if ((rc = hbs_copy_to_device(g_ctx, g_dbuf, sc, 3))) die("hbs_copy_to_device", rc);
-    if ((rc = hbs_copy_to_device(g_ctx, g_dbuf + 3, nal_buf, (uint64_t)n))) die("hbs_copy_to_device", rc);
-    run_index((uint64_t)n + 3, 1, &s, e);
+    upload_input(sc, 3, nal_buf, (uint64_t)n);
+    launch_index((uint64_t)n + 3, 1);
+    fetch_results(RES_SMALL, &s, e);
     /* a 00 00 00 / 00 00 01 inside the NAL would end it early: nal_to_rbsp rejects those (h264_nal.c:156-159) */
     if (s.nal_found < 1 || e[0].start != 3 || e[0].end != (uint64_t)n + 3 || (e[0].status & HBS_ST_ERROR)) return -1;
     if ((int)e[0].rbsp_len > *rbsp_size) return -1;                      /* h264_nal.c:179-183 */
@@ -278,7 +341,10 @@ static void print_trace(void)
 
 static int is_slice(int t) { return (t >= 0 && t <= 9) || (t >= 16 && t <= 21); }
 
-/* *stripped = 0 when nal_to_rbsp already rejected the NAL (nothing of *h is touched then) */
+/* *stripped = 0 when nal_to_rbsp already rejected the NAL (nothing of *h is touched then).
+ * One upload, the scan and the parse back to back, one download of summary + index + parsed record +
+ * slice-sized struct: the host looks at the scan's answer only afterwards (a parse of a NAL the scan
+ * rejected writes device scratch nobody reads). */
 static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int trace)
 {
     static const uint8_t sc[3] = {0, 0, 1};
@@ -290,20 +356,20 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     if (size < 0) return -1;
     need_ctx();
     need_bufs((uint64_t)size + 16, (uint64_t)size + 16);
-    if ((rc = hbs_copy_to_device(g_ctx, g_dbuf, sc, 3))) die("hbs_copy_to_device", rc);
-    if ((rc = hbs_copy_to_device(g_ctx, g_dbuf + 3, buf, (uint64_t)size))) die("hbs_copy_to_device", rc);
-    run_index((uint64_t)size + 3, 1, &s, e);
-    if (s.nal_found < 1 || e[0].start != 3 || e[0].end != (uint64_t)size + 3 || (e[0].status & HBS_ST_ERROR))
-        return -1;                                                       /* hevc_stream.c:167 */
-    *stripped = 1;
+    upload_input(sc, 3, buf, (uint64_t)size);
     /* the parameter sets in force are whatever the caller's object holds (hevc_stream.c:800-801);
      * the derived RPS tables live on the device next to the SPS */
-    if ((rc = hbs_copy_to_device(g_ctx, g_dsps_slot, h->sps, sizeof(hevc_sps_t)))) die("hbs_copy_to_device", rc);
-    if ((rc = hbs_copy_to_device(g_ctx, g_dpps, h->pps, sizeof(hevc_pps_t)))) die("hbs_copy_to_device", rc);
+    sync_context(h);
+    launch_index((uint64_t)size + 3, 1);
     if (trace) need_trace();
     if ((rc = hbs_parse_headers_trace(g_ctx, g_dout, g_dindex, 1, g_dparsed, g_dstruct, sizeof(hevc_vps_t) + 64,
                                       g_dsps_slot, g_dpps, trace ? g_dtrace : NULL, trace ? TRACE_CAP : 0,
-                                      trace ? g_dtrace_count : NULL, g_dsummary))) die("hbs_parse_headers", rc);
+                                      trace ? g_dtrace_count : NULL, (hbs_summary*)(g_dblock + RES_SUMMARY2)))) die("hbs_parse_headers", rc);
+    fetch_results(RES_SLICE, &s, e);
+    memcpy(&p, g_hres + RES_PARSED, sizeof(p));
+    if (s.nal_found < 1 || e[0].start != 3 || e[0].end != (uint64_t)size + 3 || (e[0].status & HBS_ST_ERROR))
+        return -1;                                                       /* hevc_stream.c:167 */
+    *stripped = 1;
     if (trace) {
         /* hevc_stream.c:2363-2367: the header lines, then one line per syntax element the parser read */
         printf("0.8: forbidden_zero_bit: %d \n", (buf[0] >> 7) & 1);
@@ -312,7 +378,6 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
         printf("1.3: nal->nal_temporal_id_plus1: %d \n", (size > 1 ? buf[1] : 0) & 7);
         print_trace();
     }
-    if ((rc = hbs_copy_to_host(g_ctx, &p, g_dparsed, sizeof(p)))) die("hbs_copy_to_host", rc);
     t = p.nal_unit_type;
     h->nal->nal_unit_type = t;
     h->nal->nal_layer_id = p.nal_layer_id;
@@ -321,22 +386,19 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     if (t == HEVC_NAL_UNIT_TYPE_VPS_NUT) {
         if ((rc = hbs_copy_to_host(g_ctx, h->vps, g_dstruct, sizeof(hevc_vps_t)))) die("hbs_copy_to_host", rc);
     } else if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+        /* keep it, with its derived tables, for the slices to come (device to device), then fetch the struct */
+        if ((rc = hbs_copy_device(g_ctx, g_dsps_slot, g_dstruct, hbs_sps_slot_bytes()))) die("hbs_copy_device", rc);
         if ((rc = hbs_copy_to_host(g_ctx, h->sps, g_dstruct, sizeof(hevc_sps_t)))) die("hbs_copy_to_host", rc);
-        /* keep its derived tables for the slices to come */
-        {
-            uint8_t* tmp = (uint8_t*)malloc(hbs_sps_slot_bytes());
-            if ((rc = hbs_copy_to_host(g_ctx, tmp, g_dstruct, hbs_sps_slot_bytes()))) die("hbs_copy_to_host", rc);
-            if ((rc = hbs_copy_to_device(g_ctx, g_dsps_slot, tmp, hbs_sps_slot_bytes()))) die("hbs_copy_to_device", rc);
-            free(tmp);
-        }
+        memcpy(g_sps_shadow, h->sps, sizeof(hevc_sps_t));
+        g_sps_shadow_ok = 1;
         if (h->sps->sps_seq_parameter_set_id >= 0 && h->sps->sps_seq_parameter_set_id < 32)
             memcpy(h->sps_table[h->sps->sps_seq_parameter_set_id], h->sps, sizeof(hevc_sps_t));      /* :399 */
     } else if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) {
-        if ((rc = hbs_copy_to_host(g_ctx, h->pps, g_dstruct, sizeof(hevc_pps_t)))) die("hbs_copy_to_host", rc);
+        memcpy(h->pps, g_hres + RES_STRUCT, sizeof(hevc_pps_t));          /* smaller than a slice header: already here */
         if (h->pps->pic_parameter_set_id >= 0 && h->pps->pic_parameter_set_id < 256)
             memcpy(h->pps_table[h->pps->pic_parameter_set_id], h->pps, sizeof(hevc_pps_t));          /* :498 */
     } else if (is_slice(t)) {
-        if ((rc = hbs_copy_to_host(g_ctx, h->sh, g_dstruct, sizeof(hevc_slice_header_t)))) die("hbs_copy_to_host", rc);
+        memcpy(h->sh, g_hres + RES_STRUCT, sizeof(hevc_slice_header_t));
         if (h->slice_data) {                                             /* hevc_stream.c:605-613 */
             free(h->slice_data->rbsp_buf);
             h->slice_data->rbsp_buf = NULL;
@@ -399,8 +461,7 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     else if (is_slice(t)) { src = h->sh; src_bytes = sizeof(hevc_slice_header_t); }
     else return -1;                                                      /* :1306 */
     /* parameter sets in force: what the object holds (the SPS's derived tables stay on the device) */
-    if ((rc = hbs_copy_to_device(g_ctx, g_dsps_slot, h->sps, sizeof(hevc_sps_t)))) die("hbs_copy_to_device", rc);
-    if ((rc = hbs_copy_to_device(g_ctx, g_dpps, h->pps, sizeof(hevc_pps_t)))) die("hbs_copy_to_device", rc);
+    sync_context(h);
     if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
         /* written in place in its slot so that the tables it derives replace the ones in force */
         p.struct_off = 0;

@@ -270,6 +270,12 @@ int hbs_dev_free(hbs_ctx* ctx, void* p);
 int hbs_copy_to_device(hbs_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
 int hbs_copy_to_host(hbs_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
 int hbs_fill_device(hbs_ctx* ctx, void* d_dst, int value, uint64_t bytes);
+/* page-locked host memory, a host-to-device copy that does not wait (source must be page-locked and
+ * stay untouched until the stream has passed it), device-to-device copy on the context's stream */
+int hbs_host_alloc(hbs_ctx* ctx, uint64_t bytes, void** out);
+int hbs_host_free(hbs_ctx* ctx, void* p);
+int hbs_copy_to_device_async(hbs_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+int hbs_copy_device(hbs_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);
 
 /* Synchronising copy of a device hbs_summary to the host. */
 int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_summary);
