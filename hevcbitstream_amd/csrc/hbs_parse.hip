@@ -15,7 +15,6 @@
 
 namespace hbs {
 
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
                         ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size)
@@ -189,6 +188,59 @@ __device__ __forceinline__ void zero_slice_slots(const ParsedNal* __restrict__ p
     }
 }
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kLaneWin = 64;
+constexpr uint32_t kLaneWinStride = kLaneWin + 4;
+
+/* the first wb bytes of a lane's RBSP into its LDS window */
+__device__ __forceinline__ void stage_window(uint8_t* my_win, const uint8_t* __restrict__ src, uint32_t wb)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4_t v; };
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneWin; i += 16) {
+        if (i + 16 <= wb) {
+            const u32x4_t v = reinterpret_cast<const U16*>(src + i)->v;
+            uint32_t* d = reinterpret_cast<uint32_t*>(my_win + i);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            for (uint32_t b = i; b < wb; ++b) my_win[b] = src[b];
+        }
+    }
+}
+
+/* one lane, one NAL: the walk over its syntax into the (cleared) struct at dst.  sps_slot = the SPS in force with
+ * its derived tables behind it, pps_struct = the PPS in force (nullptr: none, the all-zero set); returns the
+ * number of trace records the walk produced */
+template <int kMode>
+__device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_nal_entry& e, uint8_t* dst,
+                                               const uint8_t* my_win, uint32_t wb, const uint8_t* src,
+                                               const uint8_t* sps_slot, const uint8_t* pps_struct, const uint8_t* zeros,
+                                               ParsedNal& out, TraceRec* trace, uint32_t trace_cap, RpsRow* own_row)
+{
+    ParserT<kMode> ps;
+    ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
+    ps.b.tr = trace; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
+    ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+    const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
+    const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
+    const hevc_sps_t* last_sps = zero_sps;
+    const hevc_pps_t* last_pps = zero_pps;
+    if (slice) {
+        reinterpret_cast<hevc_slice_header_t*>(dst)->collocated_from_l0_flag = 1;
+        if (sps_slot) {
+            last_sps = reinterpret_cast<const hevc_sps_t*>(sps_slot);
+            ps.sps_rps = reinterpret_cast<const RpsTables*>(sps_slot + round16(sizeof(hevc_sps_t)));
+        }
+        if (pps_struct) last_pps = reinterpret_cast<const hevc_pps_t*>(pps_struct);
+        ps.own = own_row;
+    } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+        ps.out_rps = reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
+    }
+    const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
+    parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
+    return ps.b.tr_n;
+}
+
 /* One NAL per LANE: a wavefront walks 64 consecutive NALs at once.  The walk is a long chain of
  * dependent scalar steps (a bit at a time, as bs.h does), so one parser per wavefront left the
  * machine with ~4000 parsers in flight; the slices of a stream mostly take the same path through
@@ -203,9 +255,6 @@ __device__ __forceinline__ void zero_slice_slots(const ParsedNal* __restrict__ p
 #endif
 constexpr int kParseLanes = HBS_PARSE_LANES;          /* NALs a wavefront walks at once (lanes 0 .. kParseLanes-1) */
 constexpr unsigned kZeroBlocks = 1024;                /* spare workgroups of the parameter-set launch that clear slice slots */
-constexpr uint32_t kLaneWin = 64;
-constexpr uint32_t kLaneWinStride = kLaneWin + 4;
-
 template <int kMode>
 __global__ __launch_bounds__(256)
 void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int pass,
@@ -217,7 +266,6 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
-    struct __attribute__((packed, aligned(1))) U16 { u32x4_t v; };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (blockIdx.x >= parse_blocks) {                          /* pass 0 only: the spare workgroups */
         zero_slice_slots(parsed, n, structs, structs_cap, (uint64_t)(blockIdx.x - parse_blocks) * 4u + (uint64_t)wv,
@@ -266,56 +314,131 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         /* first bytes of my RBSP into my LDS window */
         const uint8_t* src = rbsp + e.rbsp_off;
         const uint32_t wb = e.rbsp_len < kLaneWin ? e.rbsp_len : kLaneWin;
-        if (active) {
-#pragma unroll
-            for (uint32_t i = 0; i < kLaneWin; i += 16) {
-                if (i + 16 <= wb) {
-                    const u32x4_t v = reinterpret_cast<const U16*>(src + i)->v;
-                    uint32_t* d = reinterpret_cast<uint32_t*>(my_win + i);
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                } else {
-                    for (uint32_t b = i; b < wb; ++b) my_win[b] = src[b];
-                }
-            }
-        }
+        if (active) stage_window(my_win, src, wb);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
         if (active) {
-            uint8_t* dst = structs + off;
-            ParserT<kMode> ps;
-            ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
-            ps.b.tr = trace ? trace + k * (uint64_t)trace_cap : nullptr; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
-            ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
-            const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
-            const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
-            const hevc_sps_t* last_sps = zero_sps;
-            const hevc_pps_t* last_pps = zero_pps;
+            const uint8_t* sps_slot = nullptr;
+            const uint8_t* pps_struct = nullptr;
             if (slice) {
-                reinterpret_cast<hevc_slice_header_t*>(dst)->collocated_from_l0_flag = 1;
                 const long long cs = ctx_sps[k], cp = ctx_pps[k];
-                if (cs >= 0 && parsed[cs].struct_off != ~0ull) {
-                    last_sps = reinterpret_cast<const hevc_sps_t*>(structs + parsed[cs].struct_off);
-                    ps.sps_rps = reinterpret_cast<const RpsTables*>(structs + parsed[cs].struct_off + round16(sizeof(hevc_sps_t)));
-                } else if (cs < 0 && init_sps_slot) {              /* context handed in by the caller */
-                    last_sps = reinterpret_cast<const hevc_sps_t*>(init_sps_slot);
-                    ps.sps_rps = reinterpret_cast<const RpsTables*>(init_sps_slot + round16(sizeof(hevc_sps_t)));
-                }
-                if (cp >= 0 && parsed[cp].struct_off != ~0ull)
-                    last_pps = reinterpret_cast<const hevc_pps_t*>(structs + parsed[cp].struct_off);
-                else if (cp < 0 && init_pps)
-                    last_pps = reinterpret_cast<const hevc_pps_t*>(init_pps);
-                ps.own = &my_rows[lane];
-            } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
-                ps.out_rps = reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
+                if (cs >= 0) { if (parsed[cs].struct_off != ~0ull) sps_slot = structs + parsed[cs].struct_off; }
+                else sps_slot = init_sps_slot;                    /* context handed in by the caller */
+                if (cp >= 0) { if (parsed[cp].struct_off != ~0ull) pps_struct = structs + parsed[cp].struct_off; }
+                else pps_struct = init_pps;
             }
-            const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
             ParsedNal out = parsed[k];
-            parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
+            const uint32_t tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, out,
+                                                    trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane]);
             parsed[k] = out;
-            if (trace_count) trace_count[k] = ps.b.tr_n;
+            if (trace_count) trace_count[k] = tr_n;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* A batch of at most 64 NALs (the legacy single-NAL symbols parse one per call): plan, scan, clearing,
+ * parameter sets, slices and the summary in ONE launch of one wavefront instead of ten launches. */
+template <int kMode>
+__global__ __launch_bounds__(64)
+void k4_small(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
+              ParsedNal* __restrict__ parsed, uint8_t* structs, uint64_t structs_cap,
+              const uint8_t* __restrict__ zeros, const uint8_t* init_sps_slot, const uint8_t* init_pps,
+              TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
+              RpsRow* __restrict__ own_rows /* 64 */, hbs_summary* __restrict__ sum)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t win[64 * kLaneWinStride];
+    const int lane = threadIdx.x;
+    uint8_t* const my_win = win + (uint32_t)lane * kLaneWinStride;
+    const bool have = (uint64_t)lane < n;
+
+    /* plan (k4_plan) */
+    hbs_nal_entry e;
+    e.start = e.end = e.rbsp_off = 0; e.rbsp_len = 0; e.status = 0;
+    ParsedNal p;
+    p.rc = -1; p.nal_unit_type = -1; p.nal_layer_id = -1; p.nal_temporal_id_plus1 = -1;
+    p.struct_off = ~0ull; p.slice_data_size = 0; p.slice_data_off = 0;
+    uint64_t sz = 0;
+    if (have) {
+        e = idx[lane];
+        if (!(e.status & HBS_ST_ERROR)) {
+            nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
+            sz = slot_bytes_of(p.nal_unit_type);
+        }
+    }
+    const int type = p.nal_unit_type;
+    /* slots and the parameter sets in force (k4_scan_*) */
+    Scan3 x;
+    x.sum = sz;
+    x.sps = (have && type == HEVC_NAL_UNIT_TYPE_SPS_NUT) ? (long long)lane : -1;
+    x.pps = (have && type == HEVC_NAL_UNIT_TYPE_PPS_NUT) ? (long long)lane : -1;
+    Scan3 inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const Scan3 t = scan3_shfl_up(inc, d);
+        if (lane >= d) inc = scan3_join(t, inc);
+    }
+    Scan3 ex = scan3_shfl_up(inc, 1);
+    if (lane == 0) { ex.sum = 0; ex.sps = -1; ex.pps = -1; }
+    const unsigned long long total = __shfl(inc.sum, 63, 64);
+    if (sz) p.struct_off = ex.sum;
+    uint32_t err = 0;
+
+    const bool slice = is_slice_type_nal(type);
+    const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
+    bool active = structs != nullptr && have && type >= 0 && (slice || pset);
+    if (active && p.struct_off + sz > structs_cap) { err = (uint32_t)(-HBS_E_CAPACITY); p.struct_off = ~0ull; active = false; }
+    const uint64_t off = p.struct_off;
+    uint32_t tr_n = 0;
+    if (structs != nullptr) {
+        /* the memset of every struct that gets parsed, and fresh rows for the slices' own short-term RPS */
+        uint64_t todo = __ballot(active);
+        while (todo) {
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint64_t oj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), j) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, j);
+            zero_slot(structs + oj, slot_bytes_of(__builtin_amdgcn_readlane(type, j)), lane);
+        }
+        zero_slot(reinterpret_cast<uint8_t*>(own_rows), 64 * sizeof(RpsRow), lane);
+        const uint8_t* src = rbsp + e.rbsp_off;
+        const uint32_t wb = e.rbsp_len < kLaneWin ? e.rbsp_len : kLaneWin;
+        if (active) stage_window(my_win, src, wb);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        /* where the parameter sets in force live: the lane that parsed them says */
+        const uint64_t sps_off = (uint64_t)__shfl((unsigned long long)off, ex.sps >= 0 ? (int)ex.sps : 0, 64);
+        const uint64_t pps_off = (uint64_t)__shfl((unsigned long long)off, ex.pps >= 0 ? (int)ex.pps : 0, 64);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (active && (pass == 0) == pset) {
+                const uint8_t* sps_slot = nullptr;
+                const uint8_t* pps_struct = nullptr;
+                if (slice) {
+                    if (ex.sps >= 0) { if (sps_off != ~0ull) sps_slot = structs + sps_off; }
+                    else sps_slot = init_sps_slot;
+                    if (ex.pps >= 0) { if (pps_off != ~0ull) pps_struct = structs + pps_off; }
+                    else pps_struct = init_pps;
+                }
+                tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, p,
+                                         trace ? trace + (uint64_t)lane * trace_cap : nullptr, trace_cap, &own_rows[lane]);
+            }
+            /* the slices read what the parameter-set lanes have just written */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    if (have) {
+        parsed[lane] = p;
+        if (trace_count) trace_count[lane] = tr_n;
+    }
+    const uint64_t any_err = __ballot(err != 0);
+    if (lane == 0) {
+        sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = 0; sum->stream_bytes = 0;
+        sum->stop_reason = 0; sum->error = any_err ? HBS_E_CAPACITY : 0;
+        sum->reserved[0] = total;                    /* struct arena bytes needed */
+        sum->reserved[1] = sum->reserved[2] = 0;
     }
 }
 
@@ -412,6 +535,15 @@ uint64_t parse_own_rows_bytes(uint64_t n) { return (uint64_t)parse_grid_blocks(n
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
 {
+    if (a.n >= 1 && a.n <= 64) {
+        if (a.trace)
+            k4_small<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                   a.initial_pps, a.trace, a.trace_cap, a.trace_count, a.own_rows, a.summary);
+        else
+            k4_small<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                  a.initial_pps, nullptr, 0, nullptr, a.own_rows, a.summary);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
