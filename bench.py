@@ -295,7 +295,7 @@ def main():
         if tr is not None:
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
-        if args.cpu_sample_nals > 0:
+        if world == 1 and args.cpu_sample_nals > 0:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(stream, gen_index, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:
             del rbsp, index

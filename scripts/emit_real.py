@@ -3,6 +3,10 @@ parameter-set sized NALs.  usage: python3 scripts/emit_real.py [GiB]"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+if os.environ.get("HBS_LIB"):
+    import hevcbitstream_amd.api as _api
+    _api.library_path = lambda: os.environ["HBS_LIB"]
 import hevcbitstream_amd as hbs
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 rng = np.random.default_rng(9)

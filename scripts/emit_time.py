@@ -2,6 +2,10 @@
 import sys
 import torch
 sys.path.insert(0, ".")
+import os
+if os.environ.get("HBS_LIB"):
+    import hevcbitstream_amd.api as _api
+    _api.library_path = lambda: os.environ["HBS_LIB"]
 import hevcbitstream_amd as hbs
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ctx = hbs.Context(0)
