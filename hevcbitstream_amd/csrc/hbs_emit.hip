@@ -573,6 +573,8 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
         const uint64_t g = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
         if (g >= ngroups) break;
         HBS3_T_MARK(0)
+        /* until the group's size is out, this workgroup is what its successors wait for */
+        __builtin_amdgcn_s_setprio(3);
         const SlotEntry ent = fetch_entries(idx, n, gap_mode, items, n_items, g * kEmitGroup + (uint64_t)(kEmitSlots * wv), lane);
         HBS3_T_MARK(1)
 
@@ -615,12 +617,15 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
             const unsigned long long inc = wave_incl_scan_u64(x, lane);
             const unsigned long long agg = __shfl(inc, kEmitGroup - 1, 64);
             if (lane == 0 && g != 0) st_desc3(desc + g, (agg << 2) | 1ull);
+            __builtin_amdgcn_s_setprio(0);
             const unsigned long long before = HBS_K3_EXP(1) ? g * 123000ull : k3_look_back(desc, g, lane, err);
             if (lane == 0) {
                 st_desc3(desc + g, ((before + agg) << 2) | 2ull);
                 if (g == ngroups - 1) *total = before + agg;
             }
             if (lane < kEmitGroup) l.off[lane] = before + inc - x;
+        } else {
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         HBS3_T_MARK(5)
