@@ -4,7 +4,9 @@
  * caller's buffers to and from the GPU and calls hbs_*; every byte is scanned,
  * stripped, inserted or parsed by the HIP kernels.  No CPU implementation of
  * the algorithms exists in this file, and without a gfx950 GPU the first call
- * prints a diagnostic and abort()s.
+ * prints a diagnostic and abort()s.  A call is launch and copy latency, so the
+ * wrappers keep it to one upload (page-locked staging), the kernels back to
+ * back, and one download of a result block (see need_ctx).
  *
  * Symbols and the reference interface each one replaces:
  *   find_nal_unit               h264_nal.c:38-76       (proto h264_stream.h:54)
@@ -14,7 +16,7 @@
  *   peek_hevc_nal_unit          hevc_nal.c:97-114
  *   read_hevc_nal_unit          hevc_stream.c:155-240
  *   read_debug_hevc_nal_unit    hevc_stream.c:2343-3434 (per-field trace from the GPU parser's log)
- *   write_hevc_nal_unit         hevc_stream.c:1249-1333 (syntax writers: not in this round)
+ *   write_hevc_nal_unit         hevc_stream.c:1249-1333 (the GPU parser's walk in write mode, then rbsp_to_nal)
  *   debug_bytes, h264_dbgfile   h264_stream.c:33, :117-126
  *
  * Like the reference, one parser at a time: the derived RPS tables are process
