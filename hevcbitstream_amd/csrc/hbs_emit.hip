@@ -272,22 +272,22 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
 }
 
 /* ---- single pass: count, look-back, emit ---------------------------------------------------
- * A workgroup takes a group of kEmitGroup consecutive NALs by ticket, kEmitSlots per wavefront
- * (fat wavefronts, 2 workgroups per CU, as in K12).  A wavefront loads up to kEmitRows rows of
- * 1 KiB of each of its NALs into registers in one burst (lane l = 16 bytes at 16 l of each row)
+ * The unit of work is an ITEM: rows [12 s, 12 s + 12) of a NAL ("segment"; see "work items" below).
+ * A workgroup takes a group of kEmitGroup consecutive items by ticket, kEmitSlots per wavefront
+ * (fat wavefronts, 2 workgroups per CU, as in K12).  A wavefront loads the up to kEmitRows rows of
+ * 1 KiB of each of its items into registers in one burst (lane l = 16 bytes at 16 l of each row)
  * and counts the bytes rbsp_to_nal would insert; wavefront 0 publishes the group's output size
  * and looks back over the groups in front of it (decoupled look-back: one 64-bit word per group,
  * value << 2 | status, status 1 = size of the group, 2 = size of everything up to and including
- * it; 256 groups per step); then every wavefront writes its NALs from the registers it still
- * holds (a NAL longer than kEmitRows KiB is read a second time, batch by batch).  HBM
- * traffic: RBSP read once, stream written once.  Tickets are taken by running workgroups only and
- * a workgroup finishes its groups in ticket order, so every group a look-back waits for is being
- * worked on.  (Look-back units as small as one wavefront's share were tried: with 2048 of them in
- * flight the prefix frontier cannot advance fast enough, 3x slower.)
+ * it; 256 groups per step); then every wavefront writes its items from the registers it still
+ * holds.  HBM traffic: RBSP read once, stream written once.  Tickets are taken by running
+ * workgroups only and a workgroup finishes its groups in ticket order, so every group a look-back
+ * waits for is being worked on.  (Look-back units as small as one wavefront's share were tried:
+ * with 2048 of them in flight the prefix frontier cannot advance fast enough, 3x slower.)
  *
  * Rows that chunk_flag() clears are copied straight from registers; a row with a flagged chunk
- * (or with the NAL's partial last chunk) goes through a rolled loop that runs the byte-exact
- * rules of hbs_emit.h on memory, so the unrolled code stays small. */
+ * goes through a rolled loop that runs the byte-exact rules of hbs_emit.h on memory, so the
+ * unrolled code stays small. */
 #ifdef HBS_PHASE_TIMING
 /* diagnostic build only (make diag, scripts/emit_phase.py): bit 0 skips the stores, bit 1 the look-back wait, bit 2 the count */
 __device__ int g_k3_exp = 0;

@@ -1,13 +1,16 @@
 /*
- * hbs_parse.hip -- K4 driver: one NAL per wavefront header parse over the RBSP
- * arena that K12 produced (see hbs_parse.h for the syntax readers).
+ * hbs_parse.hip -- K4 / K5 drivers: header parse and header writers, one NAL per
+ * lane, over the RBSP arena that K12 produced (see hbs_parse.h for the syntax walk).
  *
  *   k4_plan    per NAL: type from RBSP bytes 0-1 (reference hevc_stream.c:176-179),
  *              bytes of the struct it parses into
  *   k4_scan_*  struct arena offsets; for every NAL the ordinal of
  *              the last SPS / PPS in front of it (the reference's "h->sps / h->pps
  *              as left by the last parse", hevc_stream.c:800-801)
- *   k4_parse   wave per NAL; pass 1 parameter sets, pass 2 slices against them
+ *   k4_parse   a wavefront walks 64 NALs in lock step; launch 1 parameter sets (its spare
+ *              workgroups clear the slice slots), launch 2 slices against them
+ *   k4_small   all of the above for at most 64 NALs, in one launch of one wavefront
+ *   k5_write   the same walk in write mode (structs -> RBSP)
  */
 #include <hip/hip_runtime.h>
 #include "hbs_parse.h"

@@ -1,5 +1,5 @@
 """CPU single-step of the product's header readers (hbs_parse.h, the code K4
-runs per wavefront) against the oracle parser, on streams from tests/hevc_synth."""
+runs per lane) against the oracle parser, on streams from tests/hevc_synth."""
 import json
 import os
 
