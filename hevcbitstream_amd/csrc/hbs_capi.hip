@@ -31,6 +31,8 @@ struct hbs_ctx {
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
+    void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
+    void (*attachment_free)(void*);
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
     int sched;
     unsigned long long* desc;
@@ -134,6 +136,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->attachment && c->attachment_free) c->attachment_free(c->attachment);
     if (c->desc) (void)hipFree(c->desc);
     if (c->hdr) (void)hipFree(c->hdr);
     if (c->tail) (void)hipFree(c->tail);
@@ -142,6 +145,15 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->ev0) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+/* internal (hbs_ingest.hip): one object kept alive with the context, freed with it */
+void* hbs_ctx_attachment(hbs_ctx* c) { return c ? c->attachment : nullptr; }
+void hbs_ctx_attach(hbs_ctx* c, void* p, void (*free_fn)(void*))
+{
+    if (!c) return;
+    if (c->attachment && c->attachment_free && c->attachment != p) c->attachment_free(c->attachment);
+    c->attachment = p; c->attachment_free = free_fn;
 }
 
 int hbs_ctx_set_stream(hbs_ctx* c, void* s)

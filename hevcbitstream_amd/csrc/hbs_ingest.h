@@ -41,6 +41,7 @@ namespace hbs {
  *   int carry(from_buf, from_off, to_buf, to_off, len)   window-buffer to window-buffer
  *   int scan(buf, off, len, hbs_summary* out)     run K12 on buffer bytes [off, off+len); synchronous result
  *   int fetch_index(first, count, hbs_nal_entry* dst)    entries [first, first+count) of the last scan (window-relative)
+ *   hbs_nal_entry* staging(); uint64_t staging_entries() where fetch_index may put them (page-locked on the GPU)
  *   int fetch_rbsp(off, len, uint64_t dst_off)           RBSP bytes of the last scan -> caller's arena at dst_off
  *   uint64_t index_capacity()                     entries one scan can return
  */
@@ -59,7 +60,7 @@ int ingest_windowed(Backend& be, uint64_t n, uint64_t window_bytes,
     int rc = be.begin(n);
     if (rc) return rc;
 
-    struct Staging { hbs_nal_entry e[1024]; } tmp;    /* entries on their way to the caller's index */
+    hbs_nal_entry* const stage = be.staging();         /* entries on their way to the caller's index */
     uint64_t lo = 0;                   /* the walk resumes here (a NAL end, or 0) */
     uint64_t hi = 0;                   /* stream bytes uploaded so far             */
     int buf = 0;
@@ -109,13 +110,13 @@ int ingest_windowed(Backend& be, uint64_t n, uint64_t window_bytes,
         /* entries: skip the ones found again, rebase, append */
         uint64_t new_lo = lo;
         uint64_t first_kept = keep, kept = 0, rbsp_first = 0, rbsp_end = 0;
-        const uint64_t chunk = sizeof(tmp.e) / sizeof(tmp.e[0]);
+        const uint64_t chunk = be.staging_entries();
         for (uint64_t i = 0; i < keep; i += chunk) {
             const uint64_t m = (keep - i) < chunk ? (keep - i) : chunk;
-            rc = be.fetch_index(i, m, tmp.e);
+            rc = be.fetch_index(i, m, stage);
             if (rc) return rc;
             for (uint64_t j = 0; j < m; ++j) {
-                hbs_nal_entry e = tmp.e[j];
+                hbs_nal_entry e = stage[j];
                 const uint64_t gstart = a + e.start, gend = a + e.end;
                 if (have_last && gstart <= last_start) continue;            /* found again after the round-down */
                 if (first_kept == keep) { first_kept = i + j; rbsp_first = e.rbsp_off; }

@@ -10,11 +10,15 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <new>
 #include "hbs_ingest.h"
 
 extern "C" {
 int hbs_ctx_set_stream(hbs_ctx* ctx, void* hip_stream);
 void* hbs_ctx_get_stream(hbs_ctx* ctx);
+/* internal: an object that lives and dies with the context (hbs_capi.hip) */
+void* hbs_ctx_attachment(hbs_ctx* ctx);
+void hbs_ctx_attach(hbs_ctx* ctx, void* p, void (*free_fn)(void*));
 }
 
 namespace {
@@ -23,6 +27,7 @@ struct HipBackend {
     hbs_ctx* ctx;
     const uint8_t* h_stream;
     uint8_t* h_rbsp;                   /* nullable */
+    bool want_rbsp = false;
     uint64_t lead, window;
     uint64_t idx_cap;
     uint8_t* d_buf[2] = {nullptr, nullptr};
@@ -30,6 +35,8 @@ struct HipBackend {
     uint8_t* d_rbsp = nullptr;
     hbs_nal_entry* d_index = nullptr;
     hbs_summary* d_summary = nullptr;
+    hbs_nal_entry* h_stage = nullptr;  /* page-locked: a window's entries usually come down in one copy */
+    static constexpr uint64_t kStageEntries = 65536;
     hipStream_t s_in = nullptr, s_cmp = nullptr;
     hipEvent_t up_done[2] = {nullptr, nullptr}, buf_free[2] = {nullptr, nullptr};
     void* saved_stream = nullptr;
@@ -38,10 +45,15 @@ struct HipBackend {
     uint64_t lead_capacity() const { return lead; }
     uint64_t index_capacity() const { return idx_cap; }
     uint64_t fresh_len(int b) const { return fresh[b]; }
+    hbs_nal_entry* staging() const { return h_stage; }
+    uint64_t staging_entries() const { return kStageEntries; }
 
     int ok(hipError_t e) { if (e != hipSuccess) { err = e; return HBS_E_HIP; } return 0; }
 
-    int begin(uint64_t)
+    /* device buffers, streams and events: made once per (window size, RBSP wanted) and kept with the context --
+     * a hipMalloc of gigabytes costs more than the transfer of a window */
+    bool allocated = false;
+    int allocate()
     {
         const uint64_t cap = lead + window + 256;
         for (int b = 0; b < 2; ++b) {
@@ -49,17 +61,18 @@ struct HipBackend {
             if (int rc = ok(hipEventCreateWithFlags(&up_done[b], hipEventDisableTiming))) return rc;
             if (int rc = ok(hipEventCreateWithFlags(&buf_free[b], hipEventDisableTiming))) return rc;
         }
-        if (h_rbsp) if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_rbsp), cap))) return rc;
+        if (want_rbsp) if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_rbsp), cap))) return rc;
         if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_index), (idx_cap ? idx_cap : 1) * sizeof(hbs_nal_entry)))) return rc;
         if (int rc = ok(hipMalloc(reinterpret_cast<void**>(&d_summary), sizeof(hbs_summary)))) return rc;
+        if (int rc = ok(hipHostMalloc(reinterpret_cast<void**>(&h_stage), kStageEntries * sizeof(hbs_nal_entry), hipHostMallocDefault))) return rc;
         if (int rc = ok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking))) return rc;
         if (int rc = ok(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking))) return rc;
-        saved_stream = hbs_ctx_get_stream(ctx);
-        return hbs_ctx_set_stream(ctx, s_cmp);
+        allocated = true;
+        return 0;
     }
-    void end()
+    void release()
     {
-        if (s_cmp) { (void)hipStreamSynchronize(s_cmp); (void)hbs_ctx_set_stream(ctx, saved_stream); }
+        if (s_cmp) (void)hipStreamSynchronize(s_cmp);
         if (s_in) (void)hipStreamSynchronize(s_in);
         for (int b = 0; b < 2; ++b) {
             if (d_buf[b]) (void)hipFree(d_buf[b]);
@@ -69,8 +82,23 @@ struct HipBackend {
         if (d_rbsp) (void)hipFree(d_rbsp);
         if (d_index) (void)hipFree(d_index);
         if (d_summary) (void)hipFree(d_summary);
+        if (h_stage) (void)hipHostFree(h_stage);
         if (s_in) (void)hipStreamDestroy(s_in);
         if (s_cmp) (void)hipStreamDestroy(s_cmp);
+    }
+    int begin(uint64_t)
+    {
+        if (!allocated) if (int rc = allocate()) return rc;
+        fresh[0] = fresh[1] = 0;
+        /* a fresh run: both window buffers are free */
+        for (int b = 0; b < 2; ++b) if (int rc = ok(hipEventRecord(buf_free[b], s_cmp))) return rc;
+        saved_stream = hbs_ctx_get_stream(ctx);
+        return hbs_ctx_set_stream(ctx, s_cmp);
+    }
+    void end()
+    {
+        if (s_cmp) { (void)hipStreamSynchronize(s_cmp); (void)hbs_ctx_set_stream(ctx, saved_stream); }
+        if (s_in) (void)hipStreamSynchronize(s_in);
     }
     int upload(int b, uint64_t dst_off, uint64_t src_lo, uint64_t len)
     {
@@ -88,7 +116,7 @@ struct HipBackend {
     int scan(int b, uint64_t off, uint64_t len, hbs_summary* out)
     {
         if (int rc = ok(hipStreamWaitEvent(s_cmp, up_done[b], 0))) return rc;
-        int rc = hbs_index_extract(ctx, d_buf[b] + off, len, d_index, idx_cap, d_rbsp, d_rbsp ? lead + window + 256 : 0, d_summary);
+        int rc = hbs_index_extract(ctx, d_buf[b] + off, len, d_index, idx_cap, h_rbsp ? d_rbsp : nullptr, h_rbsp ? lead + window + 256 : 0, d_summary);
         if (rc) return rc;
         return hbs_read_summary(ctx, d_summary, out);
     }
@@ -113,13 +141,23 @@ extern "C" int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uin
     if (!ctx || !h_summary || (stream_bytes && !h_stream) || (index_cap && !h_index)) return HBS_E_ARG;
     window_bytes &= ~15ull;
     if (window_bytes < 4096) return HBS_E_ARG;
-    HipBackend be;
-    be.ctx = ctx; be.h_stream = h_stream; be.h_rbsp = h_rbsp;
-    be.window = window_bytes; be.lead = window_bytes;
     /* entries one window can produce: a window (with what it scans again) of 2 x window_bytes, one NAL per 32 bytes */
     const uint64_t per_window = (2 * window_bytes) / 32 + 64;
-    be.idx_cap = per_window;
-    const int rc = hbs::ingest_windowed(be, stream_bytes, window_bytes, h_index, index_cap, h_rbsp != nullptr, rbsp_cap, h_summary);
-    be.end();
+    HipBackend* be = static_cast<HipBackend*>(hbs_ctx_attachment(ctx));
+    if (be && (be->window != window_bytes || (h_rbsp != nullptr && !be->want_rbsp))) {
+        hbs_ctx_attach(ctx, nullptr, nullptr);               /* frees it */
+        be = nullptr;
+    }
+    if (!be) {
+        be = new (std::nothrow) HipBackend();
+        if (!be) return HBS_E_HIP;
+        be->ctx = ctx; be->window = window_bytes; be->lead = window_bytes; be->idx_cap = per_window;
+        be->want_rbsp = h_rbsp != nullptr;
+        hbs_ctx_attach(ctx, be, [](void* p) { HipBackend* b = static_cast<HipBackend*>(p); b->release(); delete b; });
+    }
+    be->h_stream = h_stream; be->h_rbsp = h_rbsp;
+    const int rc = hbs::ingest_windowed(*be, stream_bytes, window_bytes, h_index, index_cap, h_rbsp != nullptr, rbsp_cap, h_summary);
+    be->end();
+    if (!be->allocated) hbs_ctx_attach(ctx, nullptr, nullptr);   /* an allocation failed: do not keep the pieces */
     return rc;
 }

@@ -464,6 +464,9 @@ struct SimBackend {
         return sim4_index_extract(w.data(), len, index.data(), idx_cap, h_rbsp ? rbsp.data() : nullptr, rbsp.size(), out);
     }
     int fetch_index(uint64_t first, uint64_t count, hbs_nal_entry* dst) { memcpy(dst, index.data() + first, count * sizeof(hbs_nal_entry)); return 0; }
+    std::vector<hbs_nal_entry> stage_buf = std::vector<hbs_nal_entry>(7);      /* a small, odd staging: the chunking gets exercised */
+    hbs_nal_entry* staging() { return stage_buf.data(); }
+    uint64_t staging_entries() const { return stage_buf.size(); }
     int fetch_rbsp(uint64_t off, uint64_t len, uint64_t dst_off) { if (len) memcpy(h_rbsp + dst_off, rbsp.data() + off, len); return 0; }
 };
 }
