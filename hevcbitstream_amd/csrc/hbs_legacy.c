@@ -41,8 +41,8 @@ static uint64_t g_dbuf_cap = 0;
 static uint8_t* g_dout = NULL;       /* RBSP arena / emitted stream       */
 static uint64_t g_dout_cap = 0;
 /* one device block, so that a call's small results come back in ONE copy:
- *   [0, 64) summary | [64, 192) 4 index entries | [192, 320) 4 parsed records | [384, 448) the parse's summary |
- *   [512, ...) one struct slot (VPS-sized) */
+ *   [0, 64) summary | [64, 192) 4 parsed records | [192, 256) the parse's summary | [256, 384) 4 index entries |
+ *   [512, ...) one struct slot (VPS-sized) | behind it: find_nal_unit's own summary + 64 index entries */
 static uint8_t* g_dblock = NULL;
 static hbs_nal_entry* g_dindex = NULL;
 static hbs_summary* g_dsummary = NULL;
@@ -51,14 +51,29 @@ static uint8_t* g_dstruct = NULL;
 static uint8_t* g_dsps_slot = NULL;  /* SPS in force + its RPS tables     */
 static uint8_t* g_dpps = NULL;       /* PPS in force                      */
 #define LEGACY_INDEX_CAP 4
+#define FIND_INDEX_CAP 64
 #define RES_SUMMARY 0
-#define RES_INDEX 64
-#define RES_PARSED 192
+#define RES_PARSED 64
+#define RES_SUMMARY2 192                                   /* the parse's own summary: the scan's stays readable */
+#define RES_INDEX 256
+#define RES_SMALL (RES_INDEX + LEGACY_INDEX_CAP * 32)      /* summary + parsed + index */
 #define RES_STRUCT 512
-#define RES_SMALL 320                                      /* summary + index + parsed */
-#define RES_SUMMARY2 384                                   /* the parse's own summary: the scan's stays readable */
+#define RES_FIND (RES_STRUCT + ((sizeof(hevc_vps_t) + 64 + 255) & ~(size_t)255))      /* summary, then FIND_INDEX_CAP entries */
+#define RES_FIND_BYTES (64 + FIND_INDEX_CAP * 32)
 #define RES_SLICE (RES_STRUCT + ((sizeof(hevc_slice_header_t) + 15) & ~(size_t)15))
 static uint8_t g_hres[RES_STRUCT + 8192];                  /* host mirror of the front of the block */
+
+/* find_nal_unit scans a prefix of the caller's buffer and finds several NALs in it; the canonical loop
+ * (hevc_analyze.c:135-177) asks for them one after the other.  The rest of the last scan's answer is kept,
+ * with a copy of the bytes it was computed from, and served when the next call starts exactly at the previous
+ * NAL's end and the bytes up to the answer's terminator are still the same (memcmp): same bytes, same walk. */
+#define FIND_CACHE_MAX (1u << 20)
+static const uint8_t* g_fc_base = NULL;
+static uint8_t* g_fc_copy = NULL;
+static uint64_t g_fc_len = 0;
+static hbs_nal_entry g_fc_ent[FIND_INDEX_CAP];
+static uint8_t g_hfind[RES_FIND_BYTES];
+static uint64_t g_fc_n = 0, g_fc_next = 0;
 /* page-locked staging for uploads: [00 00 01 | NAL bytes] goes up in one copy that nobody waits for */
 static uint8_t* g_hstage = NULL;
 static uint64_t g_hstage_cap = 0;
@@ -82,7 +97,7 @@ static void need_ctx(void)
     if (g_ctx) return;
     rc = hbs_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
     if (rc) { g_ctx = NULL; die("hbs_ctx_create", rc); }
-    if ((rc = hbs_dev_alloc(g_ctx, RES_STRUCT + sizeof(hevc_vps_t) + 64, (void**)&g_dblock))) die("hbs_dev_alloc", rc);
+    if ((rc = hbs_dev_alloc(g_ctx, RES_FIND + RES_FIND_BYTES, (void**)&g_dblock))) die("hbs_dev_alloc", rc);
     g_dsummary = (hbs_summary*)(g_dblock + RES_SUMMARY);
     g_dindex = (hbs_nal_entry*)(g_dblock + RES_INDEX);
     g_dparsed = (hbs_parsed_nal*)(g_dblock + RES_PARSED);
@@ -168,26 +183,51 @@ int find_nal_unit(uint8_t* buf, int size, int* nal_start, int* nal_end)
     *nal_end = 0;
     if (size <= 0) return 0;
     need_ctx();
+    if (g_fc_next >= 1 && g_fc_next < g_fc_n) {
+        const hbs_nal_entry* prev = &g_fc_ent[g_fc_next - 1];
+        const hbs_nal_entry* cur = &g_fc_ent[g_fc_next];
+        const uint64_t need = cur->end - prev->end + 4;        /* up to and including what terminates it */
+        if (buf == g_fc_base + prev->end && !(cur->status & HBS_ST_UNTERMINATED) && cur->end + 4 <= g_fc_len &&
+            (uint64_t)size >= need && memcmp(buf, g_fc_copy + prev->end, need) == 0) {
+            *nal_start = (int)(cur->start - prev->end);
+            *nal_end = (int)(cur->end - prev->end);
+            g_fc_next++;
+            return *nal_end - *nal_start;
+        }
+    }
+    g_fc_n = g_fc_next = 0;
     /* The answer only depends on the bytes up to the first NAL's end (+3), so scan a growing
      * prefix: a NAL that is terminated inside the prefix is terminated the same way in the
      * whole buffer (its terminator starts at least 4 bytes before the prefix end). */
     for (len = 65536; ; len *= 4) {
         hbs_summary s;
-        hbs_nal_entry e[LEGACY_INDEX_CAP];
         if (len > (uint64_t)size) len = (uint64_t)size;
         need_bufs(len, 0);
         upload_input(NULL, 0, buf, len);
-        launch_index(len, 0);
-        fetch_results(RES_SMALL, &s, e);
-        if (s.nal_found >= 1 && !(e[0].status & HBS_ST_UNTERMINATED)) {
+        {
+            int rc = hbs_index_extract(g_ctx, g_dbuf, len, (hbs_nal_entry*)(g_dblock + RES_FIND + 64), FIND_INDEX_CAP, NULL, 0,
+                                       (hbs_summary*)(g_dblock + RES_FIND));
+            if (rc) die("hbs_index_extract", rc);
+            if ((rc = hbs_copy_to_host(g_ctx, g_hfind, g_dblock + RES_FIND, RES_FIND_BYTES))) die("hbs_copy_to_host", rc);
+            memcpy(&s, g_hfind, sizeof(s));
+            memcpy(g_fc_ent, g_hfind + 64, sizeof(g_fc_ent));
+        }
+        if (s.nal_found >= 1 && !(g_fc_ent[0].status & HBS_ST_UNTERMINATED)) {
             /* first NAL terminated inside the prefix (possibly empty: the loop of the callers stops) */
-            *nal_start = (int)e[0].start;
-            *nal_end = (int)e[0].end;
+            *nal_start = (int)g_fc_ent[0].start;
+            *nal_end = (int)g_fc_ent[0].end;
+            if (len <= FIND_CACHE_MAX && s.nal_count > 1) {     /* keep the rest of the answer for the calls to come */
+                if (!g_fc_copy) g_fc_copy = (uint8_t*)malloc(FIND_CACHE_MAX);
+                memcpy(g_fc_copy, buf, (size_t)len);
+                g_fc_base = buf; g_fc_len = len;
+                g_fc_n = s.nal_count < FIND_INDEX_CAP ? s.nal_count : FIND_INDEX_CAP;
+                g_fc_next = 1;
+            }
             return *nal_end - *nal_start;
         }
         if (len == (uint64_t)size) {
             if (s.nal_found >= 1) {                     /* start found, end not: h264_nal.c:71 */
-                *nal_start = (int)e[0].start;
+                *nal_start = (int)g_fc_ent[0].start;
                 *nal_end = size;
                 return -1;
             }

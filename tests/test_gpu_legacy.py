@@ -54,6 +54,49 @@ def test_find_nal_unit_large_buffer(leg, orc):
     assert leg.find_nal_unit(buf[:400000]) == orc.find_nal_unit(buf[:400000])        # no end: -1
 
 
+def test_find_nal_unit_loop_and_edited_buffer(orc):
+    """the caller's loop over ONE buffer (hevc_analyze.c:135-177): the wrapper answers most calls from the previous
+    scan of the same bytes -- and must not when the bytes changed, when the loop resumes elsewhere, or when the
+    buffer got shorter than the answer needs"""
+    import hevcbitstream_amd as hbs
+    lib = hbs.load_library()
+    u8p = C.POINTER(C.c_uint8)
+    lib.find_nal_unit.argtypes = [u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.RandomState(17)
+    for rep in range(4):
+        parts = []
+        for k in range(60):
+            parts.append(bytes([0] * int(rng.randint(2, 4)) + [1]))
+            body = rng.randint(0 if rep == 3 else 1, 256, size=int(rng.randint(1, 3000))).astype(np.uint8)
+            parts.append(body.tobytes())
+        buf = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+        base = buf.ctypes.data
+
+        def ours(p, size):
+            s, e = C.c_int(0), C.c_int(0)
+            r = lib.find_nal_unit(C.cast(base + p, u8p), size, C.byref(s), C.byref(e))
+            return r, s.value, e.value
+
+        p, n = 0, 0
+        while True:
+            want = orc.find_nal_unit(bytes(buf[p:]))
+            assert ours(p, len(buf) - p) == tuple(want), (rep, n, p)
+            if want[0] <= 0:
+                break
+            if n == 5:                                   # the bytes of the next answer change under the wrapper's feet
+                q = p + want[2] + 6
+                buf[q:q + 3] = (0, 0, 1)
+            if n == 9:                                   # ... the caller looks at a shorter buffer
+                short = len(buf) - p - want[2] - 2
+                assert ours(p + want[2], 3) == tuple(orc.find_nal_unit(bytes(buf[p + want[2]:p + want[2] + 3])))
+                del short
+            if n == 12:                                  # ... and resumes one byte off the previous NAL's end
+                assert ours(p + want[2] + 1, len(buf) - p - want[2] - 1) == tuple(orc.find_nal_unit(bytes(buf[p + want[2] + 1:])))
+            p += want[2]
+            n += 1
+        assert n >= 10
+
+
 class LegacyHevc(_orc._HevcParser):
     def __init__(self, lib):
         lib.hevc_new.restype = C.c_void_p
