@@ -40,9 +40,10 @@ static uint8_t* g_dbuf = NULL;       /* input bytes                       */
 static uint64_t g_dbuf_cap = 0;
 static uint8_t* g_dout = NULL;       /* RBSP arena / emitted stream       */
 static uint64_t g_dout_cap = 0;
-/* one device block, so that a call's small results come back in ONE copy:
+/* one device block, so that a call's results come back in ONE copy:
  *   [0, 64) summary | [64, 192) 4 parsed records | [192, 256) the parse's summary | [256, 384) 4 index entries |
- *   [512, ...) one struct slot (VPS-sized) | behind it: find_nal_unit's own summary + 64 index entries */
+ *   [512, 512 + R) the NAL's RBSP (R follows the NAL at hand) | [512 + R, ...) one struct slot (VPS-sized)
+ * a slice's header struct and its payload are then one copy of 512 + R + 4 KiB away */
 static uint8_t* g_dblock = NULL;
 static hbs_nal_entry* g_dindex = NULL;
 static hbs_summary* g_dsummary = NULL;
@@ -57,11 +58,14 @@ static uint8_t* g_dpps = NULL;       /* PPS in force                      */
 #define RES_SUMMARY2 192                                   /* the parse's own summary: the scan's stays readable */
 #define RES_INDEX 256
 #define RES_SMALL (RES_INDEX + LEGACY_INDEX_CAP * 32)      /* summary + parsed + index */
-#define RES_STRUCT 512
-#define RES_FIND (RES_STRUCT + ((sizeof(hevc_vps_t) + 64 + 255) & ~(size_t)255))      /* summary, then FIND_INDEX_CAP entries */
-#define RES_FIND_BYTES (64 + FIND_INDEX_CAP * 32)
-#define RES_SLICE (RES_STRUCT + ((sizeof(hevc_slice_header_t) + 15) & ~(size_t)15))
-static uint8_t g_hres[RES_STRUCT + 8192];                  /* host mirror of the front of the block */
+#define RES_RBSP 512
+#define RES_FIND_BYTES (64 + FIND_INDEX_CAP * 32)          /* find_nal_unit's own block: summary, then FIND_INDEX_CAP entries */
+#define SLICE_SLOT ((sizeof(hevc_slice_header_t) + 15) & ~(size_t)15)
+static uint64_t g_dblock_cap = 0;
+static uint64_t g_res_r = 0;                               /* R of the call at hand */
+static uint8_t* g_drbsp = NULL;                            /* g_dblock + RES_RBSP */
+static uint8_t* g_hres = NULL;                             /* host mirror of the front of the block */
+static uint8_t* g_dfind = NULL;
 
 /* find_nal_unit scans a prefix of the caller's buffer and finds several NALs in it; the canonical loop
  * (hevc_analyze.c:135-177) asks for them one after the other.  The rest of the last scan's answer is kept,
@@ -97,17 +101,34 @@ static void need_ctx(void)
     if (g_ctx) return;
     rc = hbs_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
     if (rc) { g_ctx = NULL; die("hbs_ctx_create", rc); }
-    if ((rc = hbs_dev_alloc(g_ctx, RES_FIND + RES_FIND_BYTES, (void**)&g_dblock))) die("hbs_dev_alloc", rc);
-    g_dsummary = (hbs_summary*)(g_dblock + RES_SUMMARY);
-    g_dindex = (hbs_nal_entry*)(g_dblock + RES_INDEX);
-    g_dparsed = (hbs_parsed_nal*)(g_dblock + RES_PARSED);
-    g_dstruct = g_dblock + RES_STRUCT;
+    if ((rc = hbs_dev_alloc(g_ctx, RES_FIND_BYTES, (void**)&g_dfind))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_dev_alloc(g_ctx, hbs_sps_slot_bytes(), (void**)&g_dsps_slot))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_dev_alloc(g_ctx, sizeof(hevc_pps_t) + 64, (void**)&g_dpps))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
     if ((rc = hbs_fill_device(g_ctx, g_dpps, 0, sizeof(hevc_pps_t)))) die("hbs_fill_device", rc);
     g_sps_shadow = (uint8_t*)malloc(sizeof(hevc_sps_t));
     g_pps_shadow = (uint8_t*)malloc(sizeof(hevc_pps_t));
+}
+
+/* the result block laid out for a NAL whose RBSP takes at most rbsp_bytes */
+static void need_block(uint64_t rbsp_bytes)
+{
+    int rc;
+    const uint64_t r = (rbsp_bytes + 64 + 255) & ~(uint64_t)255;
+    const uint64_t want = RES_RBSP + r + sizeof(hevc_vps_t) + 64;
+    if (want > g_dblock_cap) {
+        if (g_dblock) hbs_dev_free(g_ctx, g_dblock);
+        g_dblock_cap = want + r / 2;
+        if ((rc = hbs_dev_alloc(g_ctx, g_dblock_cap, (void**)&g_dblock))) die("hbs_dev_alloc", rc);
+        free(g_hres);
+        g_hres = (uint8_t*)malloc((size_t)(g_dblock_cap - sizeof(hevc_vps_t)) + 8192);
+    }
+    g_res_r = r;
+    g_dsummary = (hbs_summary*)(g_dblock + RES_SUMMARY);
+    g_dindex = (hbs_nal_entry*)(g_dblock + RES_INDEX);
+    g_dparsed = (hbs_parsed_nal*)(g_dblock + RES_PARSED);
+    g_drbsp = g_dblock + RES_RBSP;
+    g_dstruct = g_dblock + RES_RBSP + r;
 }
 
 /* [prefix | bytes] into the device input buffer at offset 0; returns without waiting */
@@ -161,7 +182,7 @@ static void need_bufs(uint64_t in_bytes, uint64_t out_bytes)
 static void launch_index(uint64_t bytes, int want_rbsp)
 {
     int rc = hbs_index_extract(g_ctx, g_dbuf, bytes, g_dindex, LEGACY_INDEX_CAP,
-                               want_rbsp ? g_dout : NULL, want_rbsp ? g_dout_cap : 0, g_dsummary);
+                               want_rbsp ? g_drbsp : NULL, want_rbsp ? g_res_r : 0, g_dsummary);
     if (rc) die("hbs_index_extract", rc);
 }
 
@@ -205,10 +226,9 @@ int find_nal_unit(uint8_t* buf, int size, int* nal_start, int* nal_end)
         need_bufs(len, 0);
         upload_input(NULL, 0, buf, len);
         {
-            int rc = hbs_index_extract(g_ctx, g_dbuf, len, (hbs_nal_entry*)(g_dblock + RES_FIND + 64), FIND_INDEX_CAP, NULL, 0,
-                                       (hbs_summary*)(g_dblock + RES_FIND));
+            int rc = hbs_index_extract(g_ctx, g_dbuf, len, (hbs_nal_entry*)(g_dfind + 64), FIND_INDEX_CAP, NULL, 0, (hbs_summary*)g_dfind);
             if (rc) die("hbs_index_extract", rc);
-            if ((rc = hbs_copy_to_host(g_ctx, g_hfind, g_dblock + RES_FIND, RES_FIND_BYTES))) die("hbs_copy_to_host", rc);
+            if ((rc = hbs_copy_to_host(g_ctx, g_hfind, g_dfind, RES_FIND_BYTES))) die("hbs_copy_to_host", rc);
             memcpy(&s, g_hfind, sizeof(s));
             memcpy(g_fc_ent, g_hfind + 64, sizeof(g_fc_ent));
         }
@@ -242,18 +262,18 @@ int nal_to_rbsp(const uint8_t* nal_buf, int* nal_size, uint8_t* rbsp_buf, int* r
     const int n = *nal_size;
     hbs_summary s;
     hbs_nal_entry e[LEGACY_INDEX_CAP];
-    int rc;
     if (n < 0) return -1;
     need_ctx();
-    need_bufs((uint64_t)n + 16, (uint64_t)n + 16);
+    need_bufs((uint64_t)n + 16, 0);
+    need_block((uint64_t)n + 16);
     /* the kernel works on Annex-B: put a start code in front of the NAL */
     upload_input(sc, 3, nal_buf, (uint64_t)n);
     launch_index((uint64_t)n + 3, 1);
-    fetch_results(RES_SMALL, &s, e);
+    fetch_results(RES_RBSP + (uint64_t)n + 16, &s, e);             /* the RBSP comes along */
     /* a 00 00 00 / 00 00 01 inside the NAL would end it early: nal_to_rbsp rejects those (h264_nal.c:156-159) */
     if (s.nal_found < 1 || e[0].start != 3 || e[0].end != (uint64_t)n + 3 || (e[0].status & HBS_ST_ERROR)) return -1;
     if ((int)e[0].rbsp_len > *rbsp_size) return -1;                      /* h264_nal.c:179-183 */
-    if ((rc = hbs_copy_to_host(g_ctx, rbsp_buf, g_dout + e[0].rbsp_off, e[0].rbsp_len))) die("hbs_copy_to_host", rc);
+    memcpy(rbsp_buf, g_hres + RES_RBSP + e[0].rbsp_off, e[0].rbsp_len);
     *nal_size = (e[0].status & HBS_ST_TRAILING03) ? n - 1 : n;           /* h264_nal.c:170-173, :197 */
     *rbsp_size = (int)e[0].rbsp_len;
     return (int)e[0].rbsp_len;
@@ -269,6 +289,7 @@ int rbsp_to_nal(const uint8_t* rbsp_buf, const int* rbsp_size, uint8_t* nal_buf,
     if (n <= 0) { *nal_size = 0; return 0; }
     need_ctx();
     need_bufs((uint64_t)n, hbs_annexb_bound((uint64_t)n, 1));
+    need_block(0);
     memset(&e, 0, sizeof(e));
     e.rbsp_off = 0; e.rbsp_len = (uint32_t)n;
     if ((rc = hbs_copy_to_device(g_ctx, g_dbuf, rbsp_buf, (uint64_t)n))) die("hbs_copy_to_device", rc);
@@ -397,17 +418,18 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     *stripped = 0;
     if (size < 0) return -1;
     need_ctx();
-    need_bufs((uint64_t)size + 16, (uint64_t)size + 16);
+    need_bufs((uint64_t)size + 16, 0);
+    need_block((uint64_t)size + 16);
     upload_input(sc, 3, buf, (uint64_t)size);
     /* the parameter sets in force are whatever the caller's object holds (hevc_stream.c:800-801);
      * the derived RPS tables live on the device next to the SPS */
     sync_context(h);
     launch_index((uint64_t)size + 3, 1);
     if (trace) need_trace();
-    if ((rc = hbs_parse_headers_trace(g_ctx, g_dout, g_dindex, 1, g_dparsed, g_dstruct, sizeof(hevc_vps_t) + 64,
+    if ((rc = hbs_parse_headers_trace(g_ctx, g_drbsp, g_dindex, 1, g_dparsed, g_dstruct, sizeof(hevc_vps_t) + 64,
                                       g_dsps_slot, g_dpps, trace ? g_dtrace : NULL, trace ? TRACE_CAP : 0,
                                       trace ? g_dtrace_count : NULL, (hbs_summary*)(g_dblock + RES_SUMMARY2)))) die("hbs_parse_headers", rc);
-    fetch_results(RES_SLICE, &s, e);
+    fetch_results(RES_RBSP + g_res_r + SLICE_SLOT, &s, e);          /* results, the RBSP, a slice-sized struct */
     memcpy(&p, g_hres + RES_PARSED, sizeof(p));
     if (s.nal_found < 1 || e[0].start != 3 || e[0].end != (uint64_t)size + 3 || (e[0].status & HBS_ST_ERROR))
         return -1;                                                       /* hevc_stream.c:167 */
@@ -436,19 +458,18 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
         if (h->sps->sps_seq_parameter_set_id >= 0 && h->sps->sps_seq_parameter_set_id < 32)
             memcpy(h->sps_table[h->sps->sps_seq_parameter_set_id], h->sps, sizeof(hevc_sps_t));      /* :399 */
     } else if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) {
-        memcpy(h->pps, g_hres + RES_STRUCT, sizeof(hevc_pps_t));          /* smaller than a slice header: already here */
+        memcpy(h->pps, g_hres + RES_RBSP + g_res_r, sizeof(hevc_pps_t));  /* smaller than a slice header: already here */
         if (h->pps->pic_parameter_set_id >= 0 && h->pps->pic_parameter_set_id < 256)
             memcpy(h->pps_table[h->pps->pic_parameter_set_id], h->pps, sizeof(hevc_pps_t));          /* :498 */
     } else if (is_slice(t)) {
-        memcpy(h->sh, g_hres + RES_STRUCT, sizeof(hevc_slice_header_t));
+        memcpy(h->sh, g_hres + RES_RBSP + g_res_r, sizeof(hevc_slice_header_t));
         if (h->slice_data) {                                             /* hevc_stream.c:605-613 */
             free(h->slice_data->rbsp_buf);
             h->slice_data->rbsp_buf = NULL;
             h->slice_data->rbsp_size = p.slice_data_size;
             if (p.slice_data_size > 0) {
                 h->slice_data->rbsp_buf = (uint8_t*)malloc((size_t)p.slice_data_size);
-                if ((rc = hbs_copy_to_host(g_ctx, h->slice_data->rbsp_buf, g_dout + e[0].rbsp_off + p.slice_data_off,
-                                           (uint64_t)p.slice_data_size))) die("hbs_copy_to_host", rc);
+                memcpy(h->slice_data->rbsp_buf, g_hres + RES_RBSP + e[0].rbsp_off + p.slice_data_off, (size_t)p.slice_data_size);
             }
         }
     }
@@ -495,6 +516,7 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     need_ctx();
     cap = (uint32_t)((long)size * 3 / 4);
     need_bufs(16, (uint64_t)cap + 16);
+    need_block(0);
     if (!d_written && (rc = hbs_dev_alloc(g_ctx, sizeof(hbs_written_nal), (void**)&d_written))) die("hbs_dev_alloc", rc);
     t = h->nal->nal_unit_type;
     if (t == HEVC_NAL_UNIT_TYPE_VPS_NUT) { src = h->vps; src_bytes = sizeof(hevc_vps_t); }
