@@ -24,7 +24,8 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_workspace_bytes", "hbs_write_headers", "hbs_parse_headers_trace", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
-           "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device"]
+           "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
+           "hbs_ctx_set_sequential_parse"]
 
 
 class HbsError(RuntimeError):

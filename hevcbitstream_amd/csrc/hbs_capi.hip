@@ -31,6 +31,7 @@ struct hbs_ctx {
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
+    int parse_sequential;         /* hbs_ctx_set_sequential_parse */
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
@@ -201,6 +202,13 @@ int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 }
 
 int hbs_ctx_get_kernel(hbs_ctx* c) { return c ? c->variant : HBS_E_ARG; }
+
+int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
+{
+    if (!c) return HBS_E_ARG;
+    c->parse_sequential = on ? 1 : 0;
+    return 0;
+}
 
 int hbs_ctx_last_kernel(hbs_ctx* c)
 {
@@ -387,6 +395,7 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.scan_tmp = w + 3 * b_n + 512;
     a.own_rows = reinterpret_cast<hbs::RpsRow*>(w + 3 * b_n + 512 + round256(1024 * 24));
     a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;
+    a.sequential = c->parse_sequential;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
 }

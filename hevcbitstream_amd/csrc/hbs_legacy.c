@@ -101,6 +101,8 @@ static void need_ctx(void)
     if (g_ctx) return;
     rc = hbs_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
     if (rc) { g_ctx = NULL; die("hbs_ctx_create", rc); }
+    /* one NAL after the other, one set of derived RPS tables for the process: the reference's semantics to the letter */
+    if ((rc = hbs_ctx_set_sequential_parse(g_ctx, 1))) die("hbs_ctx_set_sequential_parse", rc);
     if ((rc = hbs_dev_alloc(g_ctx, RES_FIND_BYTES, (void**)&g_dfind))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_dev_alloc(g_ctx, hbs_sps_slot_bytes(), (void**)&g_dsps_slot))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_dev_alloc(g_ctx, sizeof(hevc_pps_t) + 64, (void**)&g_dpps))) die("hbs_dev_alloc", rc);
@@ -450,8 +452,9 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     if (t == HEVC_NAL_UNIT_TYPE_VPS_NUT) {
         if ((rc = hbs_copy_to_host(g_ctx, h->vps, g_dstruct, sizeof(hevc_vps_t)))) die("hbs_copy_to_host", rc);
     } else if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
-        /* keep it, with its derived tables, for the slices to come (device to device), then fetch the struct */
-        if ((rc = hbs_copy_device(g_ctx, g_dsps_slot, g_dstruct, hbs_sps_slot_bytes()))) die("hbs_copy_device", rc);
+        /* keep it for the slices to come (device to device; its derived tables were written straight into the slot's
+         * tables, next to the rows earlier parameter sets and slices left there), then fetch the struct */
+        if ((rc = hbs_copy_device(g_ctx, g_dsps_slot, g_dstruct, sizeof(hevc_sps_t)))) die("hbs_copy_device", rc);
         if ((rc = hbs_copy_to_host(g_ctx, h->sps, g_dstruct, sizeof(hevc_sps_t)))) die("hbs_copy_to_host", rc);
         memcpy(g_sps_shadow, h->sps, sizeof(hevc_sps_t));
         g_sps_shadow_ok = 1;
@@ -474,6 +477,16 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
         }
     }
     return p.rc;
+}
+
+/* Test hook, not part of the reference's API: the derived RPS tables are process state there (file-static,
+ * zero at program start, hevc_stream.c:26-32) and here (on the device); this puts them back to "program start". */
+void hbs_legacy_reset_tables(void)
+{
+    int rc;
+    need_ctx();
+    if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
+    g_sps_shadow_ok = 0;
 }
 
 int read_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)

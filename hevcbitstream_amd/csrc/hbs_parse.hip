@@ -218,7 +218,8 @@ template <int kMode>
 __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_nal_entry& e, uint8_t* dst,
                                                const uint8_t* my_win, uint32_t wb, const uint8_t* src,
                                                const uint8_t* sps_slot, const uint8_t* pps_struct, const uint8_t* zeros,
-                                               ParsedNal& out, TraceRec* trace, uint32_t trace_cap, RpsRow* own_row)
+                                               ParsedNal& out, TraceRec* trace, uint32_t trace_cap, RpsRow* own_row,
+                                               RpsTables* seq_tables = nullptr)
 {
     ParserT<kMode> ps;
     ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
@@ -236,8 +237,11 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
         }
         if (pps_struct) last_pps = reinterpret_cast<const hevc_pps_t*>(pps_struct);
         ps.own = own_row;
+        /* the reference's way (one NAL after the other, hevc_stream.c:26-32): ONE set of tables that every SPS and
+         * every slice's own set writes into and reads from, rows nobody rewrote keeping what was there */
+        if (seq_tables) { ps.own = nullptr; ps.out_rps = seq_tables; }
     } else if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
-        ps.out_rps = reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
+        ps.out_rps = seq_tables ? seq_tables : reinterpret_cast<RpsTables*>(dst + round16(sizeof(hevc_sps_t)));
     }
     const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
     parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
@@ -349,9 +353,12 @@ void k4_small(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               ParsedNal* __restrict__ parsed, uint8_t* structs, uint64_t structs_cap,
               const uint8_t* __restrict__ zeros, const uint8_t* init_sps_slot, const uint8_t* init_pps,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
-              RpsRow* __restrict__ own_rows /* 64 */, hbs_summary* __restrict__ sum)
+              RpsRow* __restrict__ own_rows /* 64 */, hbs_summary* __restrict__ sum, int sequential)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[64 * kLaneWinStride];
+    /* sequential (one NAL, the legacy symbols): the tables behind the SPS in force are THE tables, as in the reference */
+    RpsTables* const seq_tables = (sequential && n == 1 && init_sps_slot)
+        ? reinterpret_cast<RpsTables*>(const_cast<uint8_t*>(init_sps_slot) + round16(sizeof(hevc_sps_t))) : nullptr;
     const int lane = threadIdx.x;
     uint8_t* const my_win = win + (uint32_t)lane * kLaneWinStride;
     const bool have = (uint64_t)lane < n;
@@ -424,7 +431,7 @@ void k4_small(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                     else pps_struct = init_pps;
                 }
                 tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, p,
-                                         trace ? trace + (uint64_t)lane * trace_cap : nullptr, trace_cap, &own_rows[lane]);
+                                         trace ? trace + (uint64_t)lane * trace_cap : nullptr, trace_cap, &own_rows[lane], seq_tables);
             }
             /* the slices read what the parameter-set lanes have just written */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -541,10 +548,10 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
     if (a.n >= 1 && a.n <= 64) {
         if (a.trace)
             k4_small<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
-                                                   a.initial_pps, a.trace, a.trace_cap, a.trace_count, a.own_rows, a.summary);
+                                                   a.initial_pps, a.trace, a.trace_cap, a.trace_count, a.own_rows, a.summary, a.sequential);
         else
             k4_small<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
-                                                  a.initial_pps, nullptr, 0, nullptr, a.own_rows, a.summary);
+                                                  a.initial_pps, nullptr, 0, nullptr, a.own_rows, a.summary, a.sequential);
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);

@@ -34,6 +34,8 @@ struct ParseArgs {
     uint32_t trace_cap;
     uint32_t* trace_count;           /* optional: records each NAL produced (may exceed trace_cap) */
     RpsRow* own_rows;                /* parse_own_rows_bytes(n): one row per lane of the parse grid */
+    int sequential;                  /* n == 1 only: the RPS tables behind initial_sps_slot are read AND written, as the
+                                        reference's file-static tables are (what the legacy single-NAL symbols need) */
 };
 
 unsigned parse_grid_blocks(uint64_t n);

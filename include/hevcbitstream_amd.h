@@ -234,6 +234,12 @@ int hbs_parse_headers_trace(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_e
                             const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
                             hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary);
 uint64_t hbs_sps_slot_bytes(void);
+/* One NAL at a time, exactly as the reference does it (what the legacy symbols use): with this on, a call with
+ * n_nals == 1 and a d_initial_sps_slot treats the RPS tables behind that SPS as THE tables (hevc_stream.c:26-32):
+ * an SPS writes its rows into them and leaves the others, a slice's own set lands in them, and a slice that names a
+ * row nobody of its SPS wrote reads what is there.  The slot is then read AND written by the call.  Batches
+ * (n_nals > 1) parse their NALs independently of one another either way. */
+int hbs_ctx_set_sequential_parse(hbs_ctx* ctx, int on);
 uint64_t hbs_sps_tables_offset(void);
 
 /*

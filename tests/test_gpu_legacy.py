@@ -132,6 +132,28 @@ def test_read_hevc_nal_unit_golden():
                     assert hashlib.md5(data).hexdigest() == step["slice_data"][1]
 
 
+def test_read_sequential_table_state():
+    """read_hevc_nal_unit NAL by NAL keeps ONE set of derived RPS tables like the reference (hevc_stream.c:26-32):
+    an SPS cut short that declares no sets, then slices that name set 0 anyway, read what earlier slices left there.
+    The oracle follows the reference on these (the batch parse reads zeros: DESIGN.md section 7)."""
+    import hevcbitstream_amd as hbs
+    from tests.test_sim_parse_logic import broken, sequence
+    lib = hbs.load_library()
+    seeds = [1036, 1064, 1320, 1496, 5224] + list(range(2000, 2040, 4))
+    for seed in seeds:
+        nals = broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True)
+        lib.hbs_legacy_reset_tables()
+        ours, orc_p = LegacyHevc(lib), _orc.OracleHevc()
+        for k, nal in enumerate(nals):
+            assert ours.read(nal) == orc_p.read(nal), (seed, k)
+            a, b = ours.snapshot(), orc_p.snapshot()
+            t = (nal[0] >> 1) & 0x3F
+            kind = "sh" if (t <= 9 or 16 <= t <= 21) else {32: "vps", 33: "sps", 34: "pps"}.get(t)
+            for name in (["nal"] + ([kind] if kind else [])):
+                assert np.array_equal(a[name], b[name]), (seed, k, name)
+        orc_p.close()
+
+
 def test_reference_hevc_analyze_links_and_runs():
     """the reference's own CLI (hevc_analyze.c, unmodified) built against include/ + this library
     by `make analyze`: its NAL walk (find_nal_unit on the GPU) must print the golden offsets/sizes,
