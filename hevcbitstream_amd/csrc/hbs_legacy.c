@@ -470,9 +470,10 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
             free(h->slice_data->rbsp_buf);
             h->slice_data->rbsp_buf = NULL;
             h->slice_data->rbsp_size = p.slice_data_size;
-            if (p.slice_data_size > 0) {
-                h->slice_data->rbsp_buf = (uint8_t*)malloc((size_t)p.slice_data_size);
-                memcpy(h->slice_data->rbsp_buf, g_hres + RES_RBSP + e[0].rbsp_off + p.slice_data_off, (size_t)p.slice_data_size);
+            if (p.slice_data_size >= 0) {                                /* malloc(0) is a pointer too, as in the reference */
+                h->slice_data->rbsp_buf = (uint8_t*)malloc((size_t)p.slice_data_size + 1);
+                if (p.slice_data_size > 0)
+                    memcpy(h->slice_data->rbsp_buf, g_hres + RES_RBSP + e[0].rbsp_off + p.slice_data_off, (size_t)p.slice_data_size);
             }
         }
     }
