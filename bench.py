@@ -23,8 +23,9 @@ Extra objects on that line:
                 its prebuilt copy is there (oracle/_ref, "reference"), else the oracle's
                 byte-at-a-time restatement (oracle/hbs_oracle_nal.c, "port").
   other_kernels (N = 1 only, outside the timed region) the other rows of the path on the same
-                GPU: RBSP -> Annex-B (hbs_emit_annexb) over the 16 GiB arena, header parse and
-                header writers (hbs_parse_headers / hbs_write_headers) on a 100 k-NAL 4K30 stream.
+                GPU: the scan alone (index only, no arena), RBSP -> Annex-B (hbs_emit_annexb) over
+                the 16 GiB arena, header parse and header writers (hbs_parse_headers /
+                hbs_write_headers) on a 100 k-NAL 4K30 stream.
 """
 import argparse
 import json
@@ -141,6 +142,24 @@ def other_kernels(torch, hbs, ctx, g, n):
     from tests.hevc_synth import stream_4k30
     res = {}
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    # find_nal_unit alone: the same stream, no RBSP arena asked for (the streaming kernel of hbs_scan5.hip)
+    index, _, summ0, cap = ctx.alloc_outputs(sb, index_cap=n + 8, want_rbsp=False)
+    kms = []
+    for i in range(4):
+        ctx.index_extract_async(g["stream"][:sb], index, cap, None, summ0)
+        if i:
+            kms.append(ctx.kernel_ms())
+    s0 = ctx.read_summary(summ0)
+    assert int(s0["error"]) == 0 and int(s0["nal_count"]) == n
+    a = index[: n * 32].view(torch.int64).view(n, 4)
+    b = g["index"][: n * 32].view(torch.int64).view(n, 4)
+    assert torch.equal(a[:, :3], b[:, :3]), "index-only NAL index != generator's index"
+    ms = sum(kms) / len(kms)
+    res["index_only"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4),
+                         "read_frac_of_hbm_peak": round((sb + 32 * n) / ms / 1e6 / HBM_PEAK_GBS, 4),
+                         "kernel": {4: "hbs::k_scan_extract4", 5: "hbs::k_scan_index5", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?"),
+                         "workload": "the bench stream, index only (find_nal_unit over the stream, no arena)"}
+    del index
     out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     summary = torch.zeros(64, dtype=torch.uint8, device="cuda")

@@ -31,6 +31,7 @@ struct hbs_ctx {
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
+    int last_index_only;          /* the last hbs_index_extract had no arena: its sparse kernel is the streaming one (5) */
     int parse_sequential;         /* hbs_ctx_set_sequential_parse */
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
@@ -126,7 +127,7 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 3 register-resident, 4 event-sparse */
     const char* sv = getenv("HBS_SCHED");
     c->sched = (sv && atoi(sv) >= 0 && atoi(sv) <= 2) ? atoi(sv) : HBS_DEFAULT_SCHED;
-    c->variant = (kv && (atoi(kv) == 0 || (atoi(kv) >= 2 && atoi(kv) <= 4))) ? atoi(kv) : HBS_DEFAULT_KERNEL;
+    c->variant = (kv && (atoi(kv) == 0 || (atoi(kv) >= 2 && atoi(kv) <= 5))) ? atoi(kv) : HBS_DEFAULT_KERNEL;
     c->last_variant = c->variant ? c->variant : 4;
     *out = c;
     return 0;
@@ -195,7 +196,7 @@ int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 
 int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant == 1 || variant > 4) return HBS_E_ARG;
+    if (!c || variant < 0 || variant == 1 || variant > 5) return HBS_E_ARG;
     c->variant = variant;
     if (variant) c->last_variant = variant;
     return 0;
@@ -213,7 +214,7 @@ int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
 int hbs_ctx_last_kernel(hbs_ctx* c)
 {
     if (!c) return HBS_E_ARG;
-    if (c->variant) return c->variant;
+    if (c->variant) return (c->variant == 5 && !c->last_index_only) ? 4 : c->variant;
     if (!c->probe_pending) return c->last_variant;
     /* automatic mode: the choice was made on the device; read the probe's counts back */
     if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
@@ -221,7 +222,7 @@ int hbs_ctx_last_kernel(hbs_ctx* c)
     hipError_t e = hipMemcpyAsync(&h, c->hdr, sizeof(h), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, e, "read-back of the density probe");
-    c->last_variant = hbs::probe_says_dense(h.probe_chunks, h.probe_flagged) ? 2 : 4;
+    c->last_variant = hbs::probe_says_dense(h.probe_chunks, h.probe_flagged) ? 2 : (c->last_index_only ? 5 : 4);
     c->probe_pending = 0;
     return c->last_variant;
 }
@@ -267,6 +268,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.index = d_index; a.index_cap = index_cap;
     a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
     a.desc = c->desc; a.hdr = c->hdr; a.tail = c->tail; a.summary = d_summary;
+    c->last_index_only = (!d_rbsp && (c->variant == 0 || c->variant == 5) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;
     a.sched = c->sched;
     a.grid_blocks = c->grid_blocks; a.grid_blocks3 = c->grid_blocks3; a.grid_blocks4 = c->grid_blocks4;

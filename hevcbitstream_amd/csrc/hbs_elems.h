@@ -1,0 +1,245 @@
+/*
+ * hbs_elems.h -- what the event-sparse scan kernels share (hbs_scan4.hip: scan + extract in one pass;
+ * hbs_scan5.hip: the index-only pair of passes): wave-level helpers over the tile algebra, the decoupled
+ * look-back over tile descriptors (one wavefront, 256 predecessors per step), and the two halves of an
+ * element -- the exact window rules on one flagged 16-byte chunk, then index entries and kept bytes once
+ * the state carried into the tile is known.  Device code only.
+ */
+#ifndef HBS_ELEMS_H
+#define HBS_ELEMS_H
+
+#include "hbs_wave.h"
+#include "hbs_sparse.h"
+#include "hbs_scan.h"
+
+namespace hbs {
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ TileAgg agg_shfl_up(const TileAgg& a, int d)
+{
+    TileAgg t;
+    t.cnt = __shfl_up(a.cnt, d, 64); t.known = __shfl_up(a.known, d, 64);
+    t.sig = __shfl_up(a.sig, d, 64); t.last = __shfl_up(a.last, d, 64);
+    return t;
+}
+
+/* inclusive scan with combine(): lane l <- elements of lanes 0..l in order */
+__device__ __forceinline__ TileAgg wave_scan_combine(TileAgg a, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const TileAgg t = agg_shfl_up(a, d);
+        if (lane >= d) a = combine(t, a);
+    }
+    return a;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+
+/* Four 16-byte descriptor loads that bypass the non-coherent cache levels (sc1: the writer is on
+ * another XCD), issued together and awaited together.  A descriptor's two 8-byte words are each
+ * self-validating, so reading them with one 16-byte load is as good as two 8-byte atomics. */
+__device__ __forceinline__ void load_desc4(u32x4& d0, u32x4& d1, u32x4& d2, u32x4& d3,
+                                           const unsigned long long* p0, const unsigned long long* p1,
+                                           const unsigned long long* p2, const unsigned long long* p3)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+
+/*
+ * Decoupled look-back by ONE wavefront, 256 predecessors per step.  Lane l reads the descriptors
+ * of the tiles at distance l, 64 + l, 128 + l, 192 + l in front of win_hi: each of the four loads
+ * covers 64 consecutive descriptors, 1 KiB, eight cache lines.  The four groups are folded nearest
+ * first up to the nearest tile that already has its prefix.  Returns false on timeout/abort.
+ * Called by every lane of wavefront 0.
+ */
+__device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
+                                           RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
+{
+    dbg_iters = 0; dbg_stalls = 0;
+    bool ok = true;
+    excl.kept = 0; excl.nals = 0; excl.inside = 0;
+    if (tile != 0) {
+        if (lane == 0) {
+            st_desc3(&desc[2 * tile], pack_agg0(mine));
+            st_desc3(&desc[2 * tile + 1], pack_agg1(mine));
+        }
+        TileAgg acc = agg_identity();                 /* tiles between the window and `tile` */
+        int64_t win_hi = (int64_t)tile - 1;
+        uint32_t spins = 0;
+        uint64_t w0[4], w1[4];
+        bool fresh = true;                            /* the window moved: read all of it */
+        for (;;) {
+            ++dbg_iters;
+            /* A descriptor that has been seen ready stays usable (an aggregate can only turn into
+             * a prefix): while waiting, only lanes that still miss one read again. */
+            bool need = fresh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
+                need = need || !((s0 == s1) && (s0 != kDescEmpty));
+            }
+            if (need) {
+                const int64_t t0 = win_hi - lane;
+                u32x4 d[4];
+                const unsigned long long* p[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t t = t0 - 64 * j;
+                    p[j] = &desc[2 * (t > 0 ? t : 0)];
+                }
+                load_desc4(d[0], d[1], d[2], d[3], p[0], p[1], p[2], p[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w0[j] = ((uint64_t)d[j].y << 32) | d[j].x;
+                    w1[j] = ((uint64_t)d[j].w << 32) | d[j].z;
+                    if (t0 - 64 * j < 0) { w0[j] = kDescPrefix; w1[j] = kDescPrefix; }   /* virtual tile -1: empty prefix */
+                }
+            }
+            fresh = false;
+            /* nearest group that holds a prefix, with everything in front of it ready */
+            int j0 = -1, lstar = 64;
+            bool stall = false;
+            uint64_t pw0 = 0, pw1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
+                const bool ready = (s0 == s1) && (s0 != kDescEmpty);
+                const uint64_t m_ready = __ballot(ready);
+                const uint64_t m_pre = __ballot(ready && s0 == kDescPrefix);
+                if (j0 < 0 && !stall) {
+                    if (m_pre != 0) {
+                        const int ls = (int)__builtin_ctzll(m_pre);
+                        const uint64_t front = (1ull << ls) - 1ull;
+                        if ((m_ready & front) != front) stall = true;
+                        else { j0 = j; lstar = ls; pw0 = w0[j]; pw1 = w1[j]; }
+                    } else if (m_ready != ~0ull) {
+                        stall = true;
+                    }
+                }
+            }
+            if (stall) {
+                ++dbg_stalls;
+                bool aborted = false;
+                if ((spins & 63u) == 63u)
+                    aborted = __hip_atomic_load(&hdr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (++spins > (1u << 20) || aborted) { ok = false; break; }
+                continue;               /* the round trip of the next poll is delay enough */
+            }
+            TileAgg total = acc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j0 < 0 || j <= j0) {
+                    const TileAgg win = window_fold3(unpack_agg(w0[j], w1[j]), (j == j0) ? lstar : 64, lane);
+                    total = combine(win, total);
+                }
+            }
+            if (j0 >= 0) {
+                const Prefix p = unpack_pre(readlane_u64(pw0, lstar), readlane_u64(pw1, lstar));
+                excl = fold(p, total);
+                break;
+            }
+            acc = total;
+            win_hi -= 256;
+            fresh = true;
+        }
+    }
+    if (lane == 0) {
+        if (ok) {
+            const Prefix incl = fold(excl, mine);
+            st_desc3(&desc[2 * tile], pack_pre0(incl));
+            st_desc3(&desc[2 * tile + 1], pack_pre1(incl));
+        } else {
+            __hip_atomic_store(&hdr->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(&hdr->error, (uint32_t)(-HBS_E_TIMEOUT));
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ Prefix prefix_uniform4(const Prefix& p)
+{
+    Prefix r;
+    r.kept = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.kept >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p.kept);
+    r.nals = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.nals >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p.nals);
+    r.inside = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.inside);
+    return r;
+}
+
+/* the seven dwords around chunk g0 of the stream, for an element */
+__device__ __forceinline__ void elem_load(ElemView& v, const uint8_t* __restrict__ stream, uint64_t g0, uint64_t n, bool padded)
+{
+    if (g0 >= 8 && (padded || g0 + 20 <= n)) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(stream + g0);
+        const u32x4 q = *reinterpret_cast<const u32x4*>(p);
+        v.xpp = p[-2]; v.xp = p[-1]; v.xn = p[4];
+        v.x0 = q.x; v.x1 = q.y; v.x2 = q.z; v.x3 = q.w;
+    } else {
+        const u32x4 q = load_chunk_guarded(stream, g0, n);
+        v.xpp = load_dword_guarded(stream, (int64_t)g0 - 8, n);
+        v.xp = load_dword_guarded(stream, (int64_t)g0 - 4, n);
+        v.xn = load_dword_guarded(stream, (int64_t)g0 + 16, n);
+        v.x0 = q.x; v.x1 = q.y; v.x2 = q.z; v.x3 = q.w;
+    }
+    v.stream = stream; v.g0 = g0; v.n = n;
+}
+
+__device__ __forceinline__ TileAgg agg_readlane(const TileAgg& a, int l)
+{
+    TileAgg r;
+    r.cnt = (uint32_t)__builtin_amdgcn_readlane((int)a.cnt, l); r.known = (uint32_t)__builtin_amdgcn_readlane((int)a.known, l);
+    r.sig = (uint32_t)__builtin_amdgcn_readlane((int)a.sig, l); r.last = (uint32_t)__builtin_amdgcn_readlane((int)a.last, l);
+    return r;
+}
+
+/* everything one lane of wavefront 0 knows about its element */
+struct Elem {
+    ElemView v;
+    ChunkMarks m;
+    BlockSum s;
+    uint32_t gap;          /* bytes of the gap in front of it            */
+    uint32_t chunk;        /* its chunk number in the tile               */
+};
+
+/* Second half for an element once the tile's carried state is known: index entries, its own kept
+ * bytes, and the segment word for the chunks behind it.  e = tile aggregate in front of its gap. */
+__device__ __forceinline__ void elem_emit(const Elem& el, const TileAgg& e, const Prefix& excl, bool can_store, uint8_t* out,
+                                          const EmitTarget& tgt, uint32_t* seg_slot)
+{
+    const ElemStart st = elem_start(e, el.gap, excl.inside);
+    const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(el.v, 0, el.v.g0, el.m, st.inside, excl.nals + e.cnt,
+                                                                          excl.kept + st.kept, tgt);
+    const uint32_t nk = (uint32_t)__builtin_popcount(keep);
+    if (can_store && keep != 0u) {
+        if (keep == 0xFFFFu) {
+            u32x4 q; q.x = el.v.x0; q.y = el.v.x1; q.z = el.v.x2; q.w = el.v.x3;
+            reinterpret_cast<Unaligned16_3*>(out + st.kept)->v = q;
+        } else {
+            uint64_t lo, hi;
+            const uint32_t cn = compact_chunk_regs(el.v.x0, el.v.x1, el.v.x2, el.v.x3, keep, lo, hi);
+            store_pieces(out + st.kept, lo, hi, cn);
+        }
+    }
+    const bool after = (el.s.last != kKindNone) ? (el.s.last == kKindStart) : st.inside;
+    *seg_slot = seg_pack((int32_t)el.chunk, st.kept + nk, after);
+}
+
+} // namespace hbs
+#endif

@@ -23,7 +23,8 @@ struct ScanArgs {
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
     int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */
     int variant;                  /* 0: automatic (density probe, then event-sparse or LDS-image kernel, decided on the device),
-                                     2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip) */
+                                     2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip),
+                                     5: index only (rbsp == nullptr), streaming kernel (hbs_scan5.hip); with an arena it means 4 */
 };
 
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
@@ -43,6 +44,10 @@ int scan4_tail_bytes();
 void launch_scan4_prepare_tail(const ScanArgs& a, hipStream_t st);
 void launch_scan4_probe(const ScanArgs& a, hipStream_t st);
 void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
+
+/* index-only streaming kernel (hbs_scan5.hip) */
+uint64_t scan5_tile_bytes();
+void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 } // namespace hbs
 #endif

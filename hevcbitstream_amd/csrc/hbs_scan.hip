@@ -643,14 +643,18 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     }
     k_init_header<<<1, 1, 0, st>>>(a.hdr);
     if (automatic && a.n) launch_scan4_probe(a, st);
-    if (automatic || a.variant == 4) launch_scan4_prepare_tail(a, st);
+    /* no arena asked for: the streaming index-only kernel takes the place of the event-sparse one */
+    const bool index_only = a.rbsp == nullptr && (automatic || a.variant == 5);
+    const int sparse_variant = (a.variant == 5 && !index_only) ? 4 : a.variant;
+    if (!index_only && (automatic || sparse_variant == 4)) launch_scan4_prepare_tail(a, st);
     if (a.index_cap) {
         e = hipMemsetAsync(a.index, 0, a.index_cap * sizeof(hbs_nal_entry), st);
         if (e != hipSuccess) return e;
     }
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
     const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;
-    const uint64_t num_tiles = (a.variant == 4) ? tiles4 : tiles2;      /* automatic: the finer of the two tilings sizes the memset */
+    const uint64_t tiles5 = (a.n + scan5_tile_bytes() - 1) / scan5_tile_bytes();
+    const uint64_t num_tiles = (sparse_variant == 4) ? tiles4 : tiles2;      /* automatic: the finer of the tilings sizes the memset */
     if (num_tiles) {
         e = hipMemsetAsync(a.desc, 0, num_tiles * 16, st);
         if (e != hipSuccess) return e;
@@ -659,13 +663,16 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
         if (a.variant == 3) {
             launch_scan_extract3_kernel(a, num_tiles, st);
-        } else if (a.variant == 4) {
+        } else if (index_only && !automatic) {
+            launch_scan_index5(a, tiles5, kGateNone, st);
+        } else if (sparse_variant == 4) {
             launch_scan_extract4_kernel(a, tiles4, kGateNone, st);
         } else if (automatic) {
             /* Both kernels are enqueued; each reads the probe's verdict from the run header and the
              * one it rules out returns at once (no host round trip, the call stays asynchronous).
              * They share the descriptor array and the ticket: whichever runs finds both untouched. */
-            launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
+            if (index_only) launch_scan_index5(a, tiles5, kGateIfSparse, st);
+            else launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateIfDense);
         } else {

@@ -1,0 +1,227 @@
+/*
+ * hbs_scan5.hip -- index only (find_nal_unit over a whole stream, no RBSP arena).
+ *
+ * Without an arena to fill nothing has to stay in registers, so the event-sparse scan turns into
+ * a STREAMING kernel: a wavefront takes a tile of 1 MiB by ticket, reads it 16 KiB at a time
+ * (16 loads of 16 bytes per lane in flight), keeps only each chunk's chunk_flag() -- one 64-bit
+ * word per KiB, in LDS -- and then treats the flagged chunks exactly as hbs_scan4.hip treats its
+ * elements: the window rules on the chunk's bytes [-8, 20) (fetched again from the stream: a few
+ * per 64 KiB in coded video, L2 hits), 64 at a time; tile aggregate; decoupled look-back over the
+ * tiles in front (hbs_elems.h); index entries.  A wavefront is alone in its workgroup, there is no
+ * barrier anywhere, and with ~20 of them per CU somebody is always reading while others walk
+ * elements or wait for their prefix: the kernel runs at the rate the GPU reads memory.
+ *
+ * Results are those of k_scan_extract4 with rbsp == nullptr, bit for bit (same element code, same
+ * end-of-stream fix-up behind it).  Replaces the byte loop of find_nal_unit (reference
+ * h264_nal.c:38-76) over a stream, as hbs_scan4.hip does.
+ */
+#include <hip/hip_runtime.h>
+#include "hbs_elems.h"
+
+namespace hbs {
+
+#ifndef HBS5_SPAN_ROWS
+#define HBS5_SPAN_ROWS 16
+#define HBS5_TILE_ROWS 1024
+#endif
+constexpr int k5SpanRows = HBS5_SPAN_ROWS;                    /* rows of 1 KiB a wavefront flags per step */
+constexpr uint64_t k5SpanBytes = (uint64_t)k5SpanRows * 1024u;
+constexpr int k5TileRows = HBS5_TILE_ROWS;                    /* KiB of stream (= flag words) per tile */
+constexpr uint64_t k5TileBytes = (uint64_t)k5TileRows * 1024u;
+constexpr int k5WordsPerLane = k5TileRows / 64;               /* lane l owns words [16 l, 16 l + 16) of its tile when elements are numbered */
+static_assert(k5TileRows % k5SpanRows == 0 && k5TileRows % 64 == 0, "tile = whole spans, whole words per lane");
+
+/* ---- the streaming half: flags of one span of k5SpanRows KiB --------------------------------- */
+
+/* lane r of the result: the flag word of row r of the span at `base` (bit l = chunk l of that row) */
+__device__ __forceinline__ unsigned long long span_flags(const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t cut, int lane)
+{
+    u32x4 q[k5SpanRows];
+    if (base + k5SpanBytes <= n) {
+#pragma unroll
+        for (int r = 0; r < k5SpanRows; ++r) q[r] = *reinterpret_cast<const u32x4*>(stream + base + 1024u * r + 16u * lane);
+    } else {
+#pragma unroll
+        for (int r = 0; r < k5SpanRows; ++r) q[r] = load_chunk_guarded(stream, base + 1024u * r + 16u * lane, n);
+    }
+    const uint32_t before = base >= 4 ? *reinterpret_cast<const uint32_t*>(stream + base - 4) : 0xFFFFFFFFu;
+    const uint32_t after = load_dword_guarded(stream, (int64_t)(base + k5SpanBytes), n);
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int r = 0; r < k5SpanRows; ++r) {
+        const uint32_t e_prev = r == 0 ? before : (uint32_t)__builtin_amdgcn_readlane((int)q[r ? r - 1 : 0].w, 63);
+        const uint32_t e_next = r == k5SpanRows - 1 ? after : (uint32_t)__builtin_amdgcn_readlane((int)q[r + 1 < k5SpanRows ? r + 1 : r].x, 0);
+        const uint32_t xp = from_prev_lane(q[r].w, e_prev);
+        const uint32_t xn = from_next_lane(q[r].x, e_next);
+        const uint64_t g0 = base + 1024u * r + 16u * lane;
+        /* the chunk cut by the stream end is always an element */
+        const bool f = g0 < n && (chunk_flag(xp, q[r].x, q[r].y, q[r].z, q[r].w, xn) || (g0 >> 4) == cut);
+        const unsigned long long m = __ballot(f);
+        if (lane == r) mine = m;
+    }
+    return mine;
+}
+
+/* ---- the element half ------------------------------------------------------------------------ */
+
+struct Lds5 {
+    unsigned long long words[k5TileRows];      /* the tile's mask                                   */
+    uint32_t lane_pre[64];                     /* elements in front of lane l's words               */
+    uint32_t seg_dummy[64];                    /* elem_emit leaves a segment word per element: nobody copies here */
+};
+
+/* chunk number (in the tile) of element i: the (i - lane_pre[o])-th set bit of owner lane o's words */
+__device__ __forceinline__ uint32_t elem_chunk(const Lds5& l, uint32_t i)
+{
+    /* owner: the last lane whose prefix is <= i */
+    uint32_t lo = 0, hi = 63;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (l.lane_pre[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    uint32_t k = i - l.lane_pre[lo];
+    uint32_t w = lo * (uint32_t)k5WordsPerLane;
+    unsigned long long x = l.words[w];
+    for (;;) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(x);
+        if (k < c) break;
+        k -= c;
+        x = l.words[++w];
+    }
+    for (; k; --k) x &= x - 1;                                /* drop the k lowest set bits */
+    return w * 64u + (uint32_t)__builtin_ctzll(x);
+}
+
+/* elements [i0, i0 + 64) of the tile, one per lane: the exact rules on each, then their combination in order.
+ * prev_chunk_end = end of the element in front of element i0 (stream offset), carried from batch to batch. */
+__device__ __forceinline__ TileAgg make_batch(Elem& el, const Lds5& l, uint32_t i0, uint32_t nelem, int lane,
+                                              const uint8_t* __restrict__ stream, uint64_t base, uint64_t n, uint64_t& prev_end)
+{
+    const uint32_t i = i0 + (uint32_t)lane;
+    const bool have = i < nelem;
+    uint32_t c = 0;
+    if (have) c = elem_chunk(l, i);
+    /* the element in front of mine: the lane below, or what the previous batch left */
+    const uint32_t c_prev = (uint32_t)__shfl_up((int)c, 1, 64);
+    const uint64_t my_prev_end = lane == 0 ? prev_end : base + 16ull * ((uint64_t)c_prev + 1u);
+    TileAgg ea = agg_identity();
+    el.gap = 0; el.chunk = 0;
+    if (have) {
+        elem_load(el.v, stream, base + 16ull * c, n, false);
+        elem_walk(el.v, el.m, el.s);
+        el.gap = span_bytes(my_prev_end, el.v.g0, n);
+        el.chunk = c;
+        ea = elem_agg(el.gap, el.s);
+    }
+    /* the last element of this batch, for the next one */
+    const uint32_t cnt = nelem - i0 < 64u ? nelem - i0 : 64u;
+    const uint32_t c_last = (uint32_t)__shfl((int)c, (int)(cnt - 1u), 64);
+    prev_end = base + 16ull * ((uint64_t)c_last + 1u);
+    return ea;
+}
+
+__global__ __launch_bounds__(64)
+void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
+                 hbs_nal_entry* __restrict__ index, uint64_t index_cap,
+                 unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate == kGateIfSparse && probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
+    __shared__ Lds5 l;
+    const int lane0 = threadIdx.x;
+    const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
+    EmitTarget tgt;
+    tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
+    for (;;) {
+        const int lane = launder_lane(lane0);
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(&hdr->ticket, 1u);
+        const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        if (tile >= num_tiles) break;
+        const uint64_t base = tile * k5TileBytes;
+        const uint64_t tile_end = base + k5TileBytes;
+        const bool last_tile = tile == num_tiles - 1;
+        __builtin_amdgcn_s_setprio(3);
+
+        /* stream the tile: flag words into LDS, one span at a time */
+#pragma unroll 1
+        for (int sp = 0; sp < k5TileRows / k5SpanRows; ++sp) {
+            const uint64_t sbase = base + (uint64_t)sp * k5SpanBytes;
+            unsigned long long w = 0;
+            if (sbase < n) w = span_flags(stream, n, sbase, cut, launder_lane(lane));
+            if (lane < k5SpanRows) l.words[sp * k5SpanRows + lane] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        /* my words; how many elements in front of them */
+        uint32_t mycnt = 0;
+#pragma unroll
+        for (int j = 0; j < k5WordsPerLane; ++j) mycnt += (uint32_t)__builtin_popcountll(l.words[lane * k5WordsPerLane + j]);
+        const uint32_t inc = wave_incl_scan32(mycnt, lane);
+        l.lane_pre[lane] = inc - mycnt;
+        const uint32_t nelem = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        /* elements -> tile aggregate, 64 at a time */
+        const uint32_t npass = (nelem + 63u) >> 6;
+        Elem el;
+        TileAgg acc = agg_identity(), e = agg_identity();
+        uint64_t prev_end = base;
+#pragma unroll 1
+        for (uint32_t p = 0; p < npass; ++p) {
+            TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+            ea = wave_scan_combine(ea, lane);
+            TileAgg up = agg_shfl_up(ea, 1);
+            if (lane == 0) up = agg_identity();
+            e = combine(acc, up);
+            acc = combine(acc, agg_readlane(ea, 63));
+        }
+        const TileAgg tagg = combine(acc, gap_agg(span_bytes(prev_end, tile_end, n)));
+
+        Prefix ex;
+        uint32_t it, stl;
+        const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
+        __builtin_amdgcn_s_setprio(0);
+        if (!ok) return;
+        if (lane == 0 && last_tile) {
+            const Prefix incl = fold(ex, tagg);
+            hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
+        }
+        const Prefix excl = prefix_uniform4(ex);
+
+        /* index entries: one batch -> the elements are still in registers; more -> walk them again */
+        if (npass == 1u) {
+            if ((uint32_t)lane < nelem) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+        } else if (npass > 1u) {
+            TileAgg accb = agg_identity();
+            prev_end = base;
+#pragma unroll 1
+            for (uint32_t p = 0; p < npass; ++p) {
+                TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+                ea = wave_scan_combine(ea, lane);
+                TileAgg up = agg_shfl_up(ea, 1);
+                if (lane == 0) up = agg_identity();
+                const TileAgg eb = combine(accb, up);
+                accb = combine(accb, agg_readlane(ea, 63));
+                if (64u * p + (uint32_t)lane < nelem) elem_emit(el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                       /* l is reused by the next tile */
+    }
+}
+
+/* ---- host side ---------------------------------------------------------------------------- */
+
+uint64_t scan5_tile_bytes() { return k5TileBytes; }
+
+void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    uint64_t waves = (uint64_t)cus * 20u;                       /* what fits: ~95 VGPRs per lane, 8.5 KiB of LDS per wavefront */
+    if (waves > num_tiles) waves = num_tiles;
+    if (waves < 1) waves = 1;
+    k_scan_index5<<<dim3((unsigned)waves), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, a.desc, a.hdr, gate);
+}
+
+} // namespace hbs

@@ -99,9 +99,11 @@ int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
  *     pairs are rare, and the slowest on zero-heavy data),
  * 2 = tile staged in an LDS image (hbs_scan.hip; same speed on any data),
  * 3 = tile in registers, dense per-row classification (hbs_scan3.hip).
- * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and kernel 4 or
- *     kernel 2 is picked from it on the device, without a host round trip.
- * Environment HBS_KERNEL=0|2|3|4 sets the default.  hbs_ctx_last_kernel waits for the last
+ * 5 = index only (no RBSP arena asked for): nothing has to stay in registers, so the bytes are
+ *     streamed and only the flagged chunks are looked at again (hbs_scan5.hip); with an arena it means 4,
+ * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and kernel 4 (5
+ *     when no arena is asked for) or kernel 2 is picked from it on the device, without a host round trip.
+ * Environment HBS_KERNEL=0|2|3|4|5 sets the default.  hbs_ctx_last_kernel waits for the last
  * hbs_index_extract and says which kernel ran it. */
 int  hbs_ctx_set_kernel(hbs_ctx* ctx, int variant);
 int  hbs_ctx_get_kernel(hbs_ctx* ctx);

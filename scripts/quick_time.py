@@ -2,6 +2,10 @@
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+if os.environ.get("HBS_LIB"):
+    import hevcbitstream_amd.api as _api
+    _api.library_path = lambda: os.environ["HBS_LIB"]
 import hevcbitstream_amd as hbs
 from tests import _orc
 

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
-@pytest.fixture(scope="module", params=[0, 2, 3, 4], ids=["automatic", "lds-image-kernel", "register-kernel", "sparse-kernel"])
+@pytest.fixture(scope="module", params=[0, 2, 3, 4, 5],
+                ids=["automatic", "lds-image-kernel", "register-kernel", "sparse-kernel", "index-only-passes"])
 def ctx(request):
     """the three implementations of the fused kernel (hbs_scan.hip 2, hbs_scan3.hip 3, hbs_scan4.hip 4) and the
     automatic choice between 4 and 2 (the default)"""
@@ -128,6 +129,29 @@ def test_index_only_and_capacity(ctx, orc):
     got_idx, _, s = run(ctx, stream, index_cap=100)
     assert int(s["error"]) == -4 and int(s["nal_found"]) == 300 and len(got_idx) == 100
     assert np.array_equal(got_idx["start"], idx["start"][:100])
+
+
+def test_index_only_streams(ctx, orc):
+    """no RBSP arena asked for (find_nal_unit over a stream): on kernel 5 and in automatic mode the flags pass + element
+    pass of hbs_scan5.hip answer -- several 1 MiB tiles, ends cut inside a chunk, regions dense in zero pairs (more than
+    64 elements per tile), zeros and start codes across tile edges"""
+    rng = np.random.RandomState(41)
+    for rep, size in enumerate([1 << 20, (1 << 20) + 7, 3 * (1 << 20) + 1234567, 70001, 5_000_013]):
+        s = rng.randint(0, 256, size=size).astype(np.uint8)
+        if rep % 2 == 0:
+            s[rng.rand(size) < 0.02] = 0                       # many elements per tile
+        for m in range(1 << 20, size - 8, 1 << 20):           # patterns across the 1 MiB tile edges
+            o = m + int(rng.randint(-4, 2))
+            s[o:o + 5] = (0, 0, 0, 1, 0x42) if rep % 2 else (0, 0, 1, 0, 0)
+        dense = ALPHA[rng.randint(0, len(ALPHA), size=min(size // 8, 200_000))]
+        a = int(rng.randint(0, size - len(dense)))
+        s[a:a + len(dense)] = dense                            # a region where nearly every chunk is an element
+        want_idx, _, why = orc.index_extract(s)
+        got_idx, got_arena, sm = run(ctx, s, want_rbsp=False)
+        assert got_arena is None and int(sm["error"]) == 0 and int(sm["stop_reason"]) == why, (rep, size)
+        assert len(got_idx) == len(want_idx), (rep, size, len(got_idx), len(want_idx))
+        for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+            assert np.array_equal(got_idx[f], want_idx[f]), (rep, size, f)
 
 
 def test_repeatable(ctx, orc):
