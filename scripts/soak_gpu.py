@@ -13,6 +13,8 @@ orc = _orc.oracle()
 ctxs = {v: hbs.Context(0) for v in (0, 2, 4)}
 for v, c in ctxs.items():
     c.set_kernel(v)
+ctx5 = hbs.Context(0)
+ctx5.set_kernel(5)
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
@@ -63,6 +65,15 @@ while time.time() < t_end:
         if not ok:
             bad += 1
             print("SCAN MISMATCH kernel", v, "iter", it, "len", len(s))
+    # the scan alone (no arena): the streaming kernel, pinned and through the automatic choice
+    for v in (5, 0):
+        c = ctx5 if v == 5 else ctxs[0]
+        got_idx, _, sm = c.index_extract(d, want_rbsp=False)
+        ok = (int(sm["error"]) == 0 and int(sm["stop_reason"]) == why and len(got_idx) == len(want_idx)
+              and all(np.array_equal(got_idx[f], want_idx[f]) for f in ("start", "end", "rbsp_off", "rbsp_len", "status")))
+        if not ok:
+            bad += 1
+            print("INDEX-ONLY MISMATCH kernel", v, "iter", it, "len", len(s))
     # emit what was extracted (accepted NALs only) and compare with the oracle's rbsp_to_nal loop
     if len(want_idx):
         keep = want_idx[(want_idx["status"] & 1) == 0]
