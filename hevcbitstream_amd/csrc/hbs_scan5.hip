@@ -176,16 +176,19 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
 
         /* elements -> tile aggregate, 64 at a time */
         const uint32_t npass = (nelem + 63u) >> 6;
-        Elem el;
-        TileAgg acc = agg_identity(), e = agg_identity();
+        /* up to 128 elements (a 1 MiB tile of coded video has ~100) are walked once and kept: two per lane */
+        Elem el, el2;
+        TileAgg acc = agg_identity(), e = agg_identity(), e2 = agg_identity();
         uint64_t prev_end = base;
 #pragma unroll 1
         for (uint32_t p = 0; p < npass; ++p) {
-            TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+            TileAgg ea;
+            if (p == 1u) ea = make_batch(el2, l, 64u, nelem, lane, stream, base, n, prev_end);
+            else ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
             ea = wave_scan_combine(ea, lane);
             TileAgg up = agg_shfl_up(ea, 1);
             if (lane == 0) up = agg_identity();
-            e = combine(acc, up);
+            if (p == 1u) e2 = combine(acc, up); else e = combine(acc, up);
             acc = combine(acc, agg_readlane(ea, 63));
         }
         const TileAgg tagg = combine(acc, gap_agg(span_bytes(prev_end, tile_end, n)));
@@ -201,10 +204,13 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
         }
         const Prefix excl = prefix_uniform4(ex);
 
-        /* index entries: one batch -> the elements are still in registers; more -> walk them again */
+        /* index entries: one or two batches -> the elements are still in registers; more -> walk them again */
         if (npass == 1u) {
             if ((uint32_t)lane < nelem) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-        } else if (npass > 1u) {
+        } else if (npass == 2u) {
+            elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+            if (64u + (uint32_t)lane < nelem) elem_emit(el2, e2, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+        } else if (npass > 2u) {
             TileAgg accb = agg_identity();
             prev_end = base;
 #pragma unroll 1
