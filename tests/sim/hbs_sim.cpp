@@ -507,3 +507,51 @@ extern "C" int sim_write_nal(int type, int layer, int tid, uint8_t* slot /* stru
     write_one_nal(ps, type, layer, tid, slot, last_pps, last_sps, zero_pps, zero_sps, res);
     return 0;
 }
+
+/* ---- the multi-bit fast paths of the bit reader / writer (hbs_bitfast.h) against bs.h's one bit at a time ---------
+ * Random buffers, cursors anywhere (the end of the buffer and beyond included), every width: bits(n), the zero
+ * count of ue, put_bits(n, v) must leave the same value, the same cursor and the same bytes as the bit loops they
+ * stand in for.  Returns the number of disagreements. */
+extern "C" int64_t sim_bitio_check(uint64_t seed, int64_t iterations)
+{
+    using namespace hbs;
+    int64_t bad = 0;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    std::vector<uint8_t> buf(64), wa(64), wb(64);
+    for (int64_t it = 0; it < iterations; ++it) {
+        const uint32_t size = (uint32_t)(rnd() % 40);
+        for (auto& b : buf) { const uint64_t r = rnd(); b = (r & 3) == 0 ? 0 : (uint8_t)(r >> 8); }     /* zero-rich: long ue prefixes */
+        const uint32_t pos = (uint32_t)(rnd() % (8 * size + 24));
+        const int n = (int)(rnd() % 44);
+        BitIOT<kModeRead> a, b;
+        a.win = buf.data(); a.full = buf.data(); a.win_bytes = (uint32_t)(rnd() % 2 ? size : 0); a.size = size; a.pos = pos;
+        a.tr = nullptr; a.tr_cap = 0; a.tr_n = 0; a.wbuf = nullptr;
+        b = a;
+        /* bits(n) against n calls of bit() (bs.h:160-169) */
+        const uint32_t va = a.bits(n);
+        uint32_t vb = 0;
+        for (int i = 0; i < n; ++i) vb |= b.bit() << ((uint32_t)(n - i - 1) & 31u);
+        if (va != vb || a.pos != b.pos) ++bad;
+        /* ue (bs.h:195-207) */
+        a.pos = b.pos = pos;
+        const uint32_t ua = a.ue_raw();
+        int i = 0;
+        while ((b.bit() == 0) && (i < 32) && (!b.eof())) ++i;
+        uint32_t ub = 0;
+        for (int k = 0; k < i; ++k) ub |= b.bit() << ((uint32_t)(i - k - 1) & 31u);
+        ub += (1u << (i & 31)) - 1u;
+        if (ua != ub || a.pos != b.pos) ++bad;
+        /* put_bits(n, v) against n calls of put() (bs.h:240-247) */
+        for (size_t k = 0; k < wa.size(); ++k) wa[k] = wb[k] = (uint8_t)rnd();
+        BitIOT<kModeWrite> wa_io, wb_io;
+        wa_io.win = wa.data(); wa_io.full = wa.data(); wa_io.win_bytes = 0; wa_io.size = size; wa_io.pos = pos;
+        wa_io.tr = nullptr; wa_io.tr_cap = 0; wa_io.tr_n = 0; wa_io.wbuf = wa.data();
+        wb_io = wa_io; wb_io.win = wb.data(); wb_io.full = wb.data(); wb_io.wbuf = wb.data();
+        const uint32_t v = (uint32_t)rnd();
+        wa_io.put_bits(n, v);
+        for (int k = 0; k < n; ++k) wb_io.put((v >> ((uint32_t)(n - k - 1) & 31u)) & 1u);
+        if (wa_io.pos != wb_io.pos || wa != wb) ++bad;
+    }
+    return bad;
+}

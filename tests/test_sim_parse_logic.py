@@ -101,3 +101,13 @@ def test_config3_downsized():
     parsed, structs = _sim.parse_headers(arena, idx)
     compare(parsed, structs, arena, idx, oracle_pass(nals))
     assert (parsed["rc"] >= 0).all()
+
+
+def test_bit_io_fast_paths_equal_the_bit_loops():
+    """hbs_bitfast.h (whole fields at once) against bs.h's one bit at a time: value, cursor and written bytes agree for
+    every width and every cursor position, the end of the buffer and beyond included"""
+    import ctypes as C
+    L = _sim.lib()
+    L.sim_bitio_check.argtypes = [C.c_uint64, C.c_int64]
+    L.sim_bitio_check.restype = C.c_int64
+    assert L.sim_bitio_check(12345, 400000) == 0
