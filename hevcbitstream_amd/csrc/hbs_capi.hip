@@ -298,8 +298,8 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
         if (c->emit_blocks <= 0) return fail(c, hipErrorUnknown, "occupancy query of the emit kernel");
         const char* eb = getenv("HBS_EMIT_BLOCKS");         /* debugging aid */
         if (eb && atoi(eb) > 0 && atoi(eb) < c->emit_blocks) c->emit_blocks = atoi(eb);
-        const char* tp = getenv("HBS_EMIT_TWO_PASS");
-        c->emit_two_pass = (tp && atoi(tp) == 1) ? 1 : 0;
+        const char* tp = getenv("HBS_EMIT_TWO_PASS");        /* 1 / 0 pin a way; default: picked on the device */
+        c->emit_two_pass = !tp ? -1 : (atoi(tp) == 1 ? 1 : 0);
     }
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::EmitArgs a;
@@ -315,6 +315,8 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.err = reinterpret_cast<uint32_t*>(tail + 256);
     a.ticket = reinterpret_cast<uint32_t*>(tail + 512);
     a.n_items = reinterpret_cast<unsigned long long*>(tail + 768);
+    a.total_dense = reinterpret_cast<unsigned long long*>(tail + 768 + 64);
+    a.probe = reinterpret_cast<uint32_t*>(tail + 768 + 128);
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_emit_annexb");

@@ -28,7 +28,9 @@ struct EmitArgs {
     uint64_t items_cap;               /* emit_items_bound(n, payload bytes)                               */
     unsigned long long* desc;         /* items_cap / 12 + 1 look-back words                               */
     int grid_blocks;                  /* resident workgroups of the single-pass kernel (emit_grid_blocks) */
-    int two_pass;                     /* 1: count / scan / emit as three steps (kept for comparison)      */
+    int two_pass;                     /* 1: count / scan / emit as three steps; 0: the single pass; -1: picked on the device by density */
+    unsigned long long* total_dense;  /* 1: the three-step path's total                                   */
+    uint32_t* probe;                  /* 2: chunks sampled, chunks flagged                                */
 };
 
 struct SynthArgs {
