@@ -13,6 +13,12 @@
  *   hbs_parse_headers   replaces  read_hevc_nal_unit() per NAL
  *                       reference: hevc_stream.c:155-240 and the readers it
  *                       dispatches to (:243-1218)
+ *   hbs_parse_headers_trace   the same with the per-field trace read_debug_hevc_nal_unit
+ *                       prints (hevc_stream.c:2343-3434)
+ *   hbs_write_headers   replaces  write_hevc_nal_unit() per NAL up to rbsp_to_nal
+ *                       reference: hevc_stream.c:1249-1327 and the writers behind it
+ *   hbs_index_extract_host    hbs_index_extract for a stream in HOST memory of any
+ *                       length, windowed (replaces the reader of hevc_analyze.c:124-210)
  *   hbs_synth_*         synthetic stream S(seed, n_nals, mode) of SURVEY.md
  *                       8(d) (no reference counterpart: it ships no streams)
  *
@@ -94,7 +100,7 @@ int  hbs_ctx_synchronize(hbs_ctx* ctx);
 int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
 int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
 int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
-/* Three implementations of the fused scan/extract kernel exist, with identical results:
+/* Several implementations of the scan kernel exist, with identical results:
  * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
  *     pairs are rare, and the slowest on zero-heavy data),
  * 2 = tile staged in an LDS image (hbs_scan.hip; same speed on any data),
