@@ -126,6 +126,11 @@ class Context:
         if rc != 0:
             raise HbsError("%s failed: %d (%s)" % (what, rc, self.lib.hbs_last_error(self.h).decode()))
 
+    def set_sequential_parse(self, on=True):
+        """parse batches NAL after NAL with ONE set of derived RPS tables, as the reference does (slow, exact on any input)"""
+        self.lib.hbs_ctx_set_sequential_parse.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.hbs_ctx_set_sequential_parse(self.h, 1 if on else 0), "hbs_ctx_set_sequential_parse")
+
     def set_kernel(self, variant):
         """0 = automatic (density probe picks 4 or 2 on the device; the default), 2 = LDS-image
         scan/extract kernel, 3 = register-resident one, 4 = event-sparse one"""

@@ -452,6 +452,92 @@ void k4_small(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     }
 }
 
+/* A whole batch the reference's way (hbs_ctx_set_sequential_parse): ONE wavefront walks the NALs in stream order,
+ * lane 0 parsing, all lanes clearing structs; one set of derived RPS tables (hevc_stream.c:26-32) that every SPS and
+ * every slice's own set writes into and reads from.  Orders of magnitude slower than k4_parse -- it exists so that
+ * streams the spec forbids (a slice naming a set its SPS does not have) can be parsed exactly like the reference
+ * when that matters.  Every SPS slot gets a snapshot of the tables as they stood right behind it. */
+template <int kMode>
+__global__ __launch_bounds__(64)
+void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
+            ParsedNal* __restrict__ parsed, uint8_t* structs, uint64_t structs_cap,
+            const uint8_t* __restrict__ zeros, const uint8_t* init_sps_slot, const uint8_t* init_pps,
+            TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
+            RpsTables* tables /* workspace */, hbs_summary* __restrict__ sum)
+{
+    const int lane = threadIdx.x;
+    const uint64_t tbl_off = round16(sizeof(hevc_sps_t));
+    /* the tables at "program start", or the ones behind the SPS the caller hands in */
+    {
+        uint4* d = reinterpret_cast<uint4*>(tables);
+        const uint4* src = init_sps_slot ? reinterpret_cast<const uint4*>(init_sps_slot + tbl_off) : nullptr;
+        for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(RpsTables) / 16); i += 64) d[i] = src ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint64_t off_run = 0, sps_off = ~0ull, pps_off = ~0ull;
+    bool have_sps = false, have_pps = false;
+    uint32_t err = 0;
+#pragma unroll 1
+    for (uint64_t k = 0; k < n; ++k) {
+        const hbs_nal_entry e = idx[k];
+        ParsedNal p;
+        p.rc = -1; p.nal_unit_type = -1; p.nal_layer_id = -1; p.nal_temporal_id_plus1 = -1;
+        p.struct_off = ~0ull; p.slice_data_size = 0; p.slice_data_off = 0;
+        uint64_t sz = 0;
+        if (!(e.status & HBS_ST_ERROR)) {
+            nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
+            sz = slot_bytes_of(p.nal_unit_type);
+        }
+        const int type = p.nal_unit_type;
+        const bool slice = is_slice_type_nal(type);
+        const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
+        if (sz) p.struct_off = off_run;
+        bool active = type >= 0 && (slice || pset);
+        if (active && off_run + sz > structs_cap) { err = (uint32_t)(-HBS_E_CAPACITY); p.struct_off = ~0ull; active = false; }
+        uint32_t tr_n = 0;
+        if (active) {
+            uint8_t* dst = structs + off_run;
+            zero_slot(dst, sz, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane == 0) {
+                const uint8_t* sps_slot = nullptr;
+                const uint8_t* pps_struct = nullptr;
+                if (slice) {
+                    if (have_sps) { if (sps_off != ~0ull) sps_slot = structs + sps_off; } else sps_slot = init_sps_slot;
+                    if (have_pps) { if (pps_off != ~0ull) pps_struct = structs + pps_off; } else pps_struct = init_pps;
+                }
+                tr_n = parse_lane<kMode>(type, slice, e, dst, nullptr, 0, rbsp + e.rbsp_off, sps_slot, pps_struct, zeros, p,
+                                         trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, nullptr, tables);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {          /* the tables as they stand now, next to the SPS */
+                uint4* d = reinterpret_cast<uint4*>(dst + tbl_off);
+                const uint4* src = reinterpret_cast<const uint4*>(tables);
+                for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(RpsTables) / 16); i += 64) d[i] = src[i];
+            }
+        }
+        if (lane == 0) {
+            parsed[k] = p;
+            if (trace_count) trace_count[k] = tr_n;
+        }
+        if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) { have_sps = true; sps_off = p.struct_off; }
+        if (type == HEVC_NAL_UNIT_TYPE_PPS_NUT) { have_pps = true; pps_off = p.struct_off; }
+        off_run += sz;
+    }
+    if (lane == 0) {
+        sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = 0; sum->stream_bytes = 0;
+        sum->stop_reason = 0; sum->error = err ? HBS_E_CAPACITY : 0;
+        sum->reserved[0] = off_run;
+        sum->reserved[1] = sum->reserved[2] = 0;
+    }
+}
+
 /* ---- K5: syntax writers (write_hevc_nal_unit, hevc_stream.c:1249-1327, up to rbsp_to_nal) ---- */
 
 __global__ void k5_slot_sizes(const ParsedNal* __restrict__ parsed, uint64_t n, unsigned long long* __restrict__ slot_size)
@@ -545,6 +631,17 @@ uint64_t parse_own_rows_bytes(uint64_t n) { return (uint64_t)parse_grid_blocks(n
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
 {
+    if (a.sequential && a.structs && a.n > 1) {                           /* a whole batch, one NAL after the other */
+        RpsTables* tables = reinterpret_cast<RpsTables*>(a.own_rows);
+        static_assert(sizeof(RpsTables) <= 64 * sizeof(RpsRow), "the own-rows workspace of one wavefront holds the tables");
+        if (a.trace)
+            k4_seq<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                 a.initial_pps, a.trace, a.trace_cap, a.trace_count, tables, a.summary);
+        else
+            k4_seq<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                a.initial_pps, nullptr, 0, nullptr, tables, a.summary);
+        return hipGetLastError();
+    }
     if (a.n >= 1 && a.n <= 64) {
         if (a.trace)
             k4_small<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,

@@ -46,3 +46,10 @@ for i in range(4):
 torch.cuda.synchronize()
 tw = min(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
 print("K5 write_headers: best %.3f ms -> %.2f M NAL/s (rc<0: %d)" % (tw, n / tw / 1e3, int((written["rc"] < 0).sum())))
+
+# the opt-in sequential walk (one wavefront, NAL after NAL, one set of RPS tables): exact on any input, and this slow
+ctx.set_sequential_parse(True)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ctx.parse_headers_async(rbsp, index, n, pt, structs, sm); e1.record(); torch.cuda.synchronize()
+print("sequential parse of the same batch: %.1f ms -> %.2f M NAL/s" % (e0.elapsed_time(e1), n / e0.elapsed_time(e1) / 1e3))
+ctx.set_sequential_parse(False)

@@ -68,6 +68,25 @@ def test_broken_slices_and_parameter_sets(ctx):
         run(ctx, broken(seq, rng, lambda t: True))
 
 
+def test_sequential_batch_is_the_reference_on_forbidden_streams():
+    """hbs_ctx_set_sequential_parse: a batch walked NAL after NAL with one set of RPS tables matches the oracle (= the
+    reference) even where slices name a set their cut-short SPS does not have -- the five streams on which the default,
+    independent parse reads zeros instead -- and on ordinary ones"""
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    c.set_sequential_parse(True)
+    try:
+        for seed in (1036, 1064, 1320, 1496, 5224, 3, 4):
+            nals = broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True) if seed > 100 else sequence(seed)
+            run(c, nals)
+        nals = []                                            # a longer stream: parameter sets changing under way
+        for seed in range(300, 312):
+            nals += sequence(seed)
+        run(c, nals)
+    finally:
+        c.close()
+
+
 def test_ten_nal_fixture(ctx):
     data = open(os.path.join(HERE, "golden", "ten_nal.hevc"), "rb").read()
     idx = json.load(open(os.path.join(HERE, "golden", "ten_nal.index.json")))
