@@ -12,6 +12,9 @@ from tests.test_sim_parse_logic import broken, sequence
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 ctx = hbs.Context(0)
+import os
+if os.environ.get("HBS_FUZZ_SEQ"):                       # the opt-in sequential walk: expected to match everywhere
+    ctx.set_sequential_parse(True)
 
 
 def gpu_parse(stream_bytes):
