@@ -268,6 +268,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if gatherer is not None:            # RCCL builds its communicator on first use: not inside anybody's timed region, whatever --warmup says
+        gatherer.submit(indexes[0], 0, 0, 0)
+        gatherer.drain()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
