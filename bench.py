@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 uniform payload (headline), 1 zero-heavy")
     ap.add_argument("--cpu-sample-nals", type=int, default=1_000_000, help="0 disables the CPU baseline leg")
     ap.add_argument("--other-kernels", type=int, default=1, help="0 skips the emit / parse / write measurements (N = 1 only)")
+    ap.add_argument("--exercise-gather", action="store_true",
+                    help="dev aid: run the N > 1 code path (RCCL group, pipelined index gather) with a one-rank group on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -232,10 +234,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.exercise_gather           # "multi" = the code path with the exchange in it
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = hbs.Context(local_rank)
     ctx.enable_timing(True)
@@ -250,8 +258,8 @@ def main():
     from hevcbitstream_amd import shard
     # N > 1: the one exchange of the path is the all-gather of the NAL index (counts, then the padded entry
     # arrays; RCCL).  It runs on the collective's stream while the next step's scan fills the other index buffer.
-    indexes = [index, torch.empty_like(index)] if world > 1 else [index]
-    gatherer = shard.IndexGatherer(torch, dist, cap, index.device, depth=2) if world > 1 else None
+    indexes = [index, torch.empty_like(index)] if multi else [index]
+    gatherer = shard.IndexGatherer(torch, dist, cap, index.device, depth=2) if multi else None
     counter = [0]
 
     def step():
@@ -264,7 +272,7 @@ def main():
     def fence():
         if gatherer is not None:
             gatherer.drain()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -295,7 +303,7 @@ def main():
     b = gen_index[: n * 32].view(torch.int64).view(n, 4)
     assert torch.equal(a[:, :3], b[:, :3]), "NAL index != generator's index"
 
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -332,7 +340,7 @@ def main():
             "config": {"workload": "start-code scan + NAL index + RBSP extraction (hbs_index_extract) over "
                                    "S(seed=0x1234+rank, n_nals=%d, mode=%s): %.3f GiB Annex-B per GPU, ~10 KiB NALs, "
                                    "resident in HBM%s" % (n, "uniform" if args.mode == 0 else "zero-heavy", sb / 2**30,
-                                                          "; + RCCL all-gather of the NAL index" if world > 1 else ""),
+                                                          "; + RCCL all-gather of the NAL index" if multi else ""),
                        "stream_bytes_per_gpu": sb, "nals_per_gpu": n,
                        "parallelism": "%d independent shard(s), one per GPU" % world,
                        "grid": "%d persistent workgroups (%d per CU) x %s" % (blocks, per_cu, geometry)},
@@ -355,7 +363,7 @@ def main():
             del rbsp, index
             out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
