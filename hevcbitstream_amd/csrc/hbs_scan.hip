@@ -644,7 +644,8 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     k_init_header<<<1, 1, 0, st>>>(a.hdr);
     if (automatic && a.n) launch_scan4_probe(a, st);
     /* no arena asked for: the streaming index-only kernel takes the place of the event-sparse one */
-    const bool index_only = a.rbsp == nullptr && (automatic || a.variant == 5);
+    /* (its 1 MiB tiles need a stream of ~0.75 GiB to occupy the GPU; below that the register-resident kernel is quicker) */
+    const bool index_only = a.rbsp == nullptr && (a.variant == 5 || (automatic && a.n >= (3ull << 28)));
     const int sparse_variant = (a.variant == 5 && !index_only) ? 4 : a.variant;
     if (!index_only && (automatic || sparse_variant == 4)) launch_scan4_prepare_tail(a, st);
     if (a.index_cap) {
