@@ -222,7 +222,9 @@ int hbs_ctx_last_kernel(hbs_ctx* c)
     hipError_t e = hipMemcpyAsync(&h, c->hdr, sizeof(h), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, e, "read-back of the density probe");
-    c->last_variant = hbs::probe_says_dense(h.probe_chunks, h.probe_flagged) ? 2 : (c->last_index_only ? 5 : 4);
+    uint64_t chunks = 0, flagged = 0;
+    for (int i = 0; i < 64; ++i) { chunks += h.probe_slot[i][0]; flagged += h.probe_slot[i][1]; }
+    c->last_variant = hbs::probe_says_dense((uint32_t)chunks, (uint32_t)flagged) ? 2 : (c->last_index_only ? 5 : 4);
     c->probe_pending = 0;
     return c->last_variant;
 }

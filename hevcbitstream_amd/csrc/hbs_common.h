@@ -78,8 +78,10 @@ struct RunHeader {
     uint32_t pad0[21];
     uint32_t ticket;          /* next unclaimed tile (dynamic tile schedules); alone on its 128-byte line */
     uint32_t pad1[31];
+    uint32_t probe_slot[64][2];   /* density probe, one pair per probe workgroup: chunks sampled, chunks flagged.  Plain
+                                     stores by the prologue kernel (no zeroing needed in front); readers add them up */
 };
-static_assert(sizeof(RunHeader) == 256, "RunHeader layout");
+static_assert(sizeof(RunHeader) == 768, "RunHeader layout");
 
 /* The kernel-choice rule of the automatic mode (hbs_scan.hip launch_scan_extract): the event-sparse
  * kernel handles flagged chunks 64 at a time on one wavefront, so once more than one chunk in
@@ -88,6 +90,18 @@ static_assert(sizeof(RunHeader) == 256, "RunHeader layout");
 constexpr uint32_t kDenseOneIn = 100;   /* measured crossover: ~1.1 % of chunks flagged (scripts/density_sweep.py) */
 HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged) { return (uint64_t)flagged * kDenseOneIn > (uint64_t)chunks; }
 enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2 };
+#ifdef __HIPCC__
+/* the density probe's verdict (hbs_common.h), by a whole wavefront: lane l reads slot l */
+__device__ __forceinline__ bool probe_dense_dev(const RunHeader* __restrict__ hdr)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t c = hdr->probe_slot[lane][0], f = hdr->probe_slot[lane][1];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); f += __shfl_xor(f, d, 64); }
+    return probe_says_dense(c, f);
+}
+#endif
+
 
 HBS_HD uint32_t popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 HBS_HD uint32_t ctz64(uint64_t v)  { return (uint32_t)__builtin_ctzll(v); }

@@ -41,8 +41,8 @@ void launch_scan_extract3_kernel(const ScanArgs& a, uint64_t num_tiles, hipStrea
 int scan4_grid_blocks(int device, int* blocks_per_cu_out);
 int scan4_tile_bytes();
 int scan4_tail_bytes();
-void launch_scan4_prepare_tail(const ScanArgs& a, hipStream_t st);
-void launch_scan4_probe(const ScanArgs& a, hipStream_t st);
+/* header, probe, padded last tile, cleared index and look-back words: one launch in front of the main kernel */
+void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, bool tail, hipStream_t st);
 void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 /* index-only streaming kernel (hbs_scan5.hip) */

@@ -525,7 +525,7 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
                     uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched, int gate)
 {
-    if (gate == kGateIfDense && !probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
+    if (gate == kGateIfDense && !probe_dense_dev(hdr)) return;
     __shared__ TileLds l;
     scan_tiles(l, stream, n, num_tiles, index, index_cap, rbsp, rbsp_cap, desc, hdr, sched);
 }
@@ -541,13 +541,7 @@ extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] 
 }
 #endif
 
-__global__ void k_init_header(RunHeader* hdr)
-{
-    hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
-    hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
-    hdr->probe_chunks = 0; hdr->probe_flagged = 0;
-}
-/* (k_scan_small below does the same in front of its tile) */
+/* the run header is initialised by k_scan_prologue (hbs_scan4.hip); k_scan_small below does the same in front of its tile */
 
 __global__ void k_tail_fixup(const uint8_t* __restrict__ stream, uint64_t n,
                              hbs_nal_entry* index, uint64_t index_cap,
@@ -641,24 +635,18 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
         return hipGetLastError();
     }
-    k_init_header<<<1, 1, 0, st>>>(a.hdr);
-    if (automatic && a.n) launch_scan4_probe(a, st);
     /* no arena asked for: the streaming index-only kernel takes the place of the event-sparse one */
     /* (its 1 MiB tiles need a stream of ~0.75 GiB to occupy the GPU; below that the register-resident kernel is quicker) */
     const bool index_only = a.rbsp == nullptr && (a.variant == 5 || (automatic && a.n >= (3ull << 28)));
     const int sparse_variant = (a.variant == 5 && !index_only) ? 4 : a.variant;
-    if (!index_only && (automatic || sparse_variant == 4)) launch_scan4_prepare_tail(a, st);
-    if (a.index_cap) {
-        e = hipMemsetAsync(a.index, 0, a.index_cap * sizeof(hbs_nal_entry), st);
-        if (e != hipSuccess) return e;
-    }
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
     const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;
     const uint64_t tiles5 = (a.n + scan5_tile_bytes() - 1) / scan5_tile_bytes();
-    const uint64_t num_tiles = (sparse_variant == 4) ? tiles4 : tiles2;      /* automatic: the finer of the tilings sizes the memset */
+    const uint64_t num_tiles = (sparse_variant == 4) ? tiles4 : tiles2;      /* automatic: the finer of the tilings sizes the clear */
+    /* one launch: run header, density probe (automatic mode), padded copy of the last tile (event-sparse kernel),
+     * cleared index and look-back words */
+    launch_scan_prologue(a, num_tiles * 2, automatic && a.n != 0, !index_only && (automatic || sparse_variant == 4), st);
     if (num_tiles) {
-        e = hipMemsetAsync(a.desc, 0, num_tiles * 16, st);
-        if (e != hipSuccess) return e;
         uint64_t grid = (uint64_t)a.grid_blocks;
         if (grid > tiles2) grid = tiles2;
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }

@@ -73,7 +73,7 @@ struct RowRegs {
 };
 
 /* All of a wavefront's rows, unguarded: the last tile of a stream is read from a padded copy
- * (k_prepare_tail4), so every address below exists.  `src` is the stream or that copy. */
+ * (k_scan_prologue), so every address below exists.  `src` is the stream or that copy. */
 __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __restrict__ src, uint64_t seg, int lane)
 {
     const u32x4* p = reinterpret_cast<const u32x4*>(src + seg) + lane;
@@ -140,7 +140,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                      unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, const uint8_t* __restrict__ tail,
                      int gate)
 {
-    if (gate == kGateIfSparse && probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
+    if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
     __shared__ Lds4 l;
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -411,21 +411,79 @@ extern "C" int hbs_debug_phase_cycles4(unsigned long long* host_out /* [1024][8]
 int scan4_tile_bytes() { return k4TileBytes; }
 int scan4_tail_bytes() { return k4TailBytes; }
 
-/* tail[k4TailLead + i] = stream[last_base + i] for i in [-k4TailLead, tile + pad), 0xFF where the
- * stream has no byte: the main kernel reads the stream's last tile from here, unguarded */
-__global__ void k_prepare_tail4(const uint8_t* __restrict__ stream, uint64_t n, uint8_t* __restrict__ tail)
+/* ---- one launch in front of the main kernel --------------------------------------------------------
+ * Everything a call needs before its tiles: the run header, the density probe of the automatic mode, the
+ * 0xFF-padded copy of the stream's last tile (the main kernel reads that tile from it, unguarded), and the
+ * cleared index and look-back words -- five launches' worth of work whose latency mattered for streams of
+ * tens of MiB.  Workgroup roles by number: [0, 64) probe windows (and workgroup 0 the header),
+ * [64, 64 + kTailBlocks) the tail copy, the rest clears. */
+constexpr int kProbeBlocks = 64;
+constexpr int kTailBlocks = 32;
+constexpr int kClearBlocksMin = 32, kClearBlocksMax = 4096;      /* sized by the words to clear: ~16 stores per thread */
+
+__global__ __launch_bounds__(256)
+void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr, uint8_t* __restrict__ tail,
+                     unsigned long long* __restrict__ index_words, uint64_t n_index_words,
+                     unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int do_tail)
 {
-    if (n == 0) return;
-    const uint64_t last_base = ((n - 1) / (uint64_t)k4TileBytes) * (uint64_t)k4TileBytes;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)k4TailBytes; i += gridDim.x * blockDim.x) {
-        const int64_t q = (int64_t)last_base + (int64_t)i - k4TailLead;
-        tail[i] = (q >= 0 && (uint64_t)q < n) ? stream[q] : (uint8_t)0xFF;
+    const int b = blockIdx.x;
+    if (b < kProbeBlocks) {
+        if (b == 0 && threadIdx.x == 0) {
+            hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
+            hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
+            hdr->probe_chunks = 0; hdr->probe_flagged = 0;
+        }
+        /* Density probe: kProbeBlocks windows of 16 KiB spread evenly over the stream; counts the chunks that
+         * chunk_flag() would hand to the element path (neighbouring chunks ignored: an estimate is all the
+         * choice needs).  Every probe workgroup writes its slot, so nothing has to be zeroed beforehand. */
+        uint32_t chunks = 0, flagged = 0;
+        if (do_probe) {
+            const uint64_t stride = (n / kProbeBlocks) & ~15ull;
+            const uint64_t base = (uint64_t)b * stride;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t off = base + (uint64_t)(k * 256 + (int)threadIdx.x) * 16u;
+                const bool in = off + 16 <= n;
+                bool f = false;
+                if (in) {
+                    const Quad q = *reinterpret_cast<const Quad*>(stream + off);
+                    f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+                }
+                chunks += (uint32_t)__builtin_popcountll(__ballot(in));
+                flagged += (uint32_t)__builtin_popcountll(__ballot(f));
+            }
+        }
+        __shared__ uint32_t part[4][2];
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = chunks; part[threadIdx.x >> 6][1] = flagged; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            hdr->probe_slot[b][0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+            hdr->probe_slot[b][1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        }
+    } else if (b < kProbeBlocks + kTailBlocks) {
+        /* tail[k4TailLead + i] = stream[last_base + i] for i in [-k4TailLead, tile + pad), 0xFF where the stream has no byte */
+        if (!do_tail || n == 0) return;
+        const uint64_t last_base = ((n - 1) / (uint64_t)k4TileBytes) * (uint64_t)k4TileBytes;
+        for (uint32_t i = (uint32_t)(b - kProbeBlocks) * 256u + threadIdx.x; i < (uint32_t)k4TailBytes; i += (uint32_t)kTailBlocks * 256u) {
+            const int64_t q = (int64_t)last_base + (int64_t)i - k4TailLead;
+            tail[i] = (q >= 0 && (uint64_t)q < n) ? stream[q] : (uint8_t)0xFF;
+        }
+    } else {
+        const uint64_t t0 = (uint64_t)(b - kProbeBlocks - kTailBlocks) * 256u + threadIdx.x;
+        const uint64_t step = (uint64_t)((int)gridDim.x - kProbeBlocks - kTailBlocks) * 256u;
+        for (uint64_t i = t0; i < n_index_words; i += step) index_words[i] = 0ull;
+        for (uint64_t i = t0; i < n_desc_words; i += step) desc[i] = 0ull;
     }
 }
 
-void launch_scan4_prepare_tail(const ScanArgs& a, hipStream_t st)
+void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, bool tail, hipStream_t st)
 {
-    if (a.n) k_prepare_tail4<<<dim3(32), dim3(256), 0, st>>>(a.stream, a.n, a.tail);
+    const uint64_t index_words = a.index_cap * (sizeof(hbs_nal_entry) / 8);
+    uint64_t clear_blocks = (index_words + desc_words) / (256u * 16u);
+    if (clear_blocks < (uint64_t)kClearBlocksMin) clear_blocks = kClearBlocksMin;
+    if (clear_blocks > (uint64_t)kClearBlocksMax) clear_blocks = kClearBlocksMax;
+    k_scan_prologue<<<dim3(kProbeBlocks + kTailBlocks + (unsigned)clear_blocks), dim3(256), 0, st>>>(
+        a.stream, a.n, a.hdr, a.tail, reinterpret_cast<unsigned long long*>(a.index), index_words,
+        a.desc, desc_words, probe ? 1 : 0, tail ? 1 : 0);
 }
 
 int scan4_grid_blocks(int device, int* blocks_per_cu_out)
@@ -445,38 +503,6 @@ void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate
     if (grid > num_tiles) grid = num_tiles;
     k_scan_extract4<<<dim3((unsigned)grid), dim3(k4Threads), 0, st>>>(
         a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.tail, gate);
-}
-
-/* Density probe of the automatic mode: kProbeBlocks windows of 16 KiB spread evenly over the
- * stream; counts the chunks that chunk_flag() would hand to the element path (neighbouring
- * chunks ignored: an estimate is all the choice needs). */
-constexpr int kProbeBlocks = 64;
-__global__ __launch_bounds__(256)
-void k_probe_density(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr)
-{
-    const uint64_t stride = (n / kProbeBlocks) & ~15ull;
-    const uint64_t base = (uint64_t)blockIdx.x * stride;
-    uint32_t chunks = 0, flagged = 0;
-    for (int k = 0; k < 4; ++k) {
-        const uint64_t off = base + (uint64_t)(k * 256 + (int)threadIdx.x) * 16u;
-        const bool in = off + 16 <= n;
-        bool f = false;
-        if (in) {
-            const Quad q = *reinterpret_cast<const Quad*>(stream + off);
-            f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
-        }
-        chunks += (uint32_t)__builtin_popcountll(__ballot(in));
-        flagged += (uint32_t)__builtin_popcountll(__ballot(f));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&hdr->probe_chunks, chunks);
-        atomicAdd(&hdr->probe_flagged, flagged);
-    }
-}
-
-void launch_scan4_probe(const ScanArgs& a, hipStream_t st)
-{
-    k_probe_density<<<dim3(kProbeBlocks), dim3(256), 0, st>>>(a.stream, a.n, a.hdr);
 }
 
 } // namespace hbs

@@ -131,7 +131,7 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
                  hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                  unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int gate)
 {
-    if (gate == kGateIfSparse && probe_says_dense(hdr->probe_chunks, hdr->probe_flagged)) return;
+    if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
     __shared__ Lds5 l;
     const int lane0 = threadIdx.x;
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
