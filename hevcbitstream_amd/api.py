@@ -25,7 +25,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
-           "hbs_ctx_set_sequential_parse"]
+           "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path"]
 
 
 class HbsError(RuntimeError):
@@ -130,6 +130,11 @@ class Context:
         """parse batches NAL after NAL with ONE set of derived RPS tables, as the reference does (slow, exact on any input)"""
         self.lib.hbs_ctx_set_sequential_parse.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.hbs_ctx_set_sequential_parse(self.h, 1 if on else 0), "hbs_ctx_set_sequential_parse")
+
+    def set_emit_path(self, path=-1):
+        """-1 = picked per call (default), 0 = the single-pass emit kernel, 1 = count / scan / emit"""
+        self.lib.hbs_ctx_set_emit_path.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.hbs_ctx_set_emit_path(self.h, path), "hbs_ctx_set_emit_path")
 
     def set_kernel(self, variant):
         """0 = automatic (density probe picks 4 or 2 on the device; the default), 2 = LDS-image
@@ -252,16 +257,18 @@ class Context:
                                       C.c_void_p(summary.data_ptr()))
         self._check(rc, "hbs_emit_annexb")
 
-    def emit_annexb(self, rbsp, index_entries, gap_mode=0):
-        """Convenience: entries is a host ndarray[NAL_ENTRY]; returns (stream ndarray, entries_out)."""
+    def emit_annexb(self, rbsp, index_entries, gap_mode=0, out_cap=None):
+        """Convenience: entries is a host ndarray[NAL_ENTRY]; returns (stream ndarray, entries_out).
+        out_cap: size of the output buffer (default: the bound that always fits)."""
         t = self.torch
         dev = t.device("cuda", self.device)
         n = len(index_entries)
         d_idx = t.from_numpy(np.ascontiguousarray(index_entries).view(np.uint8).copy()).to(dev) if n else \
             t.zeros(NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
         rbsp_bytes = int(rbsp.numel())
-        out = t.empty(int(self.lib.hbs_annexb_bound(rbsp_bytes, n)) + 64 + (int(index_entries["start"].max()) if n else 0),
-                      dtype=t.uint8, device=dev)
+        if out_cap is None:
+            out_cap = int(self.lib.hbs_annexb_bound(rbsp_bytes, n)) + 64 + (int(index_entries["start"].max()) if n else 0)
+        out = t.empty(out_cap, dtype=t.uint8, device=dev)
         d_out_idx = t.empty(max(n, 1) * NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
         summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
         if rbsp_bytes == 0:

@@ -36,6 +36,7 @@ struct hbs_ctx {
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
+    int emit_path_set;                /* hbs_ctx_set_emit_path was called: the environment no longer decides */
     int sched;
     unsigned long long* desc;
     uint64_t desc_tiles;
@@ -211,6 +212,14 @@ int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
     return 0;
 }
 
+int hbs_ctx_set_emit_path(hbs_ctx* c, int path)
+{
+    if (!c || path < -1 || path > 1) return HBS_E_ARG;
+    c->emit_two_pass = path;
+    c->emit_path_set = 1;
+    return 0;
+}
+
 int hbs_ctx_last_kernel(hbs_ctx* c)
 {
     if (!c) return HBS_E_ARG;
@@ -301,7 +310,7 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
         const char* eb = getenv("HBS_EMIT_BLOCKS");         /* debugging aid */
         if (eb && atoi(eb) > 0 && atoi(eb) < c->emit_blocks) c->emit_blocks = atoi(eb);
         const char* tp = getenv("HBS_EMIT_TWO_PASS");        /* 1 / 0 pin a way; default: picked on the device */
-        c->emit_two_pass = !tp ? -1 : (atoi(tp) == 1 ? 1 : 0);
+        if (!c->emit_path_set) c->emit_two_pass = !tp ? -1 : (atoi(tp) == 1 ? 1 : 0);
     }
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::EmitArgs a;

@@ -120,6 +120,28 @@ __device__ __forceinline__ RowFlags row_flags(const u32x4& q, uint32_t e_prev, u
     return r;
 }
 
+/* bytes rbsp_to_nal inserts into one NAL; a wavefront's work, the result wave-uniform */
+__device__ __forceinline__ uint32_t count_nal(const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, int lane)
+{
+    const uint32_t nrows = (len + 1023u) / 1024u;
+    uint32_t ins = 0;                                     /* wave-uniform */
+    uint32_t e_prev = 0xFFFFFFFFu;                        /* a NAL starts with count = 0 */
+    u32x4 qn = load_nal_chunk(rbsp, begin, len, 16u * (uint32_t)lane);
+    for (uint32_t r = 0; r < nrows; ++r) {
+        const u32x4 q = qn;
+        const uint32_t off = 1024u * r + 16u * (uint32_t)lane;
+        qn = load_nal_chunk(rbsp, begin, len, off + 1024u);
+        const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
+        if (f.mask != 0) {
+            uint32_t c = 0;
+            if (f.mine) c = count_segment(rbsp, begin, begin + off, begin + (off + 16u < len ? off + 16u : len));
+            ins += wave_sum_u32(c);
+        }
+        e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
+    }
+    return ins;
+}
+
 __global__ __launch_bounds__(256)
 void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
               unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ probe)
@@ -131,22 +153,7 @@ void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     for (uint64_t k = wave; k < n; k += nwaves) {
         const uint64_t begin = idx[k].rbsp_off;
         const uint32_t len = idx[k].rbsp_len;
-        const uint32_t nrows = (len + 1023u) / 1024u;
-        uint32_t ins = 0;                                     /* wave-uniform */
-        uint32_t e_prev = 0xFFFFFFFFu;                        /* a NAL starts with count = 0 */
-        u32x4 qn = load_nal_chunk(rbsp, begin, len, 16u * (uint32_t)lane);
-        for (uint32_t r = 0; r < nrows; ++r) {
-            const u32x4 q = qn;
-            const uint32_t off = 1024u * r + 16u * (uint32_t)lane;
-            qn = load_nal_chunk(rbsp, begin, len, off + 1024u);
-            const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
-            if (f.mask != 0) {
-                uint32_t c = 0;
-                if (f.mine) c = count_segment(rbsp, begin, begin + off, begin + (off + 16u < len ? off + 16u : len));
-                ins += wave_sum_u32(c);
-            }
-            e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
-        }
+        const uint32_t ins = count_nal(rbsp, begin, len, lane);
         if (lane == 0) nal_total[k] = gap_of(idx, k, gap_mode) + len + ins;
     }
 }
@@ -245,6 +252,68 @@ static void launch_scan_u64(const unsigned long long* v, unsigned long long* out
     k_scan_apply<<<kScanBlocks, 256, 0, st>>>(v, out, n, part, probe, when);
 }
 
+/* one NAL written by one wavefront: gap bytes at `base`, then the NAL with its 03s; `total` = gap + len + inserted */
+__device__ __forceinline__ void emit_nal(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t k,
+                                         uint64_t gap, uint64_t base, uint64_t total,
+                                         uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
+                                         uint32_t* __restrict__ err, int lane)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    const uint64_t begin = idx[k].rbsp_off;
+    const uint32_t len = idx[k].rbsp_len;
+    const uint32_t nrows = (len + 1023u) / 1024u;
+    const uint64_t nal_start = base + gap;
+    const uint64_t nal_end = base + total;
+    const bool fits = nal_end <= out_cap;
+    if (fits) {
+        uint32_t ins = 0;                                 /* bytes inserted so far, wave-uniform */
+        uint32_t e_prev = 0xFFFFFFFFu;
+        u32x4 qn = load_nal_chunk(rbsp, begin, len, 16u * (uint32_t)lane);
+        for (uint32_t r = 0; r < nrows; ++r) {
+            const u32x4 q = qn;
+            const uint32_t off = 1024u * r + 16u * (uint32_t)lane;
+            qn = load_nal_chunk(rbsp, begin, len, off + 1024u);
+            const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
+            uint8_t* dst = out + nal_start + off + ins;
+            uint32_t c = 0;
+            if (f.mask != 0) {
+                const uint64_t se = begin + (off + 16u < len ? off + 16u : len);
+                if (f.mine) c = count_segment(rbsp, begin, begin + off, se);
+                uint32_t tot;
+                dst += wave_excl_scan_u32(c, lane, tot);
+                ins += tot;
+                if (f.mine) emit_segment(rbsp, begin, begin + off, se, dst);
+            }
+            if (!f.mine) {
+                if (off + 16u <= len) {
+                    reinterpret_cast<U16*>(dst)->v = q;
+                } else if (off < len) {                    /* the NAL's last, partial chunk */
+                    const uint32_t nb = len - off;
+#pragma unroll 1
+                    for (uint32_t b = 0; b < nb; ++b) {
+                        const uint32_t w = (b >> 2) == 0 ? q.x : (b >> 2) == 1 ? q.y : (b >> 2) == 2 ? q.z : q.w;
+                        dst[b] = (uint8_t)(w >> (8u * (b & 3u)));
+                    }
+                }
+            }
+            e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
+        }
+    }
+    if (lane == 0) {
+        if (fits) {
+            for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;      /* zero_byte / leading zeros */
+            if (gap) out[nal_start - 1] = 1;
+        }
+        if (idx_out) {
+            hbs_nal_entry e;
+            e.start = nal_start; e.end = nal_end;
+            e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
+            idx_out[k] = e;
+        }
+        if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+    }
+}
+
 __global__ __launch_bounds__(256)
 void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
              const unsigned long long* __restrict__ nal_total, const unsigned long long* __restrict__ out_off,
@@ -252,67 +321,52 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
              const uint32_t* __restrict__ probe)
 {
     if (probe && !emit_probe_dense(probe)) return;
-    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t k = wave; k < n; k += nwaves) {
-        const uint64_t begin = idx[k].rbsp_off;
-        const uint32_t len = idx[k].rbsp_len;
-        const uint32_t nrows = (len + 1023u) / 1024u;
-        const uint64_t gap = gap_of(idx, k, gap_mode);
-        const uint64_t base = out_off[k];
-        const uint64_t nal_start = base + gap;
-        const uint64_t nal_end = base + nal_total[k];
-        const bool fits = nal_end <= out_cap;
-        if (fits) {
-            uint32_t ins = 0;                                 /* bytes inserted so far, wave-uniform */
-            uint32_t e_prev = 0xFFFFFFFFu;
-            u32x4 qn = load_nal_chunk(rbsp, begin, len, 16u * (uint32_t)lane);
-            for (uint32_t r = 0; r < nrows; ++r) {
-                const u32x4 q = qn;
-                const uint32_t off = 1024u * r + 16u * (uint32_t)lane;
-                qn = load_nal_chunk(rbsp, begin, len, off + 1024u);
-                const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
-                uint8_t* dst = out + nal_start + off + ins;
-                uint32_t c = 0;
-                if (f.mask != 0) {
-                    const uint64_t se = begin + (off + 16u < len ? off + 16u : len);
-                    if (f.mine) c = count_segment(rbsp, begin, begin + off, se);
-                    uint32_t tot;
-                    dst += wave_excl_scan_u32(c, lane, tot);
-                    ins += tot;
-                    if (f.mine) emit_segment(rbsp, begin, begin + off, se, dst);
-                }
-                if (!f.mine) {
-                    if (off + 16u <= len) {
-                        reinterpret_cast<U16*>(dst)->v = q;
-                    } else if (off < len) {                    /* the NAL's last, partial chunk */
-                        const uint32_t nb = len - off;
-#pragma unroll 1
-                        for (uint32_t b = 0; b < nb; ++b) {
-                            const uint32_t w = (b >> 2) == 0 ? q.x : (b >> 2) == 1 ? q.y : (b >> 2) == 2 ? q.z : q.w;
-                            dst[b] = (uint8_t)(w >> (8u * (b & 3u)));
-                        }
-                    }
-                }
-                e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
-            }
-        }
-        if (lane == 0) {
-            if (fits) {
-                for (uint64_t i = base; i + 1 < nal_start; ++i) out[i] = 0;      /* zero_byte / leading zeros */
-                if (gap) out[nal_start - 1] = 1;
-            }
-            if (idx_out) {
-                hbs_nal_entry e;
-                e.start = nal_start; e.end = nal_end;
-                e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
-                idx_out[k] = e;
-            }
-            if (!fits) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
-        }
+    for (uint64_t k = wave; k < n; k += nwaves)
+        emit_nal(rbsp, idx, k, gap_of(idx, k, gap_mode), out_off[k], nal_total[k], out, out_cap, idx_out, err, lane);
+}
+
+/* ---- a handful of small NALs: the whole call in one launch of one workgroup --------------------------
+ * (the general path is a dozen launches: what a legacy rbsp_to_nal() of one parameter set or a short
+ * batch pays for is their latency).  Wavefront w takes NALs w, w + 4, ...: sizes, a scan across the
+ * workgroup, the bytes; thread 0 writes the summary. */
+constexpr uint64_t kEmitSmallNals = 256, kEmitSmallBytes = 32768;
+
+__global__ __launch_bounds__(256)
+void k3_small(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint32_t n, int gap_mode,
+              uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
+              uint32_t* __restrict__ err, hbs_summary* __restrict__ sum)
+{
+    __shared__ unsigned long long tot[kEmitSmallNals], off[kEmitSmallNals], wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) *err = 0;
+    for (uint32_t k = (uint32_t)wv; k < n; k += 4) {
+        const uint32_t ins = count_nal(rbsp, idx[k].rbsp_off, idx[k].rbsp_len, lane);
+        if (lane == 0) tot[k] = gap_of(idx, k, gap_mode) + idx[k].rbsp_len + ins;
     }
+    __syncthreads();
+    unsigned long long total;
+    const unsigned long long mine = threadIdx.x < n ? tot[threadIdx.x] : 0ull;
+    const unsigned long long before = block_excl_scan_u64(mine, wsum, total);
+    if (threadIdx.x < n) off[threadIdx.x] = before;
+    __syncthreads();
+    for (uint32_t k = (uint32_t)wv; k < n; k += 4)
+        emit_nal(rbsp, idx, k, gap_of(idx, k, gap_mode), off[k], tot[k], out, out_cap, idx_out, err, lane);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes;
+        sum->stream_bytes = total;
+        sum->stop_reason = n ? -1 : 0; sum->error = -(int32_t)atomicMax(err, 0u);       /* read where the atomics landed */
+        sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
+    }
+}
+
+bool emit_takes_small_path(uint64_t n, uint64_t rbsp_bytes, int two_pass)
+{
+    return two_pass < 0 && n != 0 && n <= kEmitSmallNals && rbsp_bytes <= kEmitSmallBytes;
 }
 
 /* ---- single pass: count, look-back, emit ---------------------------------------------------
@@ -774,6 +828,10 @@ void k_synth_fill(uint64_t seed, uint64_t n, int mode, const unsigned long long*
 
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
 {
+    if (emit_takes_small_path(a.n, a.rbsp_bytes, a.two_pass)) {
+        k3_small<<<1, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, (uint32_t)a.n, a.gap_mode, a.out, a.out_cap, a.index_out, a.err, a.summary);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     const unsigned grid = 256 * 16;

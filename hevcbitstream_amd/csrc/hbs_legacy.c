@@ -133,17 +133,23 @@ static void need_block(uint64_t rbsp_bytes)
     g_dstruct = g_dblock + RES_RBSP + r;
 }
 
+/* the pinned staging buffer, at least `bytes` long (the previous call's upload has long been consumed: every
+ * wrapper ends with a synchronising copy) */
+static void need_stage(uint64_t bytes)
+{
+    int rc;
+    if (bytes + 64 > g_hstage_cap) {
+        if (g_hstage) hbs_host_free(g_ctx, g_hstage);
+        g_hstage_cap = bytes * 2 + 65536;
+        if ((rc = hbs_host_alloc(g_ctx, g_hstage_cap, (void**)&g_hstage))) die("hbs_host_alloc", rc);
+    }
+}
+
 /* [prefix | bytes] into the device input buffer at offset 0; returns without waiting */
 static void upload_input(const uint8_t* prefix, uint64_t prefix_len, const uint8_t* bytes, uint64_t len)
 {
     int rc;
-    if (prefix_len + len + 64 > g_hstage_cap) {
-        if (g_hstage) hbs_host_free(g_ctx, g_hstage);
-        g_hstage_cap = (prefix_len + len) * 2 + 65536;
-        if ((rc = hbs_host_alloc(g_ctx, g_hstage_cap, (void**)&g_hstage))) die("hbs_host_alloc", rc);
-    } else {
-        /* the previous call's upload has long been consumed: every wrapper ends with a synchronising copy */
-    }
+    need_stage(prefix_len + len);
     if (prefix_len) memcpy(g_hstage, prefix, prefix_len);
     if (len) memcpy(g_hstage + prefix_len, bytes, len);
     if ((rc = hbs_copy_to_device_async(g_ctx, g_dbuf, g_hstage, prefix_len + len))) die("hbs_copy_to_device_async", rc);
@@ -281,29 +287,38 @@ int nal_to_rbsp(const uint8_t* nal_buf, int* nal_size, uint8_t* rbsp_buf, int* r
     return (int)e[0].rbsp_len;
 }
 
-int rbsp_to_nal(const uint8_t* rbsp_buf, const int* rbsp_size, uint8_t* nal_buf, int* nal_size)
+/* One NAL's RBSP (n bytes at d_rbsp, already on the device or on its way there) -> nal_buf; the index entry travels
+ * through the pinned staging buffer (with `payload`, if given, right behind it: then d_rbsp must be g_dbuf + 32), the
+ * summary and the bytes come back in one copy of the result block. */
+static int emit_one(const uint8_t* payload, const uint8_t* d_rbsp, int n, uint8_t* nal_buf)
 {
-    const int n = *rbsp_size;
     hbs_nal_entry e;
     hbs_summary s;
     int rc;
     uint64_t out_bytes;
-    if (n <= 0) { *nal_size = 0; return 0; }
-    need_ctx();
-    need_bufs((uint64_t)n, hbs_annexb_bound((uint64_t)n, 1));
-    need_block(0);
+    const uint64_t bound = hbs_annexb_bound((uint64_t)n, 1);
+    need_block(bound);
     memset(&e, 0, sizeof(e));
     e.rbsp_off = 0; e.rbsp_len = (uint32_t)n;
-    if ((rc = hbs_copy_to_device(g_ctx, g_dbuf, rbsp_buf, (uint64_t)n))) die("hbs_copy_to_device", rc);
-    if ((rc = hbs_copy_to_device(g_ctx, g_dindex, &e, sizeof(e)))) die("hbs_copy_to_device", rc);
+    upload_input((const uint8_t*)&e, sizeof(e), payload, payload ? (uint64_t)n : 0);
     /* gap_mode 1, NAL 0: a 4-byte start code goes in front; it is not part of rbsp_to_nal's output */
-    if ((rc = hbs_emit_annexb(g_ctx, g_dbuf, (uint64_t)n, g_dindex, 1, 1, g_dout, g_dout_cap, NULL, g_dsummary))) die("hbs_emit_annexb", rc);
-    if ((rc = hbs_read_summary(g_ctx, g_dsummary, &s))) die("hbs_read_summary", rc);
+    if ((rc = hbs_emit_annexb(g_ctx, d_rbsp, (uint64_t)n, (const hbs_nal_entry*)g_dbuf, 1, 1, g_drbsp, g_res_r, NULL, g_dsummary))) die("hbs_emit_annexb", rc);
+    if ((rc = hbs_copy_to_host(g_ctx, g_hres, g_dblock, RES_RBSP + bound))) die("hbs_copy_to_host", rc);
+    memcpy(&s, g_hres + RES_SUMMARY, sizeof(s));
     if (s.error) die("hbs_emit_annexb(capacity)", s.error);
     out_bytes = s.stream_bytes - 4;
-    if ((rc = hbs_copy_to_host(g_ctx, nal_buf, g_dout + 4, out_bytes))) die("hbs_copy_to_host", rc);
-    *nal_size = (int)out_bytes;                                          /* h264_nal.c:130 */
+    memcpy(nal_buf, g_hres + RES_RBSP + 4, out_bytes);
     return (int)out_bytes;
+}
+
+int rbsp_to_nal(const uint8_t* rbsp_buf, const int* rbsp_size, uint8_t* nal_buf, int* nal_size)
+{
+    const int n = *rbsp_size;
+    if (n <= 0) { *nal_size = 0; return 0; }
+    need_ctx();
+    need_bufs((uint64_t)n + 64, 0);
+    *nal_size = emit_one(rbsp_buf, g_dbuf + sizeof(hbs_nal_entry), n, nal_buf);      /* h264_nal.c:130 */
+    return *nal_size;
 }
 
 /* h264_stream.c:117-126 */
@@ -524,7 +539,6 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     uint64_t src_bytes = 0;
     uint32_t cap;
     int rc, t, rbsp_size, nal_size;
-    uint8_t* rbsp;
     static hbs_written_nal* d_written = NULL;
     if (size < 0) return -1;
     need_ctx();
@@ -540,16 +554,18 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     else return -1;                                                      /* :1306 */
     /* parameter sets in force: what the object holds (the SPS's derived tables stay on the device) */
     sync_context(h);
-    if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
-        /* written in place in its slot so that the tables it derives replace the ones in force */
-        p.struct_off = 0;
-    } else {
-        if ((rc = hbs_copy_to_device(g_ctx, g_dstruct, src, src_bytes))) die("hbs_copy_to_device", rc);
-        p.struct_off = 0;
-    }
+    /* the NAL's descriptor and, unless it is an SPS (written in place in its slot, so that the tables it derives replace
+     * the ones in force), its struct: through the pinned staging buffer, no wait */
+    p.struct_off = 0;
     p.rc = 0; p.nal_unit_type = t; p.nal_layer_id = h->nal->nal_layer_id; p.nal_temporal_id_plus1 = h->nal->nal_temporal_id_plus1;
     p.slice_data_size = 0; p.slice_data_off = 0;
-    if ((rc = hbs_copy_to_device(g_ctx, g_dparsed, &p, sizeof(p)))) die("hbs_copy_to_device", rc);
+    need_stage(256 + src_bytes);
+    memcpy(g_hstage, &p, sizeof(p));
+    if ((rc = hbs_copy_to_device_async(g_ctx, g_dparsed, g_hstage, sizeof(p)))) die("hbs_copy_to_device_async", rc);
+    if (t != HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+        memcpy(g_hstage + 256, src, src_bytes);
+        if ((rc = hbs_copy_to_device_async(g_ctx, g_dstruct, g_hstage + 256, src_bytes))) die("hbs_copy_to_device_async", rc);
+    }
     if ((rc = hbs_write_headers(g_ctx, g_dparsed, 1, t == HEVC_NAL_UNIT_TYPE_SPS_NUT ? g_dsps_slot : g_dstruct,
                                 g_dsps_slot, g_dpps, g_dout, cap, d_written))) die("hbs_write_headers", rc);
     if ((rc = hbs_copy_to_host(g_ctx, &w, d_written, sizeof(w)))) die("hbs_copy_to_host", rc);
@@ -560,11 +576,9 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     }
     if (w.rc < 0) return -1;                                             /* :1312 */
     rbsp_size = (int)w.rbsp_size;
-    rbsp = (uint8_t*)malloc((size_t)rbsp_size + 16);
-    if (rbsp_size && (rc = hbs_copy_to_host(g_ctx, rbsp, g_dout, (uint64_t)rbsp_size))) die("hbs_copy_to_host", rc);
-    nal_size = size;
-    rc = rbsp_to_nal(rbsp, &rbsp_size, buf, &nal_size);                  /* :1319 */
-    free(rbsp);
-    if (rc < 0) return -1;
+    if (rbsp_size <= 0) return 0;
+    /* rbsp_to_nal (:1319) on the RBSP where the writers left it */
+    need_bufs(64, 0);
+    nal_size = emit_one(NULL, g_dout, rbsp_size, buf);
     return nal_size;
 }

@@ -250,6 +250,11 @@ uint64_t hbs_sps_slot_bytes(void);
  * (n_nals > 1) parse their NALs independently of one another either way. */
 int hbs_ctx_set_sequential_parse(hbs_ctx* ctx, int on);
 uint64_t hbs_sps_tables_offset(void);
+/* How hbs_emit_annexb works: -1 (default) picked per call -- one single-workgroup launch for a handful of small
+ * NALs (<= 256 NALs, <= 32 KiB of RBSP: the legacy rbsp_to_nal), otherwise the single-pass kernel or, on zero-heavy
+ * payload (density probe on the device), count / scan / emit; 0 pins the single-pass kernel, 1 the three steps.
+ * The bytes are the same whichever runs (h264_nal.c:92-132). */
+int hbs_ctx_set_emit_path(hbs_ctx* ctx, int path);
 
 /*
  * Synthetic workload S(seed, n_nals, mode) of SURVEY.md 8(d), generated in HBM:

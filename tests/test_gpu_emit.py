@@ -17,6 +17,14 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=[-1, 0, 1], ids=["auto", "single-pass", "three-step"])
+def path_ctx(ctx, request):
+    """every way hbs_emit_annexb can run; auto sends a handful of small NALs through the one-launch kernel"""
+    ctx.set_emit_path(request.param)
+    yield ctx
+    ctx.set_emit_path(-1)
+
+
 def fake_index(lens, gaps):
     idx = np.zeros(len(lens), dtype=NAL_ENTRY)
     off = pos = 0
@@ -35,7 +43,8 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def test_emit_random_rbsp(ctx, orc):
+def test_emit_random_rbsp(path_ctx, orc):
+    ctx = path_ctx
     rng = np.random.RandomState(31)
     for _ in range(60):
         nn = rng.randint(1, 40)
@@ -49,7 +58,8 @@ def test_emit_random_rbsp(ctx, orc):
         assert np.array_equal(got, orc.emit_annexb(arena, idx))
 
 
-def test_emit_row_and_batch_edges(ctx, orc):
+def test_emit_row_and_batch_edges(path_ctx, orc):
+    ctx = path_ctx
     """NAL lengths around the kernel's row (1 KiB) and register batch (16 KiB) sizes, mostly-plain bytes with a few
     zero runs (the register copy path), the arena ending exactly at the last NAL's last byte"""
     rng = np.random.RandomState(32)
@@ -95,13 +105,39 @@ def test_emit_long_nals(ctx, orc):
         assert pos == len(want)
 
 
-def test_emit_zero_runs(ctx, orc):
+def test_emit_zero_runs(path_ctx, orc):
+    ctx = path_ctx
     for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
         for tail in ([], [1], [4], [0, 0, 1]):
             arena = np.array([7] * 3 + [0] * z + tail, dtype=np.uint8)
             idx = fake_index([len(arena)], [4])
             got, _ = ctx.emit_annexb(dev(arena), idx)
             assert np.array_equal(got, orc.emit_annexb(arena, idx)), (z, tail)
+
+
+def test_emit_few_small_nals(ctx, orc):
+    """the one-launch path and its limits (256 NALs, 32 KiB): counts and sizes on both sides of them, empty NALs,
+    the output index, a capacity that is too small"""
+    import hevcbitstream_amd as hbs
+    rng = np.random.RandomState(34)
+    for nn, total in ((1, 1), (1, 32768), (1, 32769), (4, 32768), (5, 20000), (255, 9000), (256, 32768), (257, 9000), (64, 0), (3, 2)):
+        cuts = np.sort(rng.randint(0, total + 1, size=nn - 1)) if nn > 1 else np.zeros(0, dtype=np.int64)
+        lens = [int(x) for x in np.diff(np.concatenate(([0], cuts, [total])))]
+        gaps = [int(rng.randint(3, 6)) for _ in lens]
+        arena = ALPHA[rng.randint(0, len(ALPHA), size=total)].copy()
+        idx = fake_index(lens, gaps)
+        got, got_idx = ctx.emit_annexb(dev(arena) if total else dev(np.zeros(1, dtype=np.uint8))[:0], idx)
+        want = orc.emit_annexb(arena, idx)
+        assert np.array_equal(got, want), (nn, total)
+        pos = 0
+        for k, (n, g) in enumerate(zip(lens, gaps)):
+            assert int(got_idx["start"][k]) == pos + g and int(got_idx["rbsp_len"][k]) == n
+            pos = int(got_idx["end"][k])
+        assert pos == len(want)
+    arena = np.zeros(300, dtype=np.uint8)
+    idx = fake_index([100, 200], [4, 3])
+    with pytest.raises(hbs.HbsError):
+        ctx.emit_annexb(dev(arena), idx, out_cap=310)      # 7 + 300 + 149 inserted bytes do not fit
 
 
 @pytest.mark.parametrize("mode", [0, 1])
