@@ -328,6 +328,7 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.n_items = reinterpret_cast<unsigned long long*>(tail + 768);
     a.total_dense = reinterpret_cast<unsigned long long*>(tail + 768 + 64);
     a.probe = reinterpret_cast<uint32_t*>(tail + 768 + 128);
+    a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_emit_annexb");

@@ -832,27 +832,20 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         k3_small<<<1, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, (uint32_t)a.n, a.gap_mode, a.out, a.out_cap, a.index_out, a.err, a.summary);
         return hipGetLastError();
     }
-    hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
+    /* one clear: the look-back words and, behind them in the workspace, total / err / ticket / n_items / total_dense / probe */
+    hipError_t e = hipMemsetAsync(a.desc, 0, a.clear_bytes, st);
     if (e != hipSuccess) return e;
     const unsigned grid = 256 * 16;
     /* forced one way (HBS_EMIT_TWO_PASS=1 / =0), or -- the default -- picked on the device from a density probe */
     const uint32_t* probe = a.two_pass < 0 ? a.probe : nullptr;
     const bool want_dense = a.two_pass != 0, want_sparse = a.two_pass <= 0;
-    if (a.n && probe) {
-        e = hipMemsetAsync(a.probe, 0, 2 * sizeof(uint32_t), st);
-        if (e != hipSuccess) return e;
-        k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
-    }
+    if (a.n && probe) k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
     if (a.n && want_sparse) {
         /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
         k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse);
         k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe);
         const uint64_t ngroups = (a.items_cap + kEmitGroup - 1) / kEmitGroup;       /* upper bound */
-        e = hipMemsetAsync(a.desc, 0, ngroups * sizeof(unsigned long long), st);    /* the look-back words */
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(a.ticket, 0, sizeof(uint32_t), st);
-        if (e != hipSuccess) return e;
         uint64_t blocks = (uint64_t)a.grid_blocks;
         if (blocks > ngroups) blocks = ngroups;
         k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.items, a.n_items, a.items_cap,
@@ -862,10 +855,6 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, probe, kWhenDense);
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe);
-    }
-    if (!a.n) {
-        e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
-        if (e != hipSuccess) return e;
     }
     if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
     else k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary, a.total_dense, probe);

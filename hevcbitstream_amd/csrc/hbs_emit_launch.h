@@ -31,6 +31,7 @@ struct EmitArgs {
     int two_pass;                     /* 1: count / scan / emit as three steps; 0: the single pass; -1: picked on the device by density */
     unsigned long long* total_dense;  /* 1: the three-step path's total                                   */
     uint32_t* probe;                  /* 2: chunks sampled, chunks flagged                                */
+    uint64_t clear_bytes;             /* desc .. probe are one stretch of the workspace this long: one clear per call */
 };
 
 struct SynthArgs {
