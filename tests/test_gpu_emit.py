@@ -153,15 +153,11 @@ def test_device_generator_matches_oracle(ctx, orc, mode):
         assert np.array_equal(got_idx[f], idx[f]), f
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_roundtrip_1gib(ctx, mode):
-    """config 4 at full size, by property: generate ~1 GiB on the device, extract
-    (K12), re-emit (K3) -> byte-identical stream; extracted arena == generated arena."""
+def _roundtrip(ctx, n, mode, lo, hi):
     import torch
-    n = 104858
     g = ctx.synth_stream(0x1234, n, mode)
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
-    assert 1.0e9 < sb < 1.2e9
+    assert lo < sb < hi
     stream = g["stream"][:sb]
     index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
     ctx.index_extract_async(stream, index, cap, rbsp, summary)
@@ -177,3 +173,20 @@ def test_roundtrip_1gib(ctx, mode):
     s2 = ctx.read_summary(summary)
     assert int(s2["error"]) == 0 and int(s2["stream_bytes"]) == sb
     assert torch.equal(out[:sb], stream)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_roundtrip_1gib(ctx, mode):
+    """configs 2 and 4 at full size, by property: generate ~1 GiB on the device, extract
+    (K12), re-emit (K3) -> byte-identical stream; extracted arena == generated arena."""
+    _roundtrip(ctx, 104858, mode, 1.0e9, 1.2e9)
+
+
+def test_roundtrip_16gib(ctx):
+    """config 5's shard at full size (what bench.py times), by the same properties: every offset past 4 GiB,
+    89 478 tiles of look-back, 1 677 000 index entries"""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2**30:
+        pytest.skip("needs ~70 GiB of HBM")
+    _roundtrip(ctx, 1677000, 0, 17.0e9, 17.4e9)
+    torch.cuda.empty_cache()
