@@ -192,3 +192,48 @@ def test_automatic_choice_follows_density(orc):
             assert c.last_kernel() == want
     finally:
         c.close()
+
+
+def test_calls_capture_into_a_hip_graph(orc):
+    """hbs_index_extract only enqueues (no allocation after a warm-up call of the same size, no host wait, the
+    kernel choice made on the device): captured once in a HIP graph, it is replayed on other bytes in the same
+    buffers -- zero-heavy, then sparse again, so a replay takes the other kernel -- and stays exact."""
+    import torch
+    import hevcbitstream_amd as hbs
+    from tests._orc import NAL_ENTRY
+    from hevcbitstream_amd.api import SUMMARY
+    ctx = hbs.Context(0)
+    n = 3_000_000
+    rng = np.random.RandomState(91)
+
+    def make(zero_heavy):
+        s = rng.randint(1, 256, size=n).astype(np.uint8)
+        if zero_heavy:
+            s[rng.rand(n) < 0.12] = 0
+        for p in rng.randint(0, n - 8, size=300):
+            s[p:p + 4] = (0, 0, 1, 0x42)
+        return s
+
+    first, second = make(False), make(True)
+    d_stream = torch.from_numpy(first).cuda()
+    index, rbsp, summary, cap = ctx.alloc_outputs(n)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx.index_extract_async(d_stream, index, cap, rbsp, summary)        # warm-up: workspaces get their size
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ctx.index_extract_async(d_stream, index, cap, rbsp, summary)
+    for data in (second, first):
+        d_stream.copy_(torch.from_numpy(data))
+        g.replay()
+        torch.cuda.synchronize()
+        want_idx, want_arena, why = orc.index_extract(data)
+        sm = np.frombuffer(summary.cpu().numpy().tobytes(), dtype=SUMMARY)[0]
+        assert int(sm["error"]) == 0 and int(sm["nal_count"]) == len(want_idx) and int(sm["stop_reason"]) == why
+        got = index[: len(want_idx) * 32].cpu().numpy().view(NAL_ENTRY)
+        for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+            assert np.array_equal(got[f], want_idx[f]), f
+        tot = int(want_idx["rbsp_off"][-1] + want_idx["rbsp_len"][-1]) if len(want_idx) else 0
+        assert np.array_equal(rbsp[:tot].cpu().numpy(), want_arena[:tot])
+    ctx.close()
