@@ -51,7 +51,7 @@ clean:
 	rm -f $(LIB) tests/sim/libhbs_sim.so
 	$(MAKE) -C oracle clean
 
-# diagnostic build with per-phase shader-clock sums (scripts/phase_timing*.py); never the shipped library
+# diagnostic build with per-phase shader-clock sums (tests/tools/phase_timing*.py); never the shipped library
 DIAG_OBJS := $(patsubst $(CSRC)/%.hip,build/diag/%.o,$(HIP_SRCS))
 build/diag/%.o: $(CSRC)/%.hip $(HDRS)
 	mkdir -p build/diag && $(HIPCC) $(HIPFLAGS) -DHBS_PHASE_TIMING -c -o $@ $<

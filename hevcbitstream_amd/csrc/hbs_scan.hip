@@ -29,7 +29,7 @@
 
 namespace hbs {
 
-/* Diagnostic build only (-DHBS_PHASE_TIMING, scripts/phase_timing.py): per-phase
+/* Diagnostic build only (-DHBS_PHASE_TIMING, tests/tools/phase_timing.py): per-phase
  * shader-clock sums of every workgroup, never part of the shipped library. */
 #ifdef HBS_PHASE_TIMING
 __device__ unsigned long long g_phase_cycles[1024][8];

@@ -54,3 +54,33 @@ def test_no_gpu_fails_loudly():
 def test_struct_sizes_of_public_records():
     import hevcbitstream_amd as hbs
     assert hbs.NAL_ENTRY.itemsize == 32 and hbs.SUMMARY.itemsize == 64 and hbs.PARSED.itemsize == 32
+
+
+def test_only_the_checkers_touch_the_oracle():
+    """oracle/ is test infrastructure: the product (package sources, the C-ABI library's objects, scripts/) never
+    names it; bench.py does so only inside its cpu_baseline leg, __graft_entry__.py in build() (building the
+    checker) and smoke() (checking against it).  Tools that compare against the oracle live in tests/tools/."""
+    pat = re.compile(r"\boracle\b|_orc\b|liboracle|hbs_oracle")
+    product = []
+    for d, _, files in os.walk(os.path.join(ROOT, "hevcbitstream_amd")):
+        product += [os.path.join(d, f) for f in files if f.endswith((".py", ".hip", ".h", ".c", ".cpp"))]
+    product += [os.path.join(ROOT, "scripts", f) for f in os.listdir(os.path.join(ROOT, "scripts")) if f.endswith(".py")]
+    for path in product:
+        for ln, line in enumerate(open(path, errors="replace"), 1):
+            code = line.split("#")[0] if path.endswith(".py") else line
+            if path.endswith(".py") and pat.search(code) and ("import" in code or "oracle(" in code or "CDLL" in code):
+                raise AssertionError("%s:%d uses the oracle: %s" % (path, ln, line.strip()))
+            if not path.endswith(".py") and re.search(r'#\s*include\s*[<"][^>"]*oracle', code):
+                raise AssertionError("%s:%d includes an oracle header" % (path, ln))
+    # bench.py: every use sits inside cpu_baseline()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = re.search(r"^def cpu_baseline\(.*?(?=^def |\Z)", src, flags=re.S | re.M).group(0)
+    rest = src.replace(body, "")
+    for ln, line in enumerate(rest.splitlines(), 1):
+        code = line.split("#")[0]
+        assert not (pat.search(code) and ("import" in code or "oracle(" in code or "CDLL" in code)), "bench.py outside cpu_baseline: " + line.strip()
+    # the shipped library does not link it
+    import subprocess
+    so = os.path.join(ROOT, "hevcbitstream_amd", "libhevcbitstream_amd.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed and "hevcref" not in needed

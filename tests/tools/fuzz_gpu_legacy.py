@@ -1,5 +1,5 @@
 """read_hevc_nal_unit NAL by NAL (the legacy symbol on the GPU) against the oracle's sequential parser on corrupted
-sequences, parameter sets included (dev aid).  usage: python3 scripts/fuzz_gpu_legacy.py [first_seed] [count]"""
+sequences, parameter sets included (dev aid).  usage: python3 tests/tools/fuzz_gpu_legacy.py [first_seed] [count]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

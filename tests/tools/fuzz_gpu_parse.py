@@ -1,5 +1,5 @@
 """Extended differential run of the GPU header parse against the oracle (dev aid; the committed tests run a
-subset of the same generators).  usage: python3 scripts/fuzz_gpu_parse.py [first_seed] [count]"""
+subset of the same generators).  usage: python3 tests/tools/fuzz_gpu_parse.py [first_seed] [count]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

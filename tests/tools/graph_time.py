@@ -1,5 +1,5 @@
 """hbs_index_extract captured in a HIP graph against the same call enqueued directly (dev aid): what the
-launches of a call cost on streams of tens of MiB.  usage: python3 scripts/graph_time.py [reps of 16 MiB ...]"""
+launches of a call cost on streams of tens of MiB.  usage: python3 tests/tools/graph_time.py [reps of 16 MiB ...]"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")

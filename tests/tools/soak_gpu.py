@@ -1,6 +1,6 @@
 """Randomised soak of the byte kernels against the oracle (dev aid): scan + extract (automatic kernel choice and each
 pinned kernel) and RBSP -> Annex-B on streams with mixed zero density, NAL sizes from a few bytes to MiBs, tile-edge
-alignments.  usage: python3 scripts/soak_gpu.py [seconds] [seed]"""
+alignments.  usage: python3 tests/tools/soak_gpu.py [seconds] [seed]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
