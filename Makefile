@@ -58,4 +58,13 @@ build/diag/%.o: $(CSRC)/%.hip $(HDRS)
 diag: $(DIAG_OBJS) $(LEGACY_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/diag/libhbs_diag.so $(DIAG_OBJS) $(LEGACY_OBJ)
 
-.PHONY: all lib oracle sim clean analyze diag
+# development variant of the library with extra -D flags, for A/B timing (HBS_LIB=build/variants/<NAME>/libhbs.so)
+#   make variant NAME=ntload DEFS="-DHBS_NT_LOAD=1"
+VAR_OBJS := $(patsubst $(CSRC)/%.hip,build/variants/$(NAME)/%.o,$(HIP_SRCS))
+build/variants/$(NAME)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/variants/$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $@ $<
+variant: $(VAR_OBJS) $(LEGACY_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/$(NAME)/libhbs.so $(VAR_OBJS) $(LEGACY_OBJ)
+
+.PHONY: all lib oracle sim clean analyze diag variant

@@ -33,7 +33,8 @@ class HbsError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libhevcbitstream_amd.so")
+    # HBS_LIB: a development build of the same library (make variant NAME=...), for A/B timing only
+    return os.environ.get("HBS_LIB") or os.path.join(_HERE, "libhevcbitstream_amd.so")
 
 
 _lib = None

@@ -77,7 +77,7 @@ struct RowRegs {
 __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __restrict__ src, uint64_t seg, int lane)
 {
     const u32x4* p = reinterpret_cast<const u32x4*>(src + seg) + lane;
-#define HBS_LD(r) R.q##r = p[r * 64];
+#define HBS_LD(r) R.q##r = stream_load16(p + r * 64);
     HBS_ROWS(HBS_LD)
 #undef HBS_LD
 }
@@ -366,7 +366,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                             const uint32_t j = k - pbase; \
                             const uint32_t w = (j == (uint32_t)k4ElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(j & 63u)); \
                             if (seg_inside(w) && cc < whole) \
-                                reinterpret_cast<Unaligned16_3*>(out + (int64_t)seg_bias(w) + 16u * cc)->v = R.q##r; \
+                                arena_store16(out + (int64_t)seg_bias(w) + 16u * cc, R.q##r); \
                         } \
                     } else { \
                         const uint64_t f = HBS_ROW_FM(r); \
@@ -374,7 +374,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                         const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
                         if (!((f >> lane) & 1ull) && served && cc < whole) { \
                             const uint32_t w = l.seg[k - pbase]; \
-                            if (seg_inside(w)) reinterpret_cast<Unaligned16_3*>(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)))->v = R.q##r; \
+                            if (seg_inside(w)) arena_store16(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)), R.q##r); \
                         } \
                     } }
                 HBS_ROWS(HBS_COPY)

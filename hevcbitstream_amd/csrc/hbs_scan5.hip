@@ -40,7 +40,7 @@ __device__ __forceinline__ void span_load(Span5& s, const uint8_t* __restrict__ 
 {
     if (base + k5SpanBytes <= n) {
 #pragma unroll
-        for (int r = 0; r < k5SpanRows; ++r) s.q[r] = *reinterpret_cast<const u32x4*>(stream + base + 1024u * r + 16u * lane);
+        for (int r = 0; r < k5SpanRows; ++r) s.q[r] = stream_load16(reinterpret_cast<const u32x4*>(stream + base + 1024u * r + 16u * lane));
     } else {
 #pragma unroll
         for (int r = 0; r < k5SpanRows; ++r) s.q[r] = load_chunk_guarded(stream, base + 1024u * r + 16u * lane, n);

@@ -21,6 +21,33 @@ constexpr int k3TileBytes = k3Waves * k3WaveBytes;         /* 64 KiB */
 static_assert(k3TileBytes == kTileBytes, "both kernels share the descriptor workspace sizing");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u1 __attribute__((aligned(1)));        /* a 16-byte access at any byte address */
+
+/* Streaming accesses.  The stream is read once and the arena written once, so neither should displace
+ * anything in the caches: `nt` loads read at 6.9 TB/s where default-policy loads of the same pattern read
+ * at 6.2 (scripts/ubench/ceiling2.hip, profiles/r02/ceiling2.txt). */
+#ifndef HBS_NT_LOAD
+#define HBS_NT_LOAD 1
+#endif
+#ifndef HBS_NT_STORE
+#define HBS_NT_STORE 1
+#endif
+__device__ __forceinline__ u32x4 stream_load16(const u32x4* p)
+{
+#if HBS_NT_LOAD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void arena_store16(uint8_t* p, u32x4 v)
+{
+#if HBS_NT_STORE
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_u1*>(p));
+#else
+    *reinterpret_cast<u32x4_u1*>(p) = v;
+#endif
+}
 
 #define HBS_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
