@@ -68,17 +68,24 @@ __device__ __forceinline__ void load_desc4(u32x4& d0, u32x4& d1, u32x4& d2, u32x
  * first up to the nearest tile that already has its prefix.  Returns false on timeout/abort.
  * Called by every lane of wavefront 0.
  */
-__device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
-                                           RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
+/* first half: the tile's aggregate goes out (tile 0 publishes its prefix straight away, in the second half) */
+__device__ __forceinline__ void look_back_publish(unsigned long long* desc, uint64_t tile, const TileAgg& mine, int lane)
+{
+    if (tile != 0 && lane == 0) {
+        st_desc3(&desc[2 * tile], pack_agg0(mine));
+        st_desc3(&desc[2 * tile + 1], pack_agg1(mine));
+    }
+}
+
+/* second half: fold the tiles in front, publish the inclusive prefix.  May run long after the first (hbs_scan6.hip
+ * does other work in between, so that the predecessors have published by the time it asks). */
+__device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
+                                                  RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
 {
     dbg_iters = 0; dbg_stalls = 0;
     bool ok = true;
     excl.kept = 0; excl.nals = 0; excl.inside = 0;
     if (tile != 0) {
-        if (lane == 0) {
-            st_desc3(&desc[2 * tile], pack_agg0(mine));
-            st_desc3(&desc[2 * tile + 1], pack_agg1(mine));
-        }
         TileAgg acc = agg_identity();                 /* tiles between the window and `tile` */
         int64_t win_hi = (int64_t)tile - 1;
         uint32_t spins = 0;
@@ -172,6 +179,13 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
     return ok;
 }
 
+__device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
+                                           RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
+{
+    look_back_publish(desc, tile, mine, lane);
+    return look_back_resolve(desc, tile, mine, hdr, lane, excl, dbg_iters, dbg_stalls);
+}
+
 __device__ __forceinline__ Prefix prefix_uniform4(const Prefix& p)
 {
     Prefix r;
@@ -209,11 +223,27 @@ __device__ __forceinline__ TileAgg agg_readlane(const TileAgg& a, int l)
     return r;
 }
 
+#ifndef HBS_ELEM_BYTE_STORES
+#define HBS_ELEM_BYTE_STORES 0
+#endif
+/* what a flagged lane leaves in LDS for the thread that will handle its chunk as an element */
+struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
+
+/* lane L (a compile-time constant) of v <- the wave-uniform value s.  The s_nop covers gfx950's wait states between a
+ * VALU instruction that writes an SGPR (the v_cmp of a ballot) and a VALU instruction reading it, which the compiler
+ * cannot insert across an asm statement. */
+template <int L>
+__device__ __forceinline__ void write_lane_c(uint32_t& v, uint32_t s)
+{
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "i"(L));
+}
+
 /* everything one lane of wavefront 0 knows about its element */
 struct Elem {
     ElemView v;
     ChunkMarks m;
     BlockSum s;
+    ElemClasses cls;       /* where its bytes [-8, 20) hold 00 / 01 / 03 */
     uint32_t gap;          /* bytes of the gap in front of it            */
     uint32_t chunk;        /* its chunk number in the tile               */
 };
@@ -224,17 +254,26 @@ __device__ __forceinline__ void elem_emit(const Elem& el, const TileAgg& e, cons
                                           const EmitTarget& tgt, uint32_t* seg_slot)
 {
     const ElemStart st = elem_start(e, el.gap, excl.inside);
-    const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(el.v, 0, el.v.g0, el.m, st.inside, excl.nals + e.cnt,
-                                                                          excl.kept + st.kept, tgt);
+    const uint32_t keep = emit_chunk_fast(el.cls, el.v.g0, el.m, st.inside, excl.nals + e.cnt, excl.kept + st.kept, tgt);
     const uint32_t nk = (uint32_t)__builtin_popcount(keep);
     if (can_store && keep != 0u) {
         if (keep == 0xFFFFu) {
             u32x4 q; q.x = el.v.x0; q.y = el.v.x1; q.z = el.v.x2; q.w = el.v.x3;
             reinterpret_cast<Unaligned16_3*>(out + st.kept)->v = q;
         } else {
+#if HBS_ELEM_BYTE_STORES
+            /* a chunk with holes: every kept byte goes out by itself, to its rank (16 predicated byte stores and no
+             * loop: a loop runs as long as its longest lane, and the workgroup waits for this wavefront) */
+            uint8_t* const o = out + st.kept;
+            const uint32_t d[4] = {el.v.x0, el.v.x1, el.v.x2, el.v.x3};
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((keep >> i) & 1u) o[__builtin_popcount(keep & ((1u << i) - 1u))] = (uint8_t)(d[i >> 2] >> (8 * (i & 3)));
+#else
             uint64_t lo, hi;
             const uint32_t cn = compact_chunk_regs(el.v.x0, el.v.x1, el.v.x2, el.v.x3, keep, lo, hi);
             store_pieces(out + st.kept, lo, hi, cn);
+#endif
         }
     }
     const bool after = (el.s.last != kKindNone) ? (el.s.last == kKindStart) : st.inside;

@@ -55,6 +55,11 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #define HBS4_T_FLUSH
 #endif
 
+#ifdef HBS4_NO_PRIO
+#define HBS4_PRIO(p)
+#else
+#define HBS4_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 static_assert(k4Rows == 48, "the row lists below name every row register");
 #define HBS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47)
 #define HBS_ROW_TRIPLES(X) X(0,1,2) X(1,2,3) X(2,3,4) X(3,4,5) X(4,5,6) X(5,6,7) X(6,7,8) X(7,8,9) X(8,9,10) X(9,10,11) X(10,11,12) X(11,12,13) X(12,13,14) X(13,14,15) X(14,15,16) X(15,16,17) X(16,17,18) X(17,18,19) X(18,19,20) X(19,20,21) X(20,21,22) X(21,22,23) X(22,23,24) X(23,24,25) X(24,25,26) X(25,26,27) X(26,27,28) X(27,28,29) X(28,29,30) X(29,30,31) X(30,31,32) X(31,32,33) X(32,33,34) X(33,34,35) X(34,35,36) X(35,36,37) X(36,37,38) X(37,38,39) X(38,39,40) X(39,40,41) X(40,41,42) X(41,42,43) X(42,43,44) X(43,44,45) X(44,45,46) X(45,46,47)   /* (previous row, row, next row), inner rows */
@@ -82,9 +87,7 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 #undef HBS_LD
 }
 
-/* what a flagged lane leaves for the thread that will handle its chunk as an element */
 constexpr int kDepCap = 64;
-struct Deposit { uint32_t xpp, xp, x0, x1, x2, x3, xn, chunk; };
 
 struct Lds4 {
     uint32_t wave_tot[k4Waves];            /* elements per wavefront                        */
@@ -117,16 +120,17 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
     /* which wavefront flagged it, and as its how-manieth element */
     const uint32_t ew = (i >= wb1 ? 1u : 0u) + (i >= wb2 ? 1u : 0u) + (i >= wb3 ? 1u : 0u);
     const uint32_t ej = i - (ew == 0u ? 0u : ew == 1u ? wb1 : ew == 2u ? wb2 : wb3);
-    Deposit d;
-    d.chunk = 0xFFFFFFFFu;
-    if (ej < (uint32_t)kDepCap) d = l.dep[ew][ej];
-    if (d.chunk == c) {
+    /* field by field: a conditional copy of the whole struct ends up in scratch memory, and every later use of the
+     * element's bytes then waits for all outstanding memory operations (s_waitcnt vmcnt(0)) to read them back */
+    const bool have_dep = ej < (uint32_t)kDepCap && l.dep[ew < (uint32_t)k4Waves ? ew : 0u][ej < (uint32_t)kDepCap ? ej : 0u].chunk == c;
+    if (have_dep) {
+        const Deposit& d = l.dep[ew][ej];
         el.v.xpp = d.xpp; el.v.xp = d.xp; el.v.x0 = d.x0; el.v.x1 = d.x1; el.v.x2 = d.x2; el.v.x3 = d.x3; el.v.xn = d.xn;
         el.v.stream = src; el.v.g0 = base + 16ull * c; el.v.n = n;
     } else {
         elem_load(el.v, src, base + 16ull * c, n, padded);
     }
-    elem_walk(el.v, el.m, el.s);
+    elem_walk(el.v, el.m, el.s, el.cls);
     el.gap = span_bytes(prev_end, el.v.g0, n);
     el.chunk = c;
     return elem_agg(el.gap, el.s);
@@ -165,12 +169,12 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         const uint8_t* const src = last_tile
             ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
         /* until the tile's aggregate is out, this workgroup is what its successors wait for */
-        __builtin_amdgcn_s_setprio(3);
+        HBS4_PRIO(3);
         RowRegs R;
         fetch_row_regs(R, src, wseg, lane);
-        R.before = (wseg >= 4) ? *reinterpret_cast<const uint32_t*>(src + wseg - 4) : 0xFFFFFFFFu;
-        R.before2 = (wseg >= 8) ? *reinterpret_cast<const uint32_t*>(src + wseg - 8) : 0xFFFFFFFFu;
-        R.after = (last_tile || wv != k4Waves - 1) ? *reinterpret_cast<const uint32_t*>(src + wseg + k4WaveBytes)
+        R.before = (wseg >= 4) ? stream_load4(src + wseg - 4) : 0xFFFFFFFFu;
+        R.before2 = (wseg >= 8) ? stream_load4(src + wseg - 8) : 0xFFFFFFFFu;
+        R.after = (last_tile || wv != k4Waves - 1) ? stream_load4(src + wseg + k4WaveBytes)
                                                    : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
         HBS4_T_MARK(0)
 
@@ -284,7 +288,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             HBS4_DBG(if (g_fake_lb4) { ok = true; it = 0; stl = 0; ex.kept = tile * (uint64_t)(k4TileBytes - 4096); ex.nals = tile * 16; ex.inside = 1; } else)
             ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
             HBS4_T_COUNT(7, ((unsigned long long)stl << 32) | it)
-            __builtin_amdgcn_s_setprio(0);
+            HBS4_PRIO(0);
             const uint32_t tile_kept = tagg.known + (ex.inside ? tagg.sig : 0u);
             const bool can = rbsp != nullptr && ex.kept + tile_kept <= rbsp_cap;
             if (lane == 0) {
@@ -305,7 +309,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             HBS_PARKED(HBS_UNPARK)
 #undef HBS_UNPARK
         } else {
-            __builtin_amdgcn_s_setprio(0);
+            HBS4_PRIO(0);
         }
         __syncthreads();
         if (l.ex_ok == 0u) return;
@@ -424,7 +428,7 @@ constexpr int kClearBlocksMin = 32, kClearBlocksMax = 4096;      /* sized by the
 __global__ __launch_bounds__(256)
 void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr, uint8_t* __restrict__ tail,
                      unsigned long long* __restrict__ index_words, uint64_t n_index_words,
-                     unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int do_tail)
+                     unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int tail_tile_bytes)
 {
     const int b = blockIdx.x;
     if (b < kProbeBlocks) {
@@ -460,10 +464,12 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
             hdr->probe_slot[b][1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
         }
     } else if (b < kProbeBlocks + kTailBlocks) {
-        /* tail[k4TailLead + i] = stream[last_base + i] for i in [-k4TailLead, tile + pad), 0xFF where the stream has no byte */
-        if (!do_tail || n == 0) return;
-        const uint64_t last_base = ((n - 1) / (uint64_t)k4TileBytes) * (uint64_t)k4TileBytes;
-        for (uint32_t i = (uint32_t)(b - kProbeBlocks) * 256u + threadIdx.x; i < (uint32_t)k4TailBytes; i += (uint32_t)kTailBlocks * 256u) {
+        /* tail[k4TailLead + i] = stream[last_base + i] for i in [-k4TailLead, tile + pad), 0xFF where the stream has no byte;
+         * the tile size is that of the kernel which will read the copy */
+        if (tail_tile_bytes == 0 || n == 0) return;
+        const uint64_t last_base = ((n - 1) / (uint64_t)tail_tile_bytes) * (uint64_t)tail_tile_bytes;
+        const uint32_t tail_bytes = (uint32_t)(k4TailLead + tail_tile_bytes + 64);
+        for (uint32_t i = (uint32_t)(b - kProbeBlocks) * 256u + threadIdx.x; i < tail_bytes; i += (uint32_t)kTailBlocks * 256u) {
             const int64_t q = (int64_t)last_base + (int64_t)i - k4TailLead;
             tail[i] = (q >= 0 && (uint64_t)q < n) ? stream[q] : (uint8_t)0xFF;
         }
@@ -475,7 +481,7 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
     }
 }
 
-void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, bool tail, hipStream_t st)
+void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, int tail_tile_bytes, hipStream_t st)
 {
     const uint64_t index_words = a.index_cap * (sizeof(hbs_nal_entry) / 8);
     uint64_t clear_blocks = (index_words + desc_words) / (256u * 16u);
@@ -483,7 +489,7 @@ void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, bo
     if (clear_blocks > (uint64_t)kClearBlocksMax) clear_blocks = kClearBlocksMax;
     k_scan_prologue<<<dim3(kProbeBlocks + kTailBlocks + (unsigned)clear_blocks), dim3(256), 0, st>>>(
         a.stream, a.n, a.hdr, a.tail, reinterpret_cast<unsigned long long*>(a.index), index_words,
-        a.desc, desc_words, probe ? 1 : 0, tail ? 1 : 0);
+        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes);
 }
 
 int scan4_grid_blocks(int device, int* blocks_per_cu_out)

@@ -114,7 +114,7 @@ __device__ __forceinline__ TileAgg make_batch(Elem& el, const Lds5& l, uint32_t 
     el.gap = 0; el.chunk = 0;
     if (have) {
         elem_load(el.v, stream, base + 16ull * c, n, false);
-        elem_walk(el.v, el.m, el.s);
+        elem_walk(el.v, el.m, el.s, el.cls);
         el.gap = span_bytes(my_prev_end, el.v.g0, n);
         el.chunk = c;
         ea = elem_agg(el.gap, el.s);

@@ -122,11 +122,126 @@ struct ElemView {
 
 typedef BlockMarksT<uint32_t> ChunkMarks;      /* 16 byte positions (+2 behind) fit 32 bits */
 
-/* exact classification of one chunk */
-HBS_HD void elem_walk(const ElemView& v, ChunkMarks& m, BlockSum& s)
+/* exact classification of one chunk: the window rules of hbs_tile.h, one pattern at a time */
+HBS_HD void elem_walk_generic(const ElemView& v, ChunkMarks& m, BlockSum& s)
 {
     const uint32_t pats = chunk_patterns(v.xp, v.x0, v.x1, v.x2, v.x3, v.xn);
     walk_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, v.n, pats & 0xFFFFu, pats >> 16, m, s);
+}
+
+/*
+ * The same rules with every position of the element at once.  An element's 28 bytes [-8, 20) are
+ * classified into three bit masks (bit i = position i - 8): byte <= 3, bit 0 of the byte, bit 1 of
+ * the byte -- from which "is 00 / 01 / 02 / 03" are three ANDs -- and the rules of pattern_kind() /
+ * walk_block_t() become shifts and ANDs of those masks: no loop over patterns, no byte fetches, no
+ * divergence between the lanes of the wavefront that walks a tile's elements (the walk is serial work
+ * that a whole workgroup waits for).
+ */
+struct ElemClasses {
+    uint32_t z, e1, e3;       /* positions holding 00 / 01 / 03: what the emit half looks at */
+};
+/* four flags at bits 0, 8, 16, 24 -> bits 0..3 */
+HBS_HD uint32_t gather4(uint32_t t) { return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu; }
+
+HBS_HD void elem_class_masks(const ElemView& v, uint32_t& le3, uint32_t& b0, uint32_t& b1)
+{
+    const uint32_t d[7] = {v.xpp, v.xp, v.x0, v.x1, v.x2, v.x3, v.xn};
+    le3 = 0; b0 = 0; b1 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 7; ++k) {
+        const uint32_t x = d[k];
+        le3 |= gather4(zero_bytes(x & 0xFCFCFCFCu) >> 7) << (4 * k);
+        b0 |= gather4(x & 0x01010101u) << (4 * k);
+        b1 |= gather4((x >> 1) & 0x01010101u) << (4 * k);
+    }
+}
+
+/* bits [0, k) of a position mask; k may be negative or beyond the word */
+HBS_HD uint32_t below_pos(int64_t k) { return k <= 0 ? 0u : (k >= 32 ? 0xFFFFFFFFu : ((1u << (uint32_t)k) - 1u)); }
+
+/* Exact classification of one chunk, every position at once.  The end-of-stream clauses of pattern_kind()
+ * (h264_nal.c:52, :71 and the unchecked first end candidate :65-66) are position limits: with L = n - g0 bytes
+ * of stream from the chunk's first byte on, a terminator ending at j counts if j + 2 <= L or if it sits right
+ * behind a start code; a 00 00 01 ending at j starts a NAL if j + 3 <= L; the byte behind an emulation prevention
+ * byte at j exists if j + 1 < L.  Bytes past the end of the stream read as FF and belong to no class. */
+HBS_HD void elem_walk(const ElemView& v, ChunkMarks& m, BlockSum& s, ElemClasses& cls)
+{
+    uint32_t le3, b0, b1;
+    elem_class_masks(v, le3, b0, b1);
+    const uint32_t z = le3 & ~b0 & ~b1, e1 = le3 & b0 & ~b1, e2 = le3 & ~b0 & b1, e3 = le3 & b0 & b1;
+    cls.z = z; cls.e1 = e1; cls.e3 = e3;
+    const int64_t L = v.g0 < v.n ? (v.n - v.g0 > 64 ? 64 : (int64_t)(v.n - v.g0)) : 0;
+    const uint32_t pat = ((z << 2) & (z << 1) & le3) >> 8;            /* 00 00 {00..03} ends at position 0..19      */
+    const uint32_t zp = z >> 8, e1p = e1 >> 8, e2p = e2 >> 8, e3p = e3 >> 8;
+    const uint32_t termc = pat & ((zp & ~(z >> 5)) | e1p);            /* 00 00 01, or the first 00 00 00 of a run    */
+    const uint32_t tok = below_pos(L - 1) | ((z >> 3) & (z >> 4) & (e1 >> 5));   /* complete, or right behind a start code */
+    const uint32_t term = termc & tok & 0x3FFFFu;                     /* positions 0..17                             */
+    const uint32_t start = term & e1p & below_pos(L - 2);
+    const uint32_t epb = pat & e3p & 0xFFFFu;
+    m.ev = term & 0xFFFFu;
+    m.ev_start = start & 0xFFFFu;
+    m.err = ((pat & e2p) | (termc & ~tok) | (pat & e3p & (~le3 >> 9) & below_pos(L - 1))) & 0xFFFFu;
+    m.cand = below_pos(L < 16 ? L : 16) & ~epb & ~(term | (term >> 1) | (term >> 2));   /* a terminator's bytes are outside every NAL */
+    /* summary: bytes before the first event follow the carried state; bytes behind a start code are inside */
+    const uint32_t x = ~m.ev & 0xFFFFu;
+    const uint32_t run = (((m.ev_start << 1) + x) ^ x) & x;          /* positions from behind each start code up to the next event */
+    s.cnt = (uint32_t)__builtin_popcount(m.ev_start);
+    s.known = (uint32_t)__builtin_popcount(m.cand & run);
+    if (m.ev != 0u) {
+        s.carry = (uint32_t)__builtin_popcount(m.cand & ((1u << __builtin_ctz(m.ev)) - 1u));
+        s.last = ((m.ev_start >> (31 - __builtin_clz(m.ev))) & 1u) ? kKindStart : kKindStop;
+    } else {
+        s.carry = (uint32_t)__builtin_popcount(m.cand);
+        s.last = kKindNone;
+    }
+}
+
+/*
+ * Second half for one element (emit_block_t of hbs_tile.h with the byte fetches replaced by tests of the
+ * class masks): index entries of the events, status flags, the final keep mask.  Valid for every element:
+ * the bytes it asks about, [-5, 13) of the chunk, are among the 28 the masks describe.
+ */
+HBS_D uint32_t emit_chunk_fast(const ElemClasses& cls, uint64_t g0, const ChunkMarks& m, bool inside,
+                               uint64_t nal_ord, uint64_t rbsp_pos, const EmitTarget& tgt)
+{
+    uint32_t inside_mask = 0, cur = 0;
+    uint64_t ord = nal_ord;
+    for (uint32_t r = m.ev; r != 0; r &= r - 1) {
+        const uint32_t e = (uint32_t)__builtin_ctz(r);
+        if (inside) {
+            inside_mask |= ((1u << e) - 1u) & ~((1u << cur) - 1u);
+            const uint64_t k = ord - 1;
+            /* the terminator begins at e - 2: bytes e-5, e-4, e-3 in front of it <-> mask bits e+3, e+4, e+5 */
+            const bool zz = ((cls.z >> (e + 3)) & (cls.z >> (e + 4)) & 1u) != 0u;
+            if (k < tgt.index_cap) {
+                tgt.index[k].end = g0 + e - 2;                        /* h264_nal.c:74 */
+                if (zz && ((cls.e3 >> (e + 5)) & 1u)) atomic_or_status(&tgt.index[k], HBS_ST_TRAILING03);   /* h264_nal.c:170-173 */
+            }
+            if (zz && ((cls.e1 >> (e + 5)) & 1u)) atomic_min_u64(&tgt.hdr->first_empty, k);   /* empty NAL: the loop of hevc_analyze.c:135 stops */
+        }
+        if ((m.ev_start >> e) & 1u) {
+            const uint64_t k = ord++;
+            if (k < tgt.index_cap) {
+                tgt.index[k].start = g0 + e + 1;                      /* h264_nal.c:61-62 */
+                tgt.index[k].rbsp_off = rbsp_pos + (uint32_t)__builtin_popcount(m.cand & inside_mask);
+            } else {
+                flag_error(tgt.hdr, (uint32_t)(-HBS_E_CAPACITY));
+            }
+            inside = true;
+        } else {
+            inside = false;
+        }
+        cur = e + 1;
+    }
+    if (inside) inside_mask |= 0xFFFFu & ~((1u << cur) - 1u);
+    for (uint32_t r = m.err & inside_mask; r != 0; r &= r - 1) {
+        const uint32_t pos = (uint32_t)__builtin_ctz(r);
+        const uint64_t k = nal_ord + (uint32_t)__builtin_popcount(m.ev_start & ((1u << pos) - 1u)) - 1;
+        if (k < tgt.index_cap) atomic_or_status(&tgt.index[k], HBS_ST_ERROR);
+    }
+    return m.cand & inside_mask;
 }
 
 /* an element's marks and summary in three dwords (chunk-sized masks are 16 bits each) */

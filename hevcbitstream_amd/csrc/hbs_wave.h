@@ -32,13 +32,23 @@ typedef u32x4 u32x4_u1 __attribute__((aligned(1)));        /* a 16-byte access a
 #ifndef HBS_NT_STORE
 #define HBS_NT_STORE 1
 #endif
+/* The pointer is cast to the global address space: where hipcc cannot prove that (a pointer picked between two
+ * buffers, as the last tile's padded copy is) it emits flat_load, which counts on lgkmcnt too and so is waited
+ * for by every `s_waitcnt lgkmcnt(0)` in front of a barrier. */
+typedef const __attribute__((address_space(1))) u32x4* global_u32x4_ptr;
+typedef const __attribute__((address_space(1))) uint32_t* global_u32_ptr;
 __device__ __forceinline__ u32x4 stream_load16(const u32x4* p)
 {
+    const global_u32x4_ptr g = (global_u32x4_ptr)(uintptr_t)p;
 #if HBS_NT_LOAD
-    return __builtin_nontemporal_load(p);
+    return __builtin_nontemporal_load(g);
 #else
-    return *p;
+    return *g;
 #endif
+}
+__device__ __forceinline__ uint32_t stream_load4(const uint8_t* p)
+{
+    return *(global_u32_ptr)(uintptr_t)p;
 }
 __device__ __forceinline__ void arena_store16(uint8_t* p, u32x4 v)
 {

@@ -314,8 +314,14 @@ extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
         for (size_t i = 0; i < list.size(); ++i) {
             const uint64_t prev_end = i ? base + 16ull * (list[i - 1] + 1u) : base;
             const ElemView v = view_at(base + 16ull * list[i]);
-            ChunkMarks m; BlockSum s;
-            elem_walk(v, m, s);
+            ChunkMarks m; BlockSum s; ElemClasses cls;
+            elem_walk(v, m, s, cls);
+            {   /* the bit-parallel walk against the one-pattern-at-a-time rules of hbs_tile.h */
+                ChunkMarks mg; BlockSum sg;
+                elem_walk_generic(v, mg, sg);
+                if (m.cand != mg.cand || m.ev != mg.ev || m.ev_start != mg.ev_start || m.err != mg.err ||
+                    s.cnt != sg.cnt || s.known != sg.known || s.carry != sg.carry || s.last != sg.last) return -213;
+            }
             acc = combine(acc, elem_agg(span_bytes(prev_end, v.g0, n), s));
         }
         const uint64_t last_end = list.empty() ? base : base + 16ull * (list.back() + 1u);
@@ -332,17 +338,28 @@ extern "C" int sim4_index_extract(const uint8_t* stream, uint64_t n,
         for (size_t i = 0; i < list.size(); ++i) {
             const uint64_t prev_end = i ? base + 16ull * (list[i - 1] + 1u) : base;
             const ElemView v = view_at(base + 16ull * list[i]);
-            ChunkMarks m; BlockSum s;
+            ChunkMarks m; BlockSum s; ElemClasses cls;
             {   /* the kernel parks marks and summary in LDS between the two phases */
                 ChunkMarks m0; BlockSum s0;
-                elem_walk(v, m0, s0);
+                elem_walk(v, m0, s0, cls);
                 elem_unpack(elem_pack(m0, s0), m, s);
                 if (m.cand != m0.cand || m.ev != m0.ev || m.ev_start != m0.ev_start || m.err != m0.err ||
                     s.cnt != s0.cnt || s.known != s0.known || s.carry != s0.carry || s.last != s0.last) return -212;
             }
             const uint32_t gap = span_bytes(prev_end, v.g0, n);
             const ElemStart st = elem_start(accb, gap, excl.inside);
-            const uint32_t keep = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, m, st.inside, excl.nals + accb.cnt, excl.kept + st.kept, tgt);
+            /* the emit half with class masks against emit_block_t: the generic one runs first, on a copy of the entries it may touch */
+            const uint64_t k0 = excl.nals + accb.cnt, lo = k0 ? k0 - 1 : 0, hi = k0 + 18 < index_cap ? k0 + 18 : index_cap;
+            std::vector<hbs_nal_entry> scratch;
+            for (uint64_t k = lo; k < hi; ++k) scratch.push_back(index[k]);
+            if (scratch.empty()) scratch.push_back(hbs_nal_entry{0, 0, 0, 0, 0});
+            RunHeader h2 = hdr;
+            EmitTarget tgt2{scratch.data() - lo, index_cap, &h2};
+            const uint32_t keep_g = (uint32_t)emit_block_t<kChunk, ElemView, uint32_t>(v, 0, v.g0, m, st.inside, k0, excl.kept + st.kept, tgt2);
+            const uint32_t keep = emit_chunk_fast(cls, v.g0, m, st.inside, k0, excl.kept + st.kept, tgt);
+            if (keep != keep_g || h2.first_empty != hdr.first_empty || h2.error != hdr.error) return -214;
+            for (uint64_t k = lo; k < hi; ++k)
+                if (memcmp(&scratch[k - lo], &index[k], sizeof(hbs_nal_entry)) != 0) return -215;
             const uint32_t nk = (uint32_t)__builtin_popcount(keep);
             if (can_store && keep) {
                 uint64_t lo, hi;
