@@ -184,32 +184,49 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         uint32_t fm_lo = 0, fm_hi = 0;     /* lane r: flag mask of my row r (rows without elements: 0) */
         uint32_t wslot = 0;                /* elements of this wavefront so far      */
         {
-            uint32_t e_prev = R.before;
-#define HBS_FLAG_BODY(r, e_prev_z_expr, e_next_expr) { \
-                const uint32_t xp = from_prev_lane(R.q##r.w, e_prev); \
-                const uint32_t xn = from_next_lane(R.q##r.x, (e_next_expr)); \
-                const bool f = chunk_flag(xp, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn); \
-                const uint64_t fmask = __ballot(f); \
-                if (fmask != 0) {        /* rare: stash the mask, leave the chunk's surroundings for its element thread */ \
-                    write_lane(fm_lo, (uint32_t)fmask, r); \
-                    write_lane(fm_hi, (uint32_t)(fmask >> 32), r); \
-                    const uint32_t xpp = from_prev_lane(R.q##r.z, (e_prev_z_expr)); \
-                    const uint32_t slot = wslot + lanes_below(fmask); \
-                    if (f && slot < (uint32_t)kDepCap) { \
+            /* Four rows at a time: the test of a row is a chain of dependent steps (neighbour dwords through DPP, nine packed
+             * minima, compare, ballot), and a branch per row keeps the compiler from overlapping the chains of different rows.
+             * So a group's four ballots are formed without a branch, and only a group in which some chunk is flagged -- one in
+             * fifteen in coded video -- goes through the per-row bookkeeping. */
+#define HBS_FLAG_EVAL(r, e_prev_w, e_next_x) \
+                const uint32_t xp##r = from_prev_lane(R.q##r.w, (e_prev_w)); \
+                const uint32_t xn##r = from_next_lane(R.q##r.x, (e_next_x)); \
+                const bool f##r = chunk_flag(xp##r, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn##r); \
+                const uint64_t fmask##r = __ballot(f##r);
+#define HBS_FLAG_KEEP(r, e_prev_z) \
+                if (fmask##r != 0) {     /* stash the mask, leave the chunk's surroundings for its element thread */ \
+                    write_lane(fm_lo, (uint32_t)fmask##r, r); \
+                    write_lane(fm_hi, (uint32_t)(fmask##r >> 32), r); \
+                    const uint32_t xpp = from_prev_lane(R.q##r.z, (e_prev_z)); \
+                    const uint32_t slot = wslot + lanes_below(fmask##r); \
+                    if (f##r && slot < (uint32_t)kDepCap) { \
                         Deposit d; \
-                        d.xpp = xpp; d.xp = xp; d.x0 = R.q##r.x; d.x1 = R.q##r.y; d.x2 = R.q##r.z; d.x3 = R.q##r.w; d.xn = xn; \
+                        d.xpp = xpp; d.xp = xp##r; d.x0 = R.q##r.x; d.x1 = R.q##r.y; d.x2 = R.q##r.z; d.x3 = R.q##r.w; d.xn = xn##r; \
                         d.chunk = (uint32_t)(64 * (k4Rows * wv + r) + lane); \
                         l.dep[wv][slot] = d; \
                     } \
-                    wslot += (uint32_t)__builtin_popcountll(fmask); \
-                } \
-                e_prev = (uint32_t)__builtin_amdgcn_readlane((int)R.q##r.w, 63); }
-#define HBS_FLAG(rp, r, rn) HBS_FLAG_BODY(r, (uint32_t)__builtin_amdgcn_readlane((int)R.q##rp.z, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q##rn.x, 0))
-            HBS_FLAG_BODY(0, R.before2, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.x, 0))
-            HBS_ROW_TRIPLES(HBS_FLAG)
-            HBS_FLAG_BODY(47, (uint32_t)__builtin_amdgcn_readlane((int)R.q46.z, 63), R.after)
-#undef HBS_FLAG
-#undef HBS_FLAG_BODY
+                    wslot += (uint32_t)__builtin_popcountll(fmask##r); \
+                }
+#define HBS_FLAG_GROUP(a, wa, xa, za, b, wb, xb, zb, c, wc, xc, zc, d, wd, xd, zd) { \
+                HBS_FLAG_EVAL(a, wa, xa) HBS_FLAG_EVAL(b, wb, xb) HBS_FLAG_EVAL(c, wc, xc) HBS_FLAG_EVAL(d, wd, xd) \
+                if ((fmask##a | fmask##b | fmask##c | fmask##d) != 0) { \
+                    HBS_FLAG_KEEP(a, za) HBS_FLAG_KEEP(b, zb) HBS_FLAG_KEEP(c, zc) HBS_FLAG_KEEP(d, zd) } }
+            /* (row, dword in front of its lane 0, dword behind its lane 63, second dword in front of its lane 0) x 4; written by scripts/set_rows4.py */
+            HBS_FLAG_GROUP(0, R.before, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.x, 0), R.before2, 1, (uint32_t)__builtin_amdgcn_readlane((int)R.q0.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q2.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q0.z, 63), 2, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q3.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q1.z, 63), 3, (uint32_t)__builtin_amdgcn_readlane((int)R.q2.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q4.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q2.z, 63))
+            HBS_FLAG_GROUP(4, (uint32_t)__builtin_amdgcn_readlane((int)R.q3.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q5.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q3.z, 63), 5, (uint32_t)__builtin_amdgcn_readlane((int)R.q4.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q6.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q4.z, 63), 6, (uint32_t)__builtin_amdgcn_readlane((int)R.q5.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q7.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q5.z, 63), 7, (uint32_t)__builtin_amdgcn_readlane((int)R.q6.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q8.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q6.z, 63))
+            HBS_FLAG_GROUP(8, (uint32_t)__builtin_amdgcn_readlane((int)R.q7.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q9.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q7.z, 63), 9, (uint32_t)__builtin_amdgcn_readlane((int)R.q8.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q10.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q8.z, 63), 10, (uint32_t)__builtin_amdgcn_readlane((int)R.q9.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q11.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q9.z, 63), 11, (uint32_t)__builtin_amdgcn_readlane((int)R.q10.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q12.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q10.z, 63))
+            HBS_FLAG_GROUP(12, (uint32_t)__builtin_amdgcn_readlane((int)R.q11.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q13.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q11.z, 63), 13, (uint32_t)__builtin_amdgcn_readlane((int)R.q12.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q14.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q12.z, 63), 14, (uint32_t)__builtin_amdgcn_readlane((int)R.q13.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q15.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q13.z, 63), 15, (uint32_t)__builtin_amdgcn_readlane((int)R.q14.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q16.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q14.z, 63))
+            HBS_FLAG_GROUP(16, (uint32_t)__builtin_amdgcn_readlane((int)R.q15.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q17.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q15.z, 63), 17, (uint32_t)__builtin_amdgcn_readlane((int)R.q16.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q18.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q16.z, 63), 18, (uint32_t)__builtin_amdgcn_readlane((int)R.q17.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q19.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q17.z, 63), 19, (uint32_t)__builtin_amdgcn_readlane((int)R.q18.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q20.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q18.z, 63))
+            HBS_FLAG_GROUP(20, (uint32_t)__builtin_amdgcn_readlane((int)R.q19.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q21.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q19.z, 63), 21, (uint32_t)__builtin_amdgcn_readlane((int)R.q20.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q22.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q20.z, 63), 22, (uint32_t)__builtin_amdgcn_readlane((int)R.q21.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q23.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q21.z, 63), 23, (uint32_t)__builtin_amdgcn_readlane((int)R.q22.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q24.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q22.z, 63))
+            HBS_FLAG_GROUP(24, (uint32_t)__builtin_amdgcn_readlane((int)R.q23.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q25.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q23.z, 63), 25, (uint32_t)__builtin_amdgcn_readlane((int)R.q24.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q26.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q24.z, 63), 26, (uint32_t)__builtin_amdgcn_readlane((int)R.q25.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q27.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q25.z, 63), 27, (uint32_t)__builtin_amdgcn_readlane((int)R.q26.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q28.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q26.z, 63))
+            HBS_FLAG_GROUP(28, (uint32_t)__builtin_amdgcn_readlane((int)R.q27.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q29.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q27.z, 63), 29, (uint32_t)__builtin_amdgcn_readlane((int)R.q28.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q30.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q28.z, 63), 30, (uint32_t)__builtin_amdgcn_readlane((int)R.q29.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q31.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q29.z, 63), 31, (uint32_t)__builtin_amdgcn_readlane((int)R.q30.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q32.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q30.z, 63))
+            HBS_FLAG_GROUP(32, (uint32_t)__builtin_amdgcn_readlane((int)R.q31.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q33.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q31.z, 63), 33, (uint32_t)__builtin_amdgcn_readlane((int)R.q32.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q34.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q32.z, 63), 34, (uint32_t)__builtin_amdgcn_readlane((int)R.q33.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q35.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q33.z, 63), 35, (uint32_t)__builtin_amdgcn_readlane((int)R.q34.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q36.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q34.z, 63))
+            HBS_FLAG_GROUP(36, (uint32_t)__builtin_amdgcn_readlane((int)R.q35.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q37.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q35.z, 63), 37, (uint32_t)__builtin_amdgcn_readlane((int)R.q36.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q38.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q36.z, 63), 38, (uint32_t)__builtin_amdgcn_readlane((int)R.q37.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q39.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q37.z, 63), 39, (uint32_t)__builtin_amdgcn_readlane((int)R.q38.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q40.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q38.z, 63))
+            HBS_FLAG_GROUP(40, (uint32_t)__builtin_amdgcn_readlane((int)R.q39.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q41.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q39.z, 63), 41, (uint32_t)__builtin_amdgcn_readlane((int)R.q40.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q42.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q40.z, 63), 42, (uint32_t)__builtin_amdgcn_readlane((int)R.q41.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q43.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q41.z, 63), 43, (uint32_t)__builtin_amdgcn_readlane((int)R.q42.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q44.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q42.z, 63))
+            HBS_FLAG_GROUP(44, (uint32_t)__builtin_amdgcn_readlane((int)R.q43.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q45.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q43.z, 63), 45, (uint32_t)__builtin_amdgcn_readlane((int)R.q44.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q46.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q44.z, 63), 46, (uint32_t)__builtin_amdgcn_readlane((int)R.q45.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q47.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q45.z, 63), 47, (uint32_t)__builtin_amdgcn_readlane((int)R.q46.w, 63), R.after, (uint32_t)__builtin_amdgcn_readlane((int)R.q46.z, 63))
+#undef HBS_FLAG_GROUP
+#undef HBS_FLAG_KEEP
+#undef HBS_FLAG_EVAL
             static_assert(k4Rows == 48, "first and last row are named above");
         }
         if (edge_tile && (n & 15ull) != 0 && n > wseg && n < wseg + (uint64_t)k4WaveBytes) {
