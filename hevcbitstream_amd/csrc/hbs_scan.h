@@ -5,11 +5,6 @@
 #include <hip/hip_runtime_api.h>
 #include "hbs_common.h"
 
-/* which event-sparse kernel the automatic mode uses on sparse streams: 4 (hbs_scan4.hip) or 6 (hbs_scan6.hip) */
-#ifndef HBS_SPARSE_KERNEL
-#define HBS_SPARSE_KERNEL 4
-#endif
-
 namespace hbs {
 
 struct ScanArgs {
@@ -25,13 +20,11 @@ struct ScanArgs {
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
     int grid_blocks3, grid_blocks4;   /* ... of the register-resident and of the event-sparse kernel          */
-    int grid_blocks6;                 /* ... of the event-sparse kernel with independent wavefronts            */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
     int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */
     int variant;                  /* 0: automatic (density probe, then event-sparse or LDS-image kernel, decided on the device),
                                      2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip),
-                                     5: index only (rbsp == nullptr), streaming kernel (hbs_scan5.hip); with an arena it means the default event-sparse kernel,
-                                     6: event-sparse kernel with independent wavefronts (hbs_scan6.hip) */
+                                     5: index only (rbsp == nullptr), streaming kernel (hbs_scan5.hip); with an arena it means 4 */
 };
 
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
@@ -51,12 +44,6 @@ int scan4_tail_bytes();
 /* header, probe, padded last tile, cleared index and look-back words: one launch in front of the main kernel */
 void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, int tail_tile_bytes /* 0: no padded copy */, hipStream_t st);
 void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
-
-/* event-sparse kernel with independent wavefronts (hbs_scan6.hip) */
-int scan6_grid_blocks(int device, int* blocks_per_cu_out);
-int scan6_tile_bytes();
-int scan6_tail_bytes();
-void launch_scan_extract6_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 /* index-only streaming kernel (hbs_scan5.hip) */
 uint64_t scan5_tile_bytes();

@@ -638,17 +638,15 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     /* no arena asked for: the streaming index-only kernel takes the place of the event-sparse one */
     /* (its 1 MiB tiles need a stream of ~0.75 GiB to occupy the GPU; below that the register-resident kernel is quicker) */
     const bool index_only = a.rbsp == nullptr && (a.variant == 5 || (automatic && a.n >= (3ull << 28)));
-    /* the event-sparse kernel of this call: the default one (HBS_SPARSE_KERNEL) unless 4 or 6 is pinned */
-    const int sparse_variant = (a.variant == 5 && !index_only) ? HBS_SPARSE_KERNEL : (automatic ? HBS_SPARSE_KERNEL : a.variant);
+    const int sparse_variant = ((a.variant == 5 && !index_only) || automatic) ? 4 : a.variant;
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
-    const uint64_t tiles6 = (a.n + (uint64_t)scan6_tile_bytes() - 1) / (uint64_t)scan6_tile_bytes();
     const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;
     const uint64_t tiles5 = (a.n + scan5_tile_bytes() - 1) / scan5_tile_bytes();
     /* the finest tiling any kernel of this call may use sizes the look-back words to clear */
-    const uint64_t num_tiles = (sparse_variant == 4 && !automatic) ? tiles4 : (sparse_variant == 6 && !automatic) ? tiles6 : tiles2;
+    const uint64_t num_tiles = (sparse_variant == 4 && !automatic) ? tiles4 : tiles2;
     /* one launch: run header, density probe (automatic mode), padded copy of the last tile (event-sparse kernels),
      * cleared index and look-back words */
-    const int tail_tile = index_only ? 0 : (sparse_variant == 4) ? scan4_tile_bytes() : (sparse_variant == 6) ? scan6_tile_bytes() : 0;
+    const int tail_tile = (!index_only && sparse_variant == 4) ? scan4_tile_bytes() : 0;
     launch_scan_prologue(a, num_tiles * 2, automatic && a.n != 0, tail_tile, st);
     if (num_tiles) {
         uint64_t grid = (uint64_t)a.grid_blocks;
@@ -660,14 +658,11 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
             launch_scan_index5(a, tiles5, kGateNone, st);
         } else if (!automatic && sparse_variant == 4) {
             launch_scan_extract4_kernel(a, tiles4, kGateNone, st);
-        } else if (!automatic && sparse_variant == 6) {
-            launch_scan_extract6_kernel(a, tiles6, kGateNone, st);
         } else if (automatic) {
             /* Both kernels are enqueued; each reads the probe's verdict from the run header and the
              * one it rules out returns at once (no host round trip, the call stays asynchronous).
              * They share the descriptor array and the ticket: whichever runs finds both untouched. */
             if (index_only) launch_scan_index5(a, tiles5, kGateIfSparse, st);
-            else if (sparse_variant == 6) launch_scan_extract6_kernel(a, tiles6, kGateIfSparse, st);
             else launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateIfDense);

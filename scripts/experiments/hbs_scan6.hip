@@ -56,14 +56,14 @@ __device__ unsigned long long g_timeline6[k6TlWgs][k6Waves][k6TlIters][k6TlMarks
 #define HBS6_MARK(i) { if (blockIdx.x < k6TlWgs && tl_iter < k6TlIters && (threadIdx.x & 63) == 0) g_timeline6[blockIdx.x][threadIdx.x >> 6][tl_iter][i] = __builtin_amdgcn_s_memtime(); }
 #define HBS6_ITER_DECL int tl_iter = 0;
 #define HBS6_ITER_NEXT ++tl_iter;
-#define HBS6_TL_ARG , int tl_iter
-#define HBS6_TL_PASS , tl_iter
+#define HBS6_TL_ARG , int tl_iter, int tl_set
+#define HBS6_TL_PASS(set) , tl_iter, set
 #else
 #define HBS6_MARK(i)
 #define HBS6_ITER_DECL
 #define HBS6_ITER_NEXT
 #define HBS6_TL_ARG
-#define HBS6_TL_PASS
+#define HBS6_TL_PASS(set)
 #endif
 
 /* compile-time row loop: the row number must be a constant wherever it names a lane or a register */
@@ -340,22 +340,62 @@ __device__ __forceinline__ bool tile_resolve(const Set6& S, Slot6& sl, uint32_t*
 }
 
 /* ---- prefix, the elements' second half, copy -------------------------------------------------------- */
-/* false: the workgroup gives up (a look-back timed out somewhere) */
-__device__ __forceinline__ bool set_emit_copy(Set6& S, int set, Slot6& sl, const WaveSet6* ws, uint32_t* abort_all,
-                                              const uint8_t* __restrict__ stream, const uint8_t* __restrict__ tail, uint64_t n, uint64_t num_tiles,
-                                              uint8_t* __restrict__ rbsp, uint64_t rbsp_cap, unsigned long long* __restrict__ desc,
-                                              RunHeader* __restrict__ hdr, const EmitTarget& tgt, int wv, int lane HBS6_TL_ARG)
+/* what the element wavefront carries from one batch of elements to the next */
+struct EmitState6 { TileAgg accb; uint64_t prev_end; };
+
+/* one batch of the tile's elements, second half: index entries, their own kept bytes, the segment words of the batch */
+__device__ __forceinline__ void tile_emit_batch(const Set6& S, Slot6& sl, const WaveSet6* ws, const TileElems6& te, uint32_t p, EmitState6& st,
+                                                const TileGeo6& g, uint64_t n, const Prefix& excl, bool can_store, uint8_t* out, const EmitTarget& tgt, int lane)
 {
-    const bool mine = element_wave(set, S.gen) == wv;
-    if (mine) {
-        if (!tile_resolve(S, sl, abort_all, desc, hdr, rbsp, rbsp_cap, num_tiles, lane)) {
-            if (lane == 0) lds_store(&sl.stamp, 1024u * S.gen + 1023u);      /* wake the others: they see abort_all / ok == 0 */
-            return false;
-        }
-    } else if (!lds_wait_ge(&sl.stamp, 1024u * S.gen + 1u, abort_all)) {
-        return false;               /* the first batch's segment words are in: so are the prefix and everybody's element counts */
+    const uint32_t pbase = p * (uint32_t)k4ElemPass;
+    if (te.nflag != 0u) {
+        Elem el;
+        TileAgg ea = tile_batch(el, ws, te, pbase, lane, g, n, st.prev_end);
+        ea = wave_scan_combine(ea, lane);
+        TileAgg up = agg_shfl_up(ea, 1);
+        if (lane == 0) up = agg_identity();
+        const TileAgg e = combine(st.accb, up);
+        st.accb = combine(st.accb, agg_readlane(ea, 63));
+        if (pbase + (uint32_t)lane < te.nflag) elem_emit(el, e, excl, can_store, out, tgt, &sl.seg[lane + 1]);
     }
-    HBS6_MARK(4 + 4 * set)
+    if (lane == 0) lds_store(&sl.stamp, 1024u * S.gen + p + 1u);
+}
+
+/* The element wavefront of the set's tile: prefix, first batch.  Runs BEFORE this wavefront waits for anybody else's
+ * tile, so that the serial work of the workgroup's two tiles proceeds on two wavefronts at once. */
+__device__ __forceinline__ bool set_resolve_emit(const Set6& S, Slot6& sl, const WaveSet6* ws, uint32_t* abort_all, EmitState6& st,
+                                                 const uint8_t* __restrict__ stream, const uint8_t* __restrict__ tail, uint64_t n, uint64_t num_tiles,
+                                                 uint8_t* __restrict__ rbsp, uint64_t rbsp_cap, unsigned long long* __restrict__ desc,
+                                                 RunHeader* __restrict__ hdr, const EmitTarget& tgt, int lane)
+{
+    if (!tile_resolve(S, sl, abort_all, desc, hdr, rbsp, rbsp_cap, num_tiles, lane)) {
+        if (lane == 0) lds_store(&sl.stamp, 1024u * S.gen + 1023u);      /* wake the others: they see abort_all / ok == 0 */
+        return false;
+    }
+    Prefix excl;
+    {
+        Prefix ex;
+        ex.kept = sl.ex_kept; ex.nals = sl.ex_nals; ex.inside = sl.ex_inside;
+        excl = prefix_uniform4(ex);
+    }
+    const bool can_store = rbsp != nullptr && (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.ok) == 1u;
+    const TileGeo6 g = tile_geo(S.tile, stream, tail, num_tiles);
+    const TileElems6 te = tile_elems(sl, S.gen);
+    st.accb = agg_identity();
+    st.prev_end = g.base;
+    tile_emit_batch(S, sl, ws, te, 0u, st, g, n, excl, can_store, rbsp + excl.kept, tgt, lane);
+    return true;
+}
+
+/* everybody: copy what each batch serves; the element wavefront emits the batches behind the first in between.
+ * false: the workgroup gives up (a look-back timed out somewhere) */
+__device__ __forceinline__ bool set_copy(Set6& S, bool mine, Slot6& sl, const WaveSet6* ws, uint32_t* abort_all, EmitState6& st,
+                                         const uint8_t* __restrict__ stream, const uint8_t* __restrict__ tail, uint64_t n, uint64_t num_tiles,
+                                         uint8_t* __restrict__ rbsp, const EmitTarget& tgt, int wv, int lane HBS6_TL_ARG)
+{
+    /* the first batch's segment words are in: so are the prefix and everybody's element counts */
+    if (!mine && !lds_wait_ge(&sl.stamp, 1024u * S.gen + 1u, abort_all)) return false;
+    HBS6_MARK(4 + 4 * tl_set)
     const uint32_t okv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.ok);
     if (okv == 0u) return false;
     Prefix excl;
@@ -373,28 +413,17 @@ __device__ __forceinline__ bool set_emit_copy(Set6& S, int set, Slot6& sl, const
     const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? te.wb1 : (wv == 2) ? te.wb2 : te.wb3;
     const uint32_t whole = (uint32_t)(span_bytes(g.base, g.tile_end, n) >> 4);      /* chunks of the tile that are complete */
     const uint32_t copied0 = (mine && np > 1u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(&sl.copied)) : 0u;
-    TileAgg accb = agg_identity();
-    uint64_t prev_end = g.base;
 #pragma unroll 1
     for (uint32_t p = 0; p < np; ++p) {
         const uint32_t pbase = p * (uint32_t)k4ElemPass;
-        if (mine) {
-            /* everybody has copied what the previous batch served: its segment words may go */
-            if (p != 0u && !lds_wait_ge(&sl.copied, copied0 + (uint32_t)k6Waves * p, abort_all)) return false;
-            if (npass != 0u) {
-                Elem el;
-                TileAgg ea = tile_batch(el, ws, te, pbase, lane, g, n, prev_end);
-                ea = wave_scan_combine(ea, lane);
-                TileAgg up = agg_shfl_up(ea, 1);
-                if (lane == 0) up = agg_identity();
-                const TileAgg e = combine(accb, up);
-                accb = combine(accb, agg_readlane(ea, 63));
-                if (pbase + (uint32_t)lane < te.nflag) elem_emit(el, e, excl, can_store, out, tgt, &sl.seg[lane + 1]);
+        if (p != 0u) {
+            if (mine) {
+                /* everybody has copied what the previous batch served: its segment words may go */
+                if (!lds_wait_ge(&sl.copied, copied0 + (uint32_t)k6Waves * p, abort_all)) return false;
+                tile_emit_batch(S, sl, ws, te, p, st, g, n, excl, can_store, out, tgt, lane);
+            } else if (!lds_wait_ge(&sl.stamp, 1024u * S.gen + p + 1u, abort_all)) {
+                return false;
             }
-            if (lane == 0) lds_store(&sl.stamp, 1024u * S.gen + p + 1u);
-            HBS6_MARK(5 + 4 * set)
-        } else if (p != 0u && !lds_wait_ge(&sl.stamp, 1024u * S.gen + p + 1u, abort_all)) {
-            return false;
         }
         if (can_store) {
             /* lane j: segment word j of this batch (j = 0..63), word 64 apart: a row without elements needs one
@@ -487,18 +516,25 @@ void k_scan_extract6(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             set_flags(B, l.ws[1][wv], l.slot[1], n, num_tiles, wv, lane);
             if (element_wave(1, B.gen) == wv && !tile_aggregate_publish(B, l.slot[1], l.ws[1], &l.abort_all, stream, tail, n, num_tiles, desc, lane)) return;
         }
-        __builtin_amdgcn_s_setprio(0);
         lane = launder_lane(tid0) & 63;
         HBS6_MARK(3)
+        /* the serial work of the two tiles, each on its own wavefront, before anybody waits for anybody */
+        const bool mineA = A.tile != kNoTile && element_wave(0, A.gen) == wv, mineB = B.tile != kNoTile && element_wave(1, B.gen) == wv;
+        EmitState6 st;
+        st.accb = agg_identity(); st.prev_end = 0;
+        if (mineA && !set_resolve_emit(A, l.slot[0], l.ws[0], &l.abort_all, st, stream, tail, n, num_tiles, rbsp, rbsp_cap, desc, hdr, tgt, lane)) return;
+        if (mineB && !set_resolve_emit(B, l.slot[1], l.ws[1], &l.abort_all, st, stream, tail, n, num_tiles, rbsp, rbsp_cap, desc, hdr, tgt, lane)) return;
+        __builtin_amdgcn_s_setprio(0);
+        HBS6_MARK(5)
         if (A.tile != kNoTile) {
-            if (!set_emit_copy(A, 0, l.slot[0], l.ws[0], &l.abort_all, stream, tail, n, num_tiles, rbsp, rbsp_cap, desc, hdr, tgt, wv, lane HBS6_TL_PASS)) return;
+            if (!set_copy(A, mineA, l.slot[0], l.ws[0], &l.abort_all, st, stream, tail, n, num_tiles, rbsp, tgt, wv, lane HBS6_TL_PASS(0))) return;
             HBS6_MARK(6)
             if (!set_next(A, l.slot[0], &l.abort_all, num_tiles)) return;
             if (A.tile != kNoTile) set_load(A, stream, tail, n, num_tiles, wv, lane);
         }
         HBS6_MARK(7)
         if (B.tile != kNoTile) {
-            if (!set_emit_copy(B, 1, l.slot[1], l.ws[1], &l.abort_all, stream, tail, n, num_tiles, rbsp, rbsp_cap, desc, hdr, tgt, wv, lane HBS6_TL_PASS)) return;
+            if (!set_copy(B, mineB, l.slot[1], l.ws[1], &l.abort_all, st, stream, tail, n, num_tiles, rbsp, tgt, wv, lane HBS6_TL_PASS(1))) return;
             HBS6_MARK(10)
             if (!set_next(B, l.slot[1], &l.abort_all, num_tiles)) return;
             if (B.tile != kNoTile) set_load(B, stream, tail, n, num_tiles, wv, lane);

@@ -21,13 +21,13 @@ lib = api.load_library()
 out = np.zeros((8, 4, 48, 12), dtype=np.uint64)
 lib.hbs_debug_timeline6.argtypes = [C.c_void_p]
 assert lib.hbs_debug_timeline6(out.ctypes.data) == 0
-names = ["top", "flagsA(+E)", "-", "flagsB(+E)", "A:prefix known", "A:emit stamped", "A:copied", "A:next+load", "B:prefix known", "B:emit stamped", "B:copied", "B:next+load"]
+names = ["top", "flagsA", "-", "flagsB(+E)", "A:stamp seen", "resolve+emit done", "A:copied", "A:next+load", "B:stamp seen", "-", "B:copied", "B:next+load"]
 for wg in (0, 3):
     t0 = int(out[wg, :, 20, 0].min())
     print("workgroup", wg, "iterations 20..23, cycles relative to the first wavefront's top of iteration 20")
     for it in range(20, 24):
         for w in range(4):
             row = out[wg, w, it].astype(np.int64)
-            print("  it %d wave %d: " % (it, w) + " ".join("%s=%d" % (names[i], row[i] - t0) for i in range(12) if row[i] and i != 2))
+            print("  it %d wave %d: " % (it, w) + " ".join("%s=%d" % (names[i], row[i] - t0) for i in range(12) if row[i] and i not in (2, 9)))
     d = out[wg, 0, 10:40, 0].astype(np.int64)
     print("  mean iteration length (wave 0, iterations 10..39): %.0f cycles" % np.diff(d).mean())
