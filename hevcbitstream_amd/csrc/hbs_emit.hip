@@ -416,6 +416,27 @@ constexpr int kEmitGroup = 4 * kEmitSlots;        /* NALs per workgroup and tick
 constexpr uint32_t kEmitSpinLimit = 1u << 26;
 
 struct __attribute__((packed, aligned(1))) Chunk16 { u32x4 v; };
+/* streaming accesses of the single pass: the arena is read once and the stream written once (hbs_wave.h has the measurements) */
+#ifndef HBS_K3_NT
+#define HBS_K3_NT 1
+#endif
+typedef const __attribute__((address_space(1))) u32x4_u1* global_u32x4_u1_ptr;
+__device__ __forceinline__ u32x4 k3_load16(const uint8_t* p)
+{
+#if HBS_K3_NT
+    return __builtin_nontemporal_load((global_u32x4_u1_ptr)(uintptr_t)p);
+#else
+    return reinterpret_cast<const Chunk16*>(p)->v;
+#endif
+}
+__device__ __forceinline__ void k3_store16(uint8_t* p, u32x4 v)
+{
+#if HBS_K3_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_u1*>(p));
+#else
+    reinterpret_cast<Chunk16*>(p)->v = v;
+#endif
+}
 
 /* rows [r0, r0 + kEmitRows) of a NAL.  Unpredicated loads: a lane whose chunk starts behind the
  * NAL's last chunk reads that last chunk again (and never uses it), and the last chunk may reach up
@@ -437,7 +458,7 @@ __device__ __forceinline__ void load_rows(u32x4 (&R)[kEmitRows], const uint8_t* 
                 /* launder_lane: every row computes its offset where it needs it; kept across the slots
                  * and phases (they are all the same expression) they would fill the register file */
                 const uint32_t off = 1024u * (r0 + (uint32_t)r) + 16u * (uint32_t)launder_lane(lane);
-                R[r] = reinterpret_cast<const Chunk16*>(base + (off < lim ? off : lim))->v;
+                R[r] = k3_load16(base + (off < lim ? off : lim));
             }
         }
     }
@@ -528,7 +549,7 @@ __device__ __forceinline__ void emit_batch(const u32x4 (&R)[kEmitRows], const ui
         if (row_lo < len && !((rowmask >> r) & 1u)) {          /* wave-uniform: no flagged chunk in the row */
             const uint32_t off = row_lo + 16u * (uint32_t)launder_lane(lane);
             uint8_t* dst = dst0 + off + (uint32_t)__builtin_amdgcn_readlane((int)rowins, r);
-            if (off + 16u <= len) reinterpret_cast<Chunk16*>(dst)->v = R[r];
+            if (off + 16u <= len) k3_store16(dst, R[r]);
             if (partial && (last_off >> 10) == r0 + (uint32_t)r) {                    /* wave-uniform: the NAL's last row */
                 if (off == last_off) store_bytes(dst, R[r], len - last_off);
             }
