@@ -320,8 +320,8 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         blocks, per_cu = ctx.grid()
         variant = ctx.last_kernel()          # automatic mode: the kernel the density probe picked
-        kernel_name = {2: "hbs::k_scan_extract", 3: "hbs::k_scan_extract3", 4: "hbs::k_scan_extract4"}[variant]
-        geometry = {2: "512 threads, 64 KiB tiles (LDS image)", 3: "512 threads, 64 KiB tiles (registers)",
+        kernel_name = {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4"}[variant]
+        geometry = {2: "512 threads, 64 KiB tiles (LDS image)",
                     4: "256 threads, 192 KiB tiles held in registers, tiles handed out by ticket"}[variant]
         out = {
             "metric": "Annex-B GB/s scanned + NAL units/s, 16 GiB synthetic stream, 1/2/4/8 MI355X",

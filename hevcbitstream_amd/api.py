@@ -139,7 +139,7 @@ class Context:
 
     def set_kernel(self, variant):
         """0 = automatic (density probe picks 4 or 2 on the device; the default), 2 = LDS-image
-        scan/extract kernel, 3 = register-resident one, 4 = event-sparse one"""
+        scan/extract kernel, 4 = event-sparse one, 5 = index-only streaming one"""
         self._check(self.lib.hbs_ctx_set_kernel(self.h, variant), "hbs_ctx_set_kernel")
 
     def kernel(self):

@@ -26,7 +26,6 @@ struct hbs_ctx {
     hipStream_t stream;
     int grid_blocks;
     int blocks_per_cu;
-    int grid_blocks3, blocks_per_cu3;   /* register-resident kernel */
     int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
@@ -118,17 +117,15 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     if (hipMalloc(reinterpret_cast<void**>(&c->tail), (size_t)hbs::scan4_tail_bytes()) != hipSuccess) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks = hbs::scan_grid_blocks(device, &c->blocks_per_cu);
     if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
-    c->grid_blocks3 = hbs::scan3_grid_blocks(device, &c->blocks_per_cu3);
-    if (c->grid_blocks3 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks4 = hbs::scan4_grid_blocks(device, &c->blocks_per_cu4);
     if (c->grid_blocks4 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
-    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) { c->grid_blocks = atoi(g); c->grid_blocks3 = atoi(g) < c->grid_blocks3 ? atoi(g) : c->grid_blocks3; }
+    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
-    const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 3 register-resident, 4 event-sparse */
+    const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 4 event-sparse, 5 index-only streaming */
     const char* sv = getenv("HBS_SCHED");
     c->sched = (sv && atoi(sv) >= 0 && atoi(sv) <= 2) ? atoi(sv) : HBS_DEFAULT_SCHED;
-    c->variant = (kv && (atoi(kv) == 0 || (atoi(kv) >= 2 && atoi(kv) <= 5))) ? atoi(kv) : HBS_DEFAULT_KERNEL;
+    c->variant = (kv && (atoi(kv) == 0 || atoi(kv) == 2 || atoi(kv) == 4 || atoi(kv) == 5)) ? atoi(kv) : HBS_DEFAULT_KERNEL;
     c->last_variant = c->variant ? c->variant : 4;
     *out = c;
     return 0;
@@ -190,14 +187,14 @@ int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 {
     if (!c) return HBS_E_ARG;
     const int v = c->variant ? c->variant : c->last_variant;
-    if (blocks) *blocks = (v == 4) ? c->grid_blocks4 : (v == 3) ? c->grid_blocks3 : c->grid_blocks;
-    if (blocks_per_cu) *blocks_per_cu = (v == 4) ? c->blocks_per_cu4 : (v == 3) ? c->blocks_per_cu3 : c->blocks_per_cu;
+    if (blocks) *blocks = (v == 4) ? c->grid_blocks4 : c->grid_blocks;
+    if (blocks_per_cu) *blocks_per_cu = (v == 4) ? c->blocks_per_cu4 : c->blocks_per_cu;
     return 0;
 }
 
 int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant == 1 || variant > 5) return HBS_E_ARG;
+    if (!c || variant < 0 || variant == 1 || variant == 3 || variant > 5) return HBS_E_ARG;
     c->variant = variant;
     if (variant) c->last_variant = variant;
     return 0;
@@ -282,7 +279,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     c->last_index_only = (!d_rbsp && (c->variant == 5 || (c->variant == 0 && n >= (3ull << 28))) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;
     a.sched = c->sched;
-    a.grid_blocks = c->grid_blocks; a.grid_blocks3 = c->grid_blocks3; a.grid_blocks4 = c->grid_blocks4;
+    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4;
     c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
     if (hbs::scan_takes_small_path(n, index_cap, c->variant)) { c->probe_pending = 0; c->last_variant = 2; }
     a.ev_begin = c->timing ? c->ev0 : nullptr;

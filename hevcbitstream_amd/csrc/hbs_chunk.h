@@ -1,6 +1,6 @@
 /*
- * hbs_chunk.h -- 16-byte-chunk form of the tile logic for the register-resident
- * scan/extract kernel (hbs_scan3.hip): a lane holds one 16-byte chunk of the
+ * hbs_chunk.h -- 16-byte-chunk form of the tile logic, the base of the event-sparse
+ * kernels (hbs_sparse.h builds on it): a lane holds one 16-byte chunk of the
  * stream in four VGPRs plus the dword in front (xp) and behind (xn), and
  * everything hbs_tile.h does per 64-byte block of an LDS image happens here
  * per chunk straight from registers: same window rules, same walk_block /

@@ -19,11 +19,11 @@ struct ScanArgs {
     uint8_t* tail;                /* workspace of scan4_tail_bytes(): padded copy of the last tile (variant 4) */
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
-    int grid_blocks3, grid_blocks4;   /* ... of the register-resident and of the event-sparse kernel          */
+    int grid_blocks4;                 /* ... of the event-sparse kernel                                        */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
     int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */
     int variant;                  /* 0: automatic (density probe, then event-sparse or LDS-image kernel, decided on the device),
-                                     2: LDS-image kernel (hbs_scan.hip), 3: register-resident kernel (hbs_scan3.hip), 4: event-sparse kernel (hbs_scan4.hip),
+                                     2: LDS-image kernel (hbs_scan.hip), 4: event-sparse kernel (hbs_scan4.hip),
                                      5: index only (rbsp == nullptr), streaming kernel (hbs_scan5.hip); with an arena it means 4 */
 };
 
@@ -32,10 +32,6 @@ int scan_grid_blocks(int device, int* blocks_per_cu_out);
 hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st);
 /* automatic mode, at most one 64 KiB tile and a small index: one launch of one workgroup does the whole call */
 bool scan_takes_small_path(uint64_t n, uint64_t index_cap, int variant);
-
-/* register-resident variant (hbs_scan3.hip) */
-int scan3_grid_blocks(int device, int* blocks_per_cu_out);
-void launch_scan_extract3_kernel(const ScanArgs& a, uint64_t num_tiles, hipStream_t st);
 
 /* event-sparse variant (hbs_scan4.hip) */
 int scan4_grid_blocks(int device, int* blocks_per_cu_out);

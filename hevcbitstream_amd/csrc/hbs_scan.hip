@@ -636,7 +636,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         return hipGetLastError();
     }
     /* no arena asked for: the streaming index-only kernel takes the place of the event-sparse one */
-    /* (its 1 MiB tiles need a stream of ~0.75 GiB to occupy the GPU; below that the register-resident kernel is quicker) */
+    /* (its 1 MiB tiles need a stream of ~0.75 GiB to occupy the GPU; below that the event-sparse kernel is quicker) */
     const bool index_only = a.rbsp == nullptr && (a.variant == 5 || (automatic && a.n >= (3ull << 28)));
     const int sparse_variant = ((a.variant == 5 && !index_only) || automatic) ? 4 : a.variant;
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
@@ -652,9 +652,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         uint64_t grid = (uint64_t)a.grid_blocks;
         if (grid > tiles2) grid = tiles2;
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
-        if (a.variant == 3) {
-            launch_scan_extract3_kernel(a, num_tiles, st);
-        } else if (index_only && !automatic) {
+        if (index_only && !automatic) {
             launch_scan_index5(a, tiles5, kGateNone, st);
         } else if (!automatic && sparse_variant == 4) {
             launch_scan_extract4_kernel(a, tiles4, kGateNone, st);

@@ -1,8 +1,8 @@
 /*
- * hbs_wave.h -- wavefront-level helpers shared by the register-resident kernels
- * (hbs_scan3.hip, hbs_scan4.hip): the 8-row register image of one wavefront's
- * 8 KiB, guarded loads at the stream edges, DPP neighbour access, wave scans,
- * byte-aligned stores, and the look-back descriptor accessors.  Device only.
+ * hbs_wave.h -- wavefront-level helpers shared by the event-sparse kernels
+ * (hbs_scan4.hip, hbs_scan5.hip): guarded loads at the stream edges, streaming
+ * load / store forms, DPP neighbour access, wave scans, byte-aligned stores, and
+ * the look-back descriptor accessors.  Device only.
  */
 #ifndef HBS_WAVE_H
 #define HBS_WAVE_H
@@ -11,14 +11,6 @@
 #include "hbs_chunk.h"
 
 namespace hbs {
-
-constexpr int k3Threads = 512;
-constexpr int k3Waves = k3Threads / 64;
-constexpr int k3Rows = 8;                                  /* rows of 1 KiB per wavefront per tile */
-constexpr int k3RowBytes = 1024;
-constexpr int k3WaveBytes = k3Rows * k3RowBytes;           /* 8 KiB  */
-constexpr int k3TileBytes = k3Waves * k3WaveBytes;         /* 64 KiB */
-static_assert(k3TileBytes == kTileBytes, "both kernels share the descriptor workspace sizing");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u1 __attribute__((aligned(1)));        /* a 16-byte access at any byte address */
@@ -59,17 +51,6 @@ __device__ __forceinline__ void arena_store16(uint8_t* p, u32x4 v)
 #endif
 }
 
-#define HBS_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-
-/* one wavefront's 8 KiB: 8 rows in named registers + the dwords just outside */
-struct Rows {
-#define HBS_DECL(r) u32x4 q##r;
-    HBS_REP8(HBS_DECL)
-#undef HBS_DECL
-    uint32_t before;          /* dword in front of the segment (0xFFFFFFFF before the stream) */
-    uint32_t after;           /* dword behind it (0xFF bytes past the end of the stream)      */
-};
-
 /* Loads that may straddle either end of the stream (bytes outside read as 0xFF).  Rolled byte
  * loops on purpose: these run for the one tile that holds the stream end and for elements next
  * to it, and unrolled they would be most of the kernel's code. */
@@ -103,24 +84,6 @@ __device__ __forceinline__ u32x4 load_chunk_guarded(const uint8_t* __restrict__ 
     u32x4 v;
     v.x = w0; v.y = w1; v.z = w2; v.w = w3;
     return v;
-}
-
-/* fetch the segment that starts at stream offset seg (multiple of 8 KiB) */
-__device__ __forceinline__ void fetch_rows(Rows& R, const uint8_t* __restrict__ s, uint64_t seg, uint64_t n, int lane)
-{
-    if (seg + k3WaveBytes + 4 <= n) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(s + seg) + lane;
-#define HBS_LD(r) R.q##r = p[r * 64];
-        HBS_REP8(HBS_LD)
-#undef HBS_LD
-        R.after = *reinterpret_cast<const uint32_t*>(s + seg + k3WaveBytes);
-    } else {
-#define HBS_LD(r) R.q##r = load_chunk_guarded(s, seg + (uint64_t)(r * k3RowBytes + 16 * lane), n);
-        HBS_REP8(HBS_LD)
-#undef HBS_LD
-        R.after = load_dword_guarded(s, (int64_t)(seg + k3WaveBytes), n);
-    }
-    R.before = (seg >= 4) ? *reinterpret_cast<const uint32_t*>(s + seg - 4) : 0xFFFFFFFFu;
 }
 
 /* Opaque copy of a lane-constant value: hipcc otherwise hoists every address and predicate that
@@ -170,7 +133,7 @@ __device__ __forceinline__ void store_pieces(uint8_t* p, uint64_t lo, uint64_t h
     if (cnt & 1u) { *p = (uint8_t)lo; }
 }
 
-/* decoupled look-back, 256 tiles per step (waves 0-3 inspect descriptors); as in hbs_scan.hip */
+/* look-back descriptor accessors (agent scope: the other party is usually on another XCD) */
 __device__ __forceinline__ uint64_t ld_desc3(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_desc3(unsigned long long* p, uint64_t v) { __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

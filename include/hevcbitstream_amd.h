@@ -100,11 +100,10 @@ int  hbs_ctx_synchronize(hbs_ctx* ctx);
 int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
 int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
 int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
-/* Several implementations of the scan kernel exist, with identical results:
+/* Three implementations of the scan kernel exist, with identical results:
  * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
  *     pairs are rare, and the slowest on zero-heavy data),
  * 2 = tile staged in an LDS image (hbs_scan.hip; same speed on any data),
- * 3 = tile in registers, dense per-row classification (hbs_scan3.hip).
  * 5 = index only (no RBSP arena asked for): nothing has to stay in registers, so the bytes are
  *     streamed and only the flagged chunks are looked at again (hbs_scan5.hip); with an arena it means 4,
  * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and kernel 4 (5

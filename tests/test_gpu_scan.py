@@ -12,11 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
-@pytest.fixture(scope="module", params=[0, 2, 3, 4, 5],
-                ids=["automatic", "lds-image-kernel", "register-kernel", "sparse-kernel", "index-only-passes"])
+@pytest.fixture(scope="module", params=[0, 2, 4, 5],
+                ids=["automatic", "lds-image-kernel", "sparse-kernel", "index-only-passes"])
 def ctx(request):
-    """the three implementations of the fused kernel (hbs_scan.hip 2, hbs_scan3.hip 3, hbs_scan4.hip 4) and the
-    automatic choice between 4 and 2 (the default)"""
+    """the two implementations of the fused kernel (hbs_scan.hip 2, hbs_scan4.hip 4), the index-only streaming kernel
+    (hbs_scan5.hip) and the automatic choice between them (the default)"""
     import torch
     import hevcbitstream_amd as hbs
     assert torch.cuda.is_available()
