@@ -82,7 +82,15 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
         assert n >= sample_nals and tot > 0
         assert np.array_equal(idx["start"][:sample_nals], ent["start"]) and np.array_equal(idx["rbsp_off"][:sample_nals], ent["rbsp_off"])
         kind, what = "port", "find_nal_unit loop + nal_to_rbsp per NAL, oracle/hbs_oracle_nal.c, gcc -O2"
-    res = {"value": round(len(host) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+    cpu_model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    res = {"value": round(len(host) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind, "cpu": cpu_model,
            "nal_per_s": round(n / dt, 1),
            "sample": "first %d NALs (%.2f GiB) of rank 0's stream: %s, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, what, dt)}
     # the same loop on every host core at once, one contiguous share of the sample per thread (the reference itself is
@@ -119,19 +127,90 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
 
 
 def pmc_traffic(kernel_name, algo_bytes):
-    """profiles/r*/traffic_<kernel>.json of the newest round, if it is about this kernel and this workload"""
+    """profiles/r*/traffic_<kernel>.json of the newest round -- if it is about this kernel, this workload AND this
+    source: the file records the digest of hevcbitstream_amd/csrc at profiling time; after any change to the kernels
+    the figure is stale and the bench line says traffic: null until the PMC passes are run again."""
     import glob
+    import hevcbitstream_amd as hbs
     short = kernel_name.split("::")[-1]
+    digest = hbs.source_digest()
+    stale = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s.json" % short)), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("algorithmic_bytes_per_launch") == algo_bytes:
-            return {"traffic_bytes_per_launch": d["traffic_bytes_per_launch"],
-                    "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per the gfx950 note): "
-                              "fetch %d + write %d B per launch" % (os.path.relpath(f, ROOT), d["fetch_bytes_per_launch"], d["write_bytes_per_launch"])}
+        if d.get("algorithmic_bytes_per_launch") != algo_bytes:
+            continue
+        if d.get("source_sha256") != digest:
+            stale = stale or os.path.relpath(f, ROOT)
+            continue
+        return {"traffic_bytes_per_launch": d["traffic_bytes_per_launch"],
+                "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per the gfx950 note; "
+                          "kernel sources unchanged since: sha256 %s): fetch %d + write %d B per launch"
+                          % (os.path.relpath(f, ROOT), digest[:12], d["fetch_bytes_per_launch"], d["write_bytes_per_launch"])}
+    if stale:
+        return {"traffic_bytes_per_launch": None, "source": "%s was measured on other kernel sources (digest now %s): stale, not quoted" % (stale, digest[:12])}
     return None
+
+
+def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, structs_s):
+    """BASELINE config 3 as ONE pipeline at the size of a real 4K30 stream: the ~100 k NALs of the synthetic 4K30 sequence with
+    slice payloads of 16-28 KiB (about 2.2 GiB; built on the device: every slice's RBSP is its original bytes followed by random
+    payload, last byte 80, then K3), timed as start-code scan + index + RBSP extraction followed by the header parse, back to back
+    on one stream.  The structs must come out as they do for the small stream (same headers)."""
+    import numpy as np
+    from hevcbitstream_amd.api import NAL_ENTRY, PARSED, SUMMARY
+    ent = index_s[: m * 32].cpu().numpy().view(NAL_ENTRY)
+    old_off = ent["rbsp_off"].astype(np.int64)
+    old_len = ent["rbsp_len"].astype(np.int64)
+    is_slice = parsed_s["nal_unit_type"] < 32
+    rng = np.random.RandomState(3)
+    new_len = old_len + np.where(is_slice, rng.randint(16 << 10, 28 << 10, size=m), 0)
+    new_off = np.concatenate([[0], np.cumsum(new_len)[:-1]])
+    total = int(new_len.sum())
+    dev = d_small.device
+    big = torch.randint(0, 256, (total + 64,), dtype=torch.uint8, device=dev)
+    shift = torch.from_numpy(new_off - old_off).to(dev)
+    old_total = int(old_off[-1] + old_len[-1])
+    pos = torch.repeat_interleave(shift, torch.from_numpy(old_len).to(dev)) + torch.arange(old_total, device=dev)
+    big[pos] = rbsp_s[:old_total]
+    big[torch.from_numpy(new_off + new_len - 1).to(dev)[torch.from_numpy(is_slice).to(dev)]] = 0x80
+    ent2 = np.zeros(m, dtype=NAL_ENTRY)
+    ent2["rbsp_off"] = new_off
+    ent2["rbsp_len"] = new_len
+    idx2 = torch.from_numpy(ent2.view(np.uint8).copy()).to(dev)
+    cap_out = int(ctx.lib.hbs_annexb_bound(total, m))
+    stream2 = torch.empty(cap_out, dtype=torch.uint8, device=dev)
+    summ = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device=dev)
+    ctx.emit_annexb_async(big, total, idx2, m, 1, stream2, None, summ)
+    s = ctx.read_summary(summ)
+    assert int(s["error"]) == 0
+    sb2 = int(s["stream_bytes"])
+    del pos, shift
+    index2, rbsp2, summ2, cap2 = ctx.alloc_outputs(sb2, index_cap=m + 8)
+    parsed2 = torch.empty(m * PARSED.itemsize, dtype=torch.uint8, device=dev)
+    structs2 = torch.empty_like(structs_s)
+    psum = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    for i in range(5):
+        ev[i].record()
+        if i < 4:
+            ctx.index_extract_async(stream2[:sb2], index2, cap2, rbsp2, summ2)
+            ctx.parse_headers_async(rbsp2, index2, m, parsed2, structs2, psum)
+    torch.cuda.synchronize()
+    ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(1, 4))
+    s2 = ctx.read_summary(summ2)
+    assert int(s2["error"]) == 0 and int(s2["nal_count"]) == m and int(s2["rbsp_bytes"]) == total
+    assert torch.equal(rbsp2[:total], big[:total]), "extracted RBSP != the RBSP the stream was made from"
+    p2 = parsed2.cpu().numpy().view(PARSED)
+    # rc = bytes of the NAL consumed (grows with the payload) or -1
+    assert np.array_equal(p2["rc"] < 0, parsed_s["rc"] < 0) and np.array_equal(p2["nal_unit_type"], parsed_s["nal_unit_type"])
+    assert torch.equal(structs2, structs_s), "header structs differ from those of the same headers in the small stream"
+    return {"value": round(sb2 / ms / 1e6, 1), "unit": "GB/s of stream, scan + index + extraction + header parse", "ms": round(ms, 3),
+            "nal_per_s": round(m / ms * 1e3, 1), "stream_bytes": sb2, "nals": m,
+            "workload": "synthetic 4K30 sequence, %d NALs, slice payloads 16-28 KiB (%.2f GiB): hbs_index_extract then hbs_parse_headers, "
+                        "back to back on one stream; structs equal to those of the same headers with short payloads" % (m, sb2 / 2**30)}
 
 
 def other_kernels(torch, hbs, ctx, g, n):
@@ -192,6 +271,7 @@ def other_kernels(torch, hbs, ctx, g, n):
     ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(5))
     res["parse_headers"] = {"value": round(m / ms / 1e3, 1), "unit": "M NAL/s", "ms": round(ms, 3),
                             "workload": "synthetic 4K30 stream, %d NALs (VPS/SPS/PPS every 60 pictures, 8 slices per picture)" % m}
+    res["config3_end_to_end"] = config3_end_to_end(torch, hbs, ctx, d, index, rbsp, m, parsed, structs)
     parsed_dev = torch.from_numpy(parsed.view(np.uint8).copy()).cuda()
     wcap = 256
     written, wout = ctx.write_headers(parsed_dev, structs, m, wcap)

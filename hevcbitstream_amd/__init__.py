@@ -6,7 +6,7 @@ torch tensors.  All work happens in the HIP kernels; there is no CPU fallback --
 loading fails loudly when the library has not been built, and creating a
 context fails when there is no gfx950 GPU."""
 from .api import (Context, HbsError, NAL_ENTRY, PARSED, SUMMARY, ST_ERROR, ST_TRAILING03,  # noqa: F401
-                  ST_UNTERMINATED, library_path, load_library)
+                  ST_UNTERMINATED, library_path, load_library, source_digest)
 
 __all__ = ["Context", "HbsError", "NAL_ENTRY", "PARSED", "SUMMARY", "ST_ERROR", "ST_TRAILING03",
-           "ST_UNTERMINATED", "library_path", "load_library"]
+           "ST_UNTERMINATED", "library_path", "load_library", "source_digest"]

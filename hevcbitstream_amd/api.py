@@ -37,6 +37,19 @@ def library_path():
     return os.environ.get("HBS_LIB") or os.path.join(_HERE, "libhevcbitstream_amd.so")
 
 
+def source_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.c, sorted by name): profiles record it, and bench.py quotes a
+    profile's counter figures only while it still matches (a changed kernel must be profiled again)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".c")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 _lib = None
 
 

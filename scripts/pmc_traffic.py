@@ -1,7 +1,9 @@
 """HBM traffic per launch of the fused kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 usage: pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <algorithmic_bytes> [out.json]
 Counters are in KiB; FETCH_SIZE is doubled per the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hevcbitstream_amd
 
 def rows(d, sub, name):
     out = []
@@ -26,6 +28,7 @@ res = {"kernel_substring": sub, "launches": {"fetch_pass": len(f), "write_pass":
        "traffic_bytes_per_launch": int(fetch + write), "algorithmic_bytes_per_launch": algo,
        "ratio_traffic_over_algorithmic": round((fetch + write) / algo, 4),
        "raw_KiB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
+       "source_sha256": hevcbitstream_amd.source_digest(),     # of hevcbitstream_amd/csrc: bench.py quotes this file only while it matches
        "dispatch": {k: fm.get(k) for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count")},
        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (no trace domains); KiB units; FETCH_SIZE x2 (gfx950)"}
 js = json.dumps(res, indent=1)
