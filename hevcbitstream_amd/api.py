@@ -18,6 +18,10 @@ WRITTEN = np.dtype([("rc", "<i4"), ("rbsp_size", "<u4"), ("slice_data_size", "<i
 PARSED = np.dtype([("rc", "<i4"), ("nal_unit_type", "<i4"), ("nal_layer_id", "<i4"), ("nal_temporal_id_plus1", "<i4"),
                    ("struct_off", "<u8"), ("slice_data_size", "<i4"), ("slice_data_off", "<u4")])
 
+SEI_MAX_MESSAGES = 6
+EXT_NAL = np.dtype([("num_sei_messages", "<i4"), ("primary_pic_type", "<i4"), ("filler_bytes", "<u4"), ("reserved", "<u4"),
+                    ("sei", [("payloadType", "<i4"), ("payloadSize", "<i4"), ("payload_off", "<u4"), ("reserved", "<u4")], (SEI_MAX_MESSAGES,))])
+
 EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stream", "hbs_ctx_use_own_stream",
            "hbs_ctx_get_stream",
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_index_extract_host", "hbs_read_summary",
@@ -25,7 +29,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
-           "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path"]
+           "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended"]
 
 
 class HbsError(RuntimeError):
@@ -330,6 +334,17 @@ class Context:
                                         C.c_void_p(structs.data_ptr()) if structs is not None else None,
                                         structs.numel() if structs is not None else 0, C.c_void_p(summary.data_ptr()))
         self._check(rc, "hbs_parse_headers")
+
+    def parse_extended(self, rbsp, index, n_nals, parsed_dev):
+        """The NAL types the reference never dispatches (AUD, EOS, EOB, filler data, SEI), behind parse_headers on the same
+        arrays: updates parsed_dev[k].rc for those NALs in place and returns the hbs_ext_nal records (ndarray[EXT_NAL])."""
+        t = self.torch
+        ext = t.empty(max(n_nals, 1) * EXT_NAL.itemsize, dtype=t.uint8, device=t.device("cuda", self.device))
+        self._bind_stream()
+        self.lib.hbs_parse_extended.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        self._check(self.lib.hbs_parse_extended(self.h, C.c_void_p(rbsp.data_ptr()), C.c_void_p(index.data_ptr()), n_nals,
+                                                C.c_void_p(parsed_dev.data_ptr()), C.c_void_p(ext.data_ptr())), "hbs_parse_extended")
+        return ext[: n_nals * EXT_NAL.itemsize].cpu().numpy().view(EXT_NAL).copy()
 
     def parse_headers(self, rbsp, index, n_nals, poison=None):
         """Plan, allocate the struct arena, parse.  Returns (parsed ndarray[PARSED], structs device tensor).

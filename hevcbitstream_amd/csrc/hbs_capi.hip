@@ -363,6 +363,16 @@ int hbs_parse_headers(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_
     return hbs_parse_headers_ctx(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, nullptr, nullptr, d_summary);
 }
 
+int hbs_parse_extended(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                       hbs_parsed_nal* d_parsed, hbs_ext_nal* d_ext)
+{
+    if (!c || (n_nals && (!d_rbsp || !d_index || !d_parsed || !d_ext))) return HBS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    static_assert(sizeof(hbs_parsed_nal) == sizeof(hbs::ParsedNal), "hbs_parsed_nal is hbs::ParsedNal");
+    const hipError_t e = hbs::launch_parse_extended(d_rbsp, d_index, n_nals, reinterpret_cast<hbs::ParsedNal*>(d_parsed), d_ext, c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "hbs_parse_extended");
+}
+
 int hbs_parse_headers_ctx(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                           hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
                           const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary)

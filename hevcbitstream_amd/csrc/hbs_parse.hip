@@ -14,6 +14,7 @@
  */
 #include <hip/hip_runtime.h>
 #include "hbs_parse.h"
+#include "hbs_parse_ext.h"
 #include "hbs_parse_launch.h"
 
 namespace hbs {
@@ -35,6 +36,38 @@ __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* _
         parsed[k] = p;
         slot_size[k] = sz;
     }
+}
+
+/* the NAL types the reference has readers for but never dispatches (hbs_parse_ext.h), one NAL per thread:
+ * they are a few bytes each and there are a handful per picture */
+__global__ void k4_ext(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
+                       ParsedNal* __restrict__ parsed, hbs_ext_nal* __restrict__ ext)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const hbs_nal_entry e = idx[k];
+        hbs_ext_nal x;
+        ParsedNal p;
+        p.nal_unit_type = -1;
+        if (!(e.status & HBS_ST_ERROR)) nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
+        if (is_extended_nal_type(p.nal_unit_type)) {
+            const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
+            const int32_t rc = read_extended_nal(rbsp + e.rbsp_off, e.rbsp_len, p.nal_unit_type, consumed, &x);
+            parsed[k].rc = rc;
+        } else {
+            x.num_sei_messages = 0; x.primary_pic_type = 0; x.filler_bytes = 0; x.reserved = 0;
+            for (int i = 0; i < HBS_SEI_MAX_MESSAGES; ++i) { x.sei[i].payloadType = 0; x.sei[i].payloadSize = 0; x.sei[i].payload_off = 0; x.sei[i].reserved = 0; }
+        }
+        ext[k] = x;
+    }
+}
+
+hipError_t launch_parse_extended(const uint8_t* rbsp, const hbs_nal_entry* index, uint64_t n, ParsedNal* parsed, hbs_ext_nal* ext, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    k4_ext<<<dim3((unsigned)blocks), 256, 0, st>>>(rbsp, index, n, parsed, ext);
+    return hipGetLastError();
 }
 
 /* ---- exclusive sum of slot sizes, and last SPS / PPS ordinal before each NAL ----------------

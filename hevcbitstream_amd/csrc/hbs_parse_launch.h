@@ -41,6 +41,7 @@ struct ParseArgs {
 unsigned parse_grid_blocks(uint64_t n);
 uint64_t parse_own_rows_bytes(uint64_t n);
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);
+hipError_t launch_parse_extended(const uint8_t* rbsp, const hbs_nal_entry* index, uint64_t n, ParsedNal* parsed, hbs_ext_nal* ext, hipStream_t st);
 
 struct WrittenNal;
 

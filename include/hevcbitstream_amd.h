@@ -222,6 +222,32 @@ typedef struct hbs_parsed_nal {
 
 int hbs_parse_headers(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                       hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary);
+/*
+ * Opt-in extension: the NAL types read_hevc_nal_unit() returns -1 for without reading them
+ * (hevc_stream.c:221-222) -- access unit delimiter 35, end of sequence 36, end of bitstream 37, filler data 38,
+ * prefix / suffix SEI 39 / 40 -- read the way the reference's own, never dispatched readers would
+ * (read_hevc_access_unit_delimiter_rbsp hevc_stream.c:573-577, read_filler_data_rbsp :590-597, the SEI message loop
+ * :524-563 with h264_sei.c's opaque payloads).  Call it behind hbs_parse_headers on the same arrays: for every NAL of
+ * those types d_parsed[k].rc becomes the bytes consumed (or -1 when the cursor ran past the RBSP, as :225 does) and
+ * d_ext[k] is filled; other NALs' records are zeroed and their d_parsed entries left alone.  hbs_parse_headers by
+ * itself keeps the reference's -1.
+ */
+#define HBS_SEI_MAX_MESSAGES 6
+typedef struct hbs_sei_message {
+    int32_t  payloadType, payloadSize;     /* sei_t, h264_sei.h:38-47 */
+    uint32_t payload_off;                  /* where the payload bytes start inside the NAL's RBSP (not copied) */
+    uint32_t reserved;
+} hbs_sei_message;
+typedef struct hbs_ext_nal {
+    int32_t  num_sei_messages;             /* messages the NAL holds; the first HBS_SEI_MAX_MESSAGES are recorded */
+    int32_t  primary_pic_type;             /* hevc_aud_t */
+    uint32_t filler_bytes;                 /* ff_byte count of a filler data NAL */
+    uint32_t reserved;
+    hbs_sei_message sei[HBS_SEI_MAX_MESSAGES];
+} hbs_ext_nal;
+int hbs_parse_extended(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                       hbs_parsed_nal* d_parsed, hbs_ext_nal* d_ext);
+
 /* Same, for a batch that continues an earlier one: d_initial_sps_slot (an SPS
  * slot = hevc_sps_t followed at hbs_sps_tables_offset() by its derived RPS
  * tables, hbs_sps_slot_bytes() in all) and d_initial_pps (hevc_pps_t) are the

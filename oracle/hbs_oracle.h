@@ -87,6 +87,19 @@ int orc_read_hevc_nal_unit(orc_hevc* o, const uint8_t* buf, int size);
 const uint8_t* orc_hevc_rbsp(orc_hevc* o, int* size);
 int orc_hevc_slice_data_off(orc_hevc* o);
 
+/* ---- the NAL types read_hevc_nal_unit never dispatches (35..40): what their unused readers would read -------
+ * hevc_stream.c:573-577 (AUD), :580-587 (EOS / EOB: nothing), :590-597 (filler data), :524-563 (SEI message loop,
+ * behind HAVE_SEI) with h264_stream.c:62-98 (more_rbsp_data, _read_ff_coded_number) and h264_sei.c:69-87 (opaque
+ * payload).  Same frame as read_hevc_nal_unit: nal_to_rbsp, 16 header bits, the reader, -1 on bs_overrun.
+ * Returns -2 when the NAL is of another type. */
+#define ORC_SEI_MAX 6
+typedef struct {
+    int32_t num_sei_messages, primary_pic_type;
+    uint32_t filler_bytes, reserved;
+    struct { int32_t payloadType, payloadSize; uint32_t payload_off, reserved; } sei[ORC_SEI_MAX];
+} orc_ext_nal;
+int orc_read_extended_nal(const uint8_t* nal_buf, int size, orc_ext_nal* out, int* nal_unit_type);
+
 #ifdef __cplusplus
 }
 #endif

@@ -915,3 +915,79 @@ int orc_read_hevc_nal_unit(orc_hevc* o, const uint8_t* buf, int size)
     if (obs_overrun(b)) return -1;                               /* :225 */
     return nal_size;                                             /* :239 */
 }
+
+/* ---- extension: the readers the reference has but never calls --------------------------------------------- */
+
+/* h264_stream.c:88-98 */
+static int ff_coded_number(obs_t* b)
+{
+    int n1 = 0, n2;
+    do { n2 = (int)obs_u8(b); n1 += n2; } while (n2 == 0xff);
+    return n1;
+}
+
+/* h264_stream.c:62-84 */
+static int more_rbsp_data(const obs_t* bs)
+{
+    obs_t t = *bs;
+    if (obs_eof(bs)) return 0;
+    if (obs_u1(&t) == 0) return 1;                 /* bs_peek_u1: no rbsp_stop_bit yet */
+    while (!obs_eof(&t)) if (obs_u1(&t) == 1) return 1;
+    return 0;
+}
+
+/* bs.h:365-370 */
+static uint32_t next_bits(const obs_t* bs, int n)
+{
+    obs_t t = *bs;
+    return obs_u(&t, n);
+}
+
+int orc_read_extended_nal(const uint8_t* nal_buf, int size, orc_ext_nal* out, int* nal_unit_type)
+{
+    int nal_size = size, rbsp_size = size, type;
+    uint8_t* rbsp = (uint8_t*)calloc(1, (size_t)(size > 0 ? size : 1));
+    obs_t bs, *b = &bs;
+    memset(out, 0, sizeof(*out));
+    if (orc_nal_to_rbsp(nal_buf, &nal_size, rbsp, &rbsp_size) < 0) { free(rbsp); *nal_unit_type = -1; return -1; }
+    obs_init(b, rbsp, rbsp_size);
+    obs_skip(b, 1);                                 /* hevc_stream.c:176-179 */
+    type = (int)obs_u(b, 6);
+    (void)obs_u(b, 6);
+    (void)obs_u(b, 3);
+    *nal_unit_type = type;
+    switch (type) {
+    case 35:                                        /* :573-577 */
+        out->primary_pic_type = (int32_t)obs_u(b, 3);
+        trailing_bits(b);
+        break;
+    case 36: case 37:                               /* :580-587 */
+        break;
+    case 38:                                        /* :590-597 */
+        while (next_bits(b, 8) == 0xFF) { obs_skip(b, 8); out->filler_bytes++; }
+        trailing_bits(b);
+        break;
+    case 39: case 40:                               /* :524-563 */
+        do {
+            const int pt = ff_coded_number(b), ps = ff_coded_number(b);
+            int i;
+            if (out->num_sei_messages < ORC_SEI_MAX) {
+                out->sei[out->num_sei_messages].payloadType = pt;
+                out->sei[out->num_sei_messages].payloadSize = ps;
+                out->sei[out->num_sei_messages].payload_off = (uint32_t)obs_pos(b);
+            }
+            out->num_sei_messages++;
+            for (i = 0; i < ps; i++) (void)obs_u8(b);   /* h264_sei.c:80-81 */
+        } while (more_rbsp_data(b));
+        trailing_bits(b);
+        break;
+    default:
+        free(rbsp);
+        return -2;
+    }
+    {
+        const int over = obs_overrun(b);
+        free(rbsp);
+        return over ? -1 : nal_size;                /* :225, :239 */
+    }
+}

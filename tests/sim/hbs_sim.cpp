@@ -17,6 +17,7 @@
 #include "../../hevcbitstream_amd/csrc/hbs_sparse.h"
 #include "../../hevcbitstream_amd/csrc/hbs_emit.h"
 #include "../../hevcbitstream_amd/csrc/hbs_parse.h"
+#include "../../hevcbitstream_amd/csrc/hbs_parse_ext.h"
 #include "../../hevcbitstream_amd/csrc/hbs_ingest.h"
 
 using namespace hbs;
@@ -571,4 +572,14 @@ extern "C" int64_t sim_bitio_check(uint64_t seed, int64_t iterations)
         if (wa_io.pos != wb_io.pos || wa != wb) ++bad;
     }
     return bad;
+}
+
+/* the opt-in extension's reader (hbs_parse_ext.h) on one NAL's RBSP, as k4_ext runs it per thread */
+extern "C" int sim_read_extended_nal(const uint8_t* rbsp, uint32_t size, int consumed, hbs_ext_nal* out, int* nal_unit_type)
+{
+    hbs::ParsedNal p;
+    hbs::nal_header_of(rbsp, size, p);
+    *nal_unit_type = p.nal_unit_type;
+    if (!hbs::is_extended_nal_type(p.nal_unit_type)) return -2;
+    return hbs::read_extended_nal(rbsp, size, p.nal_unit_type, consumed, out);
 }
