@@ -415,6 +415,7 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.initial_pps = d_initial_pps;
     a.total = reinterpret_cast<unsigned long long*>(w + 3 * b_n);
     a.err = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256);
+    a.div_flag = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256 + 64);
     a.scan_tmp = w + 3 * b_n + 512;
     a.own_rows = reinterpret_cast<hbs::RpsRow*>(w + 3 * b_n + 512 + round256(1024 * 24));
     a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;

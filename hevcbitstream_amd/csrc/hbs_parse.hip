@@ -252,9 +252,10 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
                                                const uint8_t* my_win, uint32_t wb, const uint8_t* src,
                                                const uint8_t* sps_slot, const uint8_t* pps_struct, const uint8_t* zeros,
                                                ParsedNal& out, TraceRec* trace, uint32_t trace_cap, RpsRow* own_row,
-                                               RpsTables* seq_tables = nullptr)
+                                               RpsTables* seq_tables = nullptr, int* diverged = nullptr)
 {
     ParserT<kMode> ps;
+    ps.diverged = 0;
     ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
     ps.b.tr = trace; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
     ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
@@ -278,6 +279,7 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
     }
     const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
     parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
+    if (diverged) *diverged = ps.diverged;
     return ps.b.tr_n;
 }
 
@@ -303,7 +305,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot,
               const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
-              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks)
+              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks, uint32_t* __restrict__ div_flag)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -369,8 +371,10 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 else pps_struct = init_pps;
             }
             ParsedNal out = parsed[k];
+            int dv = 0;
             const uint32_t tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, out,
-                                                    trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane]);
+                                                    trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane], nullptr, &dv);
+            if (dv) atomicOr(div_flag, 1u);        /* the batch is walked again, NAL after NAL (k4_seq) */
             parsed[k] = out;
             if (trace_count) trace_count[k] = tr_n;
         }
@@ -386,7 +390,7 @@ void k4_small(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               ParsedNal* __restrict__ parsed, uint8_t* structs, uint64_t structs_cap,
               const uint8_t* __restrict__ zeros, const uint8_t* init_sps_slot, const uint8_t* init_pps,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
-              RpsRow* __restrict__ own_rows /* 64 */, hbs_summary* __restrict__ sum, int sequential)
+              RpsRow* __restrict__ own_rows /* 64 */, hbs_summary* __restrict__ sum, int sequential, uint32_t* __restrict__ div_flag)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[64 * kLaneWinStride];
     /* sequential (one NAL, the legacy symbols): the tables behind the SPS in force are THE tables, as in the reference */
@@ -463,8 +467,10 @@ void k4_small(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                     if (ex.pps >= 0) { if (pps_off != ~0ull) pps_struct = structs + pps_off; }
                     else pps_struct = init_pps;
                 }
+                int dv = 0;
                 tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, p,
-                                         trace ? trace + (uint64_t)lane * trace_cap : nullptr, trace_cap, &own_rows[lane], seq_tables);
+                                         trace ? trace + (uint64_t)lane * trace_cap : nullptr, trace_cap, &own_rows[lane], seq_tables, &dv);
+                if (dv && n > 1) atomicOr(div_flag, 1u);
             }
             /* the slices read what the parameter-set lanes have just written */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -496,9 +502,18 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
             ParsedNal* __restrict__ parsed, uint8_t* structs, uint64_t structs_cap,
             const uint8_t* __restrict__ zeros, const uint8_t* init_sps_slot, const uint8_t* init_pps,
             TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
-            RpsTables* tables /* workspace */, hbs_summary* __restrict__ sum)
+            RpsTables* tables /* workspace */, hbs_summary* __restrict__ sum, const uint32_t* __restrict__ gate)
 {
+    /* behind the parallel parse: only when one of its slices saw that its answer depends on what NALs in front of
+     * its SPS left in the tables (ParserT::diverged) */
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    /* one wavefront, so everything it hands from lane to lane stays on one compute unit: workgroup-scope fences (a wait
+     * for the stores) are enough; with agent scope (write-back and invalidate of the caches, six times per NAL) the walk ran
+     * at 92 k NAL/s */
+    __shared__ __attribute__((aligned(16))) uint8_t win[2 * kLaneWinStride];
     const int lane = threadIdx.x;
+    uint8_t* const my_win = win + (uint32_t)(lane & 1) * kLaneWinStride;      /* (a pointer the compiler cannot fold: hipcc 7.2 emits an
+                                                                                 illegal compare for the null check of a constant LDS address) */
     const uint64_t tbl_off = round16(sizeof(hevc_sps_t));
     /* the tables at "program start", or the ones behind the SPS the caller hands in */
     {
@@ -506,9 +521,9 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
         const uint4* src = init_sps_slot ? reinterpret_cast<const uint4*>(init_sps_slot + tbl_off) : nullptr;
         for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(RpsTables) / 16); i += 64) d[i] = src ? src[i] : make_uint4(0, 0, 0, 0);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint64_t off_run = 0, sps_off = ~0ull, pps_off = ~0ull;
     bool have_sps = false, have_pps = false;
     uint32_t err = 0;
@@ -533,9 +548,9 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
         if (active) {
             uint8_t* dst = structs + off_run;
             zero_slot(dst, sz, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (lane == 0) {
                 const uint8_t* sps_slot = nullptr;
                 const uint8_t* pps_struct = nullptr;
@@ -543,12 +558,17 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
                     if (have_sps) { if (sps_off != ~0ull) sps_slot = structs + sps_off; } else sps_slot = init_sps_slot;
                     if (have_pps) { if (pps_off != ~0ull) pps_struct = structs + pps_off; } else pps_struct = init_pps;
                 }
-                tr_n = parse_lane<kMode>(type, slice, e, dst, nullptr, 0, rbsp + e.rbsp_off, sps_slot, pps_struct, zeros, p,
+                /* the first bytes of the RBSP from LDS, as in k4_parse: the bit reader asks for them one at a time */
+                const uint8_t* src = rbsp + e.rbsp_off;
+                const uint32_t wb = e.rbsp_len < kLaneWin ? e.rbsp_len : kLaneWin;
+                stage_window(my_win, src, wb);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                tr_n = parse_lane<kMode>(type, slice, e, dst, my_win, wb, src, sps_slot, pps_struct, zeros, p,
                                          trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, nullptr, tables);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {          /* the tables as they stand now, next to the SPS */
                 uint4* d = reinterpret_cast<uint4*>(dst + tbl_off);
                 const uint4* src = reinterpret_cast<const uint4*>(tables);
@@ -669,22 +689,39 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         static_assert(sizeof(RpsTables) <= 64 * sizeof(RpsRow), "the own-rows workspace of one wavefront holds the tables");
         if (a.trace)
             k4_seq<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
-                                                 a.initial_pps, a.trace, a.trace_cap, a.trace_count, tables, a.summary);
+                                                 a.initial_pps, a.trace, a.trace_cap, a.trace_count, tables, a.summary, nullptr);
         else
             k4_seq<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
-                                                a.initial_pps, nullptr, 0, nullptr, tables, a.summary);
+                                                a.initial_pps, nullptr, 0, nullptr, tables, a.summary, nullptr);
         return hipGetLastError();
     }
+    /* The parallel parse reads every slice against the tables of the SPS in front of it.  A slice whose answer depends on
+     * more than that -- it names a set that SPS does not have, or rewrites one of its rows: streams the spec forbids --
+     * raises div_flag, and the batch is then walked again the reference's way, NAL after NAL with one set of tables
+     * (k4_seq, gated on the flag: no host round trip; it returns at once on ordinary streams). */
+    hipError_t e = hipMemsetAsync(a.div_flag, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    RpsTables* const seq_tables_ws = reinterpret_cast<RpsTables*>(a.own_rows);
+    auto exact_pass = [&]() {
+        if (!a.structs || a.n < 2) return;
+        if (a.trace)
+            k4_seq<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                 a.initial_pps, a.trace, a.trace_cap, a.trace_count, seq_tables_ws, a.summary, a.div_flag);
+        else
+            k4_seq<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                a.initial_pps, nullptr, 0, nullptr, seq_tables_ws, a.summary, a.div_flag);
+    };
     if (a.n >= 1 && a.n <= 64) {
         if (a.trace)
             k4_small<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
-                                                   a.initial_pps, a.trace, a.trace_cap, a.trace_count, a.own_rows, a.summary, a.sequential);
+                                                   a.initial_pps, a.trace, a.trace_cap, a.trace_count, a.own_rows, a.summary, a.sequential, a.div_flag);
         else
             k4_small<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
-                                                  a.initial_pps, nullptr, 0, nullptr, a.own_rows, a.summary, a.sequential);
+                                                  a.initial_pps, nullptr, 0, nullptr, a.own_rows, a.summary, a.sequential, a.div_flag);
+        exact_pass();
         return hipGetLastError();
     }
-    hipError_t e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
+    e = hipMemsetAsync(a.err, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.total, 0, sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
@@ -703,13 +740,14 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
             for (int pass = 0; pass < 2; ++pass) {
                 const unsigned grid = pblocks + (pass == 0 ? kZeroBlocks : 0u);
                 if (a.trace)
-                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks);
+                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks, a.div_flag);
                 else
-                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks);
+                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag);
             }
         }
     }
     k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);
+    exact_pass();
     return hipGetLastError();
 }
 

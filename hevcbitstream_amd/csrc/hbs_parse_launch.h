@@ -29,6 +29,7 @@ struct ParseArgs {
     const uint8_t* initial_pps;      /* optional: hevc_pps_t in force before NAL 0 */
     unsigned long long* total;
     uint32_t* err;
+    uint32_t* div_flag;              /* set by a slice whose answer depends on NALs in front of its SPS: the batch is then parsed again in order */
     void* scan_tmp;                  /* 1024 x 24 bytes */
     TraceRec* trace;                 /* optional: trace_cap records per NAL (device) */
     uint32_t trace_cap;

@@ -87,6 +87,26 @@ def test_sequential_batch_is_the_reference_on_forbidden_streams():
         c.close()
 
 
+def test_default_batch_is_the_reference_on_forbidden_streams():
+    """the DEFAULT batch parse on the same streams: a slice that names a set its SPS does not have (or rewrites one of its
+    rows) raises a flag on the device and the batch is walked again in order behind the parallel parse -- no switch to set,
+    and ordinary streams do not pay for it (the gated kernel returns at once)"""
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    try:
+        for seed in (1036, 1064, 1320, 1496, 5224, 3, 4):
+            nals = broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True) if seed > 100 else sequence(seed)
+            run(c, nals)
+        nals = []                                            # several sequences in one batch, the forbidden ones among them
+        for seed in (300, 1036, 301, 1320, 302, 5224, 303):
+            nals += broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True) if seed > 1000 else sequence(seed)
+        run(c, nals)
+        for seed in range(6000, 6120):                       # parameter sets corrupted too: the family the divergence was found in
+            run(c, broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True))
+    finally:
+        c.close()
+
+
 def test_ten_nal_fixture(ctx):
     data = open(os.path.join(HERE, "golden", "ten_nal.hevc"), "rb").read()
     idx = json.load(open(os.path.join(HERE, "golden", "ten_nal.index.json")))
