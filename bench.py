@@ -341,13 +341,17 @@ def main():
     indexes = [index, torch.empty_like(index)] if multi else [index]
     gatherer = shard.IndexGatherer(torch, dist, cap, index.device, depth=2) if multi else None
     counter = [0]
+    last_slot = [None]
 
     def step():
-        buf = indexes[counter[0] % len(indexes)]
+        k = counter[0] % len(indexes)
+        buf = indexes[k]
         counter[0] += 1
+        if gatherer is not None:
+            gatherer.release(k)          # the gather of two steps ago still reads (and the scan's prologue clears) this buffer
         ctx.index_extract_async(stream, buf, cap, rbsp, summary)
         if gatherer is not None:
-            gatherer.submit(buf, n, sb, rb)
+            last_slot[0] = gatherer.submit(buf, n, sb, rb)
 
     def fence():
         if gatherer is not None:
@@ -383,6 +387,14 @@ def main():
     b = gen_index[: n * 32].view(torch.int64).view(n, 4)
     assert torch.equal(a[:, :3], b[:, :3]), "NAL index != generator's index"
 
+    if multi and last_slot[0] is not None:
+        # what the exchange delivered: every rank's rows of the last step, against that rank's own index (the gathered copy of MY
+        # rows must be my index; the others are checked by their owners, and all ranks hold the same bytes)
+        all_index, meta = gatherer.result(last_slot[0])
+        assert [int(x) for x in meta[rank].tolist()] == [n, sb, rb], meta
+        mine = all_index[rank, : n * 32].view(torch.int64).view(n, 4)
+        assert torch.equal(mine[:, :3], b[:, :3]), "gathered index rows of this rank != its index"
+        assert int(meta[:, 0].sum().item()) == n * world
     if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -442,7 +454,15 @@ def main():
         if world == 1 and args.other_kernels:
             del rbsp, index
             out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n)
-        print(json.dumps(out))
+        # RCCL writes a version banner to C stdout, which is block-buffered when piped: push it out first, so that the JSON
+        # line is the LAST line of rank 0's stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

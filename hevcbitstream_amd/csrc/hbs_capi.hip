@@ -201,6 +201,7 @@ int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 }
 
 int hbs_ctx_get_kernel(hbs_ctx* c) { return c ? c->variant : HBS_E_ARG; }
+int hbs_ctx_device(hbs_ctx* c) { return c ? c->device : HBS_E_ARG; }
 
 int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
 {

@@ -1,13 +1,98 @@
-"""Multi-GPU sharding of the hot path: one process per GPU, each rank indexes
-its own independent stream shard; the only exchange is the gather of the NAL
-index (counts first, then the padded entry arrays) -- RCCL over xGMI with the
-`nccl` backend, `gloo` in the CPU tests.  No collective touches the data path:
-stream bytes and RBSP arenas stay on their GPUs."""
+"""Multi-GPU sharding of the hot path: one process per GPU, each rank indexes its own bytes; the only exchange is the
+gather of the NAL index -- counts first, then exactly count x 32 bytes per rank.  No collective touches the data path:
+stream bytes and RBSP arenas stay on their GPUs.
+
+Two carriers of the same exchange:
+  * LibraryComm -- the C ABI (include/hevcbitstream_amd.h: hbs_comm_*, hbs_gather_index; RCCL over xGMI, looked up by the
+    library at run time).  torch.distributed only carries the 128-byte communicator id to the ranks.  What a C caller uses,
+    and what bench.py uses on GPUs.
+  * gather_index / IndexGatherer -- torch.distributed collectives (`nccl` = RCCL on GPU tensors, `gloo` on CPU tensors in the
+    world-size-2 CPU tests, which exercise the host-side protocol without a GPU).
+Also: parts of ONE stream (cut_points / part_ranges over hbs_find_cut_host)."""
+import ctypes as C
+
 import numpy as np
 
-from .api import NAL_ENTRY
+from .api import NAL_ENTRY, HbsError, load_library
 
 ENTRY_BYTES = NAL_ENTRY.itemsize
+HALO_BYTES = 8                      # bytes of the next part scanned behind a part (they end its last NAL)
+
+
+class LibraryComm:
+    """hbs_comm of the C ABI.  Collective: every rank constructs it; rank 0's id travels through `dist` (any backend)."""
+
+    def __init__(self, ctx, dist, rank, world, group=None):
+        self.ctx, self.lib, self.rank, self.world = ctx, load_library(), rank, world
+        lib = self.lib
+        lib.hbs_comm_unique_id.argtypes = [C.c_char_p]
+        lib.hbs_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.hbs_comm_destroy.argtypes = [C.c_void_p]
+        lib.hbs_comm_destroy.restype = None
+        lib.hbs_gather_index.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        ident = C.create_string_buffer(128)
+        if rank == 0 and lib.hbs_comm_unique_id(ident) != 0:
+            raise HbsError("hbs_comm_unique_id failed (RCCL not found?)")
+        box = [bytes(ident.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        h = C.c_void_p()
+        rc = lib.hbs_comm_create(ctx.h, box[0], rank, world, C.byref(h))
+        if rc != 0:
+            raise HbsError("hbs_comm_create(rank %d of %d) failed: %d" % (rank, world, rc))
+        self.h = h
+
+    def gather_index(self, local_index, n_local, all_index, stream_base=0, rbsp_base=0, root=-1):
+        """Enqueue the exchange on the context's stream.  local_index / all_index: device uint8 tensors of entries.  Returns the
+        per-rank counts (list of int); the payload lands in all_index (receiving ranks) in stream order."""
+        self.ctx._bind_stream()
+        counts = (C.c_uint64 * self.world)()
+        rc = self.lib.hbs_gather_index(self.ctx.h, self.h, C.c_void_p(local_index.data_ptr()), n_local, stream_base, rbsp_base, root,
+                                       C.c_void_p(all_index.data_ptr()) if all_index is not None else None,
+                                       (all_index.numel() // ENTRY_BYTES) if all_index is not None else 0, counts)
+        if rc != 0:
+            raise HbsError("hbs_gather_index failed: %d" % rc)
+        return [int(c) for c in counts]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hbs_comm_destroy(self.h)
+            self.h = None
+
+
+def find_cut_host(host_bytes, start):
+    """hbs_find_cut_host: offset of the first start code (00 00 01) at or after `start` that has 8 bytes behind it, or None"""
+    lib = load_library()
+    lib.hbs_find_cut_host.restype = C.c_uint64
+    lib.hbs_find_cut_host.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    a = np.ascontiguousarray(host_bytes, dtype=np.uint8)
+    p = lib.hbs_find_cut_host(a.ctypes.data, len(a), start)
+    return None if p == 0xFFFFFFFFFFFFFFFF else int(p)
+
+
+def part_ranges(host_bytes, world):
+    """Cut ONE stream for `world` ranks: [(lo, hi, hi_with_halo)] per rank.  Rank r's part starts at the first start code at or
+    after r x n / world (rank 0: at 0) and is scanned up to hi_with_halo = min(n, hi + HALO_BYTES).  A rank whose nominal
+    range holds no start code gets an empty part.  Every rank computes this from bytes it can read; in a real deployment
+    a rank only needs [its nominal start, its nominal end + the distance to the next start code) of the file."""
+    n = len(host_bytes)
+    cuts = [0]
+    for r in range(1, world):
+        c = find_cut_host(host_bytes, max(cuts[-1], r * n // world))
+        cuts.append(n if c is None else c)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1], min(n, cuts[r + 1] + HALO_BYTES) if cuts[r + 1] < n else n) for r in range(world)]
+
+
+def trim_part(entries, part_bytes, is_last):
+    """host-side mirror of hbs_trim_part for entries already on the host: the NAL(s) the halo opens belong to the next part"""
+    if is_last:
+        return entries
+    keep = len(entries)
+    while keep and int(entries["start"][keep - 1]) >= part_bytes + 3:
+        keep -= 1
+    return entries[:keep]
 
 
 def shard_seed(base_seed, rank):
@@ -36,8 +121,10 @@ class IndexGatherer:
     """The same exchange, pipelined: the gather of one step's index runs on the collective's own
     stream while the next step's scan is already writing the other index buffer.  `depth` results
     are kept in flight (preallocated receive buffers); submit() hands back the slot to pass to
-    result() later.  The caller alternates its OWN index buffers likewise: a buffer handed to
-    submit() may be written again once the submit() `depth` steps later has returned."""
+    result() later.  The caller alternates its OWN index buffers likewise, `depth` of them, and calls
+    release(buffer_number) BEFORE it enqueues the scan that rewrites a buffer: that makes the current
+    stream wait for the gather that still reads it (without it a scan could overwrite -- its prologue
+    even clears -- an index the collective is in the middle of sending)."""
 
     def __init__(self, torch, dist, capacity, device, depth=2, group=None):
         self.torch, self.dist, self.group = torch, dist, group
@@ -59,6 +146,10 @@ class IndexGatherer:
         w1 = self.dist.all_gather_into_tensor(self.recv[slot], local_index[: self.capacity * ENTRY_BYTES], group=self.group, async_op=True)
         self.work[slot] = (w0, w1)
         return slot
+
+    def release(self, slot):
+        """the gather that read the caller's buffer `slot` (slot = step % depth) is done, as far as the current stream is concerned"""
+        self._wait(slot)
 
     def _wait(self, slot):
         if self.work[slot] is not None:

@@ -308,6 +308,50 @@ int hbs_write_headers(hbs_ctx* ctx, const hbs_parsed_nal* d_parsed, uint64_t n_n
                       const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
                       uint8_t* d_rbsp_out, uint32_t rbsp_cap, hbs_written_nal* d_written);
 
+/*
+ * ---- Several GPUs: one process per GPU, one context each ------------------------------------------
+ * Every rank indexes its own bytes; the one exchange of the path is the gather of the NAL index: the counts (8 bytes per
+ * rank) to everybody, then exactly count x 32 bytes per rank, to `root` or (root = -1) to every rank, over RCCL (xGMI inside
+ * a node).  Stream bytes and RBSP arenas never travel.  RCCL is looked up at run time (librccl.so.1; the copy the process
+ * already carries, if any), so the library has no link-time dependency on it.
+ *
+ *   hbs_comm_unique_id   rank 0 makes the 128-byte id; the caller hands it to every rank by its own means (MPI, a file, a socket,
+ *                        torch.distributed ...)
+ *   hbs_comm_create      every rank, collectively: the communicator (ncclCommInitRank)
+ *   hbs_comm_adopt       instead: wrap an ncclComm_t the application already owns (same RCCL copy); not destroyed by hbs_comm_destroy
+ *   hbs_gather_index     collective, on the context's stream; returns when the sizes are known (one wait for the 8-byte counts),
+ *                        the payload then moves asynchronously on that stream.  d_index: this rank's n_local entries;
+ *                        stream_base / rbsp_base: added to start, end / rbsp_off of this rank's entries on the way out (0 for
+ *                        independent streams; the part's cut offset for parts of ONE stream); d_all (cap_all entries; receivers
+ *                        only): the ranks' entries back to back in rank order; counts_out[world] (host): entries per rank.
+ *                        HBS_E_CAPACITY if cap_all is too small on a receiving rank.
+ */
+#define HBS_COMM_ID_BYTES 128
+typedef struct hbs_comm hbs_comm;
+int  hbs_comm_unique_id(uint8_t id[HBS_COMM_ID_BYTES]);
+int  hbs_comm_create(hbs_ctx* ctx, const uint8_t id[HBS_COMM_ID_BYTES], int rank, int world, hbs_comm** out);
+int  hbs_comm_adopt(hbs_ctx* ctx, void* nccl_comm, int rank, int world, hbs_comm** out);
+void hbs_comm_destroy(hbs_comm* comm);
+int  hbs_comm_rank(const hbs_comm* comm);
+int  hbs_comm_world(const hbs_comm* comm);
+int  hbs_gather_index(hbs_ctx* ctx, hbs_comm* comm, const hbs_nal_entry* d_index, uint64_t n_local,
+                      uint64_t stream_base, uint64_t rbsp_base, int root,
+                      hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out);
+int  hbs_ctx_device(hbs_ctx* ctx);
+/*
+ * ONE stream over several GPUs.  A part begins at the first start code (00 00 01) at or after its nominal boundary:
+ * hbs_find_cut_host(bytes, n, from) returns that offset in a HOST buffer (plain C, no GPU involved; ~0: none with 8 bytes behind
+ * it -- the part in front then runs to the end).  Both neighbours of a boundary apply the same rule to the same bytes, so they
+ * agree without a collective.  A rank uploads its part [cut_r, cut_r+1) FOLLOWED BY the next 8 bytes of the stream (they
+ * terminate its last NAL as they do in the whole stream, h264_nal.c:64-72), runs hbs_index_extract on that, and drops the NAL the
+ * halo opens with hbs_trim_part(part_bytes = cut_r+1 - cut_r): n_kept entries and rbsp_kept arena bytes are the part's.  The last
+ * part has no halo and nothing to trim.  hbs_gather_index(stream_base = cut_r, rbsp_base = RBSP bytes of the parts in front or 0)
+ * then yields the whole stream's index; RBSP arenas stay where they are.
+ */
+uint64_t hbs_find_cut_host(const uint8_t* bytes, uint64_t n, uint64_t from);
+int  hbs_trim_part(hbs_ctx* ctx, const hbs_nal_entry* d_index, uint64_t nal_count, uint64_t rbsp_bytes, uint64_t part_bytes,
+                   uint64_t* n_kept, uint64_t* rbsp_kept);
+
 /* Device-memory helpers for callers without HIP headers (the legacy C layer):
  * allocate / free on the context's GPU, synchronising copies, async fill. */
 int hbs_dev_alloc(hbs_ctx* ctx, uint64_t bytes, void** out);

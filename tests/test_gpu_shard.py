@@ -36,6 +36,7 @@ def test_pipelined_gather_on_rccl_one_rank():
         slots = []
         for step in range(5):                                  # scans and gathers in flight together
             buf = indexes[step % 2]
+            gat.release(step % 2)                              # the gather of step - 2 is done with this buffer
             ctx.index_extract_async(stream, buf, cap, rbsp, summary)
             slots.append(gat.submit(buf, n, sb, rb))
         all_index, meta = gat.result(slots[-1])
@@ -50,3 +51,54 @@ def test_pipelined_gather_on_rccl_one_rank():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_library_gather_and_parts_of_one_stream(orc):
+    """The C ABI's exchange (hbs_comm_*, hbs_gather_index: RCCL looked up by the library) on a one-rank communicator -- to all and
+    to a root -- and ONE stream cut in three parts, each scanned with its halo, trimmed (hbs_trim_part) and gathered with its cut
+    offset as base: the concatenation must be the whole stream's index (oracle = reference semantics)."""
+    import ctypes as C
+    import torch
+    import hevcbitstream_amd as hbs
+    from hevcbitstream_amd import shard
+    ctx = hbs.Context(0)
+    comm = shard.LibraryComm(ctx, None, 0, 1)
+    try:
+        for seed, mode in ((0x77, 0), (0x78, 1)):
+            stream, idx, arena = orc.gen_stream(seed, 300, mode)
+            want, want_arena, why = orc.index_extract(stream)
+            parts = shard.part_ranges(stream, 3)
+            assert parts[0][0] == 0 and parts[-1][1] == len(stream) and all(p[0] < p[1] for p in parts)
+            pieces, rbsp_base = [], 0
+            lib = ctx.lib
+            lib.hbs_trim_part.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            for r, (lo, hi, hh) in enumerate(parts):
+                d = torch.from_numpy(stream[lo:hh].copy()).cuda()
+                index, rbsp, summary, cap = ctx.alloc_outputs(d.numel())
+                ctx.index_extract_async(d, index, cap, rbsp, summary)
+                s = ctx.read_summary(summary)
+                kept, rkept = C.c_uint64(0), C.c_uint64(0)
+                n_found, r_found = int(s["nal_count"]), int(s["rbsp_bytes"])
+                if hh > hi:                                      # a halo behind the part: the NAL it opens is the next part's
+                    assert lib.hbs_trim_part(ctx.h, C.c_void_p(index.data_ptr()), n_found, r_found, hi - lo, C.byref(kept), C.byref(rkept)) == 0
+                    assert kept.value == n_found - 1
+                else:
+                    kept.value, rkept.value = n_found, r_found
+                for root in (-1, 0):
+                    all_index = torch.zeros((kept.value + 4) * 32, dtype=torch.uint8, device="cuda")
+                    counts = comm.gather_index(index, kept.value, all_index, stream_base=lo, rbsp_base=rbsp_base, root=root)
+                    assert counts == [kept.value]
+                    got = all_index[: kept.value * 32].cpu().numpy().view(hbs.NAL_ENTRY)
+                pieces.append(got.copy())
+                # this part's RBSP is the whole stream's, where it belongs
+                assert np.array_equal(rbsp[: rkept.value].cpu().numpy(), want_arena[rbsp_base: rbsp_base + rkept.value])
+                rbsp_base += rkept.value
+            glob = np.concatenate(pieces)
+            assert len(glob) == len(want)
+            for f in ("start", "end", "rbsp_off", "rbsp_len"):
+                assert np.array_equal(glob[f], want[f]), f
+            assert np.array_equal(glob["status"][:-1], want["status"][:-1])
+            assert rbsp_base == len(want_arena)
+    finally:
+        comm.close()
+        ctx.close()

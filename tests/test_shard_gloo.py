@@ -59,6 +59,62 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _worker_parts(rank, world, port, ret):
+    """ONE stream over two ranks: each takes its part (cut at a start code, hbs_find_cut_host), scans it with the halo behind it
+    (the oracle stands in for the GPU scan here), drops the NAL the halo opens, and the parts' entries meet with their cut
+    offsets added -- counts first, then exactly count x 32 bytes per rank."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _orc
+    from hevcbitstream_amd import shard
+    orc = _orc.oracle()
+    ok = True
+    for seed, mode in ((0x600, 0), (0x601, 1), (0x602, 0)):
+        stream, idx, arena = orc.gen_stream(seed, 60, mode)                 # the same bytes on both ranks (a shared file)
+        lo, hi, hh = shard.part_ranges(stream, world)[rank]
+        e, a, why = orc.index_extract(stream[lo:hh])
+        e = shard.trim_part(e, hi - lo, is_last=(rank == world - 1))
+        rbsp_mine = int(e["rbsp_off"][-1] + e["rbsp_len"][-1]) if len(e) else 0
+        # counts (and the RBSP bytes of the parts in front) first
+        meta = torch.zeros(world * 2, dtype=torch.int64)
+        dist.all_gather_into_tensor(meta, torch.tensor([len(e), rbsp_mine], dtype=torch.int64))
+        meta = meta.view(world, 2)
+        rbsp_base = int(meta[:rank, 1].sum())
+        e = e.copy()
+        e["start"] += np.uint64(lo); e["end"] += np.uint64(lo); e["rbsp_off"] += np.uint64(rbsp_base)
+        # then exactly count x 32 bytes per rank
+        pieces = []
+        for r in range(world):
+            buf = torch.from_numpy(e.view(np.uint8).copy()) if r == rank else torch.empty(int(meta[r, 0]) * 32, dtype=torch.uint8)
+            dist.broadcast(buf, src=r)
+            pieces.append(buf.numpy().view(_orc.NAL_ENTRY))
+        glob = np.concatenate(pieces)
+        want, want_arena, w = orc.index_extract(stream)
+        ok = ok and len(glob) == len(want) and all(np.array_equal(glob[f], want[f]) for f in ("start", "end", "rbsp_off", "rbsp_len"))
+    if rank == 0:
+        ret.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_parts_of_one_stream():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker_parts, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
 def test_two_rank_index_gather():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
