@@ -30,7 +30,7 @@ build/obj/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(HIP_OBJS) $(LEGACY_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) $(LEGACY_OBJ) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) $(LEGACY_OBJ) -ldl -lpthread
 	ln -sf libhevcbitstream_amd.so hevcbitstream_amd/libhevcbitstream.so
 
 # the reference's own CLI, unmodified, against OUR headers and library (dev container only)

@@ -31,7 +31,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
            "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world",
-           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part"]
+           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps"]
 
 
 class HbsError(RuntimeError):
@@ -187,11 +187,21 @@ class Context:
         t = self.torch
         dev = t.device("cuda", self.device)
         if index_cap is None:
-            index_cap = stream_bytes // 3 + 2
+            index_cap = self.default_index_cap(stream_bytes)
         index = t.empty(max(index_cap, 1) * NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
         rbsp = t.empty(stream_bytes + 16, dtype=t.uint8, device=dev) if want_rbsp else None
         summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
         return index, rbsp, summary, index_cap
+
+    @staticmethod
+    def default_index_cap(stream_bytes):
+        """Entries to provide when the caller does not say.  The worst case -- a start code every three bytes -- is
+        stream_bytes / 3 entries of 32 bytes, ten times the stream, all of it cleared by every scan: fine for small
+        streams (tests full of tiny NALs), ruinous for a 1 GiB one.  From 64 MiB on: one entry per 64 stream bytes (coded
+        video has one per several KiB); a stream with more NALs than that reports HBS_E_CAPACITY in its summary and
+        nal_found says how many entries it needs (index_extract() below then runs it again with that many)."""
+        worst = stream_bytes // 3 + 2
+        return worst if stream_bytes <= (64 << 20) else min(worst, stream_bytes // 64 + 4096)
 
     def index_extract_async(self, stream, index, index_cap, rbsp, summary):
         """Enqueue K12 on the current torch stream.  All arguments are device tensors."""
@@ -215,6 +225,11 @@ class Context:
         index, rbsp, summary, cap = self.alloc_outputs(stream.numel(), index_cap, want_rbsp)
         self.index_extract_async(stream, index, cap, rbsp, summary)
         s = self.read_summary(summary)
+        if index_cap is None and int(s["error"]) == -4 and int(s["nal_found"]) > cap:      # HBS_E_CAPACITY: the default was too small
+            del index
+            index, rbsp, summary, cap = self.alloc_outputs(stream.numel(), int(s["nal_found"]) + 8, want_rbsp)
+            self.index_extract_async(stream, index, cap, rbsp, summary)
+            s = self.read_summary(summary)
         n = int(s["nal_count"])
         ent = index[: n * NAL_ENTRY.itemsize].cpu().numpy().view(NAL_ENTRY).copy()
         arena = rbsp[: int(s["rbsp_bytes"])].cpu().numpy() if want_rbsp else None
@@ -287,7 +302,14 @@ class Context:
             t.zeros(NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
         rbsp_bytes = int(rbsp.numel())
         if out_cap is None:
-            out_cap = int(self.lib.hbs_annexb_bound(rbsp_bytes, n)) + 64 + (int(index_entries["start"].max()) if n else 0)
+            if gap_mode == 0 and n:          # the recorded gaps come on top of the 3/2 bound
+                e = index_entries
+                gaps = int(e["start"][0]) + int((e["start"][1:].astype(np.int64) - e["end"][:-1].astype(np.int64)).clip(min=0).sum())
+                self.lib.hbs_annexb_bound_gaps.restype = C.c_uint64
+                self.lib.hbs_annexb_bound_gaps.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+                out_cap = int(self.lib.hbs_annexb_bound_gaps(rbsp_bytes, n, gaps)) + 64
+            else:
+                out_cap = int(self.lib.hbs_annexb_bound(rbsp_bytes, n)) + 64
         out = t.empty(out_cap, dtype=t.uint8, device=dev)
         d_out_idx = t.empty(max(n, 1) * NAL_ENTRY.itemsize, dtype=t.uint8, device=dev)
         summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)

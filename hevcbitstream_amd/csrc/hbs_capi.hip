@@ -357,6 +357,8 @@ uint64_t hbs_sps_tables_offset(void) { return hbs::round16(sizeof(hevc_sps_t)); 
 
 uint64_t hbs_synth_rbsp_bound(uint64_t n_nals) { return n_nals * 12288ull + 16; }
 uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals) { return rbsp_bytes + rbsp_bytes / 2 + 4 * n_nals + 16; }
+/* gap_mode 0: the gaps are whatever the index says (a start code, plus any zero bytes that stood in front of it) */
+uint64_t hbs_annexb_bound_gaps(uint64_t rbsp_bytes, uint64_t n_nals, uint64_t gap_bytes) { (void)n_nals; return rbsp_bytes + rbsp_bytes / 2 + gap_bytes + 16; }
 
 int hbs_parse_headers(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                       hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary)

@@ -19,19 +19,43 @@
  *   write_hevc_nal_unit         hevc_stream.c:1249-1333 (the GPU parser's walk in write mode, then rbsp_to_nal)
  *   debug_bytes, h264_dbgfile   h264_stream.c:33, :117-126
  *
- * Like the reference, one parser at a time: the derived RPS tables are process
- * state (hevc_stream.c:26-32), here a device buffer.
+ * Threads.  In the reference find_nal_unit / nal_to_rbsp / rbsp_to_nal are pure and may be called from any
+ * number of threads; here they share one GPU context, its staging buffers and (find_nal_unit) the cache of the last
+ * scan's answer -- so every entry point below takes ONE process-wide lock for its duration.  Calls from several
+ * threads are safe and serialised (tests/test_gpu_legacy.py runs two threads against each other).  What stays process
+ * state, as in the reference (hevc_stream.c:26-32 keeps it in file-static arrays, on which its read_* of DIFFERENT
+ * hevc_stream_t objects race): the derived RPS tables of the last SPS read -- here a device buffer, so two parsers used
+ * in turn see each other's tables exactly as they do with the reference library.
+ * Without a gfx950 GPU the first call prints a diagnostic once and every call returns its failure value (0 from
+ * find_nal_unit, -1 from the others) instead of working on the CPU; failures in the middle of a call (device memory
+ * exhausted, a lost GPU) still abort().
  */
+#define _GNU_SOURCE             /* PTHREAD_MUTEX_RECURSIVE under -std=c99 */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "../../include/hevcbitstream_amd.h"
 #include "../../include/h264_stream.h"
 #include "../../include/hevc_stream.h"
 
 FILE* h264_dbgfile = NULL;
+
+/* one lock for everything below (recursive: write_hevc_nal_unit ends in the emit path rbsp_to_nal uses) */
+static pthread_mutex_t g_lock;
+static pthread_once_t g_lock_once = PTHREAD_ONCE_INIT;
+static void lock_init(void)
+{
+    pthread_mutexattr_t a;
+    pthread_mutexattr_init(&a);
+    pthread_mutexattr_settype(&a, PTHREAD_MUTEX_RECURSIVE);
+    pthread_mutex_init(&g_lock, &a);
+    pthread_mutexattr_destroy(&a);
+}
+static void legacy_lock(void) { pthread_once(&g_lock_once, lock_init); pthread_mutex_lock(&g_lock); }
+static void legacy_unlock(void) { pthread_mutex_unlock(&g_lock); }
 
 /* ---- one lazily created GPU context and its scratch ---------------------------------- */
 
@@ -94,13 +118,21 @@ static void die(const char* what, int rc)
     abort();
 }
 
-static void need_ctx(void)
+static int g_no_gpu = 0;
+/* 0, or -1: there is no gfx950 GPU to run on (said once; the callers return their failure value) */
+static int need_ctx(void)
 {
     int rc;
     const char* dev = getenv("HBS_DEVICE");
-    if (g_ctx) return;
+    if (g_ctx) return 0;
+    if (g_no_gpu) return -1;
     rc = hbs_ctx_create(&g_ctx, dev ? atoi(dev) : 0);
-    if (rc) { g_ctx = NULL; die("hbs_ctx_create", rc); }
+    if (rc) {
+        g_ctx = NULL; g_no_gpu = 1;
+        fprintf(stderr, "libhevcbitstream (MI355X build): hbs_ctx_create failed (%d). This library has no CPU path: it needs a gfx950 GPU; "
+                        "every call will fail.\n", rc);
+        return -1;
+    }
     /* one NAL after the other, one set of derived RPS tables for the process: the reference's semantics to the letter */
     if ((rc = hbs_ctx_set_sequential_parse(g_ctx, 1))) die("hbs_ctx_set_sequential_parse", rc);
     if ((rc = hbs_dev_alloc(g_ctx, RES_FIND_BYTES, (void**)&g_dfind))) die("hbs_dev_alloc", rc);
@@ -110,6 +142,7 @@ static void need_ctx(void)
     if ((rc = hbs_fill_device(g_ctx, g_dpps, 0, sizeof(hevc_pps_t)))) die("hbs_fill_device", rc);
     g_sps_shadow = (uint8_t*)malloc(sizeof(hevc_sps_t));
     g_pps_shadow = (uint8_t*)malloc(sizeof(hevc_pps_t));
+    return 0;
 }
 
 /* the result block laid out for a NAL whose RBSP takes at most rbsp_bytes */
@@ -205,13 +238,13 @@ static void fetch_results(uint64_t bytes, hbs_summary* sum, hbs_nal_entry* ent)
 
 /* ---- byte layer ------------------------------------------------------------------------- */
 
-int find_nal_unit(uint8_t* buf, int size, int* nal_start, int* nal_end)
+static int find_nal_unit_unlocked(uint8_t* buf, int size, int* nal_start, int* nal_end)
 {
     uint64_t len;
     *nal_start = 0;
     *nal_end = 0;
     if (size <= 0) return 0;
-    need_ctx();
+    if (need_ctx()) return 0;
     if (g_fc_next >= 1 && g_fc_next < g_fc_n) {
         const hbs_nal_entry* prev = &g_fc_ent[g_fc_next - 1];
         const hbs_nal_entry* cur = &g_fc_ent[g_fc_next];
@@ -264,14 +297,14 @@ int find_nal_unit(uint8_t* buf, int size, int* nal_start, int* nal_end)
     }
 }
 
-int nal_to_rbsp(const uint8_t* nal_buf, int* nal_size, uint8_t* rbsp_buf, int* rbsp_size)
+static int nal_to_rbsp_unlocked(const uint8_t* nal_buf, int* nal_size, uint8_t* rbsp_buf, int* rbsp_size)
 {
     static const uint8_t sc[3] = {0, 0, 1};
     const int n = *nal_size;
     hbs_summary s;
     hbs_nal_entry e[LEGACY_INDEX_CAP];
     if (n < 0) return -1;
-    need_ctx();
+    if (need_ctx()) return -1;
     need_bufs((uint64_t)n + 16, 0);
     need_block((uint64_t)n + 16);
     /* the kernel works on Annex-B: put a start code in front of the NAL */
@@ -311,14 +344,39 @@ static int emit_one(const uint8_t* payload, const uint8_t* d_rbsp, int n, uint8_
     return (int)out_bytes;
 }
 
-int rbsp_to_nal(const uint8_t* rbsp_buf, const int* rbsp_size, uint8_t* nal_buf, int* nal_size)
+static int rbsp_to_nal_unlocked(const uint8_t* rbsp_buf, const int* rbsp_size, uint8_t* nal_buf, int* nal_size)
 {
     const int n = *rbsp_size;
     if (n <= 0) { *nal_size = 0; return 0; }
-    need_ctx();
+    if (need_ctx()) return -1;
     need_bufs((uint64_t)n + 64, 0);
     *nal_size = emit_one(rbsp_buf, g_dbuf + sizeof(hbs_nal_entry), n, nal_buf);      /* h264_nal.c:130 */
     return *nal_size;
+}
+
+int find_nal_unit(uint8_t* buf, int size, int* nal_start, int* nal_end)
+{
+    int r;
+    legacy_lock();
+    r = find_nal_unit_unlocked(buf, size, nal_start, nal_end);
+    legacy_unlock();
+    return r;
+}
+int nal_to_rbsp(const uint8_t* nal_buf, int* nal_size, uint8_t* rbsp_buf, int* rbsp_size)
+{
+    int r;
+    legacy_lock();
+    r = nal_to_rbsp_unlocked(nal_buf, nal_size, rbsp_buf, rbsp_size);
+    legacy_unlock();
+    return r;
+}
+int rbsp_to_nal(const uint8_t* rbsp_buf, const int* rbsp_size, uint8_t* nal_buf, int* nal_size)
+{
+    int r;
+    legacy_lock();
+    r = rbsp_to_nal_unlocked(rbsp_buf, rbsp_size, nal_buf, nal_size);
+    legacy_unlock();
+    return r;
 }
 
 /* h264_stream.c:117-126 */
@@ -434,7 +492,7 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     int rc, t;
     *stripped = 0;
     if (size < 0) return -1;
-    need_ctx();
+    if (need_ctx()) return -1;
     need_bufs((uint64_t)size + 16, 0);
     need_block((uint64_t)size + 16);
     upload_input(sc, 3, buf, (uint64_t)size);
@@ -500,15 +558,21 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
 void hbs_legacy_reset_tables(void)
 {
     int rc;
-    need_ctx();
-    if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
-    g_sps_shadow_ok = 0;
+    legacy_lock();
+    if (need_ctx() == 0) {
+        if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
+        g_sps_shadow_ok = 0;
+    }
+    legacy_unlock();
 }
 
 int read_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
-    int stripped;
-    return read_nal(h, buf, size, &stripped, 0);
+    int stripped, r;
+    legacy_lock();
+    r = read_nal(h, buf, size, &stripped, 0);
+    legacy_unlock();
+    return r;
 }
 
 /*
@@ -520,8 +584,11 @@ int read_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
  */
 int read_debug_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
-    int stripped;
-    return read_nal(h, buf, size, &stripped, 1);
+    int stripped, r;
+    legacy_lock();
+    r = read_nal(h, buf, size, &stripped, 1);
+    legacy_unlock();
+    return r;
 }
 
 /*
@@ -531,7 +598,7 @@ int read_debug_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
  * the derived RPS tables of the last SPS read or written; a slice write replaces h->slice_data's
  * payload by the zeros behind the header in the RBSP buffer (:1699-1706).
  */
-int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
+static int write_hevc_nal_unit_unlocked(hevc_stream_t* h, uint8_t* buf, int size)
 {
     hbs_parsed_nal p;
     hbs_written_nal w;
@@ -541,7 +608,7 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     int rc, t, rbsp_size, nal_size;
     static hbs_written_nal* d_written = NULL;
     if (size < 0) return -1;
-    need_ctx();
+    if (need_ctx()) return -1;
     cap = (uint32_t)((long)size * 3 / 4);
     need_bufs(16, (uint64_t)cap + 16);
     need_block(0);
@@ -581,4 +648,13 @@ int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
     need_bufs(64, 0);
     nal_size = emit_one(NULL, g_dout, rbsp_size, buf);
     return nal_size;
+}
+
+int write_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
+{
+    int r;
+    legacy_lock();
+    r = write_hevc_nal_unit_unlocked(h, buf, size);
+    legacy_unlock();
+    return r;
 }

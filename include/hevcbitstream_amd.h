@@ -83,7 +83,20 @@ typedef struct hbs_summary {
 
 typedef struct hbs_ctx hbs_ctx;
 
-/* Create a context on HIP device `device` (one per GPU / per rank). */
+/* Create a context on HIP device `device` (one per GPU / per rank).
+ *
+ * Threads and streams.  A context owns ONE set of scratch on its GPU (run header, look-back words, ticket, the workspaces of
+ * K3 / K4 / K5, the window buffers of hbs_index_extract_host) and binds to ONE stream at a time, so:
+ *   - a context is used by one thread at a time (the library takes no lock in the batch API: callers that share a
+ *     context serialise their calls themselves);
+ *   - DIFFERENT contexts are independent: any number of threads, one context each, may call at the same time on the
+ *     same or on different GPUs (tests/test_gpu_legacy.py::test_batch_api_two_contexts_two_threads);
+ *   - all work of a context is ordered by the stream it is bound to when the call is made.  Re-binding the stream
+ *     (hbs_ctx_set_stream) while work enqueued through the previous one may still be running is the caller's to order
+ *     (an event between the two streams): the scratch is shared by both.  hbs_index_extract_host uses two private streams
+ *     and returns only when they are idle.
+ * The legacy single-NAL symbols (find_nal_unit ... write_hevc_nal_unit) share one internal context behind a process-wide
+ * lock: safe from any thread, serialised (hbs_legacy.c). */
 int  hbs_ctx_create(hbs_ctx** out, int device);
 void hbs_ctx_destroy(hbs_ctx* ctx);
 /* A new context enqueues on a non-blocking stream of its own.  set_stream
@@ -177,7 +190,11 @@ int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t strea
  *   gap_mode 1   synthetic rule: 00 00 00 01 when k % 4 == 0, else 00 00 01
  *   d_index_out  (optional) entries with start/end in the emitted stream
  *   d_summary    stream_bytes = bytes emitted; error = HBS_E_CAPACITY if
- *                out_cap was too small (hbs_annexb_bound() is always enough)
+ *                out_cap was too small.  hbs_annexb_bound(rbsp_bytes, n_nals) is always enough for
+ *                gap_mode 1; with gap_mode 0 the recorded gaps (zero bytes between NALs, any number
+ *                of them) come on top: hbs_annexb_bound_gaps(rbsp_bytes, n_nals, gap_bytes) with
+ *                gap_bytes = the sum of the gaps -- at most the `start` of the last entry of the
+ *                index the gaps are taken from
  *
  * Emitting what hbs_index_extract extracted reproduces the input stream byte
  * for byte when every NAL was accepted (no HBS_ST_ERROR), none ended in
@@ -188,6 +205,7 @@ int hbs_emit_annexb(hbs_ctx* ctx, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
                     const hbs_nal_entry* d_index_in, uint64_t n_nals, int gap_mode,
                     uint8_t* d_out, uint64_t out_cap, hbs_nal_entry* d_index_out, hbs_summary* d_summary);
 uint64_t hbs_annexb_bound(uint64_t rbsp_bytes, uint64_t n_nals);
+uint64_t hbs_annexb_bound_gaps(uint64_t rbsp_bytes, uint64_t n_nals, uint64_t gap_bytes);
 
 /*
  * K4: header parse, one NAL per lane (64 per wavefront), over the RBSP arena and index that

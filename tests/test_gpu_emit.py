@@ -190,3 +190,28 @@ def test_roundtrip_16gib(ctx):
         pytest.skip("needs ~70 GiB of HBM")
     _roundtrip(ctx, 1677000, 0, 17.0e9, 17.4e9)
     torch.cuda.empty_cache()
+
+
+def test_gap_mode_0_with_long_zero_runs_fits_the_public_bound(orc):
+    """hbs_annexb_bound_gaps: a stream with long zero runs between its NALs (trailing_zero_8bits, padding) re-emitted with the
+    recorded gaps into a buffer sized by the public bound -- hbs_annexb_bound alone ignores the gaps"""
+    import ctypes as C
+    import torch
+    import hevcbitstream_amd as hbs
+    rng = np.random.RandomState(12)
+    parts = []
+    for k in range(200):
+        parts.append(b"\x00" * int(rng.randint(0, 3000)) + b"\x00\x00\x01\x02\x01" + bytes(rng.randint(4, 256, size=int(rng.randint(1, 400))).astype(np.uint8)) + b"\x80")
+    stream = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    ctx = hbs.Context(0)
+    ent, arena, s = ctx.index_extract(torch.from_numpy(stream).cuda())
+    assert len(ent) == 200
+    gaps = int(ent["start"][0]) + int((ent["start"][1:].astype(np.int64) - ent["end"][:-1].astype(np.int64)).sum())
+    lib = ctx.lib
+    lib.hbs_annexb_bound_gaps.restype = C.c_uint64
+    lib.hbs_annexb_bound_gaps.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    bound = int(lib.hbs_annexb_bound_gaps(len(arena), len(ent), gaps))
+    assert int(lib.hbs_annexb_bound(len(arena), len(ent))) < len(stream) <= bound       # the gap-less bound would not do
+    back, ent2 = ctx.emit_annexb(torch.from_numpy(arena).cuda(), ent, gap_mode=0, out_cap=bound)
+    assert np.array_equal(back, stream)
+    ctx.close()

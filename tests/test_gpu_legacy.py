@@ -246,3 +246,130 @@ def test_write_hevc_nal_unit_golden():
                 assert bytes(out[:rc]).hex() == st["out"], (v["seed"], k, kind, st["edits"])
             if kind == "sh":
                 assert p.slice_data()[0] == st["slice_data_size"], (v["seed"], k)
+
+
+def test_peek_hevc_nal_unit_against_the_reference():
+    """peek_hevc_nal_unit (hevc_nal.c:97-114): every 2-byte header, and buffers shorter than a header, against the
+    compiled reference when its prebuilt library travelled with the tree, else against the rule of :103-111 spelled out"""
+    import hevcbitstream_amd as hbs
+    lib = hbs.load_library()
+    lib.hevc_new.restype = C.c_void_p
+    lib.peek_hevc_nal_unit.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+    ours = LegacyHevc(lib)
+    ref = None
+    refso = os.path.join(ROOT, "oracle", "_ref", "libhevcref.so")
+    if os.path.exists(refso):
+        rl = C.CDLL(refso)
+        rl.hevc_new.restype = C.c_void_p
+        rl.peek_hevc_nal_unit.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]
+        ref = (rl, _orc._HevcParser.__new__(_orc._HevcParser))
+        ref[1].h = rl.hevc_new()
+        ref[1]._views(ref[1].h)
+    cases = [(bytes([b0, b1]), 2) for b0 in range(256) for b1 in range(0, 256, 5)] + [(b"\x40\x01\x0c", 3), (b"\x26", 1), (b"", 0), (b"\x7e\xff", 2)]
+    for data, size in cases:
+        buf = np.frombuffer(data + b"\x00" * 8, dtype=np.uint8).copy()
+        rc = lib.peek_hevc_nal_unit(ours.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), size)
+        got = tuple(int(x) for x in ours.snapshot()["nal"])
+        if ref is not None:
+            want_rc = ref[0].peek_hevc_nal_unit(ref[1].h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), size)
+            want = tuple(int(x) for x in ref[1].snapshot()["nal"])
+        else:
+            b0 = data[0] if size > 0 else 0
+            b1 = data[1] if size > 1 else 0
+            t = (b0 >> 1) & 0x3F
+            want = (0, t, ((b0 & 1) << 5) | (b1 >> 3), b1 & 7)
+            want_rc = -1 if (t <= 0 or t > 63) else t
+        assert rc == want_rc, (data.hex(), size, rc, want_rc)
+        assert got[1:] == want[1:], (data.hex(), got, want)
+
+
+def test_legacy_symbols_from_two_threads(leg, orc):
+    """find_nal_unit / nal_to_rbsp / rbsp_to_nal are pure and re-entrant in the reference (h264_nal.c:38-200); here they share one
+    GPU context behind a lock: two threads hammering them at once (ctypes drops the GIL inside a call) get the right answers"""
+    import threading
+    gold = json.load(open(os.path.join(HERE, "golden", "l2_vectors.json")))
+    errors = []
+
+    def finder():
+        try:
+            for _ in range(3):
+                for hx, want in gold["find"][:150]:
+                    if list(leg.find_nal_unit(bytes.fromhex(hx))) != want:
+                        errors.append(("find", hx))
+        except Exception as e:          # noqa: BLE001
+            errors.append(("find", repr(e)))
+
+    def converter():
+        try:
+            for _ in range(2):
+                for hx, (r, ns, rs, data) in gold["n2r"][:120]:
+                    got = leg.nal_to_rbsp(bytes.fromhex(hx))
+                    if not (got[0] == r and got[1] == ns and got[2] == rs and (r < 0 or got[3].hex() == data)):
+                        errors.append(("n2r", hx))
+                for hx, (r, data) in gold["r2n"][:120]:
+                    got = leg.rbsp_to_nal(bytes.fromhex(hx))
+                    if not (got[0] == r and got[2].hex() == data):
+                        errors.append(("r2n", hx))
+        except Exception as e:          # noqa: BLE001
+            errors.append(("conv", repr(e)))
+
+    th = [threading.Thread(target=finder), threading.Thread(target=converter), threading.Thread(target=finder)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+
+
+def test_batch_api_two_contexts_two_threads(orc):
+    """the batch API's contract (include/hevcbitstream_amd.h): a context belongs to one thread at a time; different contexts
+    (each with its own scratch and its own stream) run side by side.  Plain C ABI through ctypes: no torch in this file."""
+    import threading
+    import hevcbitstream_amd as hbs
+    lib = hbs.load_library()
+    lib.hbs_dev_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.hbs_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hbs_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.hbs_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    errors = []
+    gen_lock = threading.Lock()          # the oracle is test infrastructure and makes no promise about threads
+
+    def worker(seed):
+        try:
+            h = C.c_void_p()
+            assert lib.hbs_ctx_create(C.byref(h), 0) == 0
+            for rep in range(6):
+                with gen_lock:
+                    stream, idx, arena = orc.gen_stream(seed + rep, 400 + 50 * rep, rep % 2)
+                n, cap = len(stream), len(idx) + 8
+                bufs = []
+                for nbytes in (n + 64, cap * 32, n + 64, 64):
+                    p = C.c_void_p()
+                    assert lib.hbs_dev_alloc(h, nbytes, C.byref(p)) == 0
+                    bufs.append(p)
+                d_stream, d_index, d_rbsp, d_sum = bufs
+                assert lib.hbs_copy_to_device(h, d_stream, stream.ctypes.data, n) == 0
+                assert lib.hbs_index_extract(h, d_stream, n, d_index, cap, d_rbsp, n + 16, d_sum) == 0
+                summ = np.zeros(1, dtype=hbs.SUMMARY)
+                assert lib.hbs_read_summary(h, d_sum, summ.ctypes.data) == 0
+                got_idx = np.zeros(len(idx), dtype=hbs.NAL_ENTRY)
+                got_arena = np.zeros(len(arena), dtype=np.uint8)
+                assert lib.hbs_copy_to_host(h, got_idx.ctypes.data, d_index, got_idx.nbytes) == 0
+                assert lib.hbs_copy_to_host(h, got_arena.ctypes.data, d_rbsp, got_arena.nbytes) == 0
+                ok = int(summ[0]["nal_count"]) == len(idx) and int(summ[0]["rbsp_bytes"]) == len(arena)
+                ok = ok and all(np.array_equal(got_idx[f], idx[f]) for f in ("start", "end", "rbsp_off", "rbsp_len", "status")) and np.array_equal(got_arena, arena)
+                if not ok:
+                    errors.append((seed, rep, int(summ[0]["nal_count"]), len(idx), int(summ[0]["rbsp_bytes"]), len(arena), int(summ[0]["error"]),
+                                   [f for f in ("start", "end", "rbsp_off", "rbsp_len", "status") if not np.array_equal(got_idx[f], idx[f])]))
+                for p in bufs:
+                    lib.hbs_dev_free(h, p)
+            lib.hbs_ctx_destroy(h)
+        except Exception as e:          # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(0x900 + 16 * i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
