@@ -26,3 +26,17 @@ def ref():
     if r is None:
         pytest.skip("oracle/_ref/libhevcref.so not built (reference sources absent)")
     return r
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_brings_the_gpu_up_first():
+    """On the GPU box: let torch initialise HIP before the library does.  The other order (a test file that only uses the
+    C ABI first, then a torch-based one in the same process) makes torch report 'No HIP GPUs are available' on this image."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+            torch.cuda.synchronize()
+    except Exception:       # noqa: BLE001 -- no GPU, or no torch: the CPU suite does not need either
+        pass
+    yield
