@@ -98,7 +98,92 @@ struct Lds4 {
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
     uint32_t ex_inside, ex_ok;
     uint32_t ticket;
+    TileAgg wagg[k4Waves];                 /* dense tiles: the aggregate of each wavefront's rows */
 };
+
+/* ---- dense tiles -------------------------------------------------------------------------------------
+ * A tile in which zero pairs are everywhere (cabac_zero_words or 00 00 03 padding, zero stuffing between NALs) would
+ * keep wavefront 0 walking its thousands of elements 64 at a time while the look-backs of every tile behind it wait:
+ * a 1 % share of such bytes made a stream 7.6 times slower (scripts/mixed_time.py).  Past kDenseElems elements a tile is
+ * therefore handled the other way round: EVERY chunk is an element (no gaps, no lists, no deposits), each wavefront
+ * walks its own 48 rows -- one row per step, one chunk per lane, the bit-parallel rules of hbs_sparse.h -- and the four
+ * wavefront aggregates meet in LDS.  The rows are read again for it (they sit in the cache: a rolled loop over 48 named
+ * registers does not exist, and unrolled the walk would be 150 KB of code).  Rows without any terminator, which is
+ * what padding looks like, fold with one add per chunk; only rows that hold an event pay for the ordered scan. */
+constexpr uint32_t kDenseElems = 512;
+
+struct DenseRow {
+    Elem el;                /* this lane's chunk of the row */
+    bool row_has_event;
+};
+
+/* row r of a wavefront's segment, this lane's chunk as an element.  qp / qc / qn: previous, current, next row. */
+__device__ __forceinline__ void dense_row(DenseRow& d, const u32x4& qp, const u32x4& qc, const u32x4& qn, int r,
+                                          uint32_t before, uint32_t before2, uint32_t after,
+                                          const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t chunk0, int lane)
+{
+    const uint32_t e_prev_w = r == 0 ? before : (uint32_t)__builtin_amdgcn_readlane((int)qp.w, 63);
+    const uint32_t e_prev_z = r == 0 ? before2 : (uint32_t)__builtin_amdgcn_readlane((int)qp.z, 63);
+    const uint32_t e_next_x = r == k4Rows - 1 ? after : (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0);
+    d.el.v.xpp = from_prev_lane(qc.z, e_prev_z);
+    d.el.v.xp = from_prev_lane(qc.w, e_prev_w);
+    d.el.v.x0 = qc.x; d.el.v.x1 = qc.y; d.el.v.x2 = qc.z; d.el.v.x3 = qc.w;
+    d.el.v.xn = from_next_lane(qc.x, e_next_x);
+    d.el.v.stream = src; d.el.v.g0 = wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane; d.el.v.n = n;
+    elem_walk(d.el.v, d.el.m, d.el.s, d.el.cls);
+    d.el.gap = 0;
+    d.el.chunk = chunk0 + 64u * (uint32_t)r + (uint32_t)lane;
+    d.row_has_event = __ballot(d.el.s.last != kKindNone) != 0ull;
+}
+
+__device__ __forceinline__ u32x4 dense_fetch(const uint8_t* src, uint64_t wseg, int r, int lane)
+{
+    return *reinterpret_cast<const u32x4*>(src + wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane);    /* the padded copy / the stream: always there */
+}
+
+/* first half: the aggregate of this wavefront's rows */
+__device__ __forceinline__ TileAgg dense_aggregate(const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
+                                                   uint32_t chunk0, int lane)
+{
+    TileAgg acc = agg_identity();
+    u32x4 qp = dense_fetch(src, wseg, 0, lane), qc = qp, qn;
+#pragma unroll 1
+    for (int r = 0; r < k4Rows; ++r) {
+        qn = dense_fetch(src, wseg, r + 1 < k4Rows ? r + 1 : r, lane);
+        DenseRow d;
+        dense_row(d, qp, qc, qn, r, before, before2, after, src, wseg, n, chunk0, lane);
+        if (!d.row_has_event) {
+            acc = combine(acc, gap_agg(wave_sum32(d.el.s.carry)));       /* chunks without a terminator: (0, 0, carry, none) each */
+        } else {
+            const TileAgg ea = wave_scan_combine(elem_agg(0u, d.el.s), lane);
+            acc = combine(acc, agg_readlane(ea, 63));
+        }
+        qp = qc; qc = qn;
+    }
+    return acc;
+}
+
+/* second half: index entries and kept bytes of this wavefront's rows; acc0 = aggregate of the tile in front of them */
+__device__ __forceinline__ void dense_emit(const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
+                                           uint32_t chunk0, int lane, TileAgg acc0, const Prefix& excl, bool can_store, uint8_t* out,
+                                           const EmitTarget& tgt, uint32_t* scratch_word)
+{
+    TileAgg acc = acc0;
+    u32x4 qp = dense_fetch(src, wseg, 0, lane), qc = qp, qn;
+#pragma unroll 1
+    for (int r = 0; r < k4Rows; ++r) {
+        qn = dense_fetch(src, wseg, r + 1 < k4Rows ? r + 1 : r, lane);
+        DenseRow d;
+        dense_row(d, qp, qc, qn, r, before, before2, after, src, wseg, n, chunk0, lane);
+        const TileAgg ea = wave_scan_combine(elem_agg(0u, d.el.s), lane);
+        TileAgg up = agg_shfl_up(ea, 1);
+        if (lane == 0) up = agg_identity();
+        const TileAgg e = combine(acc, up);
+        acc = combine(acc, agg_readlane(ea, 63));
+        if (d.el.v.g0 < n) elem_emit(d.el, e, excl, can_store, out, tgt, scratch_word);
+        qp = qc; qc = qn;
+    }
+}
 
 
 
@@ -137,6 +222,56 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
 }
 
 
+/* One dense tile, by the whole workgroup (every thread calls it): aggregates, look-back, emission, the next ticket.  A function
+ * of its own, not inlined: inlined, its registers add to the 192 the rows occupy and the COMMON path spills 33 of them around
+ * every tile's first barrier (index-only scans ran 23 % slower).  false: a look-back timed out, the workgroup gives up. */
+__device__ __attribute__((noinline))
+bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
+                uint64_t tile, bool last_tile, uint8_t* rbsp, uint64_t rbsp_cap, unsigned long long* desc, RunHeader* hdr, const EmitTarget& tgt)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t chunk0 = (uint32_t)(64 * k4Rows * wv);
+    const TileAgg wa = dense_aggregate(src, wseg, n, before, before2, after, chunk0, lane);
+    if (lane == 0) l.wagg[wv] = wa;
+    __syncthreads();
+    TileAgg before_me = agg_identity(), tagg = agg_identity();
+#pragma unroll
+    for (int w = 0; w < k4Waves; ++w) { if (w < wv) before_me = combine(before_me, l.wagg[w]); tagg = combine(tagg, l.wagg[w]); }
+    if (wv == 0) {
+        Prefix ex;
+        uint32_t it, stl;
+        const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
+        HBS4_PRIO(0);
+        const uint32_t tile_kept = tagg.known + (ex.inside ? tagg.sig : 0u);
+        const bool can = rbsp != nullptr && ex.kept + tile_kept <= rbsp_cap;
+        if (lane == 0) {
+            l.ex_kept = ex.kept; l.ex_nals = ex.nals; l.ex_inside = ex.inside;
+            l.ex_ok = !ok ? 0u : (rbsp != nullptr && !can) ? 2u : 1u;
+            if (ok && rbsp != nullptr && !can) atomicMax(&hdr->error, (uint32_t)(-HBS_E_CAPACITY));
+            if (ok && last_tile) {
+                const Prefix incl = fold(ex, tagg);
+                hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
+            }
+        }
+    } else {
+        HBS4_PRIO(0);
+    }
+    __syncthreads();
+    if (l.ex_ok == 0u) return false;
+    Prefix excl;
+    {
+        Prefix ex;
+        ex.kept = l.ex_kept; ex.nals = l.ex_nals; ex.inside = l.ex_inside;
+        excl = prefix_uniform4(ex);
+    }
+    dense_emit(src, wseg, n, before, before2, after, chunk0, lane, before_me, excl, rbsp != nullptr && l.ex_ok == 1u, rbsp + excl.kept, tgt,
+               &l.dep[wv][lane & (kDepCap - 1)].xpp);
+    if (tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+    __syncthreads();
+    return true;
+}
+
 __global__ __launch_bounds__(k4Threads, 2)
 void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                      hbs_nal_entry* __restrict__ index, uint64_t index_cap,
@@ -154,6 +289,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
     __syncthreads();
     HBS4_T_DECL
 
+    uint32_t d_before = 0, d_before2 = 0, d_after = 0;
+    uint64_t d_tile = 0;
+    for (;;) {
+    bool dense_pending = false;
     for (;;) {
         int tid = launder_lane(tid0);
         int lane = tid & 63;
@@ -260,6 +399,13 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         static_assert(k4Waves == 4, "four wavefront totals");
         const uint32_t wb1 = wt0, wb2 = wt0 + wt1, wb3 = wb2 + wt2, nflag = wb3 + wt3;
         const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? wb1 : (wv == 2) ? wb2 : wb3;
+        if (nflag > kDenseElems) {
+            /* ---- dense tile: every chunk an element, every wavefront its own rows (dense_tile).  The call is made OUTSIDE the
+             * tile loop, where nothing of a tile is live: inside it, what has to survive the call is spilled on the common path. */
+            d_before = R.before; d_before2 = R.before2; d_after = R.after; d_tile = tile;
+            dense_pending = true;
+            break;
+        }
         /* readlanes: only in wave-uniform control flow */
 #define HBS_ROW_PRE(r) (wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, (r)))
 #define HBS_ROW_FM(r) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, (r)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, (r)))
@@ -413,6 +559,15 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         }
 #undef HBS_ROW_PRE
 #undef HBS_ROW_FM
+    }
+    if (!dense_pending) break;
+    {
+        const uint64_t base = d_tile * (uint64_t)k4TileBytes;
+        const bool last_tile = d_tile == num_tiles - 1;
+        const uint8_t* const src = last_tile
+            ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
+        if (!dense_tile(l, src, base + (uint64_t)(wv * k4WaveBytes), n, d_before, d_before2, d_after, d_tile, last_tile, rbsp, rbsp_cap, desc, hdr, tgt)) return;
+    }
     }
     HBS4_T_FLUSH
 }
