@@ -213,6 +213,54 @@ def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, s
                         "back to back on one stream; structs equal to those of the same headers with short payloads" % (m, sb2 / 2**30)}
 
 
+def make_mixed(torch, stream, sb, percent=1.0, region_bytes=640 << 10):
+    """A stream that is sparse on average with dense regions the density probe does not see: `percent` of the stream's bytes
+    overwritten by 00 00 03 padding (cabac_zero_words-like runs, valid inside a NAL) in regions of `region_bytes`, placed
+    midway BETWEEN the probe's 64 sample windows (k * (sb / 64)).  Returns (mixed stream, dense bytes)."""
+    stride = (sb // 64) & ~15
+    n_regions = max(1, int(sb * percent / 100.0 / region_bytes))
+    pat = torch.tensor([0, 0, 3], dtype=torch.uint8, device=stream.device).repeat(region_bytes // 3 + 1)[:region_bytes]
+    mixed = stream.clone()
+    placed = 0
+    for k in range(n_regions):
+        off = (k % 64) * stride + stride // 2 + (k // 64) * (region_bytes + 4096)
+        off = (off // 3) * 3
+        if off + region_bytes + 16 >= sb:
+            continue
+        mixed[off: off + region_bytes] = pat
+        mixed[off + region_bytes] = 0x80        # the byte behind the last 00 00 03: neither <= 3 nor part of a zero run
+        placed += 1
+    return mixed, placed * region_bytes
+
+
+def mixed_stream_line(torch, ctx, stream, sb, n_cap, uniform_ms):
+    """the automatic mode on the mixed stream against the uniform one; outputs checked against the LDS-image kernel (whose
+    cost does not depend on the data) entry by entry and byte by byte on the device"""
+    mixed, dense_bytes = make_mixed(torch, stream, sb)
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_cap)
+    ks = []
+    for i in range(4):
+        ctx.index_extract_async(mixed, index, cap, rbsp, summary)
+        if i:
+            ks.append(ctx.kernel_ms())
+    s = ctx.read_summary(summary)
+    kern = ctx.last_kernel()
+    ks.sort()
+    ms = ks[len(ks) // 2]
+    index2, rbsp2, summary2, _ = ctx.alloc_outputs(sb, index_cap=n_cap)
+    ctx.set_kernel(2)
+    ctx.index_extract_async(mixed, index2, cap, rbsp2, summary2)
+    s2 = ctx.read_summary(summary2)
+    ctx.set_kernel(0)
+    m, rb = int(s2["nal_count"]), int(s2["rbsp_bytes"])
+    assert int(s["error"]) == 0 and int(s["nal_count"]) == m and int(s["rbsp_bytes"]) == rb
+    assert torch.equal(index[: m * 32], index2[: m * 32]) and torch.equal(rbsp[:rb], rbsp2[:rb]), "mixed stream: differs from the LDS-image kernel"
+    return {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4), "kernel": kern,
+            "over_uniform": round(ms / uniform_ms, 3), "dense_bytes": dense_bytes, "nals": m,
+            "workload": "the bench stream with %.2f %% of its bytes overwritten by 00 00 03 padding in 640 KiB regions between the "
+                        "density probe's windows (the probe says sparse; the dense tiles take the per-tile dense path)" % (100.0 * dense_bytes / sb)}
+
+
 def other_kernels(torch, hbs, ctx, g, n):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
@@ -239,6 +287,7 @@ def other_kernels(torch, hbs, ctx, g, n):
                          "kernel": {4: "hbs::k_scan_extract4", 5: "hbs::k_scan_index5", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?"),
                          "workload": "the bench stream, index only (find_nal_unit over the stream, no arena)"}
     del index
+    res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
     out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
@@ -452,6 +501,7 @@ def main():
         if world == 1 and args.cpu_sample_nals > 0:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(stream, gen_index, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:
+            g["uniform_kernel_ms"] = k_ms
             del rbsp, index
             out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n)
         # RCCL writes a version banner to C stdout, which is block-buffered when piped: push it out first, so that the JSON

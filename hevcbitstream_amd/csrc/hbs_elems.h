@@ -280,5 +280,36 @@ __device__ __forceinline__ void elem_emit(const Elem& el, const TileAgg& e, cons
     *seg_slot = seg_pack((int32_t)el.chunk, st.kept + nk, after);
 }
 
+/* ---- a whole KiB row as 64 elements (dense tiles of hbs_scan4.hip, dense rows of hbs_scan5.hip) --------------------- */
+struct DenseRow {
+    Elem el;                /* this lane's chunk of the row */
+    bool row_has_event;
+};
+
+/* row r of a wavefront's segment, this lane's chunk as an element.  qp / qc / qn: previous, current, next row. */
+__device__ __forceinline__ void dense_row(DenseRow& d, const u32x4& qp, const u32x4& qc, const u32x4& qn, int r, int nrows,
+                                          uint32_t before, uint32_t before2, uint32_t after,
+                                          const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t chunk0, int lane)
+{
+    const uint32_t e_prev_w = r == 0 ? before : (uint32_t)__builtin_amdgcn_readlane((int)qp.w, 63);
+    const uint32_t e_prev_z = r == 0 ? before2 : (uint32_t)__builtin_amdgcn_readlane((int)qp.z, 63);
+    const uint32_t e_next_x = r == nrows - 1 ? after : (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0);
+    d.el.v.xpp = from_prev_lane(qc.z, e_prev_z);
+    d.el.v.xp = from_prev_lane(qc.w, e_prev_w);
+    d.el.v.x0 = qc.x; d.el.v.x1 = qc.y; d.el.v.x2 = qc.z; d.el.v.x3 = qc.w;
+    d.el.v.xn = from_next_lane(qc.x, e_next_x);
+    d.el.v.stream = src; d.el.v.g0 = wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane; d.el.v.n = n;
+    elem_walk(d.el.v, d.el.m, d.el.s, d.el.cls);
+    d.el.gap = 0;
+    d.el.chunk = chunk0 + 64u * (uint32_t)r + (uint32_t)lane;
+    d.row_has_event = __ballot(d.el.s.last != kKindNone) != 0ull;
+}
+
+__device__ __forceinline__ u32x4 dense_fetch(const uint8_t* src, uint64_t wseg, int r, int lane)
+{
+    return *reinterpret_cast<const u32x4*>(src + wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane);    /* the padded copy / the stream: always there */
+}
+
+
 } // namespace hbs
 #endif

@@ -112,35 +112,6 @@ struct Lds4 {
  * what padding looks like, fold with one add per chunk; only rows that hold an event pay for the ordered scan. */
 constexpr uint32_t kDenseElems = 512;
 
-struct DenseRow {
-    Elem el;                /* this lane's chunk of the row */
-    bool row_has_event;
-};
-
-/* row r of a wavefront's segment, this lane's chunk as an element.  qp / qc / qn: previous, current, next row. */
-__device__ __forceinline__ void dense_row(DenseRow& d, const u32x4& qp, const u32x4& qc, const u32x4& qn, int r,
-                                          uint32_t before, uint32_t before2, uint32_t after,
-                                          const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t chunk0, int lane)
-{
-    const uint32_t e_prev_w = r == 0 ? before : (uint32_t)__builtin_amdgcn_readlane((int)qp.w, 63);
-    const uint32_t e_prev_z = r == 0 ? before2 : (uint32_t)__builtin_amdgcn_readlane((int)qp.z, 63);
-    const uint32_t e_next_x = r == k4Rows - 1 ? after : (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0);
-    d.el.v.xpp = from_prev_lane(qc.z, e_prev_z);
-    d.el.v.xp = from_prev_lane(qc.w, e_prev_w);
-    d.el.v.x0 = qc.x; d.el.v.x1 = qc.y; d.el.v.x2 = qc.z; d.el.v.x3 = qc.w;
-    d.el.v.xn = from_next_lane(qc.x, e_next_x);
-    d.el.v.stream = src; d.el.v.g0 = wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane; d.el.v.n = n;
-    elem_walk(d.el.v, d.el.m, d.el.s, d.el.cls);
-    d.el.gap = 0;
-    d.el.chunk = chunk0 + 64u * (uint32_t)r + (uint32_t)lane;
-    d.row_has_event = __ballot(d.el.s.last != kKindNone) != 0ull;
-}
-
-__device__ __forceinline__ u32x4 dense_fetch(const uint8_t* src, uint64_t wseg, int r, int lane)
-{
-    return *reinterpret_cast<const u32x4*>(src + wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane);    /* the padded copy / the stream: always there */
-}
-
 /* first half: the aggregate of this wavefront's rows */
 __device__ __forceinline__ TileAgg dense_aggregate(const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
                                                    uint32_t chunk0, int lane)
@@ -151,7 +122,7 @@ __device__ __forceinline__ TileAgg dense_aggregate(const uint8_t* src, uint64_t 
     for (int r = 0; r < k4Rows; ++r) {
         qn = dense_fetch(src, wseg, r + 1 < k4Rows ? r + 1 : r, lane);
         DenseRow d;
-        dense_row(d, qp, qc, qn, r, before, before2, after, src, wseg, n, chunk0, lane);
+        dense_row(d, qp, qc, qn, r, k4Rows, before, before2, after, src, wseg, n, chunk0, lane);
         if (!d.row_has_event) {
             acc = combine(acc, gap_agg(wave_sum32(d.el.s.carry)));       /* chunks without a terminator: (0, 0, carry, none) each */
         } else {
@@ -174,7 +145,7 @@ __device__ __forceinline__ void dense_emit(const uint8_t* src, uint64_t wseg, ui
     for (int r = 0; r < k4Rows; ++r) {
         qn = dense_fetch(src, wseg, r + 1 < k4Rows ? r + 1 : r, lane);
         DenseRow d;
-        dense_row(d, qp, qc, qn, r, before, before2, after, src, wseg, n, chunk0, lane);
+        dense_row(d, qp, qc, qn, r, k4Rows, before, before2, after, src, wseg, n, chunk0, lane);
         const TileAgg ea = wave_scan_combine(elem_agg(0u, d.el.s), lane);
         TileAgg up = agg_shfl_up(ea, 1);
         if (lane == 0) up = agg_identity();

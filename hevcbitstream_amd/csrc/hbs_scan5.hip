@@ -126,6 +126,42 @@ __device__ __forceinline__ TileAgg make_batch(Elem& el, const Lds5& l, uint32_t 
     return ea;
 }
 
+/* ---- tiles dense in elements: a row at a time ------------------------------------------------------------------
+ * Past two batches the elements of a tile are walked 64 at a time, each batch finding its chunks in the flag words and
+ * fetching their bytes one element per lane: a tile inside 00 00 03 padding or zero stuffing (65536 elements per MiB)
+ * took milliseconds that way, and the look-backs of every tile behind it waited -- an index-only scan of a stream with
+ * 1 % of such bytes ran 14.6 times slower than without (scripts/mixed_time.py).  When the flagged rows of a tile hold 16
+ * or more elements each on average, the tile is walked by ROWS instead: every KiB row that has a flag is one batch, all 64
+ * of its chunks elements (no gaps inside the row), read with one coalesced load that is issued a row ahead. */
+struct RowWalk5 {
+    u32x4 qp, qc, qn;
+    uint32_t before, before2, after;
+};
+__device__ __forceinline__ void rows_begin(RowWalk5& w, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t tile_end, int lane)
+{
+    w.before = load_dword_guarded(stream, (int64_t)base - 4, n);
+    w.before2 = load_dword_guarded(stream, (int64_t)base - 8, n);
+    w.after = load_dword_guarded(stream, (int64_t)tile_end, n);
+    w.qc = load_chunk_guarded(stream, base + 16ull * (uint64_t)lane, n);
+    w.qp = w.qc;
+}
+/* row r as a batch: its elements in d, the gap in front of it on lane 0; false: the row holds no flag (skipped).  The next
+ * row's load is issued first (a ring of four rows ahead was tried: slower, 5.2 against 4.2 ms on the mixed stream). */
+__device__ __forceinline__ bool rows_step(RowWalk5& w, DenseRow& d, const Lds5& l, int r, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base,
+                                          int lane, uint64_t& prev_end)
+{
+    w.qn = load_chunk_guarded(stream, base + 1024ull * (uint64_t)(r + 1 < k5TileRows ? r + 1 : r) + 16ull * (uint64_t)lane, n);
+    const bool flagged = l.words[r] != 0ull;
+    if (flagged) {
+        dense_row(d, w.qp, w.qc, w.qn, r, k5TileRows, w.before, w.before2, w.after, stream, base, n, 0u, lane);
+        const uint64_t row_lo = base + 1024ull * (uint64_t)r;
+        d.el.gap = lane == 0 ? span_bytes(prev_end, row_lo, n) : 0u;
+        prev_end = row_lo + 1024ull;
+    }
+    w.qp = w.qc; w.qc = w.qn;
+    return flagged;
+}
+
 __global__ __launch_bounds__(64)
 void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                  hbs_nal_entry* __restrict__ index, uint64_t index_cap,
@@ -174,12 +210,35 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+        /* rows that hold a flag: by rows, or by elements? */
+        uint32_t myrows = 0;
+#pragma unroll
+        for (int j = 0; j < k5WordsPerLane; ++j) myrows += l.words[lane * k5WordsPerLane + j] != 0ull ? 1u : 0u;
+        const uint32_t flagged_rows = wave_sum32(myrows);
+        const bool by_rows = nelem > 128u && nelem >= 16u * flagged_rows;
+
         /* elements -> tile aggregate, 64 at a time */
         const uint32_t npass = (nelem + 63u) >> 6;
         /* up to 128 elements (a 1 MiB tile of coded video has ~100) are walked once and kept: two per lane */
         Elem el, el2;
         TileAgg acc = agg_identity(), e = agg_identity(), e2 = agg_identity();
         uint64_t prev_end = base;
+        if (by_rows) {
+            RowWalk5 w;
+            rows_begin(w, stream, n, base, tile_end, lane);
+#pragma unroll 1
+            for (int r = 0; r < k5TileRows; ++r) {
+                DenseRow d;
+                if (!rows_step(w, d, l, r, stream, n, base, lane, prev_end)) continue;
+                const uint32_t gap0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.el.gap);
+                if (!d.row_has_event) {
+                    acc = combine(acc, gap_agg(gap0 + wave_sum32(d.el.s.carry)));      /* nothing but state-dependent bytes */
+                } else {
+                    const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
+                    acc = combine(acc, agg_readlane(ea, 63));
+                }
+            }
+        } else {
 #pragma unroll 1
         for (uint32_t p = 0; p < npass; ++p) {
             TileAgg ea;
@@ -190,6 +249,7 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             if (lane == 0) up = agg_identity();
             if (p == 1u) e2 = combine(acc, up); else e = combine(acc, up);
             acc = combine(acc, agg_readlane(ea, 63));
+        }
         }
         const TileAgg tagg = combine(acc, gap_agg(span_bytes(prev_end, tile_end, n)));
 
@@ -205,7 +265,23 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
         const Prefix excl = prefix_uniform4(ex);
 
         /* index entries: one or two batches -> the elements are still in registers; more -> walk them again */
-        if (npass == 1u) {
+        if (by_rows) {
+            TileAgg accb = agg_identity();
+            prev_end = base;
+            RowWalk5 w;
+            rows_begin(w, stream, n, base, tile_end, lane);
+#pragma unroll 1
+            for (int r = 0; r < k5TileRows; ++r) {
+                DenseRow d;
+                if (!rows_step(w, d, l, r, stream, n, base, lane, prev_end)) continue;
+                const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
+                TileAgg up = agg_shfl_up(ea, 1);
+                if (lane == 0) up = agg_identity();
+                const TileAgg eb = combine(accb, up);
+                accb = combine(accb, agg_readlane(ea, 63));
+                if (d.el.v.g0 < n) elem_emit(d.el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+            }
+        } else if (npass == 1u) {
             if ((uint32_t)lane < nelem) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
         } else if (npass == 2u) {
             elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);

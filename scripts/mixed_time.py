@@ -13,23 +13,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def make_mixed(torch, stream, sb, percent, region_bytes):
-    """overwrite `percent` of the stream with 00 00 03 runs, in regions between the probe windows (64 windows at k * (sb / 64))"""
-    stride = (sb // 64) & ~15
-    n_regions = max(1, int(sb * percent / 100.0 / region_bytes))
-    pat = torch.tensor([0, 0, 3], dtype=torch.uint8, device=stream.device).repeat(region_bytes // 3 + 1)[:region_bytes]
-    mixed = stream.clone()
-    placed = 0
-    for k in range(n_regions):
-        w = k % 64
-        off = w * stride + stride // 2 + (k // 64) * (region_bytes + 4096)
-        off = (off // 3) * 3
-        if off + region_bytes + 16 >= sb:
-            continue
-        mixed[off: off + region_bytes] = pat
-        mixed[off + region_bytes] = 0x80        # the byte behind the last 00 00 03 must not be <= 3 ... and not 0
-        placed += 1
-    return mixed, placed * region_bytes
+from bench import make_mixed          # the generator lives with the benchmark that reports it
 
 
 def run(ctx, torch, stream, sb, cap, reps=5, want_rbsp=True):
