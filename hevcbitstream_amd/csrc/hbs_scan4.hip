@@ -88,10 +88,11 @@ __device__ __forceinline__ void fetch_row_regs(RowRegs& R, const uint8_t* __rest
 }
 
 constexpr int kDepCap = 64;
+constexpr uint32_t kDenseElems = 512;      /* a tile with more elements than this is walked by rows (dense tiles, below) */
 
 struct Lds4 {
     uint32_t wave_tot[k4Waves];            /* elements per wavefront                        */
-    uint16_t list[k4ChunksPerTile];        /* flagged chunks of the tile, in stream order   */
+    uint16_t list[kDenseElems];            /* flagged chunks of the tile, in stream order (a tile with more takes the dense path) */
     uint32_t seg[k4ElemPass + 1];          /* segment words: [0] tile start, [i+1] element i of the pass */
     Deposit dep[k4Waves][kDepCap];         /* bytes of the first elements of each wavefront, left by the flag pass */
     u32x4 park[kParkRows][64];             /* rows of wavefront 0 while it handles elements and looks back */
@@ -110,7 +111,6 @@ struct Lds4 {
  * wavefront aggregates meet in LDS.  The rows are read again for it (they sit in the cache: a rolled loop over 48 named
  * registers does not exist, and unrolled the walk would be 150 KB of code).  Rows without any terminator, which is
  * what padding looks like, fold with one add per chunk; only rows that hold an event pay for the ordered scan. */
-constexpr uint32_t kDenseElems = 512;
 
 /* first half: the aggregate of this wavefront's rows */
 __device__ __forceinline__ TileAgg dense_aggregate(const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
@@ -388,7 +388,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 l.list[rp + lanes_below(f)] = (uint16_t)(64 * (k4Rows * wv + r) + lane);
         }
         __syncthreads();
-        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < 1024; i += k4Threads) g_dbg4[256 + i] = l.list[i]; })
+        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < (int)kDenseElems; i += k4Threads) g_dbg4[256 + i] = l.list[i]; })
         HBS4_T_MARK(1)
 
         /* ---- 2..4 on wavefront 0: elements -> tile aggregate -> look-back -> emit ----------- */

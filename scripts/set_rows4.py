@@ -9,7 +9,29 @@ s = re.sub(r'#define HBS_ROWS\(X\) .*', '#define HBS_ROWS(X) ' + ' '.join('X(%d)
 s = re.sub(r'#define HBS_ROW_TRIPLES\(X\) .*', '#define HBS_ROW_TRIPLES(X) ' + ' '.join('X(%d,%d,%d)' % (i - 1, i, i + 1) for i in range(1, rows - 1)) + '   /* (previous row, row, next row), inner rows */', s)
 s = re.sub(r'constexpr int kParkRows = \d+;', 'constexpr int kParkRows = %d;' % (rows - park_first), s)
 s = re.sub(r'#define HBS_PARKED\(X\) .*', '#define HBS_PARKED(X) ' + ' '.join('X(%d,%d)' % (i, park_first + i) for i in range(rows - park_first)), s)
-s = re.sub(r'HBS_FLAG_BODY\(\d+, \(uint32_t\)__builtin_amdgcn_readlane\(\(int\)R\.q\d+\.z, 63\), R\.after\)', 'HBS_FLAG_BODY(%d, (uint32_t)__builtin_amdgcn_readlane((int)R.q%d.z, 63), R.after)' % (rows - 1, rows - 2), s)
+assert rows % 4 == 0, "the flag pass takes rows four at a time"
+
+
+def rl(reg, comp, lane_no):
+    return '(uint32_t)__builtin_amdgcn_readlane((int)R.q%d.%s, %d)' % (reg, comp, lane_no)
+
+
+def group(first):
+    args = []
+    for r in range(first, first + 4):
+        args += [str(r),
+                 'R.before' if r == 0 else rl(r - 1, 'w', 63),
+                 'R.after' if r == rows - 1 else rl(r + 1, 'x', 0),
+                 'R.before2' if r == 0 else rl(r - 1, 'z', 63)]
+    return '            HBS_FLAG_GROUP(' + ', '.join(args) + ')'
+
+
+lines = s.split('\n')
+first = next(i for i, ln in enumerate(lines) if ln.startswith('            HBS_FLAG_GROUP('))
+last = max(i for i, ln in enumerate(lines) if ln.startswith('            HBS_FLAG_GROUP('))
+assert all(ln.startswith('            HBS_FLAG_GROUP(') for ln in lines[first:last + 1])
+lines[first:last + 1] = [group(g) for g in range(0, rows, 4)]
+s = '\n'.join(lines)
 s = re.sub(r'static_assert\(k4Rows == \d+, "first and last row are named above"\);', 'static_assert(k4Rows == %d, "first and last row are named above");' % rows, s)
 open(p, 'w').write(s)
 p = 'hevcbitstream_amd/csrc/hbs_sparse.h'
