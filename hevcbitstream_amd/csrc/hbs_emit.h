@@ -42,6 +42,55 @@ HBS_HD uint32_t count_segment(const uint8_t* rbsp, uint64_t nal_begin, uint64_t 
     return ins;
 }
 
+/* ---- the same walk over a 16-byte chunk held in registers (what the kernels run: one 16-byte load per flagged chunk
+ * instead of a chain of byte loads) -------------------------------------------------------------------------- */
+
+/* `count` on entering a chunk, from the four bytes in front of it (little-endian dword, nearest byte on top):
+ * 0, 1, 2, or kLeadUnknown when all four are zero and the run has to be followed further back (lead_count()) */
+constexpr uint32_t kLeadUnknown = 3;
+HBS_HD uint32_t lead_count4(uint32_t xp)
+{
+    if ((xp >> 24) != 0u) return 0u;
+    if (((xp >> 16) & 0xFFu) != 0u) return 1u;
+    if (((xp >> 8) & 0xFFu) != 0u) return 2u;
+    if ((xp & 0xFFu) != 0u) return 1u;
+    return kLeadUnknown;
+}
+
+/* bytes 0..nb-1 of the chunk w0..w3 (little-endian words) entered with `count`: bit i of the result = a 03 goes in
+ * front of byte i (reference h264_nal.c:110-116) */
+HBS_HD uint32_t insert_mask16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nb, uint32_t count)
+{
+    uint32_t m = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t w = i < 4 ? w0 : i < 8 ? w1 : i < 12 ? w2 : w3;
+        const uint32_t v = (w >> (8u * (i & 3u))) & 0xFFu;
+        const bool ins = count == 2u && v <= 3u && i < nb;
+        m |= (ins ? 1u : 0u) << i;
+        if (ins) count = 0;
+        count = (v == 0u) ? count + 1u : 0u;
+    }
+    return m;
+}
+
+/* writes the chunk's nb bytes with the 03s of `mask`; returns the bytes written */
+HBS_HD uint32_t emit_chunk16(uint8_t* dst, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nb, uint32_t mask)
+{
+    uint32_t j = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (uint32_t i = 0; i < nb; ++i) {
+        if ((mask >> i) & 1u) dst[j++] = 3u;
+        dst[j++] = (uint8_t)w0;
+        w0 = (w0 >> 8) | (w1 << 24); w1 = (w1 >> 8) | (w2 << 24); w2 = (w2 >> 8) | (w3 << 24); w3 >>= 8;
+    }
+    return j;
+}
+
 /* 16-byte staging register for byte-aligned output */
 struct OutBuf {
     uint64_t lo, hi;

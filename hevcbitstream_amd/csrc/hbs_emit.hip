@@ -105,6 +105,30 @@ __device__ __forceinline__ u32x4 load_nal_chunk(const uint8_t* __restrict__ rbsp
     return v;
 }
 
+/* A flagged chunk, exactly: its bytes (one 16-byte load), the count it is entered with (the dword in front; a run of four
+ * or more zeros is followed back in memory), the 03s it gets.  off is a multiple of 16 below len. */
+struct ExactChunk { u32x4 q; uint32_t nb, mask; };
+__device__ __forceinline__ ExactChunk exact_chunk(const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, uint32_t off)
+{
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+    ExactChunk e;
+    e.q = load_nal_chunk(rbsp, begin, len, off);
+    e.nb = len - off < 16u ? len - off : 16u;
+    uint32_t count = 0;                                   /* a NAL starts with count = 0 */
+    if (off != 0) {
+        count = lead_count4(reinterpret_cast<const U4*>(rbsp + begin + off - 4u)->v);
+        if (count == kLeadUnknown) count = lead_count(rbsp, begin, begin + off);
+    }
+    e.mask = insert_mask16(e.q.x, e.q.y, e.q.z, e.q.w, e.nb, count);
+    return e;
+}
+__device__ __forceinline__ void store_exact(uint8_t* dst, const ExactChunk& e)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    if (e.mask == 0u && e.nb == 16u) reinterpret_cast<U16*>(dst)->v = e.q;
+    else (void)emit_chunk16(dst, e.q.x, e.q.y, e.q.z, e.q.w, e.nb, e.mask);
+}
+
 /* One row of a NAL: which of its chunks may need a 03 (conservative), from the row's registers. */
 struct RowFlags {
     bool mine;             /* my chunk */
@@ -134,7 +158,7 @@ __device__ __forceinline__ uint32_t count_nal(const uint8_t* __restrict__ rbsp, 
         const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
         if (f.mask != 0) {
             uint32_t c = 0;
-            if (f.mine) c = count_segment(rbsp, begin, begin + off, begin + (off + 16u < len ? off + 16u : len));
+            if (f.mine) c = (uint32_t)__builtin_popcount(exact_chunk(rbsp, begin, len, off).mask);
             ins += wave_sum_u32(c);
         }
         e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
@@ -277,12 +301,13 @@ __device__ __forceinline__ void emit_nal(const uint8_t* __restrict__ rbsp, const
             uint8_t* dst = out + nal_start + off + ins;
             uint32_t c = 0;
             if (f.mask != 0) {
-                const uint64_t se = begin + (off + 16u < len ? off + 16u : len);
-                if (f.mine) c = count_segment(rbsp, begin, begin + off, se);
+                ExactChunk ec;
+                ec.mask = 0; ec.nb = 0;
+                if (f.mine) { ec = exact_chunk(rbsp, begin, len, off); c = (uint32_t)__builtin_popcount(ec.mask); }
                 uint32_t tot;
                 dst += wave_excl_scan_u32(c, lane, tot);
                 ins += tot;
-                if (f.mine) emit_segment(rbsp, begin, begin + off, se, dst);
+                if (f.mine) store_exact(dst, ec);
             }
             if (!f.mine) {
                 if (off + 16u <= len) {
@@ -488,7 +513,10 @@ __device__ __forceinline__ void flag_batch(const u32x4 (&R)[kEmitRows], uint32_t
             myflags |= (mine ? 1u : 0u) << r;
             e_prev = (uint32_t)__builtin_amdgcn_readlane((int)R[r].w, 63);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#ifndef HBS_K3_FLAG_INTERLEAVE
+#define HBS_K3_FLAG_INTERLEAVE 1
+#endif
+        if ((r % HBS_K3_FLAG_INTERLEAVE) == HBS_K3_FLAG_INTERLEAVE - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -502,7 +530,7 @@ __device__ __forceinline__ uint32_t count_batch(const uint8_t* __restrict__ rbsp
         const uint32_t r = (uint32_t)__builtin_ctz(rm);
         const uint32_t off = 1024u * (r0 + r) + 16u * (uint32_t)lane;
         uint32_t c = 0;
-        if ((myflags >> r) & 1u) c = count_segment(rbsp, begin, begin + off, begin + (off + 16u < len ? off + 16u : len));
+        if ((myflags >> r) & 1u) c = (uint32_t)__builtin_popcount(exact_chunk(rbsp, begin, len, off).mask);
         ins += wave_sum_u32(c);
     }
     return ins;
@@ -527,12 +555,13 @@ __device__ __forceinline__ void emit_batch(const u32x4 (&R)[kEmitRows], const ui
         const uint32_t r = (uint32_t)__builtin_ctz(rm);
         const uint32_t off = 1024u * (r0 + r) + 16u * (uint32_t)lane;
         const bool mine = ((myflags >> r) & 1u) != 0;
-        const uint64_t se = begin + (off + 16u < len ? off + 16u : len);
         uint32_t c = 0, tot;
-        if (mine) c = count_segment(rbsp, begin, begin + off, se);
+        ExactChunk ec;
+        ec.mask = 0; ec.nb = 0;
+        if (mine) { ec = exact_chunk(rbsp, begin, len, off); c = (uint32_t)__builtin_popcount(ec.mask); }
         uint8_t* dst = dst0 + off + ins + wave_excl_scan_u32(c, lane, tot);
         if (mine) {
-            emit_segment(rbsp, begin, begin + off, se, dst);
+            store_exact(dst, ec);
         } else if (off < len) {
             const u32x4 q = load_nal_chunk(rbsp, begin, len, off);
             if (off + 16u <= len) reinterpret_cast<Chunk16*>(dst)->v = q;

@@ -1,4 +1,5 @@
-"""Timing of K3 (hbs_emit_annexb) on a ~1 GiB synthetic arena (dev aid, not the bench)."""
+"""Timing of K3 (hbs_emit_annexb) on a synthetic arena (dev aid, not the bench): ~1 GiB by default,
+HBS_EMIT_NALS=1677000 for the bench's 16 GiB."""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -8,16 +9,17 @@ if os.environ.get("HBS_LIB"):
     _api.library_path = lambda: os.environ["HBS_LIB"]
 import hevcbitstream_amd as hbs
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+N = int(os.environ.get("HBS_EMIT_NALS", 104858))
 ctx = hbs.Context(0)
-g = ctx.synth_stream(0x1234, 104858, mode)          # runs the generator + K3 once
+g = ctx.synth_stream(0x1234, N, mode)          # runs the generator + K3 once
 rb, sb = g["rbsp_bytes"], g["stream_bytes"]
 print("rbsp bytes", rb, "stream bytes", sb)
 out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
-idx_out = torch.empty(104858 * 32, dtype=torch.uint8, device="cuda")
+idx_out = torch.empty(N * 32, dtype=torch.uint8, device="cuda")
 summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
 for i in range(6):
-    ctx.emit_annexb_async(g["rbsp"], rb, g["index"], 104858, 1, out, idx_out, summary)
+    ctx.emit_annexb_async(g["rbsp"], rb, g["index"], N, 1, out, idx_out, summary)
     ev[i].record()
 torch.cuda.synchronize()
 ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]

@@ -152,6 +152,19 @@ extern "C" int64_t sim_emit_annexb(const uint8_t* rbsp, const hbs_nal_entry* idx
             const bool f = chunk_flag(nal_dword((int64_t)off - 4), nal_dword(off), nal_dword(off + 4), nal_dword(off + 8),
                                       nal_dword(off + 12), nal_dword(off + 16));
             const uint32_t c = count_segment(rbsp, begin, sb, se);
+            {   /* the register form the kernels run must say the same: count, mask, bytes */
+                uint32_t lc = off ? lead_count4(nal_dword((int64_t)off - 4)) : 0u;
+                if (lc == kLeadUnknown) lc = lead_count(rbsp, begin, sb);
+                if (lc != lead_count(rbsp, begin, sb)) return -3;
+                const uint32_t nb = (uint32_t)(se - sb);
+                const uint32_t w0 = nal_dword(off), w1 = nal_dword(off + 4), w2 = nal_dword(off + 8), w3 = nal_dword(off + 12);
+                const uint32_t m = insert_mask16(w0, w1, w2, w3, nb, lc);
+                if ((uint32_t)__builtin_popcount(m) != c) return -3;
+                uint8_t a[32], b[32];
+                const uint32_t na = emit_chunk16(a, w0, w1, w2, w3, nb, m);
+                emit_segment(rbsp, begin, sb, se, b);
+                if (na != nb + c || memcmp(a, b, na) != 0) return -3;
+            }
             if (!f) {
                 if (c != 0) return -2;             /* the test must be conservative */
                 memcpy(out + dst, rbsp + sb, se - sb);
