@@ -435,6 +435,9 @@ extern "C" int hbs_debug_phase_cycles_emit(unsigned long long* host_out /* [1024
 #define HBS_EMIT_SLOTS 3
 #define HBS_EMIT_ROWS 12
 #endif
+#ifndef HBS_EMIT_WGS
+#define HBS_EMIT_WGS 2                            /* workgroups per CU the register budget is set for */
+#endif
 constexpr int kEmitSlots = HBS_EMIT_SLOTS;        /* NALs a wavefront works on at a time */
 constexpr int kEmitRows = HBS_EMIT_ROWS;          /* rows of 1 KiB per slot held in registers */
 constexpr int kEmitGroup = 4 * kEmitSlots;        /* NALs per workgroup and ticket */
@@ -696,7 +699,7 @@ struct Lds3 {
     uint32_t ticket;
 };
 
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, HBS_EMIT_WGS)
 void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
               const unsigned long long* __restrict__ items, const unsigned long long* __restrict__ n_items_ptr, uint64_t items_cap,
               unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,

@@ -510,10 +510,9 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
     /* one wavefront, so everything it hands from lane to lane stays on one compute unit: workgroup-scope fences (a wait
      * for the stores) are enough; with agent scope (write-back and invalidate of the caches, six times per NAL) the walk ran
      * at 92 k NAL/s */
-    __shared__ __attribute__((aligned(16))) uint8_t win[2 * kLaneWinStride];
+    __shared__ __attribute__((aligned(16))) uint8_t win[64 * kLaneWinStride];
     const int lane = threadIdx.x;
-    uint8_t* const my_win = win + (uint32_t)(lane & 1) * kLaneWinStride;      /* (a pointer the compiler cannot fold: hipcc 7.2 emits an
-                                                                                 illegal compare for the null check of a constant LDS address) */
+    uint8_t* const my_win = win + (uint32_t)lane * kLaneWinStride;
     const uint64_t tbl_off = round16(sizeof(hevc_sps_t));
     /* the tables at "program start", or the ones behind the SPS the caller hands in */
     {
@@ -521,67 +520,100 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
         const uint4* src = init_sps_slot ? reinterpret_cast<const uint4*>(init_sps_slot + tbl_off) : nullptr;
         for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(RpsTables) / 16); i += 64) d[i] = src ? src[i] : make_uint4(0, 0, 0, 0);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint64_t off_run = 0, sps_off = ~0ull, pps_off = ~0ull;
     bool have_sps = false, have_pps = false;
     uint32_t err = 0;
+    /* 64 NALs at a time.  What does not depend on the NALs in front -- entry, header, slot, the cleared struct, the first
+     * bytes of the RBSP in LDS -- is done for the 64 at once, one NAL per lane (k4_small's plan); then the lanes take their
+     * turn in stream order, each walking its own NAL against the one set of tables.  What remains is the walk itself: one
+     * lane's dependent LDS and table reads, ~12 us per slice header (81 k NAL/s on the 4K30 batch of scripts/parse_time.py;
+     * fetching entry, header and window per NAL when its turn came it was 77 k). */
 #pragma unroll 1
-    for (uint64_t k = 0; k < n; ++k) {
-        const hbs_nal_entry e = idx[k];
+    for (uint64_t k0 = 0; k0 < n; k0 += 64) {
+        const uint64_t k = k0 + (uint64_t)lane;
+        const bool have = k < n;
+        hbs_nal_entry e;
+        e.start = e.end = e.rbsp_off = 0; e.rbsp_len = 0; e.status = 0;
         ParsedNal p;
         p.rc = -1; p.nal_unit_type = -1; p.nal_layer_id = -1; p.nal_temporal_id_plus1 = -1;
         p.struct_off = ~0ull; p.slice_data_size = 0; p.slice_data_off = 0;
         uint64_t sz = 0;
-        if (!(e.status & HBS_ST_ERROR)) {
-            nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
-            sz = slot_bytes_of(p.nal_unit_type);
+        if (have) {
+            e = idx[k];
+            if (!(e.status & HBS_ST_ERROR)) {
+                nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
+                sz = slot_bytes_of(p.nal_unit_type);
+            }
         }
         const int type = p.nal_unit_type;
         const bool slice = is_slice_type_nal(type);
         const bool pset = type == HEVC_NAL_UNIT_TYPE_VPS_NUT || type == HEVC_NAL_UNIT_TYPE_SPS_NUT || type == HEVC_NAL_UNIT_TYPE_PPS_NUT;
-        if (sz) p.struct_off = off_run;
-        bool active = type >= 0 && (slice || pset);
-        if (active && off_run + sz > structs_cap) { err = (uint32_t)(-HBS_E_CAPACITY); p.struct_off = ~0ull; active = false; }
+        unsigned long long inc = sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        const uint64_t off = off_run + (inc - sz);
+        if (sz) p.struct_off = off;
+        bool active = have && type >= 0 && (slice || pset);
+        if (active && off + sz > structs_cap) { err = (uint32_t)(-HBS_E_CAPACITY); p.struct_off = ~0ull; active = false; }
+        off_run += (uint64_t)__shfl(inc, 63, 64);
+        const uint64_t act_mask = __ballot(active);
+        const uint64_t walk_mask = __ballot(have && type >= 0 && (slice || pset));      /* ... and those the capacity check turned away */
+        for (uint64_t todo = act_mask; todo != 0; todo &= todo - 1) {
+            const int j = (int)__builtin_ctzll(todo);
+            const uint64_t oj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), j) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, j);
+            zero_slot(structs + oj, slot_bytes_of(__builtin_amdgcn_readlane(type, j)), lane);
+        }
+        const uint8_t* const src = rbsp + e.rbsp_off;
+        const uint32_t wb = e.rbsp_len < kLaneWin ? e.rbsp_len : kLaneWin;
+        if (active) stage_window(my_win, src, wb);
+        /* one wavefront, so everything it hands from lane to lane stays on one compute unit: workgroup-scope fences (a
+         * wait for the stores) are enough; with agent scope (write-back and invalidate of the caches) the walk is slower */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         uint32_t tr_n = 0;
-        if (active) {
-            uint8_t* dst = structs + off_run;
-            zero_slot(dst, sz, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane == 0) {
+        const int last = (n - k0 < 64) ? (int)(n - k0) : 64;
+#pragma unroll 1
+        for (int j = 0; j < last; ++j) {
+            if (!((walk_mask >> j) & 1ull)) continue;                     /* wave-uniform */
+            const bool active_j = ((act_mask >> j) & 1ull) != 0;
+            const int type_j = __builtin_amdgcn_readlane(type, j);
+            if (active_j && lane == j) {
                 const uint8_t* sps_slot = nullptr;
                 const uint8_t* pps_struct = nullptr;
                 if (slice) {
                     if (have_sps) { if (sps_off != ~0ull) sps_slot = structs + sps_off; } else sps_slot = init_sps_slot;
                     if (have_pps) { if (pps_off != ~0ull) pps_struct = structs + pps_off; } else pps_struct = init_pps;
                 }
-                /* the first bytes of the RBSP from LDS, as in k4_parse: the bit reader asks for them one at a time */
-                const uint8_t* src = rbsp + e.rbsp_off;
-                const uint32_t wb = e.rbsp_len < kLaneWin ? e.rbsp_len : kLaneWin;
-                stage_window(my_win, src, wb);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                tr_n = parse_lane<kMode>(type, slice, e, dst, my_win, wb, src, sps_slot, pps_struct, zeros, p,
+                tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, p,
                                          trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, nullptr, tables);
             }
+            if (type_j == HEVC_NAL_UNIT_TYPE_SPS_NUT || type_j == HEVC_NAL_UNIT_TYPE_PPS_NUT) {
+                const uint64_t oj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), j) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, j);
+                /* a set without room for its struct is still the set in force, with nothing to read from */
+                if (type_j == HEVC_NAL_UNIT_TYPE_SPS_NUT) { have_sps = true; sps_off = active_j ? oj : ~0ull; }
+                else { have_pps = true; pps_off = active_j ? oj : ~0ull; }
+            }
+            if (!active_j) continue;
+            /* the next lane reads what this one left in the tables and the structs */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) {          /* the tables as they stand now, next to the SPS */
-                uint4* d = reinterpret_cast<uint4*>(dst + tbl_off);
-                const uint4* src = reinterpret_cast<const uint4*>(tables);
-                for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(RpsTables) / 16); i += 64) d[i] = src[i];
+            if (type_j == HEVC_NAL_UNIT_TYPE_SPS_NUT) {          /* the tables as they stand now, next to the SPS */
+                uint4* d = reinterpret_cast<uint4*>(structs + sps_off + tbl_off);
+                const uint4* tsrc = reinterpret_cast<const uint4*>(tables);
+                for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(RpsTables) / 16); i += 64) d[i] = tsrc[i];
             }
         }
-        if (lane == 0) {
+        if (have) {
             parsed[k] = p;
             if (trace_count) trace_count[k] = tr_n;
         }
-        if (type == HEVC_NAL_UNIT_TYPE_SPS_NUT) { have_sps = true; sps_off = p.struct_off; }
-        if (type == HEVC_NAL_UNIT_TYPE_PPS_NUT) { have_pps = true; pps_off = p.struct_off; }
-        off_run += sz;
     }
     if (lane == 0) {
         sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = 0; sum->stream_bytes = 0;
