@@ -523,7 +523,9 @@ __device__ __forceinline__ void flag_batch(const u32x4 (&R)[kEmitRows], uint32_t
     }
 }
 
-/* bytes rbsp_to_nal inserts into the batch (its flagged chunks, byte-exact, on memory) */
+/* bytes rbsp_to_nal inserts into the batch: its flagged chunks, exactly, each fetched again (one 16-byte load) in a rolled
+ * loop.  (Counting them inside flag_batch from the registers that are at hand -- no load at all -- put 36 copies of the walk
+ * into the unrolled flag pass and ran 8 % slower: 9.2-9.6 against 8.6-8.9 ms on the 16 GiB arena.) */
 __device__ __forceinline__ uint32_t count_batch(const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, uint32_t r0, int lane,
                                                 uint32_t rowmask, uint32_t myflags)
 {
