@@ -1,5 +1,7 @@
 """HBM traffic per launch of the fused kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
-usage: pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <algorithmic_bytes> [out.json]
+usage: pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <algorithmic_bytes> [out.json] [near_max]
+near_max: the profiled command also ran the kernel on smaller inputs (bench.py's config-3 leg): keep only the launches whose
+counter is within 10 % of the largest one, i.e. those on the 16 GiB workload; the dropped ones stay listed in raw_KiB.
 Counters are in KiB; FETCH_SIZE is doubled per the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md."""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,15 +21,19 @@ def rows(d, sub, name):
     return list(by.values()), meta
 
 fd, wd, sub, algo = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-f, fm = rows(fd, sub, "FETCH_SIZE")
-w, wm = rows(wd, sub, "WRITE_SIZE")
+f_all, fm = rows(fd, sub, "FETCH_SIZE")
+w_all, wm = rows(wd, sub, "WRITE_SIZE")
+near_max = len(sys.argv) > 6 and sys.argv[6] == "near_max"
+f = [x for x in f_all if not near_max or x >= 0.9 * max(f_all)]
+w = [x for x in w_all if not near_max or x >= 0.9 * max(w_all)]
 fetch = sum(f) / len(f) * 1024 * 2
 write = sum(w) / len(w) * 1024
 res = {"kernel_substring": sub, "launches": {"fetch_pass": len(f), "write_pass": len(w)},
        "fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write),
        "traffic_bytes_per_launch": int(fetch + write), "algorithmic_bytes_per_launch": algo,
        "ratio_traffic_over_algorithmic": round((fetch + write) / algo, 4),
-       "raw_KiB": {"FETCH_SIZE": f, "WRITE_SIZE": w},
+       "raw_KiB": {"FETCH_SIZE": f_all, "WRITE_SIZE": w_all},
+       "launches_kept": "within 10 % of the largest (the 16 GiB workload)" if near_max else "all",
        "source_sha256": hevcbitstream_amd.source_digest(),     # of hevcbitstream_amd/csrc: bench.py quotes this file only while it matches
        "dispatch": {k: fm.get(k) for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count")},
        "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (no trace domains); KiB units; FETCH_SIZE x2 (gfx950)"}

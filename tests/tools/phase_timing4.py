@@ -33,7 +33,7 @@ assert lib.hbs_debug_phase_cycles4(out.ctypes.data) == 0
 names = ["ticket+fetch issue", "flags+list", "elements A", "lookback", "elements B", "copy"]
 nwg = min(blocks, 1024)
 act = out[:nwg, :6].astype(np.float64)
-tile_bytes = int(os.environ.get("HBS4_TILE", 65536))
+tile_bytes = int(os.environ.get("HBS4_TILE", 196608))
 tiles = d.numel() / tile_bytes / blocks
 tot = act.sum(axis=1).mean()
 print("v4 mode", mode, "rbsp", want_rbsp, "grid", blocks, "per CU", per_cu, "tiles/WG %.1f -> cycles/tile %.0f" % (tiles, tot / tiles))
