@@ -181,6 +181,48 @@ void k_read_ldsdma(const uint8_t* __restrict__ src, uint32_t* __restrict__ out, 
     if (nrows == 1) out[threadIdx.x] = ring[threadIdx.x];
 }
 
+// copy through LDS-DMA: a wavefront owns two buffers of DEPTH KiB in LDS; the loads of step i+1 fly while step i is read
+// back from LDS and stored (non-temporal, byte-misaligned by `shift`)
+template <int DEPTH>
+__global__ __launch_bounds__(256)
+void k_copy_ldsdma(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t nrows /* KiB */, int shift)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __attribute__((address_space(3))) uint8_t* my = (__attribute__((address_space(3))) uint8_t*)ring + wave * 2 * DEPTH * 1024;
+    const uint8_t* mine = ring + wave * 2 * DEPTH * 1024;
+    const size_t piece = 4 * DEPTH;      // rows per workgroup step
+    const size_t step = (size_t)gridDim.x * piece;
+    size_t r0 = (size_t)blockIdx.x * piece + (size_t)wave * DEPTH;
+    int b = 0;
+    if (r0 + DEPTH <= nrows) {
+#pragma unroll
+        for (int r = 0; r < DEPTH; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (r0 + r) * 1024 + 16 * lane),
+                                             (__attribute__((address_space(3))) void*)(my + (b * DEPTH + r) * 1024), 16, 0, 2);
+    }
+    for (; r0 + DEPTH <= nrows; r0 += step) {
+        const size_t rn = r0 + step;
+        const bool more = rn + DEPTH <= nrows;
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < DEPTH; ++r)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (rn + r) * 1024 + 16 * lane),
+                                                 (__attribute__((address_space(3))) void*)(my + ((b ^ 1) * DEPTH + r) * 1024), 16, 0, 2);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < DEPTH; ++r) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(mine + (b * DEPTH + r) * 1024 + 16 * lane);
+            __builtin_nontemporal_store(v, &reinterpret_cast<U16*>(dst + (r0 + r) * 1024 + 16 * lane + shift)->v);
+        }
+        b ^= 1;
+    }
+}
+
 template <class F> float time_ms(F f, int reps = 5)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -258,6 +300,19 @@ int main(int argc, char** argv)
         ro(nm, time_ms([&] { k_read_ldsdma<8, 1><<<g, 256, 32768>>>(src, out, n >> 10); }));
         snprintf(nm, 64, "ldsdma depth16 nt grid %d", g);
         ro(nm, time_ms([&] { k_read_ldsdma<16, 1><<<g, 256, 65536>>>(src, out, n >> 10); }));
+    }
+    for (int shift : {0, 7}) {
+        for (int g : {512, 1024, 2048}) {
+            char nm[64];
+            snprintf(nm, 64, "ldsdma depth8 grid %d shift %d", g, shift);
+            rw(nm, time_ms([&] { k_copy_ldsdma<8><<<g, 256, 65536>>>(src, dst, n >> 10, shift); }));
+            snprintf(nm, 64, "ldsdma depth4 grid %d shift %d", g, shift);
+            rw(nm, time_ms([&] { k_copy_ldsdma<4><<<g, 256, 32768>>>(src, dst, n >> 10, shift); }));
+        }
+        char nm[64];
+        snprintf(nm, 64, "ldsdma depth16 grid 256 shift %d", shift);
+        hipFuncSetAttribute((const void*)k_copy_ldsdma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        rw(nm, time_ms([&] { k_copy_ldsdma<16><<<256, 256, 131072>>>(src, dst, n >> 10, shift); }));
     }
     hipError_t e = hipDeviceSynchronize();
     printf("status: %s\n", hipGetErrorString(e));
