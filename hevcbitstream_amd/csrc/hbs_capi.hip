@@ -35,6 +35,7 @@ struct hbs_ctx {
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
+    int emit_tile_blocks, emit_tiles; /* ... of the arena-tile kernel; 0 never / 1 when eligible / 2 pinned */
     int emit_path_set;                /* hbs_ctx_set_emit_path was called: the environment no longer decides */
     int sched;
     unsigned long long* desc;
@@ -212,8 +213,11 @@ int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
 
 int hbs_ctx_set_emit_path(hbs_ctx* c, int path)
 {
-    if (!c || path < -1 || path > 1) return HBS_E_ARG;
-    c->emit_two_pass = path;
+    if (!c || path < -1 || path > 2) return HBS_E_ARG;
+    /* -1: everything picked per call; 0: the item kernel (k3_fused); 1: count / scan / emit; 2: the arena-tile kernel whenever the
+     * index allows it (the item kernel when it does not) */
+    c->emit_two_pass = path == 2 ? 0 : path;
+    c->emit_tiles = path == 2 ? 2 : (path == -1 ? 1 : 0);
     c->emit_path_set = 1;
     return 0;
 }
@@ -308,7 +312,11 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
         const char* eb = getenv("HBS_EMIT_BLOCKS");         /* debugging aid */
         if (eb && atoi(eb) > 0 && atoi(eb) < c->emit_blocks) c->emit_blocks = atoi(eb);
         const char* tp = getenv("HBS_EMIT_TWO_PASS");        /* 1 / 0 pin a way; default: picked on the device */
-        if (!c->emit_path_set) c->emit_two_pass = !tp ? -1 : (atoi(tp) == 1 ? 1 : 0);
+        if (!c->emit_path_set) { c->emit_two_pass = !tp ? -1 : (atoi(tp) == 1 ? 1 : 0); c->emit_tiles = !tp ? 1 : 0; }
+        const char* et = getenv("HBS_EMIT_TILES");          /* 0 / 1 / 2: never / when eligible / pinned */
+        if (!c->emit_path_set && et && atoi(et) >= 0 && atoi(et) <= 2) c->emit_tiles = atoi(et);
+        c->emit_tile_blocks = hbs::emit_tile_grid_blocks(c->device);
+        if (c->emit_tile_blocks <= 0) return fail(c, hipErrorUnknown, "occupancy query of the arena-tile emit kernel");
     }
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::EmitArgs a;
@@ -326,6 +334,8 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.n_items = reinterpret_cast<unsigned long long*>(tail + 768);
     a.total_dense = reinterpret_cast<unsigned long long*>(tail + 768 + 64);
     a.probe = reinterpret_cast<uint32_t*>(tail + 768 + 128);
+    a.tflag = reinterpret_cast<uint32_t*>(tail + 768 + 192);
+    a.tiles = c->emit_tiles; a.tile_blocks = c->emit_tile_blocks;
     a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);

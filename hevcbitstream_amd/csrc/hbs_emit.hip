@@ -16,7 +16,9 @@
  */
 #include <hip/hip_runtime.h>
 #include "hbs_wave.h"
+#include <utility>
 #include "hbs_sparse.h"
+#include "hbs_elems.h"
 #include "hbs_emit.h"
 #include "hbs_emit_launch.h"
 
@@ -29,6 +31,10 @@ namespace hbs {
  * arena and both ways are enqueued; the one it rules out returns at once. */
 constexpr uint32_t kEmitDenseOneIn = 800;
 __device__ __forceinline__ bool emit_probe_dense(const uint32_t* probe) { return (uint64_t)probe[1] * kEmitDenseOneIn > (uint64_t)probe[0]; }
+
+/* the arena-tile kernel (k3_tiles, below) takes the sparse case when k3t_check found the index eligible: tflag[0] = a
+ * violation was seen, tflag[1] = the global conditions hold */
+__device__ __forceinline__ bool tile_path_on(const uint32_t* tflag) { return tflag && tflag[1] == 1u && tflag[0] == 0u; }
 
 enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2 };
 __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when)
@@ -668,9 +674,9 @@ __global__ void k3_seg_count(const hbs_nal_entry* __restrict__ idx, uint64_t n, 
 
 __global__ void k3_expand(const unsigned long long* __restrict__ segs, const unsigned long long* __restrict__ item_base, uint64_t n,
                           const unsigned long long* __restrict__ n_items, unsigned long long* __restrict__ items, uint64_t items_cap,
-                          const uint32_t* __restrict__ probe)
+                          const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    if (probe && emit_probe_dense(probe)) return;
+    if ((probe && emit_probe_dense(probe)) || tile_path_on(tflag)) return;      /* (the tile kernel keeps its own table in `items`) */
     if (*n_items == n || *n_items > items_cap) return;       /* identity: nothing to build; too many: the main kernel reports it */
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long base = item_base[k], m = segs[k];
@@ -706,9 +712,10 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
               const unsigned long long* __restrict__ items, const unsigned long long* __restrict__ n_items_ptr, uint64_t items_cap,
               unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
               uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
-              unsigned long long* __restrict__ total, uint32_t* __restrict__ err, const uint32_t* __restrict__ probe)
+              unsigned long long* __restrict__ total, uint32_t* __restrict__ err, const uint32_t* __restrict__ probe,
+              const uint32_t* __restrict__ tflag)
 {
-    if (probe && emit_probe_dense(probe)) return;
+    if ((probe && emit_probe_dense(probe)) || tile_path_on(tflag)) return;
     __shared__ Lds3 l;
     const int lane0 = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -881,6 +888,466 @@ void k_synth_fill(uint64_t seed, uint64_t n, int mode, const unsigned long long*
 
 /* ---- host side --------------------------------------------------------------- */
 
+/* ---- arena tiles: K3 with K12's shape -----------------------------------------------------------------------
+ * k3_fused cuts the work by NAL: a slot holds one NAL's (segment's) rows, 83 % full on 8-12 KiB NALs, loads and stores both
+ * byte-misaligned, 120 KiB per look-back.  When the NALs of the index lie back to back in the arena -- what hbs_index_extract
+ * produces, and what hbs_write_headers + a scan produce -- the arena itself can be tiled the way K12 tiles a stream: 192 KiB of
+ * ARENA per workgroup, 48 aligned rows of 1 KiB per wavefront in registers, and the few 16-byte chunks that need more than
+ * a copy are "elements" walked exactly by wavefront 0: chunks chunk_flag() cannot clear (a 03 may have to go in) and chunks
+ * in which a NAL begins (its start code goes in, the count of zeros restarts, its index entry is written).  A tile's
+ * aggregate is one number -- the bytes inserted in it -- so the look-back is k3_fused's.  Every other chunk is one 16-byte
+ * store at (its arena offset + bytes inserted in front of it).  Same bytes as the other paths (h264_nal.c:92-132 per NAL).
+ *
+ * Eligibility is decided on the device (k3t_check): NALs contiguous and in order, first byte 16-byte aligned, gaps below
+ * 1 MiB, no 192 KiB window with more than 256 NAL starts, workspace large enough; otherwise k3_fused runs as before. */
+constexpr int kTRows = 48, kTWaves = 4, kTThreads = 64 * kTWaves;
+constexpr uint32_t kTWaveBytes = (uint32_t)kTRows * 1024u, kTTileBytes = (uint32_t)kTWaves * kTWaveBytes;
+constexpr int kTChunks = (int)(kTTileBytes / 16u);
+constexpr int kTParkRows = 28;
+constexpr uint32_t kTMaxStarts = 256, kTMaxGap = 1u << 20;
+constexpr uint64_t kTMinArena = 1ull << 20;
+constexpr int kTElemPass = 64;
+/* an entry of the tile's element list: chunk number | why it is one */
+constexpr uint32_t kTListFlag = 0x8000u;      /* chunk_flag(): a 03 may have to go in                     */
+constexpr uint32_t kTListStart = 0x4000u;     /* a NAL begins in it (or it is the arena's partial last chunk) */
+constexpr uint32_t kTListChunk = 0x3FFFu;
+static_assert(kTChunks <= (int)kTListChunk + 1, "a chunk number fits the list entry");
+
+
+__global__ __launch_bounds__(256)
+void k3t_check(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+               uint64_t items_cap, uint64_t desc_words, int pinned, uint32_t* __restrict__ tflag)
+{
+    bool bad = false;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t off = idx[k].rbsp_off;
+        if (k > 0 && off != idx[k - 1].rbsp_off + idx[k - 1].rbsp_len) bad = true;
+        if (gap_of(idx, k, gap_mode) >= (uint64_t)kTMaxGap) bad = true;
+        if (k + kTMaxStarts < n && idx[k + kTMaxStarts].rbsp_off - off < (uint64_t)kTTileBytes) bad = true;
+    }
+    if (bad) atomicOr(&tflag[0], 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t a0 = idx[0].rbsp_off;
+        const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
+        const uint64_t ntiles = arena_len / kTTileBytes + 1;
+        const bool ok = ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
+                        ntiles + 1 <= items_cap && ntiles + 1 <= desc_words;
+        tflag[1] = ok ? 1u : 0u;
+    }
+}
+
+/* first_k[t] = the first NAL that begins at or behind tile t's first byte (t = 0 .. ntiles, the last one = n) */
+__global__ __launch_bounds__(256)
+void k3t_first(const hbs_nal_entry* __restrict__ idx, uint64_t n, unsigned long long* __restrict__ first_k,
+               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
+{
+    if ((probe && emit_probe_dense(probe)) || !tile_path_on(tflag)) return;
+    const uint64_t a0 = idx[0].rbsp_off;
+    const uint64_t ntiles = (idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0) / kTTileBytes + 1;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k <= n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = k == 0 ? 0 : (idx[k - 1].rbsp_off - a0) / kTTileBytes + 1;
+        const uint64_t hi = k < n ? (idx[k].rbsp_off - a0) / kTTileBytes : ntiles;
+        for (uint64_t t = lo; t <= hi; ++t) first_k[t] = k;
+    }
+}
+
+struct LdsT {
+    unsigned long long rowbits[kTWaves * kTRows];    /* chunks in which a NAL begins (and the arena's last, partial chunk) */
+    uint32_t starts[kTMaxStarts];                    /* where the tile's NALs begin, tile-relative, in order */
+    uint32_t gaps[kTMaxStarts];                      /* bytes in front of each (zeros + 01)                  */
+    uint32_t lens[kTMaxStarts];                      /* their rbsp_len (for the output index)                */
+    uint16_t list[kTChunks];                         /* the tile's elements, in order                        */
+    uint32_t seg[kTElemPass + 1];                    /* bytes inserted in the tile up to and including element i of the batch; [0]: before the batch */
+    u32x4 park[kTParkRows][64];
+    uint32_t wave_tot[kTWaves];
+    unsigned long long before;                       /* bytes inserted in front of the tile                  */
+    uint32_t ok;
+    uint32_t ticket;
+};
+
+struct TileCtx {
+    const uint8_t* arena;         /* first byte of the first NAL */
+    uint64_t arena_len, tile_lo;  /* tile_lo: arena offset of the tile */
+    uint64_t k_lo;                /* first NAL that begins in the tile */
+    uint32_t m;                   /* how many do */
+    uint64_t prev_begin;          /* arena offset at which the NAL in progress at the tile's first byte begins */
+    uint64_t a0;                  /* idx[0].rbsp_off */
+};
+
+__device__ __forceinline__ uint32_t lower_bound_lds(const uint32_t* a, uint32_t m, uint32_t v)
+{
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* n (0..16) bytes from the low end of lo:hi to dst, with at most four stores */
+__device__ __forceinline__ void store_n(uint8_t* dst, uint64_t lo, uint64_t hi, uint32_t n)
+{
+    struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+    struct __attribute__((packed, aligned(1))) U2 { uint16_t v; };
+    if (n & 16u) { reinterpret_cast<U8*>(dst)->v = lo; reinterpret_cast<U8*>(dst + 8)->v = hi; return; }
+    if (n & 8u) { reinterpret_cast<U8*>(dst)->v = lo; dst += 8; lo = hi; }
+    if (n & 4u) { reinterpret_cast<U4*>(dst)->v = (uint32_t)lo; dst += 4; lo >>= 32; }
+    if (n & 2u) { reinterpret_cast<U2*>(dst)->v = (uint16_t)lo; dst += 2; lo >>= 16; }
+    if (n & 1u) *dst = (uint8_t)lo;
+}
+/* lo:hi >>= 8 n bytes (n = 0..16) */
+__device__ __forceinline__ void shift_bytes(uint64_t& lo, uint64_t& hi, uint32_t n)
+{
+    if (n >= 8u) { lo = n >= 16u ? 0ull : hi >> (8u * (n - 8u)); hi = 0ull; }
+    else if (n) { lo = (lo >> (8u * n)) | (hi << (64u - 8u * n)); hi >>= 8u * n; }
+}
+
+/* One element: entry `ent` of the tile's list (chunk number + why).  Returns the bytes that go in (03s and the gaps of the NALs
+ * that begin in it); kEmit: also writes the chunk with them at out + pos (when `store`) and the index entries of those NALs.
+ * out = where the tile's byte 0 goes with nothing inserted in the tile, abs0 = its offset in the output, pos = this chunk's
+ * offset from there. */
+template <bool kEmit>
+__device__ __forceinline__ uint32_t tile_element(const TileCtx& t, const LdsT& l, uint32_t ent, uint8_t* __restrict__ out, uint64_t abs0, uint64_t pos,
+                                                 bool store, hbs_nal_entry* __restrict__ idx_out, u32x4& qk, bool have_q)
+{   /* qk: the chunk's bytes, fetched by the counting call (its latency then lies under the look-back) and handed to the emitting one */
+    const uint32_t c = ent & kTListChunk;
+    const uint32_t p = 16u * c;
+    const uint64_t x0 = t.tile_lo + p;
+    const uint32_t nb = t.arena_len - x0 < 16u ? (uint32_t)(t.arena_len - x0) : 16u;
+    if (!have_q) qk = load_chunk_guarded(t.arena, x0, t.arena_len);
+    const uint32_t j0 = lower_bound_lds(l.starts, t.m, p);
+    if (ent & kTListStart) {
+        /* NALs begin here and chunk_flag() cleared the chunk: no 03 can go in (a start only resets the count), so what goes in
+         * is the gaps, and the chunk's bytes go out in pieces between them */
+        uint32_t ins = 0, j = j0;
+        uint64_t lo = 0, hi = 0;
+        uint8_t* dst = out + pos;
+        uint32_t done = 0;                                           /* bytes of the chunk written so far */
+        if (kEmit && store) { lo = ((uint64_t)qk.y << 32) | qk.x; hi = ((uint64_t)qk.w << 32) | qk.z; }
+#pragma unroll 1
+        while (j < t.m) {
+            const uint32_t sj = l.starts[j];
+            if (sj >= p + 16u) break;
+            const uint32_t gap = l.gaps[j];
+            if (kEmit) {
+                const uint32_t i = sj - p;
+                if (store) {
+                    store_n(dst, lo, hi, i - done);
+                    shift_bytes(lo, hi, i - done);
+                    dst += i - done;
+                    if (gap <= 8u) store_n(dst, gap ? 1ull << (8u * (gap - 1u)) : 0ull, 0ull, gap);
+                    else { for (uint32_t g = 0; g + 1 < gap; ++g) dst[g] = 0; dst[gap - 1] = 1; }
+                    dst += gap;
+                }
+                done = i;
+                if (idx_out) {
+                    const uint64_t k = t.k_lo + j;
+                    const uint64_t at = abs0 + pos + i + ins;        /* where its gap begins = where the NAL in front ends */
+                    if (k > 0) idx_out[k - 1].end = at;
+                    idx_out[k].start = at + gap; idx_out[k].rbsp_off = t.a0 + x0 + i; idx_out[k].rbsp_len = l.lens[j]; idx_out[k].status = 0;
+                }
+            }
+            ins += gap;
+            ++j;
+        }
+        if (kEmit && store) store_n(dst, lo, hi, nb - done);
+        return ins;
+    }
+    u32x4 q = qk;
+    const uint32_t j1 = lower_bound_lds(l.starts, t.m, p + 16u);
+    /* the count the chunk is entered with: zeros in front of it inside the NAL in progress */
+    const uint64_t begin = j0 > 0 ? t.tile_lo + l.starts[j0 - 1] : t.prev_begin;
+    uint32_t count = 0;
+    if (x0 > begin) {
+        const uint64_t d = x0 - begin;
+        uint32_t xp = load_dword_guarded(t.arena, (int64_t)x0 - 4, t.arena_len);
+        if (d < 4) xp |= 0xFFFFFFFFu >> (8u * (uint32_t)d);           /* bytes of the NAL in front: not zeros of this one */
+        count = lead_count4(xp);
+        if (count == kLeadUnknown) count = d == 4 ? 2u : lead_count(t.arena, begin, x0);
+    }
+    if (j0 == j1) {                                                  /* no NAL begins here: a flagged chunk as in the other paths */
+        const uint32_t mask = insert_mask16(q.x, q.y, q.z, q.w, nb, count);
+        if (kEmit && store) {
+            ExactChunk e;
+            e.q = q; e.nb = nb; e.mask = mask;
+            store_exact(out + pos, e);
+        }
+        return (uint32_t)__builtin_popcount(mask);
+    }
+    /* both (rare): byte by byte */
+    uint32_t ins = 0, j = j0;
+    uint8_t* dst = out + pos;
+#pragma unroll 1
+    for (uint32_t i = 0; i < 16u; ++i) {
+        while (j < j1 && l.starts[j] == p + i) {                     /* NAL k_lo + j begins in front of byte i (empty NALs: several) */
+            const uint32_t gap = l.gaps[j];
+            if (kEmit) {
+                const uint64_t k = t.k_lo + j;
+                const uint64_t at = abs0 + pos + i + ins;
+                if (store) {
+                    for (uint32_t g = 0; g + 1 < gap; ++g) dst[i + ins + g] = 0;
+                    if (gap) dst[i + ins + gap - 1] = 1;
+                }
+                if (idx_out) {
+                    if (k > 0) idx_out[k - 1].end = at;
+                    idx_out[k].start = at + gap; idx_out[k].rbsp_off = t.a0 + x0 + i; idx_out[k].rbsp_len = l.lens[j]; idx_out[k].status = 0;
+                }
+            }
+            ins += gap;
+            count = 0;
+            ++j;
+        }
+        if (i < nb) {
+            const uint32_t v = q.x & 0xFFu;
+            if (count == 2u && v <= 3u) { if (kEmit && store) dst[i + ins] = 3; ++ins; count = 0; }
+            if (kEmit && store) dst[i + ins] = (uint8_t)v;
+            count = (v == 0u) ? count + 1u : 0u;
+            q.x = (q.x >> 8) | (q.y << 24); q.y = (q.y >> 8) | (q.z << 24); q.z = (q.z >> 8) | (q.w << 24); q.w >>= 8;
+        }
+    }
+    return ins;
+}
+
+template <class F, int... Is>
+__device__ __forceinline__ void t_rows_apply(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void t_for_n(F&& f) { t_rows_apply(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+__global__ __launch_bounds__(kTThreads, 2)
+void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+              const unsigned long long* __restrict__ first_k, unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
+              uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
+              unsigned long long* __restrict__ total, uint32_t* __restrict__ err,
+              const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
+{
+    if ((probe && emit_probe_dense(probe)) || !tile_path_on(tflag)) return;
+    __shared__ LdsT l;
+    const int tid0 = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    TileCtx t;
+    t.a0 = idx[0].rbsp_off;
+    t.arena = rbsp + t.a0;
+    t.arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - t.a0;
+    const uint64_t ntiles = t.arena_len / kTTileBytes + 1;
+    HBS3_T_DECL
+    for (;;) {
+        const int lane = launder_lane(tid0) & 63;
+        const int tid = launder_lane(tid0);
+        __syncthreads();                                           /* the previous tile is done with l */
+        if (tid == 0) l.ticket = atomicAdd(ticket, 1u);
+        if (tid < kTWaves * kTRows) l.rowbits[tid] = 0ull;
+        __syncthreads();
+        const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
+        if (tile >= ntiles) break;
+        HBS3_T_MARK(0)
+        __builtin_amdgcn_s_setprio(3);
+        t.tile_lo = tile * (uint64_t)kTTileBytes;
+        const bool last_tile = tile == ntiles - 1;
+        const uint64_t wseg = t.tile_lo + (uint64_t)(wv * (int)kTWaveBytes);
+
+        /* ---- my rows ---------------------------------------------------------------------------------------- */
+        u32x4 q[kTRows];
+        uint32_t before;
+        if (t.arena_len >= 16u) {
+            /* unpredicated: a chunk that would reach past the arena's end reads the arena's last 16 bytes instead (its register is
+             * never used: the chunk is behind the end, or it is the partial last chunk, an element that fetches its own bytes) */
+            const uint64_t room = t.arena_len - 16u - t.tile_lo;
+            const uint32_t lim = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
+            const uint8_t* const tb = t.arena + t.tile_lo;
+#pragma unroll
+            for (int r = 0; r < kTRows; ++r) {
+                const uint32_t rel = (uint32_t)(wv * (int)kTWaveBytes + 1024 * r) + 16u * (uint32_t)lane;
+                q[r] = stream_load16(reinterpret_cast<const u32x4*>(tb + (rel < lim ? rel : lim)));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kTRows; ++r) q[r] = load_chunk_guarded(t.arena, wseg + 1024u * r + 16u * lane, t.arena_len);
+        }
+        before = load_dword_guarded(t.arena, (int64_t)wseg - 4, t.arena_len);
+
+        /* ---- the NALs that begin in the tile ------------------------------------------------------------------ */
+        t.k_lo = first_k[tile];
+        t.m = (uint32_t)(first_k[tile + 1] - t.k_lo);
+        t.prev_begin = t.k_lo > 0 ? idx[t.k_lo - 1].rbsp_off - t.a0 : 0ull;
+        if ((uint32_t)tid < t.m) {
+            const uint64_t k = t.k_lo + (uint32_t)tid;
+            const uint32_t rel = (uint32_t)(idx[k].rbsp_off - t.a0 - t.tile_lo);
+            l.starts[tid] = rel;
+            l.gaps[tid] = (uint32_t)gap_of(idx, k, gap_mode);
+            l.lens[tid] = idx[k].rbsp_len;
+            atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+        }
+        const uint32_t cut_chunk = (last_tile && (t.arena_len & 15ull) != 0) ? (uint32_t)((t.arena_len - t.tile_lo) >> 4) : 0xFFFFFFFFu;
+        if (last_tile && tid == 0 && (t.arena_len & 15ull) != 0) {  /* the arena's last, partial chunk is written bytewise */
+            const uint32_t rel = (uint32_t)(t.arena_len - t.tile_lo);
+            atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+        }
+
+        HBS3_T_MARK(1)
+        /* ---- flags: chunks a 03 may have to go into (four rows per branch, as in K12) ----------------------------- */
+        uint32_t fm_lo = 0, fm_hi = 0;
+        t_for_n<kTRows / 4>([&](auto gc) {
+            constexpr int g0 = 4 * decltype(gc)::value;
+            uint64_t fmask[4];
+            t_for_n<4>([&](auto kc) {
+                constexpr int k = decltype(kc)::value, r = g0 + k;
+                const uint32_t e_prev = (r == 0) ? before : (uint32_t)__builtin_amdgcn_readlane((int)q[r ? r - 1 : 0].w, 63);
+                const uint32_t xp = from_prev_lane(q[r].w, e_prev);
+                fmask[k] = __ballot(chunk_flag(xp, q[r].x, q[r].y, q[r].z, q[r].w, 0xFFFFFFFFu));
+            });
+            if ((fmask[0] | fmask[1] | fmask[2] | fmask[3]) != 0) {
+                t_for_n<4>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value, r = g0 + k;
+                    if (fmask[k] != 0) { write_lane_c<r>(fm_lo, (uint32_t)fmask[k]); write_lane_c<r>(fm_hi, (uint32_t)(fmask[k] >> 32)); }
+                });
+            }
+        });
+        __syncthreads();                                           /* rowbits, starts, gaps are complete */
+        uint32_t sm_lo = 0, sm_hi = 0;                             /* lane r: chunks of row r in which a NAL begins */
+        if (lane < kTRows) {
+            const unsigned long long sb = l.rowbits[wv * kTRows + lane];
+            sm_lo = (uint32_t)sb; sm_hi = (uint32_t)(sb >> 32);
+            unsigned long long f = (((unsigned long long)fm_hi << 32) | fm_lo) | sb;
+            /* chunks behind the arena's end hold nothing */
+            const uint64_t row_lo = wseg + 1024ull * (uint32_t)lane;
+            if (row_lo > t.arena_len) f = 0;
+            else if (row_lo + 1024u > t.arena_len) f &= (2ull << ((t.arena_len - row_lo) >> 4)) - 1ull;     /* up to the chunk that holds the end */
+            /* what chunk_flag() said, apart: fz = flagged (a 03 may go in), the rest of f = only a NAL start */
+            const unsigned long long fz = f & (((unsigned long long)fm_hi << 32) | fm_lo);
+            sm_lo = (uint32_t)(f & ~fz) ; sm_hi = (uint32_t)((f & ~fz) >> 32);        /* start only: no 03 can go into these */
+            fm_lo = (uint32_t)f; fm_hi = (uint32_t)(f >> 32);
+            (void)sb;
+        }
+        const uint32_t cnt = (lane < kTRows) ? (uint32_t)__builtin_popcount(fm_lo) + (uint32_t)__builtin_popcount(fm_hi) : 0u;
+        const uint32_t inc = wave_incl_scan32(cnt, lane);
+        const uint32_t local_pre = inc - cnt;
+        const uint64_t rowmask = __ballot(cnt != 0u);
+        if (lane == 63) l.wave_tot[wv] = inc;
+        __syncthreads();
+        const uint32_t wt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[0]), wt1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[1]);
+        const uint32_t wt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[2]), wt3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[3]);
+        const uint32_t nflag = wt0 + wt1 + wt2 + wt3;
+        const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? wt0 : (wv == 2) ? wt0 + wt1 : wt0 + wt1 + wt2;
+        for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
+            const int r = __builtin_ctzll(rm);
+            const uint32_t rp = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
+            const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, r);
+            const uint64_t so = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)sm_lo, r);
+            const uint32_t chunk = (uint32_t)(64 * (kTRows * wv + r) + lane);
+            if ((f >> lane) & 1ull)          /* (the arena's partial last chunk was not seen by chunk_flag(): the general way) */
+                l.list[rp + lanes_below(f)] = (uint16_t)(chunk | ((((so >> lane) & 1ull) && chunk != cut_chunk) ? kTListStart : kTListFlag));
+        }
+        __syncthreads();
+        HBS3_T_MARK(2)
+
+        /* ---- wavefront 0: the elements' inserted bytes -> the tile's size -> where it starts -------------------------- */
+        const uint32_t npass = (nflag + (uint32_t)kTElemPass - 1u) / (uint32_t)kTElemPass;
+        uint32_t e_first = 0;
+        u32x4 q_first = u32x4{0u, 0u, 0u, 0u};
+        const uint64_t tile_bytes = t.arena_len - t.tile_lo < (uint64_t)kTTileBytes ? t.arena_len - t.tile_lo : (uint64_t)kTTileBytes;
+        if (wv == 0) {
+#pragma unroll
+            for (int i = 0; i < kTParkRows; ++i) l.park[i][lane] = q[kTRows - kTParkRows + i];
+            unsigned long long tile_ins = 0;
+#pragma unroll 1
+            for (uint32_t p = 0; p < npass; ++p) {
+                const uint32_t i = p * (uint32_t)kTElemPass + (uint32_t)lane;
+                uint32_t e = 0;
+                u32x4 qtmp;
+                if (i < nflag) e = tile_element<false>(t, l, l.list[i], nullptr, 0, 0, false, nullptr, p == 0 ? q_first : qtmp, false);
+                if (p == 0) e_first = e;                         /* the first batch (nearly always the only one) is not counted again */
+                tile_ins += wave_sum32(e);
+            }
+            HBS3_T_MARK(3)
+            if (lane == 0 && tile != 0) st_desc3(desc + tile, (tile_ins << 2) | 1ull);
+            __builtin_amdgcn_s_setprio(0);
+            const unsigned long long bf = k3_look_back(desc, tile, lane, err);
+            HBS3_T_MARK(4)
+            if (lane == 0) {
+                st_desc3(desc + tile, ((bf + tile_ins) << 2) | 2ull);
+                const uint64_t end_pos = t.tile_lo + tile_bytes + bf + tile_ins;       /* output offset behind the tile */
+                l.before = bf;
+                l.ok = end_pos <= out_cap ? 1u : 0u;
+                if (end_pos > out_cap) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+                if (last_tile) {
+                    *total = end_pos;
+                    if (idx_out) idx_out[n - 1].end = end_pos;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kTParkRows; ++i) q[kTRows - kTParkRows + i] = l.park[i][lane];
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+        HBS3_T_MARK(5)
+        const bool can_store = l.ok != 0u;
+        uint8_t* const tout = out + t.tile_lo + l.before;            /* where byte 0 of the tile goes when nothing is inserted in it */
+        const uint32_t whole = (uint32_t)(tile_bytes >> 4);           /* chunks of the tile that are complete */
+
+        /* ---- the bytes: elements by wavefront 0, 64 at a time, each batch followed by the copy of the chunks behind it ---- */
+        uint32_t ins_run = 0;                                       /* wavefront 0: bytes inserted by the batches done */
+        const uint32_t np = npass ? npass : 1u;
+#pragma unroll 1
+        for (uint32_t p = 0; p < np; ++p) {
+            const uint32_t pbase = p * (uint32_t)kTElemPass;
+            if (wv == 0) {
+#pragma unroll
+                for (int i = 0; i < kTParkRows; ++i) l.park[i][lane] = q[kTRows - kTParkRows + i];
+                const uint32_t i = pbase + (uint32_t)lane;
+                uint32_t e = 0, c = 0;
+                u32x4 qe = q_first;
+                if (i < nflag) { c = l.list[i]; e = p == 0u ? e_first : tile_element<false>(t, l, c, nullptr, 0, 0, false, nullptr, qe, false); }
+                const uint32_t inc_e = wave_incl_scan32(e, lane);
+                const uint32_t mine_before = ins_run + inc_e - e;
+                if (i < nflag && (can_store || idx_out))
+                    (void)tile_element<true>(t, l, c, tout, t.tile_lo + l.before, 16ull * (c & kTListChunk) + mine_before, can_store, idx_out, qe, true);
+                if (lane == 0) l.seg[0] = ins_run;
+                l.seg[lane + 1] = ins_run + inc_e;
+                ins_run += (uint32_t)__builtin_amdgcn_readlane((int)inc_e, 63);
+#pragma unroll
+                for (int i2 = 0; i2 < kTParkRows; ++i2) q[kTRows - kTParkRows + i2] = l.park[i2][lane];
+            }
+            __syncthreads();
+            if (can_store) {
+                const int lane = launder_lane(tid0) & 63;          /* the store addresses are formed here, not in front of the element code */
+                const uint32_t cc0 = (uint32_t)(64 * kTRows * wv + lane);
+                const uint32_t segv = l.seg[lane];
+                const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[kTElemPass]);
+                t_for_n<kTRows>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const uint32_t cc = cc0 + 64u * r;
+                    const uint32_t rowpre = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
+                    if (!((rowmask >> r) & 1ull)) {             /* no element in this row: one word for all lanes */
+                        const uint32_t k = rowpre;
+                        const bool served = p == 0u ? k <= (uint32_t)kTElemPass : (k > pbase && k <= pbase + (uint32_t)kTElemPass);
+                        if (served) {
+                            const uint32_t j = k - pbase;
+                            const uint32_t w = (j == (uint32_t)kTElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(j & 63u));
+                            if (cc < whole) arena_store16(tout + w + 16u * cc, q[r]);
+                        }
+                    } else {
+                        const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, r);
+                        const uint32_t k = rowpre + lanes_below(f);
+                        const bool served = p == 0u ? k <= (uint32_t)kTElemPass : (k > pbase && k <= pbase + (uint32_t)kTElemPass);
+                        if (!((f >> lane) & 1ull) && served && cc < whole) arena_store16(tout + l.seg[k - pbase] + 16u * cc, q[r]);
+                    }
+                });
+            }
+            if (p + 1 < np) __syncthreads();                       /* the batch's words are read: the next batch may write them */
+        }
+        HBS3_T_MARK(6)
+    }
+    HBS3_T_FLUSH
+}
+
+int emit_tile_grid_blocks(int device)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_tiles, kTThreads, 0) != hipSuccess || per_cu < 1) return -1;
+    return prop.multiProcessorCount * per_cu;
+}
+
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
 {
     if (emit_takes_small_path(a.n, a.rbsp_bytes, a.two_pass)) {
@@ -895,16 +1362,27 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     const uint32_t* probe = a.two_pass < 0 ? a.probe : nullptr;
     const bool want_dense = a.two_pass != 0, want_sparse = a.two_pass <= 0;
     if (a.n && probe) k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
+    /* arena tiles when the index allows it (decided on the device), the item kernel otherwise; path 0 pins the item kernel */
+    const uint32_t* tflag = (a.n && want_sparse && a.tiles != 0) ? a.tflag : nullptr;
+    if (tflag) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.items_cap, emit_desc_words(a.items_cap), a.tiles == 2 ? 1 : 0, a.tflag);
     if (a.n && want_sparse) {
         /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
         k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse);
-        k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe);
+        k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe, tflag);
         const uint64_t ngroups = (a.items_cap + kEmitGroup - 1) / kEmitGroup;       /* upper bound */
         uint64_t blocks = (uint64_t)a.grid_blocks;
         if (blocks > ngroups) blocks = ngroups;
         k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.items, a.n_items, a.items_cap,
-                                                         a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err, probe);
+                                                         a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err, probe, tflag);
+        if (tflag) {
+            k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.items, probe, tflag);
+            uint64_t tb = (uint64_t)a.tile_blocks;
+            const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
+            if (tb > max_tiles) tb = max_tiles;
+            k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.items, a.desc, a.ticket, a.out, a.out_cap,
+                                                              a.index_out, a.total, a.err, probe, tflag);
+        }
     }
     if (a.n && want_dense) {
         k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe);

@@ -32,6 +32,9 @@ struct EmitArgs {
     unsigned long long* total_dense;  /* 1: the three-step path's total                                   */
     uint32_t* probe;                  /* 2: chunks sampled, chunks flagged                                */
     uint64_t clear_bytes;             /* desc .. probe are one stretch of the workspace this long: one clear per call */
+    uint32_t* tflag;                  /* 2, inside that stretch: the arena-tile kernel's eligibility (k3t_check)       */
+    int tiles;                        /* 0: never the arena-tile kernel; 1: when the index is eligible; 2: ... whatever the arena's size */
+    int tile_blocks;                  /* resident workgroups of the arena-tile kernel (emit_tile_grid_blocks)          */
 };
 
 struct SynthArgs {
@@ -47,6 +50,7 @@ struct SynthArgs {
 };
 
 int emit_grid_blocks(int device);
+int emit_tile_grid_blocks(int device);
 uint64_t emit_items_bound(uint64_t n, uint64_t payload_bytes);
 uint64_t emit_desc_words(uint64_t items_cap);
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st);

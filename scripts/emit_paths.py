@@ -1,0 +1,37 @@
+"""K3 three ways on the same arena (dev aid): the item kernel (path 0), count / scan / emit (1), arena tiles (2) -- outputs and
+output indexes compared, best-of-5 time of each.  HBS_EMIT_NALS sets the arena (default 104858 NALs ~ 1 GiB)."""
+import os
+import sys
+import torch
+sys.path.insert(0, ".")
+import hevcbitstream_amd as hbs
+N = int(os.environ.get("HBS_EMIT_NALS", 104858))
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ctx = hbs.Context(0)
+ctx.set_emit_path(0)
+g = ctx.synth_stream(0x1234, N, mode)
+rb, sb = g["rbsp_bytes"], g["stream_bytes"]
+summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
+ref_out = ref_idx = None
+for path in (0, 1, 2):
+    ctx.set_emit_path(path)
+    out = torch.zeros(sb + 4096, dtype=torch.uint8, device="cuda")
+    idx_out = torch.zeros(N * 32, dtype=torch.uint8, device="cuda")
+    ts = []
+    for i in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.emit_annexb_async(g["rbsp"], rb, g["index"], N, 1, out, idx_out, summary)
+        e1.record()
+        torch.cuda.synchronize()
+        if i:
+            ts.append(e0.elapsed_time(e1))
+    s = ctx.read_summary(summary)
+    assert int(s["error"]) == 0 and int(s["stream_bytes"]) == sb, (path, s)
+    if ref_out is None:
+        ref_out, ref_idx = out, idx_out
+        assert torch.equal(out[:sb], g["stream"][:sb])
+    else:
+        assert torch.equal(out[:sb], ref_out[:sb]), "path %d: bytes differ" % path
+        assert torch.equal(idx_out, ref_idx), "path %d: output index differs" % path
+    print("path %d: best %.3f ms -> %.1f GB/s emitted, %.1f GB/s of traffic" % (path, min(ts), sb / min(ts) / 1e6, (rb + sb) / min(ts) / 1e6))

@@ -17,7 +17,7 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=[-1, 0, 1], ids=["auto", "single-pass", "three-step"])
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "single-pass", "three-step", "arena-tiles"])
 def path_ctx(ctx, request):
     """every way hbs_emit_annexb can run; auto sends a handful of small NALs through the one-launch kernel"""
     ctx.set_emit_path(request.param)

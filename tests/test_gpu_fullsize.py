@@ -135,7 +135,7 @@ def test_index_arena_and_reemission_against_the_reference(mode, n_nals):
     out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
     idx_out = torch.empty(n_nals * 32, dtype=torch.uint8, device="cuda")
     dev_index = torch.from_numpy(got.view(np.uint8).copy()).cuda()
-    for path in (0, 1):                      # single pass, three-step
+    for path in (0, 1, 2):                   # single pass (by items), three-step, arena tiles
         ctx.set_emit_path(path)
         out.zero_()
         ctx.emit_annexb_async(rbsp, ref_rb, dev_index, n_nals, 1, out, idx_out, summary)
