@@ -152,7 +152,8 @@ class Context:
         self._check(self.lib.hbs_ctx_set_sequential_parse(self.h, 1 if on else 0), "hbs_ctx_set_sequential_parse")
 
     def set_emit_path(self, path=-1):
-        """-1 = picked per call (default), 0 = the single-pass emit kernel, 1 = count / scan / emit"""
+        """-1 = picked per call (default), 0 = the single-pass emit kernel by NALs, 1 = count / scan / emit, 2 = the single pass by
+        arena tiles whenever the index allows it"""
         self.lib.hbs_ctx_set_emit_path.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.hbs_ctx_set_emit_path(self.h, path), "hbs_ctx_set_emit_path")
 

@@ -294,8 +294,11 @@ uint64_t hbs_sps_slot_bytes(void);
 int hbs_ctx_set_sequential_parse(hbs_ctx* ctx, int on);
 uint64_t hbs_sps_tables_offset(void);
 /* How hbs_emit_annexb works: -1 (default) picked per call -- one single-workgroup launch for a handful of small
- * NALs (<= 256 NALs, <= 32 KiB of RBSP: the legacy rbsp_to_nal), otherwise the single-pass kernel or, on zero-heavy
- * payload (density probe on the device), count / scan / emit; 0 pins the single-pass kernel, 1 the three steps.
+ * NALs (<= 256 NALs, <= 32 KiB of RBSP: the legacy rbsp_to_nal); otherwise a single pass: by ARENA TILES when the
+ * index's NALs lie back to back in the arena in index order (what hbs_index_extract and hbs_write_headers produce;
+ * checked on the device together with a few size limits, hbs_emit.hip: k3t_check), else by NALs (items of <= 12 KiB);
+ * or, on zero-heavy payload (density probe on the device), count / scan / emit.  0 pins the single pass by NALs,
+ * 1 the three steps, 2 the arena tiles whenever the index allows them (whatever the arena's size and density).
  * The bytes are the same whichever runs (h264_nal.c:92-132). */
 int hbs_ctx_set_emit_path(hbs_ctx* ctx, int path);
 

@@ -15,6 +15,8 @@ for v, c in ctxs.items():
     c.set_kernel(v)
 ctx5 = hbs.Context(0)
 ctx5.set_kernel(5)
+ctx_tiles = hbs.Context(0)
+ctx_tiles.set_emit_path(2)            # the arena-tile emit kernel whenever the index allows it, whatever the size
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
@@ -78,9 +80,22 @@ while time.time() < t_end:
     if len(want_idx):
         keep = want_idx[(want_idx["status"] & 1) == 0]
         if len(keep):
-            got, _ = ctxs[0].emit_annexb(torch.from_numpy(want_arena.copy()).cuda(), keep)
-            if not np.array_equal(got, orc.emit_annexb(want_arena, keep)):
+            got, ent = ctxs[0].emit_annexb(torch.from_numpy(want_arena.copy()).cuda(), keep)
+            want_stream = orc.emit_annexb(want_arena, keep)
+            if not np.array_equal(got, want_stream):
                 bad += 1
                 print("EMIT MISMATCH iter", it, "nals", len(keep))
+            got_t, ent_t = ctx_tiles.emit_annexb(torch.from_numpy(want_arena.copy()).cuda(), keep)
+            if not np.array_equal(got_t, want_stream) or not np.array_equal(ent_t, ent):
+                bad += 1
+                print("EMIT (arena tiles) MISMATCH iter", it, "nals", len(keep))
+            # ... and with every NAL kept (back to back in the arena: what the tile kernel is for), synthetic 3- / 4-byte start codes
+            full = want_idx.copy()
+            full["status"] = 0
+            a, ea = ctxs[0].emit_annexb(torch.from_numpy(want_arena.copy()).cuda(), full, gap_mode=1)
+            b, eb = ctx_tiles.emit_annexb(torch.from_numpy(want_arena.copy()).cuda(), full, gap_mode=1)
+            if not np.array_equal(a, b) or not np.array_equal(ea, eb):
+                bad += 1
+                print("EMIT (arena tiles, all NALs) MISMATCH iter", it, "nals", len(full))
     it += 1
 print("iterations", it, "mismatches", bad)
