@@ -8,6 +8,7 @@ import hevcbitstream_amd.api as api
 api.library_path = lambda: so
 import hevcbitstream_amd as hbs
 ctx = hbs.Context(0)
+ctx.set_emit_path(0)      # the single pass by NALs (k3_fused); scripts/emit_phase_tiles.py is the same for the arena-tile kernel
 lib = api.load_library()
 n = int(os.environ.get("HBS_EMIT_NALS", 104858))
 g = ctx.synth_stream(0x1234, n, 0)

@@ -1,4 +1,4 @@
-"""Timing of K3 (hbs_emit_annexb) on a synthetic arena (dev aid, not the bench): ~1 GiB by default,
+"""Timing of K3 (hbs_emit_annexb, default path: arena tiles on these arenas) on a synthetic arena (dev aid, not the bench): ~1 GiB by default,
 HBS_EMIT_NALS=1677000 for the bench's 16 GiB."""
 import sys
 import torch

@@ -10,11 +10,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-sample-nals 0 > $O/pmc_write_line.json 2> $O/pmc_write.err
 python3 scripts/pmc_traffic.py $O/pmc_fetch0 $O/pmc_write0 k_scan_extract4 34403064115 $O/traffic_k_scan_extract4.json | tail -12
 python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write k_scan_index5 17231091218 $O/traffic_k_scan_index5.json | tail -12
-python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write k3_fused 34403064115 $O/traffic_k3_fused.json near_max | tail -12
+python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write k3_tiles 34403064115 $O/traffic_k3_tiles.json near_max | tail -12
 for p in fetch write; do
   f=$(find $O/pmc_${p}0 -name "*counter_collection.csv" | head -1)
   (head -1 $f; grep "k_scan_extract4" $f) > $O/pmc_${p}_k_scan_extract4.csv
-  for k in k_scan_index5 k3_fused; do
+  for k in k_scan_index5 k3_tiles; do
     f=$(find $O/pmc_$p -name "*counter_collection.csv" | head -1)
     (head -1 $f; grep "$k" $f) > $O/pmc_${p}_$k.csv
   done

@@ -11,4 +11,7 @@ python3 scripts/legacy_time.py 2>/dev/null > $O/legacy_time.txt
 python3 scripts/ingest_time.py 2>/dev/null > $O/ingest_time.txt
 python3 tests/tools/phase_timing4.py 2>/dev/null > $O/phase_timing4.txt
 HBS_EMIT_NALS=1677000 python3 scripts/emit_phase_cycles.py 2>/dev/null > $O/emit_phase_cycles.txt
-tail -n 3 $O/scan_time.txt $O/mixed_time.txt $O/phase_timing4.txt
+HBS_EMIT_NALS=1677000 python3 scripts/emit_paths.py 2>/dev/null > $O/emit_paths_16GiB.txt
+python3 scripts/emit_paths.py 2>/dev/null > $O/emit_paths_1GiB.txt
+HBS_EMIT_NALS=1677000 python3 scripts/emit_phase_tiles.py 2>/dev/null > $O/emit_phase_tiles.txt
+tail -n 3 $O/scan_time.txt $O/mixed_time.txt $O/phase_timing4.txt $O/emit_paths_16GiB.txt
