@@ -1006,14 +1006,15 @@ __device__ __forceinline__ void shift_bytes(uint64_t& lo, uint64_t& hi, uint32_t
  * offset from there. */
 template <bool kEmit>
 __device__ __forceinline__ uint32_t tile_element(const TileCtx& t, const LdsT& l, uint32_t ent, uint8_t* __restrict__ out, uint64_t abs0, uint64_t pos,
-                                                 bool store, hbs_nal_entry* __restrict__ idx_out, u32x4& qk, bool have_q)
-{   /* qk: the chunk's bytes, fetched by the counting call (its latency then lies under the look-back) and handed to the emitting one */
+                                                 bool store, hbs_nal_entry* __restrict__ idx_out, u32x4& qk, uint32_t& jk, bool have_q)
+{   /* qk, jk: the chunk's bytes and the first NAL start at or behind it, found by the counting call (the fetch then lies under the
+     * look-back) and handed to the emitting one */
     const uint32_t c = ent & kTListChunk;
     const uint32_t p = 16u * c;
     const uint64_t x0 = t.tile_lo + p;
     const uint32_t nb = t.arena_len - x0 < 16u ? (uint32_t)(t.arena_len - x0) : 16u;
-    if (!have_q) qk = load_chunk_guarded(t.arena, x0, t.arena_len);
-    const uint32_t j0 = lower_bound_lds(l.starts, t.m, p);
+    if (!have_q) { qk = load_chunk_guarded(t.arena, x0, t.arena_len); jk = lower_bound_lds(l.starts, t.m, p); }
+    const uint32_t j0 = jk;
     if (ent & kTListStart) {
         /* NALs begin here and chunk_flag() cleared the chunk: no 03 can go in (a start only resets the count), so what goes in
          * is the gaps, and the chunk's bytes go out in pieces between them */
@@ -1242,6 +1243,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const uint32_t npass = (nflag + (uint32_t)kTElemPass - 1u) / (uint32_t)kTElemPass;
         uint32_t e_first = 0;
         u32x4 q_first = u32x4{0u, 0u, 0u, 0u};
+        uint32_t j_first = 0;
         const uint64_t tile_bytes = t.arena_len - t.tile_lo < (uint64_t)kTTileBytes ? t.arena_len - t.tile_lo : (uint64_t)kTTileBytes;
         if (wv == 0) {
 #pragma unroll
@@ -1252,7 +1254,8 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 const uint32_t i = p * (uint32_t)kTElemPass + (uint32_t)lane;
                 uint32_t e = 0;
                 u32x4 qtmp;
-                if (i < nflag) e = tile_element<false>(t, l, l.list[i], nullptr, 0, 0, false, nullptr, p == 0 ? q_first : qtmp, false);
+                uint32_t jtmp;
+                if (i < nflag) e = tile_element<false>(t, l, l.list[i], nullptr, 0, 0, false, nullptr, p == 0 ? q_first : qtmp, p == 0 ? j_first : jtmp, false);
                 if (p == 0) e_first = e;                         /* the first batch (nearly always the only one) is not counted again */
                 tile_ins += wave_sum32(e);
             }
@@ -1295,11 +1298,12 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 const uint32_t i = pbase + (uint32_t)lane;
                 uint32_t e = 0, c = 0;
                 u32x4 qe = q_first;
-                if (i < nflag) { c = l.list[i]; e = p == 0u ? e_first : tile_element<false>(t, l, c, nullptr, 0, 0, false, nullptr, qe, false); }
+                uint32_t je = j_first;
+                if (i < nflag) { c = l.list[i]; e = p == 0u ? e_first : tile_element<false>(t, l, c, nullptr, 0, 0, false, nullptr, qe, je, false); }
                 const uint32_t inc_e = wave_incl_scan32(e, lane);
                 const uint32_t mine_before = ins_run + inc_e - e;
                 if (i < nflag && (can_store || idx_out))
-                    (void)tile_element<true>(t, l, c, tout, t.tile_lo + l.before, 16ull * (c & kTListChunk) + mine_before, can_store, idx_out, qe, true);
+                    (void)tile_element<true>(t, l, c, tout, t.tile_lo + l.before, 16ull * (c & kTListChunk) + mine_before, can_store, idx_out, qe, je, true);
                 if (lane == 0) l.seg[0] = ins_run;
                 l.seg[lane + 1] = ins_run + inc_e;
                 ins_run += (uint32_t)__builtin_amdgcn_readlane((int)inc_e, 63);
