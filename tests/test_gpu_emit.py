@@ -105,6 +105,45 @@ def test_emit_long_nals(ctx, orc):
         assert pos == len(want)
 
 
+def test_emit_arena_tile_edges(ctx, orc):
+    """the arena-tile kernel (path 2) on what its geometry makes special -- NALs that begin on, one byte before and one byte behind a
+    192 KiB tile border and a 16-byte chunk border, empty NALs alone, in a row, at the very start and at the very end, an arena that
+    ends on a tile border / a chunk border / in the middle of a chunk, zeros on both sides of a NAL border (a start restarts the
+    count: no 03 across it), gaps from 3 to 300 bytes -- and on indexes it must hand to the kernel by NALs (a first byte that is not
+    16-byte aligned, a gap of 1 MiB, more than 256 NALs in one tile).  Bytes against the oracle, output index against path 0."""
+    T = 192 * 1024
+    rng = np.random.RandomState(35)
+    cases = []
+    # lengths that put NAL starts around tile and chunk borders; arena ends on a tile border, a chunk border, mid-chunk
+    for tail in (0, 16, 7):
+        lens = [0, 5, 11, 15, 1, T - 32 - 1, 1, 1, 0, 0, 0, 30, T - 30 - 16, 16, 17, 0, 2 * T - 33 + tail, 0, 0]
+        cases.append((lens, [int(rng.randint(3, 12)) for _ in lens], 0))
+    cases.append(([T, T, T], [3, 4, 300], 0))
+    cases.append(([100, 200, 300000], [3, 3, 3], 8))                       # first byte at arena offset 8: not eligible
+    cases.append(([5000, 5000, 400000], [3, 1 << 20, 4], 0))               # a gap of 1 MiB: not eligible
+    cases.append(([64] * 700 + [300000], [3] * 701, 0))                    # 700 NALs in the first tile: not eligible
+    for lens, gaps, lead in cases:
+        arena = rng.randint(1, 256, size=lead + sum(lens)).astype(np.uint8)
+        pos = lead
+        for n in lens:                                                     # zeros on both sides of every border, and a few inside
+            arena[max(pos - 3, 0): pos + 3] = 0
+            pos += n
+        for q in rng.randint(0, max(len(arena) - 8, 1), size=len(arena) // 3000 + 2):
+            arena[q:q + rng.randint(2, 6)] = 0
+            arena[q + 5] = rng.randint(0, 5)
+        idx = fake_index(lens, gaps)
+        idx["rbsp_off"] += lead
+        want = orc.emit_annexb(arena, idx)
+        ctx.set_emit_path(0)
+        by_nals, idx_nals = ctx.emit_annexb(dev(arena), idx)
+        ctx.set_emit_path(2)
+        by_tiles, idx_tiles = ctx.emit_annexb(dev(arena), idx)
+        ctx.set_emit_path(-1)
+        assert np.array_equal(by_nals, want), (lens[:6], "by NALs")
+        assert np.array_equal(by_tiles, want), (lens[:6], "by arena tiles")
+        assert np.array_equal(idx_tiles, idx_nals), (lens[:6], "output index")
+
+
 def test_emit_zero_runs(path_ctx, orc):
     ctx = path_ctx
     for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
