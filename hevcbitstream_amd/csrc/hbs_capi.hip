@@ -304,7 +304,9 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     /* NALs that do not overlap add up to at most rbsp_bytes; an index whose NALs add up to more gets HBS_E_CAPACITY */
     const uint64_t items_cap = hbs::emit_items_bound(n_nals, out_cap < rbsp_bytes ? out_cap : rbsp_bytes);
     const uint64_t b_items = round256(items_cap * 8), b_desc = round256(hbs::emit_desc_words(items_cap) * 8);
-    int rc = ensure_ws(c, b_seg + 2 * b_n + b_items + b_desc + 1024);
+    const uint64_t first_cap = rbsp_bytes / (192u * 1024u) + 4;          /* arena tiles of the tile kernel (hbs_emit.hip: kTTileBytes) */
+    const uint64_t b_first = round256(first_cap * 8);
+    int rc = ensure_ws(c, b_seg + 2 * b_n + b_items + b_desc + 1024 + b_first);
     if (rc) return rc;
     if (c->emit_blocks <= 0) {
         c->emit_blocks = hbs::emit_grid_blocks(c->device);
@@ -335,6 +337,7 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.total_dense = reinterpret_cast<unsigned long long*>(tail + 768 + 64);
     a.probe = reinterpret_cast<uint32_t*>(tail + 768 + 128);
     a.tflag = reinterpret_cast<uint32_t*>(tail + 768 + 192);
+    a.first_k = reinterpret_cast<unsigned long long*>(tail + 1024); a.first_cap = first_cap;
     a.tiles = c->emit_tiles; a.tile_blocks = c->emit_tile_blocks;
     a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;

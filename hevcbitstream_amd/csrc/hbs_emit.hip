@@ -35,6 +35,8 @@ __device__ __forceinline__ bool emit_probe_dense(const uint32_t* probe) { return
 /* the arena-tile kernel (k3_tiles, below) takes the sparse case when k3t_check found the index eligible: tflag[0] = a
  * violation was seen, tflag[1] = the global conditions hold */
 __device__ __forceinline__ bool tile_path_on(const uint32_t* tflag) { return tflag && tflag[1] == 1u && tflag[0] == 0u; }
+/* tflag[2]: the tile kernel met a tile dense in elements and gave up -- the kernel by NALs, enqueued behind it, does the call */
+__device__ __forceinline__ bool tile_path_done(const uint32_t* tflag) { return tile_path_on(tflag) && tflag[2] == 0u; }
 
 enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2 };
 __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when)
@@ -676,7 +678,8 @@ __global__ void k3_expand(const unsigned long long* __restrict__ segs, const uns
                           const unsigned long long* __restrict__ n_items, unsigned long long* __restrict__ items, uint64_t items_cap,
                           const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    if ((probe && emit_probe_dense(probe)) || tile_path_on(tflag)) return;      /* (the tile kernel keeps its own table in `items`) */
+    (void)tflag;
+    if (probe && emit_probe_dense(probe)) return;
     if (*n_items == n || *n_items > items_cap) return;       /* identity: nothing to build; too many: the main kernel reports it */
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long base = item_base[k], m = segs[k];
@@ -715,7 +718,7 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err, const uint32_t* __restrict__ probe,
               const uint32_t* __restrict__ tflag)
 {
-    if ((probe && emit_probe_dense(probe)) || tile_path_on(tflag)) return;
+    if ((probe && emit_probe_dense(probe)) || tile_path_done(tflag)) return;      /* the tile kernel, in front of this one, did it */
     __shared__ Lds3 l;
     const int lane0 = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -907,6 +910,9 @@ constexpr int kTParkRows = 28;
 constexpr uint32_t kTMaxStarts = 256, kTMaxGap = 1u << 20;
 constexpr uint64_t kTMinArena = 192ull << 20;      /* below, the kernel by NALs is as fast or faster (0.12 against 0.115 ms at 128 MiB, 0.173 against 0.186 at 256 MiB) */
 constexpr int kTElemPass = 64;
+constexpr uint32_t kTDenseLimit = 512;        /* a tile with more elements than this: wavefront 0 would walk them 64 at a time while every tile
+                                                 behind waits (~5 us a batch) -- the call is handed to the kernel by NALs instead, whose cost
+                                                 grows gently with the density of zero pairs */
 /* an entry of the tile's element list: chunk number | why it is one */
 constexpr uint32_t kTListFlag = 0x8000u;      /* chunk_flag(): a 03 may have to go in                     */
 constexpr uint32_t kTListStart = 0x4000u;     /* a NAL begins in it (or it is the arena's partial last chunk) */
@@ -916,7 +922,7 @@ static_assert(kTChunks <= (int)kTListChunk + 1, "a chunk number fits the list en
 
 __global__ __launch_bounds__(256)
 void k3t_check(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-               uint64_t items_cap, uint64_t desc_words, int pinned, uint32_t* __restrict__ tflag)
+               uint64_t first_cap, uint64_t desc_words, int pinned, uint32_t* __restrict__ tflag)
 {
     bool bad = false;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
@@ -931,7 +937,7 @@ void k3t_check(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict
         const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
         const uint64_t ntiles = arena_len / kTTileBytes + 1;
         const bool ok = ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
-                        ntiles + 1 <= items_cap && ntiles + 1 <= desc_words;
+                        ntiles + 1 <= first_cap && ntiles + 1 <= desc_words;
         tflag[1] = ok ? 1u : 0u;
     }
 }
@@ -962,7 +968,7 @@ struct LdsT {
     uint32_t wave_tot[kTWaves];
     unsigned long long before;                       /* bytes inserted in front of the tile                  */
     uint32_t ok;
-    uint32_t ticket;
+    uint32_t ticket, abort;
 };
 
 struct TileCtx {
@@ -1133,11 +1139,19 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const int lane = launder_lane(tid0) & 63;
         const int tid = launder_lane(tid0);
         __syncthreads();                                           /* the previous tile is done with l */
-        if (tid == 0) l.ticket = atomicAdd(ticket, 1u);
+        if (tid == 0) {
+            l.ticket = atomicAdd(ticket, 1u);
+            l.abort = __hip_atomic_load(&tflag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid < kTWaves * kTRows) l.rowbits[tid] = 0ull;
         __syncthreads();
         const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
         if (tile >= ntiles) break;
+        if (l.abort != 0u) {
+            /* somebody gave up: nothing written from here on matters, but the tiles that wait for this one must not wait for ever */
+            if (tid == 0) st_desc3(desc + tile, 2ull);
+            continue;
+        }
         HBS3_T_MARK(0)
         __builtin_amdgcn_s_setprio(3);
         t.tile_lo = tile * (uint64_t)kTTileBytes;
@@ -1227,6 +1241,14 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const uint32_t wt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[2]), wt3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[3]);
         const uint32_t nflag = wt0 + wt1 + wt2 + wt3;
         const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? wt0 : (wv == 2) ? wt0 + wt1 : wt0 + wt1 + wt2;
+        if (nflag > kTDenseLimit) {                                /* dense in elements: give the call up (see kTDenseLimit) */
+            if (tid == 0) {
+                atomicOr(const_cast<uint32_t*>(&tflag[2]), 1u);
+                st_desc3(desc + tile, 2ull);                       /* "everything up to here: 0 bytes" -- whoever waits goes on, writing what will be overwritten */
+            }
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
             const int r = __builtin_ctzll(rm);
             const uint32_t rp = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
@@ -1343,6 +1365,16 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     HBS3_T_FLUSH
 }
 
+/* between the tile kernel that gave up and the kernel by NALs that takes over: the look-back words and counters they share */
+__global__ __launch_bounds__(256)
+void k3t_reset(unsigned long long* __restrict__ desc, uint64_t words, uint32_t* __restrict__ ticket, unsigned long long* __restrict__ total,
+               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
+{
+    if ((probe && emit_probe_dense(probe)) || !tile_path_on(tflag) || tflag[2] == 0u) return;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) desc[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *ticket = 0u; *total = 0ull; }
+}
+
 int emit_tile_grid_blocks(int device)
 {
     hipDeviceProp_t prop;
@@ -1367,26 +1399,28 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     const bool want_dense = a.two_pass != 0, want_sparse = a.two_pass <= 0;
     if (a.n && probe) k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
     /* arena tiles when the index allows it (decided on the device), the item kernel otherwise; path 0 pins the item kernel */
-    const uint32_t* tflag = (a.n && want_sparse && a.tiles != 0) ? a.tflag : nullptr;
-    if (tflag) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.items_cap, emit_desc_words(a.items_cap), a.tiles == 2 ? 1 : 0, a.tflag);
+    const uint32_t* tflag = (a.n && want_sparse && a.tiles != 0 && (a.tiles == 2 || a.rbsp_bytes >= kTMinArena)) ? a.tflag : nullptr;
+    if (tflag) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap), a.tiles == 2 ? 1 : 0, a.tflag);
     if (a.n && want_sparse) {
         /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
         k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse);
         k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe, tflag);
+        if (tflag) {
+            /* arena tiles first; the kernel by NALs behind them runs when they do not apply -- or gave up on a tile dense in elements */
+            k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.first_k, probe, tflag);
+            uint64_t tb = (uint64_t)a.tile_blocks;
+            const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
+            if (tb > max_tiles) tb = max_tiles;
+            k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap,
+                                                              a.index_out, a.total, a.err, probe, tflag);
+            k3t_reset<<<256, 256, 0, st>>>(a.desc, emit_desc_words(a.items_cap), a.ticket, a.total, probe, tflag);
+        }
         const uint64_t ngroups = (a.items_cap + kEmitGroup - 1) / kEmitGroup;       /* upper bound */
         uint64_t blocks = (uint64_t)a.grid_blocks;
         if (blocks > ngroups) blocks = ngroups;
         k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.items, a.n_items, a.items_cap,
                                                          a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err, probe, tflag);
-        if (tflag) {
-            k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.items, probe, tflag);
-            uint64_t tb = (uint64_t)a.tile_blocks;
-            const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
-            if (tb > max_tiles) tb = max_tiles;
-            k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.items, a.desc, a.ticket, a.out, a.out_cap,
-                                                              a.index_out, a.total, a.err, probe, tflag);
-        }
     }
     if (a.n && want_dense) {
         k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe);

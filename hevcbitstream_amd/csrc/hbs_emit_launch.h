@@ -32,7 +32,9 @@ struct EmitArgs {
     unsigned long long* total_dense;  /* 1: the three-step path's total                                   */
     uint32_t* probe;                  /* 2: chunks sampled, chunks flagged                                */
     uint64_t clear_bytes;             /* desc .. probe are one stretch of the workspace this long: one clear per call */
-    uint32_t* tflag;                  /* 2, inside that stretch: the arena-tile kernel's eligibility (k3t_check)       */
+    uint32_t* tflag;                  /* 3, inside that stretch: the arena-tile kernel's eligibility (k3t_check) and its "gave up" */
+    unsigned long long* first_k;      /* first_cap entries: per arena tile, the first NAL that begins in it               */
+    uint64_t first_cap;
     int tiles;                        /* 0: never the arena-tile kernel; 1: when the index is eligible; 2: ... whatever the arena's size */
     int tile_blocks;                  /* resident workgroups of the arena-tile kernel (emit_tile_grid_blocks)          */
 };

@@ -144,6 +144,27 @@ def test_emit_arena_tile_edges(ctx, orc):
         assert np.array_equal(idx_tiles, idx_nals), (lens[:6], "output index")
 
 
+def test_emit_arena_tiles_give_up_on_dense_tiles(ctx, orc):
+    """an arena that is sparse but for one stretch of 00 00 03 padding (cabac_zero_words): the tile holding it has thousands of
+    elements, the arena-tile kernel gives the call up (hbs_emit.hip: kTDenseLimit) and the kernel by NALs, enqueued behind it,
+    produces the bytes and the output index -- whatever the tile kernel had written by then is overwritten"""
+    T = 192 * 1024
+    rng = np.random.RandomState(36)
+    for dense_at, dense_len in ((3 * T + 1000, 150_000), (100, 30_000), (9 * T - 40_000, 80_000)):
+        lens = [int(x) for x in rng.randint(2000, 60000, size=60)]
+        arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+        arena[dense_at: dense_at + dense_len] = np.tile(np.array([0, 0, 3], dtype=np.uint8), dense_len // 3 + 1)[:dense_len]
+        idx = fake_index(lens, [int(rng.randint(3, 6)) for _ in lens])
+        want = orc.emit_annexb(arena, idx)
+        ctx.set_emit_path(0)
+        _, idx_nals = ctx.emit_annexb(dev(arena), idx)
+        ctx.set_emit_path(2)
+        by_tiles, idx_tiles = ctx.emit_annexb(dev(arena), idx)
+        ctx.set_emit_path(-1)
+        assert np.array_equal(by_tiles, want), dense_at
+        assert np.array_equal(idx_tiles, idx_nals), dense_at
+
+
 def test_emit_zero_runs(path_ctx, orc):
     ctx = path_ctx
     for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
