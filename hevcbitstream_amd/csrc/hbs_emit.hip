@@ -10,9 +10,11 @@
  * A 03 is only ever inserted behind two zero bytes, so chunk_flag() (hbs_sparse.h:
  * no two adjacent zeros start in bytes [-2, 16) of the chunk) clears nearly every
  * 16-byte chunk for a plain copy; flagged chunks run the byte-exact rbsp_to_nal
- * rules of hbs_emit.h.  k3_fused does it in one pass (RBSP read once, stream
- * written once; see the comment in front of it); k3_count / scan / k3_emit is the
- * older three-step version (RBSP read twice), kept for comparison.
+ * rules of hbs_emit.h.  Single pass (RBSP read once, stream written once), two ways:
+ * k3_tiles cuts the ARENA into 192 KiB tiles as K12 cuts a stream (when the index's
+ * NALs lie back to back; see "arena tiles" below), k3_fused cuts the work by NAL
+ * (any index; see the comment in front of it).  k3_count / scan / k3_emit is the
+ * older three-step version (RBSP read twice): zero-heavy arenas, picked by a probe.
  */
 #include <hip/hip_runtime.h>
 #include "hbs_wave.h"
