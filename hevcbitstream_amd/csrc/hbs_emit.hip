@@ -139,16 +139,33 @@ __device__ __forceinline__ void store_exact(uint8_t* dst, const ExactChunk& e)
     else (void)emit_chunk16(dst, e.q.x, e.q.y, e.q.z, e.q.w, e.nb, e.mask);
 }
 
+/* the same from registers that already hold the chunk and the dword in front of it (the kernels that walk a NAL row by row) */
+__device__ __forceinline__ ExactChunk exact_from_regs(const u32x4& q, uint32_t xp, const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, uint32_t off)
+{
+    ExactChunk e;
+    e.q = q;
+    e.nb = len - off < 16u ? len - off : 16u;
+    uint32_t count = 0;
+    if (off != 0) {
+        count = lead_count4(xp);
+        if (count == kLeadUnknown) count = lead_count(rbsp, begin, begin + off);
+    }
+    e.mask = insert_mask16(q.x, q.y, q.z, q.w, e.nb, count);
+    return e;
+}
+
 /* One row of a NAL: which of its chunks may need a 03 (conservative), from the row's registers. */
 struct RowFlags {
     bool mine;             /* my chunk */
     uint64_t mask;         /* the row's  */
+    uint32_t xp;           /* the four bytes in front of my chunk */
 };
 __device__ __forceinline__ RowFlags row_flags(const u32x4& q, uint32_t e_prev, uint32_t e_next, uint32_t off, uint32_t len)
 {
     const uint32_t xp = from_prev_lane(q.w, e_prev);
     const uint32_t xn = from_next_lane(q.x, e_next);
     RowFlags r;
+    r.xp = xp;
     r.mine = off < len && chunk_flag(xp, q.x, q.y, q.z, q.w, xn);
     r.mask = __ballot(r.mine);
     return r;
@@ -168,7 +185,7 @@ __device__ __forceinline__ uint32_t count_nal(const uint8_t* __restrict__ rbsp, 
         const RowFlags f = row_flags(q, e_prev, (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0), off, len);
         if (f.mask != 0) {
             uint32_t c = 0;
-            if (f.mine) c = (uint32_t)__builtin_popcount(exact_chunk(rbsp, begin, len, off).mask);
+            if (f.mine) c = (uint32_t)__builtin_popcount(exact_from_regs(q, f.xp, rbsp, begin, len, off).mask);
             ins += wave_sum_u32(c);
         }
         e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 63);
@@ -313,7 +330,7 @@ __device__ __forceinline__ void emit_nal(const uint8_t* __restrict__ rbsp, const
             if (f.mask != 0) {
                 ExactChunk ec;
                 ec.mask = 0; ec.nb = 0;
-                if (f.mine) { ec = exact_chunk(rbsp, begin, len, off); c = (uint32_t)__builtin_popcount(ec.mask); }
+                if (f.mine) { ec = exact_from_regs(q, f.xp, rbsp, begin, len, off); c = (uint32_t)__builtin_popcount(ec.mask); }
                 uint32_t tot;
                 dst += wave_excl_scan_u32(c, lane, tot);
                 ins += tot;
