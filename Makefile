@@ -60,11 +60,14 @@ diag: $(DIAG_OBJS) $(LEGACY_OBJ)
 
 # development variant of the library with extra -D flags, for A/B timing (HBS_LIB=build/variants/<NAME>/libhbs.so)
 #   make variant NAME=ntload DEFS="-DHBS_NT_LOAD=1"
-VAR_OBJS := $(patsubst $(CSRC)/%.hip,build/variants/$(NAME)/%.o,$(HIP_SRCS))
+#   make variant NAME=d4 DEFS="-DHBS4_COPY_DEPTH=4" ONLY="hbs_scan4"      (recompile only the named files; the rest from build/obj)
+ONLY ?= $(patsubst $(CSRC)/%.hip,%,$(HIP_SRCS))
+VAR_OBJS := $(patsubst %,build/variants/$(NAME)/%.o,$(ONLY))
+VAR_REST := $(filter-out $(patsubst %,build/obj/%.o,$(ONLY)),$(HIP_OBJS))
 build/variants/$(NAME)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/variants/$(NAME)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $@ $<
-variant: $(VAR_OBJS) $(LEGACY_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/$(NAME)/libhbs.so $(VAR_OBJS) $(LEGACY_OBJ)
+variant: $(VAR_OBJS) $(VAR_REST) $(LEGACY_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/$(NAME)/libhbs.so $(VAR_OBJS) $(VAR_REST) $(LEGACY_OBJ)
 
 .PHONY: all lib oracle sim clean analyze diag variant

@@ -55,6 +55,15 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #define HBS4_T_FLUSH
 #endif
 
+#ifndef HBS4_WG_PER_CU
+#define HBS4_WG_PER_CU 2      /* workgroups per CU = wavefronts per SIMD the register budget is cut for */
+#endif
+#ifndef HBS4_PROGRESSIVE
+#define HBS4_PROGRESSIVE 1     /* the fetch inside the flag pass, four rows at a time */
+#endif
+#ifndef HBS4_COPY_DEPTH
+#define HBS4_COPY_DEPTH 3      /* stores of a wavefront in flight during the copy (-1: no limit) */
+#endif
 #ifdef HBS4_NO_PRIO
 #define HBS4_PRIO(p)
 #else
@@ -243,7 +252,7 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     return true;
 }
 
-__global__ __launch_bounds__(k4Threads, 2)
+__global__ __launch_bounds__(k4Threads, HBS4_WG_PER_CU)
 void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                      hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                      uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
@@ -281,11 +290,16 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         /* until the tile's aggregate is out, this workgroup is what its successors wait for */
         HBS4_PRIO(3);
         RowRegs R;
-        fetch_row_regs(R, src, wseg, lane);
+        /* The dwords around the segment first: the first group of the flag pass needs them, and a load issued behind the rows
+         * would make it wait for all of them.  The rows themselves are fetched INSIDE the flag pass, four at a time. */
         R.before = (wseg >= 4) ? stream_load4(src + wseg - 4) : 0xFFFFFFFFu;
         R.before2 = (wseg >= 8) ? stream_load4(src + wseg - 8) : 0xFFFFFFFFu;
         R.after = (last_tile || wv != k4Waves - 1) ? stream_load4(src + wseg + k4WaveBytes)
                                                    : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
+        const u32x4* const rowp = reinterpret_cast<const u32x4*>(src + wseg) + lane;
+#if !HBS4_PROGRESSIVE
+        fetch_row_regs(R, src, wseg, lane);
+#endif
         HBS4_T_MARK(0)
 
         /* ---- 1. flag masks of my rows --------------------------------------------------- */
@@ -320,21 +334,51 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 #define HBS_FLAG_GROUP(a, wa, xa, za, b, wb, xb, zb, c, wc, xc, zc, d, wd, xd, zd) { \
                 HBS_FLAG_EVAL(a, wa, xa) HBS_FLAG_EVAL(b, wb, xb) HBS_FLAG_EVAL(c, wc, xc) HBS_FLAG_EVAL(d, wd, xd) \
                 if ((fmask##a | fmask##b | fmask##c | fmask##d) != 0) { \
-                    HBS_FLAG_KEEP(a, za) HBS_FLAG_KEEP(b, zb) HBS_FLAG_KEEP(c, zc) HBS_FLAG_KEEP(d, zd) } }
+                    HBS_FLAG_KEEP(a, za) HBS_FLAG_KEEP(b, zb) HBS_FLAG_KEEP(c, zc) HBS_FLAG_KEEP(d, zd) } \
+                HBS_FLAG_FENCE }
+            /* The fetch runs inside the flag pass: HBS_LD4 issues four rows, and a group is flagged when the rows up to its fourth
+             * neighbour's have been issued -- loads return in order, so the group waits for `vmcnt(3)`, not for the tile, and a
+             * wavefront never has more than 7 row loads in flight.  Two things come of it.  The flag pass hides under the fetch.
+             * And the CU's memory queue stays short: with 48 loads per wavefront issued at once (and 48 stores in the copy), the
+             * look-back polls of the OTHER workgroup on this CU waited behind them, 2.7 us a poll; a model of this kernel
+             * (scripts/ubench/ceiling3.hip, profiles/r03/ceiling3_*.txt) moves 5.9 TB/s with both throttled and 5.1-5.3 without.
+             * The sched_barriers keep the compiler from hoisting the loads back to the top. */
+#if HBS4_PROGRESSIVE
+#define HBS_LD4(a, b, c, d) { R.q##a = stream_load16(rowp + a * 64); R.q##b = stream_load16(rowp + b * 64); \
+                R.q##c = stream_load16(rowp + c * 64); R.q##d = stream_load16(rowp + d * 64); __builtin_amdgcn_sched_barrier(0); }
+#define HBS_FLAG_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define HBS_LD4(a, b, c, d)
+#define HBS_FLAG_FENCE
+#endif
             /* (row, dword in front of its lane 0, dword behind its lane 63, second dword in front of its lane 0) x 4; written by scripts/set_rows4.py */
+            HBS_LD4(0, 1, 2, 3)
+            HBS_LD4(4, 5, 6, 7)
             HBS_FLAG_GROUP(0, R.before, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.x, 0), R.before2, 1, (uint32_t)__builtin_amdgcn_readlane((int)R.q0.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q2.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q0.z, 63), 2, (uint32_t)__builtin_amdgcn_readlane((int)R.q1.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q3.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q1.z, 63), 3, (uint32_t)__builtin_amdgcn_readlane((int)R.q2.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q4.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q2.z, 63))
+            HBS_LD4(8, 9, 10, 11)
             HBS_FLAG_GROUP(4, (uint32_t)__builtin_amdgcn_readlane((int)R.q3.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q5.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q3.z, 63), 5, (uint32_t)__builtin_amdgcn_readlane((int)R.q4.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q6.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q4.z, 63), 6, (uint32_t)__builtin_amdgcn_readlane((int)R.q5.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q7.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q5.z, 63), 7, (uint32_t)__builtin_amdgcn_readlane((int)R.q6.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q8.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q6.z, 63))
+            HBS_LD4(12, 13, 14, 15)
             HBS_FLAG_GROUP(8, (uint32_t)__builtin_amdgcn_readlane((int)R.q7.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q9.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q7.z, 63), 9, (uint32_t)__builtin_amdgcn_readlane((int)R.q8.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q10.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q8.z, 63), 10, (uint32_t)__builtin_amdgcn_readlane((int)R.q9.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q11.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q9.z, 63), 11, (uint32_t)__builtin_amdgcn_readlane((int)R.q10.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q12.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q10.z, 63))
+            HBS_LD4(16, 17, 18, 19)
             HBS_FLAG_GROUP(12, (uint32_t)__builtin_amdgcn_readlane((int)R.q11.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q13.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q11.z, 63), 13, (uint32_t)__builtin_amdgcn_readlane((int)R.q12.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q14.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q12.z, 63), 14, (uint32_t)__builtin_amdgcn_readlane((int)R.q13.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q15.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q13.z, 63), 15, (uint32_t)__builtin_amdgcn_readlane((int)R.q14.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q16.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q14.z, 63))
+            HBS_LD4(20, 21, 22, 23)
             HBS_FLAG_GROUP(16, (uint32_t)__builtin_amdgcn_readlane((int)R.q15.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q17.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q15.z, 63), 17, (uint32_t)__builtin_amdgcn_readlane((int)R.q16.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q18.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q16.z, 63), 18, (uint32_t)__builtin_amdgcn_readlane((int)R.q17.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q19.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q17.z, 63), 19, (uint32_t)__builtin_amdgcn_readlane((int)R.q18.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q20.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q18.z, 63))
+            HBS_LD4(24, 25, 26, 27)
             HBS_FLAG_GROUP(20, (uint32_t)__builtin_amdgcn_readlane((int)R.q19.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q21.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q19.z, 63), 21, (uint32_t)__builtin_amdgcn_readlane((int)R.q20.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q22.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q20.z, 63), 22, (uint32_t)__builtin_amdgcn_readlane((int)R.q21.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q23.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q21.z, 63), 23, (uint32_t)__builtin_amdgcn_readlane((int)R.q22.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q24.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q22.z, 63))
+            HBS_LD4(28, 29, 30, 31)
             HBS_FLAG_GROUP(24, (uint32_t)__builtin_amdgcn_readlane((int)R.q23.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q25.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q23.z, 63), 25, (uint32_t)__builtin_amdgcn_readlane((int)R.q24.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q26.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q24.z, 63), 26, (uint32_t)__builtin_amdgcn_readlane((int)R.q25.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q27.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q25.z, 63), 27, (uint32_t)__builtin_amdgcn_readlane((int)R.q26.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q28.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q26.z, 63))
+            HBS_LD4(32, 33, 34, 35)
             HBS_FLAG_GROUP(28, (uint32_t)__builtin_amdgcn_readlane((int)R.q27.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q29.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q27.z, 63), 29, (uint32_t)__builtin_amdgcn_readlane((int)R.q28.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q30.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q28.z, 63), 30, (uint32_t)__builtin_amdgcn_readlane((int)R.q29.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q31.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q29.z, 63), 31, (uint32_t)__builtin_amdgcn_readlane((int)R.q30.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q32.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q30.z, 63))
+            HBS_LD4(36, 37, 38, 39)
             HBS_FLAG_GROUP(32, (uint32_t)__builtin_amdgcn_readlane((int)R.q31.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q33.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q31.z, 63), 33, (uint32_t)__builtin_amdgcn_readlane((int)R.q32.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q34.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q32.z, 63), 34, (uint32_t)__builtin_amdgcn_readlane((int)R.q33.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q35.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q33.z, 63), 35, (uint32_t)__builtin_amdgcn_readlane((int)R.q34.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q36.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q34.z, 63))
+            HBS_LD4(40, 41, 42, 43)
             HBS_FLAG_GROUP(36, (uint32_t)__builtin_amdgcn_readlane((int)R.q35.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q37.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q35.z, 63), 37, (uint32_t)__builtin_amdgcn_readlane((int)R.q36.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q38.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q36.z, 63), 38, (uint32_t)__builtin_amdgcn_readlane((int)R.q37.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q39.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q37.z, 63), 39, (uint32_t)__builtin_amdgcn_readlane((int)R.q38.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q40.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q38.z, 63))
+            HBS_LD4(44, 45, 46, 47)
             HBS_FLAG_GROUP(40, (uint32_t)__builtin_amdgcn_readlane((int)R.q39.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q41.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q39.z, 63), 41, (uint32_t)__builtin_amdgcn_readlane((int)R.q40.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q42.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q40.z, 63), 42, (uint32_t)__builtin_amdgcn_readlane((int)R.q41.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q43.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q41.z, 63), 43, (uint32_t)__builtin_amdgcn_readlane((int)R.q42.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q44.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q42.z, 63))
             HBS_FLAG_GROUP(44, (uint32_t)__builtin_amdgcn_readlane((int)R.q43.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q45.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q43.z, 63), 45, (uint32_t)__builtin_amdgcn_readlane((int)R.q44.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q46.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q44.z, 63), 46, (uint32_t)__builtin_amdgcn_readlane((int)R.q45.w, 63), (uint32_t)__builtin_amdgcn_readlane((int)R.q47.x, 0), (uint32_t)__builtin_amdgcn_readlane((int)R.q45.z, 63), 47, (uint32_t)__builtin_amdgcn_readlane((int)R.q46.w, 63), R.after, (uint32_t)__builtin_amdgcn_readlane((int)R.q46.z, 63))
 #undef HBS_FLAG_GROUP
+#undef HBS_LD4
+#undef HBS_FLAG_FENCE
 #undef HBS_FLAG_KEEP
 #undef HBS_FLAG_EVAL
             static_assert(k4Rows == 48, "first and last row are named above");
@@ -495,6 +539,13 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[k4ElemPass]);
                 /* Straight-line over the named rows.  A chunk with k elements in front of it is
                  * served by the batch that holds element k-1 (k = 0: the tile start, batch 0). */
+                /* At most kCopyDepth stores of a wavefront in flight (see the flag pass: a short memory queue on the CU is what
+                 * lets the other workgroup's look-back through; depth 3 is the model's optimum, 5 and more lose all of it). */
+#if HBS4_COPY_DEPTH >= 0
+#define HBS_COPY_THROTTLE asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS4_COPY_DEPTH) : "memory");
+#else
+#define HBS_COPY_THROTTLE
+#endif
 #define HBS_COPY(r) { \
                     const uint32_t cc = cc0 + 64u * r; \
                     if (!((rowmask >> r) & 1ull)) {          /* no element in this row: one k, one word for all lanes */ \
@@ -514,9 +565,11 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                             const uint32_t w = l.seg[k - pbase]; \
                             if (seg_inside(w)) arena_store16(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)), R.q##r); \
                         } \
-                    } }
+                    } \
+                    HBS_COPY_THROTTLE }
                 HBS_ROWS(HBS_COPY)
 #undef HBS_COPY
+#undef HBS_COPY_THROTTLE
             }
             /* The next tile is claimed only now: tiles are looked back in ticket order, and a ticket
              * taken before the copy (whose duration varies with memory load) makes successors wait for

@@ -1,8 +1,9 @@
 """Regenerate the row lists of hbs_scan4.hip / hbs_sparse.h for N rows per wavefront (dev aid).
-usage: set_rows4.py N [park_first]"""
-import re, sys
+usage: [CSRC=dir] set_rows4.py N [park_first]      (CSRC: a copy of hevcbitstream_amd/csrc to edit instead, for `make variant CSRC=dir`)"""
+import os, re, sys
+csrc = os.environ.get("CSRC", "hevcbitstream_amd/csrc")
 rows = int(sys.argv[1]); park_first = int(sys.argv[2]) if len(sys.argv) > 2 else rows - 16
-p = 'hevcbitstream_amd/csrc/hbs_scan4.hip'
+p = csrc + '/hbs_scan4.hip'
 s = open(p).read()
 s = re.sub(r'static_assert\(k4Rows == \d+, "the row lists below name every row register"\);', 'static_assert(k4Rows == %d, "the row lists below name every row register");' % rows, s)
 s = re.sub(r'#define HBS_ROWS\(X\) .*', '#define HBS_ROWS(X) ' + ' '.join('X(%d)' % i for i in range(rows)), s)
@@ -26,15 +27,31 @@ def group(first):
     return '            HBS_FLAG_GROUP(' + ', '.join(args) + ')'
 
 
+def ld4(first):
+    return '            HBS_LD4(%d, %d, %d, %d)' % (first, first + 1, first + 2, first + 3)
+
+
+def body():
+    """the fetch and the flag pass, interleaved: group g is flagged with the rows up to 4g+7 issued, so 3 to 7 loads of the
+    wavefront are in flight at any time (scripts/ubench/ceiling3.hip: deeper queues delay the other workgroup's look-back polls)"""
+    out = [ld4(0)] + ([ld4(4)] if rows > 4 else [])
+    for g in range(0, rows, 4):
+        out.append(group(g))
+        if g + 8 < rows:
+            out.append(ld4(g + 8))
+    return out
+
+
 lines = s.split('\n')
-first = next(i for i, ln in enumerate(lines) if ln.startswith('            HBS_FLAG_GROUP('))
-last = max(i for i, ln in enumerate(lines) if ln.startswith('            HBS_FLAG_GROUP('))
-assert all(ln.startswith('            HBS_FLAG_GROUP(') for ln in lines[first:last + 1])
-lines[first:last + 1] = [group(g) for g in range(0, rows, 4)]
+is_gen = lambda ln: ln.startswith('            HBS_FLAG_GROUP(') or ln.startswith('            HBS_LD4(')
+first = next(i for i, ln in enumerate(lines) if is_gen(ln))
+last = max(i for i, ln in enumerate(lines) if is_gen(ln))
+assert all(is_gen(ln) for ln in lines[first:last + 1])
+lines[first:last + 1] = body()
 s = '\n'.join(lines)
 s = re.sub(r'static_assert\(k4Rows == \d+, "first and last row are named above"\);', 'static_assert(k4Rows == %d, "first and last row are named above");' % rows, s)
 open(p, 'w').write(s)
-p = 'hevcbitstream_amd/csrc/hbs_sparse.h'
+p = csrc + '/hbs_sparse.h'
 s = open(p).read()
 s = re.sub(r'constexpr int k4Rows          = \d+;', 'constexpr int k4Rows          = %d;' % rows, s)
 open(p, 'w').write(s)

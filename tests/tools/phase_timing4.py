@@ -12,11 +12,12 @@ orc = _orc.oracle()
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 want_rbsp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
-d = torch.from_numpy(base).cuda().repeat(64)
+rep = int(os.environ.get('HBS4_REPEAT', 64))
+d = torch.from_numpy(base).cuda().repeat(rep)
 ctx = hbs.Context(0)
 ctx.set_kernel(4)
 blocks, per_cu = ctx.grid()
-index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * 64 + 16)
+index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * rep + 16)
 lib = api.load_library()
 if os.environ.get('HBS4_FAKE_LB'):
     assert lib.hbs_debug_fake_lb4(C.c_int(1)) == 0
