@@ -940,7 +940,7 @@ static_assert(kTChunks <= (int)kTListChunk + 1, "a chunk number fits the list en
 
 
 __global__ __launch_bounds__(256)
-void k3t_check(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
                uint64_t first_cap, uint64_t desc_words, int pinned, uint32_t* __restrict__ tflag)
 {
     bool bad = false;
@@ -955,7 +955,14 @@ void k3t_check(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict
         const uint64_t a0 = idx[0].rbsp_off;
         const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
         const uint64_t ntiles = arena_len / kTTileBytes + 1;
-        const bool ok = ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
+        /* The tile kernel's row loads are unpredicated 16-byte loads anywhere in [a0, a0 + arena_len), clamped to the arena's
+         * last 16 bytes: the arena must lie inside the caller's buffer (an index built by hand, or a corrupt one, may point
+         * past it: such a call goes to the kernel by NALs, which checks every NAL against rbsp_bytes) and hold a whole chunk.
+         * Subtractions only: none of the sums can wrap. */
+        const uint64_t last_off = idx[n - 1].rbsp_off, last_len = idx[n - 1].rbsp_len;
+        const bool inside = a0 <= last_off && last_off <= rbsp_bytes && last_len <= rbsp_bytes - last_off;
+        const bool ok = inside && arena_len >= 16u &&
+                        ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
                         ntiles + 1 <= first_cap && ntiles + 1 <= desc_words;
         tflag[1] = ok ? 1u : 0u;
     }
@@ -1132,6 +1139,9 @@ __device__ __forceinline__ uint32_t tile_element(const TileCtx& t, const LdsT& l
     return ins;
 }
 
+#ifndef HBS3T_COPY_DEPTH
+#define HBS3T_COPY_DEPTH 3      /* stores of a wavefront in flight during k3_tiles' copy */
+#endif
 template <class F, int... Is>
 __device__ __forceinline__ void t_rows_apply(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -1177,47 +1187,44 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const bool last_tile = tile == ntiles - 1;
         const uint64_t wseg = t.tile_lo + (uint64_t)(wv * (int)kTWaveBytes);
 
-        /* ---- my rows ---------------------------------------------------------------------------------------- */
+        /* ---- my rows, fetched INSIDE the flag pass, four at a time (as K12 does since round 3, hbs_scan4.hip): a group is
+         * flagged as soon as its rows are there, with the next group's loads in flight, so a wavefront never has more than
+         * eight row loads outstanding.  That hides the flag pass under the fetch and, more to the point, keeps the CU's memory
+         * queue short, so that the look-back polls of the other workgroup on this CU do not wait behind 48 loads (or, in the
+         * copy, 48 stores: throttled below).  The NAL starts of the tile are fetched on the way: the two first_k words in front
+         * of the rows, the index entries behind the second group's loads -- in issue order each is back when it is needed. */
         u32x4 q[kTRows];
         uint32_t before;
-        if (t.arena_len >= 16u) {
-            /* unpredicated: a chunk that would reach past the arena's end reads the arena's last 16 bytes instead (its register is
-             * never used: the chunk is behind the end, or it is the partial last chunk, an element that fetches its own bytes) */
-            const uint64_t room = t.arena_len - 16u - t.tile_lo;
-            const uint32_t lim = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
-            const uint8_t* const tb = t.arena + t.tile_lo;
-#pragma unroll
-            for (int r = 0; r < kTRows; ++r) {
+        /* unpredicated (k3t_check: the arena holds at least one chunk and lies inside the caller's buffer): a chunk that would
+         * reach past the arena's end reads the arena's last 16 bytes instead (its register is never used: the chunk is behind the
+         * end, or it is the partial last chunk, an element that fetches its own bytes) */
+        const uint64_t room = t.arena_len - 16u - t.tile_lo;
+        const uint32_t lim = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
+        const uint8_t* const tb = t.arena + t.tile_lo;
+        auto load_group = [&](auto gc) {
+            constexpr int g0 = 4 * decltype(gc)::value;
+            t_for_n<4>([&](auto kc) {
+                constexpr int r = g0 + decltype(kc)::value;
                 const uint32_t rel = (uint32_t)(wv * (int)kTWaveBytes + 1024 * r) + 16u * (uint32_t)lane;
                 q[r] = stream_load16(reinterpret_cast<const u32x4*>(tb + (rel < lim ? rel : lim)));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < kTRows; ++r) q[r] = load_chunk_guarded(t.arena, wseg + 1024u * r + 16u * lane, t.arena_len);
-        }
-        before = load_dword_guarded(t.arena, (int64_t)wseg - 4, t.arena_len);
-
-        /* ---- the NALs that begin in the tile ------------------------------------------------------------------ */
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        };
         t.k_lo = first_k[tile];
-        t.m = (uint32_t)(first_k[tile + 1] - t.k_lo);
-        t.prev_begin = t.k_lo > 0 ? idx[t.k_lo - 1].rbsp_off - t.a0 : 0ull;
-        if ((uint32_t)tid < t.m) {
-            const uint64_t k = t.k_lo + (uint32_t)tid;
-            const uint32_t rel = (uint32_t)(idx[k].rbsp_off - t.a0 - t.tile_lo);
-            l.starts[tid] = rel;
-            l.gaps[tid] = (uint32_t)gap_of(idx, k, gap_mode);
-            l.lens[tid] = idx[k].rbsp_len;
-            atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
-        }
+        const uint64_t k_hi = first_k[tile + 1];
+        before = load_dword_guarded(t.arena, (int64_t)wseg - 4, t.arena_len);
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(std::integral_constant<int, 0>{});
+        static_assert(kTRows >= 8 && kTRows % 4 == 0, "groups of four rows, two groups in flight");
+        load_group(std::integral_constant<int, 1>{});
         const uint32_t cut_chunk = (last_tile && (t.arena_len & 15ull) != 0) ? (uint32_t)((t.arena_len - t.tile_lo) >> 4) : 0xFFFFFFFFu;
-        if (last_tile && tid == 0 && (t.arena_len & 15ull) != 0) {  /* the arena's last, partial chunk is written bytewise */
-            const uint32_t rel = (uint32_t)(t.arena_len - t.tile_lo);
-            atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
-        }
 
         HBS3_T_MARK(1)
         /* ---- flags: chunks a 03 may have to go into (four rows per branch, as in K12) ----------------------------- */
         uint32_t fm_lo = 0, fm_hi = 0;
+        uint64_t nk_off = 0, nk_prev = 0;                          /* this thread's NAL of the tile: its rbsp_off; the NAL in front of the tile */
+        uint64_t nk_start = 0, nk_pend = 0;                        /* ... its start in the caller's stream and the end of the NAL in front (gap_of) */
+        uint32_t nk_len = 0;
         t_for_n<kTRows / 4>([&](auto gc) {
             constexpr int g0 = 4 * decltype(gc)::value;
             uint64_t fmask[4];
@@ -1232,6 +1239,41 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                     constexpr int k = decltype(kc)::value, r = g0 + k;
                     if (fmask[k] != 0) { write_lane_c<r>(fm_lo, (uint32_t)fmask[k]); write_lane_c<r>(fm_hi, (uint32_t)(fmask[k] >> 32)); }
                 });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g0 == 0) {
+                /* the NALs that begin in the tile: their index entries are asked for now (first_k is back: it was issued in front
+                 * of the rows this group waited for) and used behind the next group */
+                t.m = (uint32_t)(k_hi - t.k_lo);
+                /* without a branch (clamped entry numbers; gap_of() by hand): a load inside a branch makes the compiler wait for
+                 * everything in flight where the paths meet */
+                const uint64_t kk = t.k_lo + (uint32_t)tid < n ? t.k_lo + (uint32_t)tid : n - 1;
+                nk_prev = idx[t.k_lo > 0 ? t.k_lo - 1 : 0].rbsp_off;
+                nk_off = idx[kk].rbsp_off;
+                nk_len = idx[kk].rbsp_len;
+                nk_start = idx[kk].start;
+                nk_pend = idx[kk > 0 ? kk - 1 : 0].end;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (g0 / 4 + 2 < kTRows / 4) load_group(std::integral_constant<int, g0 / 4 + 2>{});
+            if constexpr (g0 == 4 || kTRows == 4) {
+                /* every loaded register stays live up to here: one that is dead earlier (the upper half of an offset of which
+                 * only the lower is used) is handed out as a temporary at once, and writing it waits for the load */
+                asm volatile("" :: "v"(nk_off), "v"(nk_start), "v"(nk_pend), "v"(nk_len));
+                t.prev_begin = t.k_lo > 0 ? nk_prev - t.a0 : 0ull;
+                if ((uint32_t)tid < t.m) {
+                    const uint32_t rel = (uint32_t)(nk_off - t.a0 - t.tile_lo);
+                    l.starts[tid] = rel;
+                    const uint64_t k = t.k_lo + (uint32_t)tid;
+                    l.gaps[tid] = (uint32_t)(gap_mode == 1 ? synth_gap(k) : nk_start - (k ? nk_pend : 0ull));
+                    l.lens[tid] = nk_len;
+                    atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+                }
+                if (last_tile && tid == 0 && (t.arena_len & 15ull) != 0) {  /* the arena's last, partial chunk is written bytewise */
+                    const uint32_t rel = (uint32_t)(t.arena_len - t.tile_lo);
+                    atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         });
         __syncthreads();                                           /* rowbits, starts, gaps are complete */
@@ -1375,6 +1417,8 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                         const bool served = p == 0u ? k <= (uint32_t)kTElemPass : (k > pbase && k <= pbase + (uint32_t)kTElemPass);
                         if (!((f >> lane) & 1ull) && served && cc < whole) arena_store16(tout + l.seg[k - pbase] + 16u * cc, q[r]);
                     }
+                    /* at most kTCopyDepth stores of a wavefront in flight: see the fetch */
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS3T_COPY_DEPTH) : "memory");
                 });
             }
             if (p + 1 < np) __syncthreads();                       /* the batch's words are read: the next batch may write them */
@@ -1419,7 +1463,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     if (a.n && probe) k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
     /* arena tiles when the index allows it (decided on the device), the item kernel otherwise; path 0 pins the item kernel */
     const uint32_t* tflag = (a.n && want_sparse && a.tiles != 0 && (a.tiles == 2 || a.rbsp_bytes >= kTMinArena)) ? a.tflag : nullptr;
-    if (tflag) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap), a.tiles == 2 ? 1 : 0, a.tflag);
+    if (tflag) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap), a.tiles == 2 ? 1 : 0, a.tflag);
     if (a.n && want_sparse) {
         /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
         k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe);
