@@ -36,9 +36,13 @@ __device__ __forceinline__ bool emit_probe_dense(const uint32_t* probe) { return
 
 /* the arena-tile kernel (k3_tiles, below) takes the sparse case when k3t_check found the index eligible: tflag[0] = a
  * violation was seen, tflag[1] = the global conditions hold */
-__device__ __forceinline__ bool tile_path_on(const uint32_t* tflag) { return tflag && tflag[1] == 1u && tflag[0] == 0u; }
+__device__ __forceinline__ bool tile_path_on(const uint32_t* tflag) { return tflag && tflag[1] == 1u && tflag[0] == 0u && tflag[3] == 0u; }
 /* tflag[2]: the tile kernel met a tile dense in elements and gave up -- the kernel by NALs, enqueued behind it, does the call */
 __device__ __forceinline__ bool tile_path_done(const uint32_t* tflag) { return tile_path_on(tflag) && tflag[2] == 0u; }
+
+/* tflag[3] (k3t_check, in front of everything that follows the index into the arena): an entry of the index lies outside the
+ * caller's RBSP buffer.  The call then ends with HBS_E_ARG and nothing is read through the index. */
+__device__ __forceinline__ bool index_bad(const uint32_t* vflag) { return vflag[3] != 0u; }
 
 enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2 };
 __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when)
@@ -195,9 +199,9 @@ __device__ __forceinline__ uint32_t count_nal(const uint8_t* __restrict__ rbsp, 
 
 __global__ __launch_bounds__(256)
 void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-              unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ probe)
+              unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ probe, const uint32_t* __restrict__ vflag)
 {
-    if (probe && !emit_probe_dense(probe)) return;
+    if ((probe && !emit_probe_dense(probe)) || index_bad(vflag)) return;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -370,9 +374,9 @@ __global__ __launch_bounds__(256)
 void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
              const unsigned long long* __restrict__ nal_total, const unsigned long long* __restrict__ out_off,
              uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
-             const uint32_t* __restrict__ probe)
+             const uint32_t* __restrict__ probe, const uint32_t* __restrict__ vflag)
 {
-    if (probe && !emit_probe_dense(probe)) return;
+    if ((probe && !emit_probe_dense(probe)) || index_bad(vflag)) return;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -394,6 +398,16 @@ void k3_small(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_n
     __shared__ unsigned long long tot[kEmitSmallNals], off[kEmitSmallNals], wsum[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) *err = 0;
+    /* every entry inside the caller's buffer, or nothing is read through the index (HBS_E_ARG) */
+    const bool outside = threadIdx.x < n && (idx[threadIdx.x].rbsp_off > rbsp_bytes || idx[threadIdx.x].rbsp_len > rbsp_bytes - idx[threadIdx.x].rbsp_off);
+    if (__syncthreads_or(outside ? 1 : 0)) {
+        if (threadIdx.x == 0) {
+            sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes; sum->stream_bytes = 0;
+            sum->stop_reason = -1; sum->error = HBS_E_ARG;
+            sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
+        }
+        return;
+    }
     for (uint32_t k = (uint32_t)wv; k < n; k += 4) {
         const uint32_t ins = count_nal(rbsp, idx[k].rbsp_off, idx[k].rbsp_len, lane);
         if (lane == 0) tot[k] = gap_of(idx, k, gap_mode) + idx[k].rbsp_len + ins;
@@ -735,9 +749,9 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
               unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
               uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err, const uint32_t* __restrict__ probe,
-              const uint32_t* __restrict__ tflag)
+              const uint32_t* __restrict__ tflag, const uint32_t* __restrict__ vflag)
 {
-    if ((probe && emit_probe_dense(probe)) || tile_path_done(tflag)) return;      /* the tile kernel, in front of this one, did it */
+    if ((probe && emit_probe_dense(probe)) || tile_path_done(tflag) || index_bad(vflag)) return;      /* the tile kernel, in front of this one, did it */
     __shared__ Lds3 l;
     const int lane0 = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -941,16 +955,18 @@ static_assert(kTChunks <= (int)kTListChunk + 1, "a chunk number fits the list en
 
 __global__ __launch_bounds__(256)
 void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-               uint64_t first_cap, uint64_t desc_words, int pinned, uint32_t* __restrict__ tflag)
+               uint64_t first_cap, uint64_t desc_words, int want_tiles, int pinned, uint32_t* __restrict__ tflag, uint32_t* __restrict__ err)
 {
-    bool bad = false;
+    bool bad = false, outside = false;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t off = idx[k].rbsp_off;
+        if (off > rbsp_bytes || idx[k].rbsp_len > rbsp_bytes - off) outside = true;      /* every kernel behind this one trusts the index */
         if (k > 0 && off != idx[k - 1].rbsp_off + idx[k - 1].rbsp_len) bad = true;
         if (gap_of(idx, k, gap_mode) >= (uint64_t)kTMaxGap) bad = true;
         if (k + kTMaxStarts < n && idx[k + kTMaxStarts].rbsp_off - off < (uint64_t)kTTileBytes) bad = true;
     }
     if (bad) atomicOr(&tflag[0], 1u);
+    if (outside) { atomicOr(&tflag[3], 1u); atomicMax(err, (uint32_t)(-HBS_E_ARG)); }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint64_t a0 = idx[0].rbsp_off;
         const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
@@ -961,7 +977,7 @@ void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
          * Subtractions only: none of the sums can wrap. */
         const uint64_t last_off = idx[n - 1].rbsp_off, last_len = idx[n - 1].rbsp_len;
         const bool inside = a0 <= last_off && last_off <= rbsp_bytes && last_len <= rbsp_bytes - last_off;
-        const bool ok = inside && arena_len >= 16u &&
+        const bool ok = want_tiles && inside && arena_len >= 16u &&
                         ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
                         ntiles + 1 <= first_cap && ntiles + 1 <= desc_words;
         tflag[1] = ok ? 1u : 0u;
@@ -1463,7 +1479,9 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     if (a.n && probe) k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
     /* arena tiles when the index allows it (decided on the device), the item kernel otherwise; path 0 pins the item kernel */
     const uint32_t* tflag = (a.n && want_sparse && a.tiles != 0 && (a.tiles == 2 || a.rbsp_bytes >= kTMinArena)) ? a.tflag : nullptr;
-    if (tflag) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap), a.tiles == 2 ? 1 : 0, a.tflag);
+    /* always: it is also what checks every entry of the index against rbsp_bytes (tflag[3]) before anything follows one into the arena */
+    if (a.n) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap),
+                                             tflag ? 1 : 0, a.tiles == 2 ? 1 : 0, a.tflag, a.err);
     if (a.n && want_sparse) {
         /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
         k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe);
@@ -1483,12 +1501,12 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         uint64_t blocks = (uint64_t)a.grid_blocks;
         if (blocks > ngroups) blocks = ngroups;
         k3_fused<<<dim3((unsigned)blocks), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.items, a.n_items, a.items_cap,
-                                                         a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err, probe, tflag);
+                                                         a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err, probe, tflag, a.tflag);
     }
     if (a.n && want_dense) {
-        k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe);
+        k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, probe, kWhenDense);
-        k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe);
+        k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe, a.tflag);
     }
     if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
     else k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary, a.total_dense, probe);

@@ -77,7 +77,7 @@ typedef struct hbs_summary {
     int32_t  stop_reason;   /* 0: no more start codes; -1: last NAL unterminated;
                                1: stopped at an empty NAL (find_nal_unit == 0 with
                                a start code found, hevc_analyze.c:135)            */
-    int32_t  error;         /* 0 or HBS_E_CAPACITY / HBS_E_TIMEOUT                */
+    int32_t  error;         /* 0 or HBS_E_CAPACITY / HBS_E_TIMEOUT / HBS_E_ARG    */
     uint64_t reserved[3];
 } hbs_summary;
 
@@ -182,7 +182,9 @@ int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t strea
  * 00 00).
  *
  *   d_rbsp, rbsp_bytes                the arena and its size: nothing at or behind d_rbsp + rbsp_bytes
- *                                     is read, and the NALs must add up to at most rbsp_bytes
+ *                                     is read -- an entry with rbsp_off + rbsp_len > rbsp_bytes ends the
+ *                                     call with HBS_E_ARG in the summary before any byte is read through
+ *                                     the index -- and the NALs must add up to at most rbsp_bytes
  *                                     (they do unless entries overlap; else HBS_E_CAPACITY)
  *   d_index_in[k].rbsp_off/rbsp_len   where NAL k's RBSP lives in d_rbsp
  *   gap_mode 0   gap of NAL k = d_index_in[k].start - d_index_in[k-1].end

@@ -165,6 +165,53 @@ def test_emit_arena_tiles_give_up_on_dense_tiles(ctx, orc):
         assert np.array_equal(idx_tiles, idx_nals), dense_at
 
 
+def test_emit_arena_tiles_refuse_an_index_outside_the_arena(ctx, orc):
+    """round 2's advice: the arena-tile kernel reads its rows unpredicated, so an index that points past the caller's RBSP
+    buffer (built by hand, or corrupt) must not reach it even when the path is pinned: k3t_check compares the index with
+    rbsp_bytes (every entry: the call ends with HBS_E_ARG before any kernel follows the index into the arena, whichever emit
+    path is pinned); arenas shorter than one 16-byte chunk go to the kernel by NALs and are right"""
+    import hevcbitstream_amd as hbs
+    rng = np.random.RandomState(37)
+    lens = [int(x) for x in rng.randint(2000, 60000, size=40)]
+    arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+    good = fake_index(lens, [4] * len(lens))
+    ctx.set_emit_path(2)
+    try:
+        want = orc.emit_annexb(arena, good)
+        got, _ = ctx.emit_annexb(dev(arena), good)
+        assert np.array_equal(got, want)
+        bads = []
+        for shift in (1 << 20, 1 << 33, (1 << 64) - (1 << 20)):
+            bad = good.copy()
+            bad["rbsp_off"] = bad["rbsp_off"] + np.uint64(shift)          # contiguous, aligned -- and outside the buffer
+            bads.append(bad)
+        bad = good.copy()
+        bad["rbsp_len"][-1] += 4096                                       # the last NAL runs past the end
+        bads.append(bad)
+        bad = good.copy()
+        bad["rbsp_off"][7] = np.uint64(1 << 40)                           # one entry in the middle
+        bads.append(bad)
+        for path in (2, 0, 1, -1):
+            ctx.set_emit_path(path)
+            for bad in bads:
+                with pytest.raises(hbs.HbsError):                         # HBS_E_ARG, and nothing was read through the index
+                    ctx.emit_annexb(dev(arena), bad, out_cap=2 * len(arena))
+            few = fake_index([100, 200], [4, 3])
+            few["rbsp_off"][1] = np.uint64(1 << 33)
+            with pytest.raises(hbs.HbsError):                             # the one-launch path (auto) checks too
+                ctx.emit_annexb(dev(arena[:300]), few)
+            got, _ = ctx.emit_annexb(dev(arena), good)                    # the context is fine afterwards
+            assert np.array_equal(got, want)
+        ctx.set_emit_path(2)
+        for total in (1, 5, 15, 16, 17):
+            small = ALPHA[rng.randint(0, len(ALPHA), size=total)].copy()
+            idx = fake_index([total], [3])
+            got, _ = ctx.emit_annexb(dev(small), idx)
+            assert np.array_equal(got, orc.emit_annexb(small, idx)), total
+    finally:
+        ctx.set_emit_path(-1)
+
+
 def test_emit_zero_runs(path_ctx, orc):
     ctx = path_ctx
     for z in (2, 3, 4, 5, 255, 256, 257, 513, 70000):
