@@ -281,6 +281,12 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.index = d_index; a.index_cap = index_cap;
     a.rbsp = d_rbsp; a.rbsp_cap = d_rbsp ? rbsp_cap : 0;
     a.desc = c->desc; a.hdr = c->hdr; a.tail = c->tail; a.summary = d_summary;
+    a.ws5 = nullptr;
+    if (!d_rbsp && n) {                                       /* the index-only kernels keep tile aggregates and elements between their passes */
+        rc = ensure_ws(c, hbs::scan5_workspace_bytes(n));
+        if (rc) return rc;
+        a.ws5 = c->ws;
+    }
     c->last_index_only = (!d_rbsp && (c->variant == 5 || (c->variant == 0 && n >= (3ull << 28))) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;
     a.sched = c->sched;

@@ -17,6 +17,8 @@ struct ScanArgs {
     unsigned long long* desc;     /* workspace: 2 words per 16 KiB tile           */
     RunHeader* hdr;               /* workspace                                    */
     uint8_t* tail;                /* workspace of scan4_tail_bytes(): padded copy of the last tile (variant 4) */
+    void* ws5;                    /* workspace of scan5_workspace_bytes(n): tile aggregates and recorded elements of the index-only
+                                     kernels (hbs_scan5.hip); needed only when rbsp == nullptr */
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
     int grid_blocks4;                 /* ... of the event-sparse kernel                                        */
@@ -43,6 +45,7 @@ void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate
 
 /* index-only streaming kernel (hbs_scan5.hip) */
 uint64_t scan5_tile_bytes();
+uint64_t scan5_workspace_bytes(uint64_t stream_bytes);
 void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 } // namespace hbs

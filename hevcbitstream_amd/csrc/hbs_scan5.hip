@@ -6,16 +6,17 @@
  * (the next 16 KiB already in flight), keeps only each chunk's chunk_flag() -- one 64-bit
  * word per KiB, in LDS -- and then treats the flagged chunks exactly as hbs_scan4.hip treats its
  * elements: the window rules on the chunk's bytes [-8, 20) (fetched again from the stream: a few
- * per 64 KiB in coded video, L2 hits), 64 at a time; tile aggregate; decoupled look-back over the
- * tiles in front (hbs_elems.h); index entries.  A wavefront is alone in its workgroup, there is no
- * barrier anywhere, and somebody is always reading while others walk elements or wait for their
- * prefix: 5.1 TB/s on the 16 GiB bench stream, 83 % of the rate this GPU reads memory at.
+ * per 64 KiB in coded video, L2 hits), 64 at a time; tile aggregate.  A wavefront is alone in its
+ * workgroup, there is no barrier anywhere -- and, since round 3, no look-back either: the tiles'
+ * prefixes are formed by two small kernels behind the streaming one and a fourth writes the index
+ * entries from the elements the first one recorded (see "two passes" below).
  *
  * Results are those of k_scan_extract4 with rbsp == nullptr, bit for bit (same element code, same
  * end-of-stream fix-up behind it).  Replaces the byte loop of find_nal_unit (reference
  * h264_nal.c:38-76) over a stream, as hbs_scan4.hip does.
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hbs_elems.h"
 
 namespace hbs {
@@ -162,17 +163,126 @@ __device__ __forceinline__ bool rows_step(RowWalk5& w, DenseRow& d, const Lds5& 
     return flagged;
 }
 
+/* ---- two passes, no look-back (round 3) ---------------------------------------------------------------------------
+ * Until round 3 this was ONE kernel: a wavefront streamed its tile, walked its elements, published the tile's aggregate,
+ * looked back over the tiles in front (hbs_elems.h) and wrote its index entries.  With nothing held in registers the
+ * look-back looked cheap, but a wavefront that waits for its predecessors is a wavefront that does not read, and tiles
+ * finish in convoys: without the look-back (wrong results, timing only) the same kernel took 2.65 ms instead of 2.97 on
+ * the 16 GiB bench stream, the pure read of its geometry 2.53 (profiles/r03/idx_ablation.txt, ceiling3_read.txt).
+ * An index-only scan does not need one: nothing a tile does while it streams depends on the tiles in front of it.  So:
+ *
+ *   k_index5_stream   tile by ticket: flag words, elements, the tile's aggregate -- and the elements themselves (what the
+ *                     emit half needs of each: 32 bytes) into the workspace, up to 256 per tile (the bench stream has ~145 per
+ *                     MiB).  No waiting anywhere.
+ *   k_index5_chunks   aggregate of every 64 consecutive tiles (one wavefront each)
+ *   k_index5_prefix   one wavefront: the prefix in front of every chunk of 64 tiles, 64 chunks per step
+ *   k_index5_emit     one wavefront per tile: its prefix (chunk prefix + the tiles of its chunk in front of it), then the
+ *                     index entries from the recorded elements.  A tile with more elements than are recorded, or one
+ *                     that was walked by rows, is streamed and walked again here, with the prefix known: rare, and
+ *                     nobody waits for it.
+ *
+ * The passes behind the first move ~0.5 % of the stream's bytes.  Same results as before, bit for bit. */
+struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
+static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
+struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
+constexpr uint32_t k5RecCap = 256;                                        /* elements recorded per tile */
+constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
+constexpr int k5ChunkTiles = 64;
+
+struct Ws5 {
+    TileAgg* tagg;       /* [tiles]                  */
+    uint32_t* nrec;      /* [tiles]                  */
+    TileAgg* cagg;       /* [chunks]                 */
+    Pre5* cpre;          /* [chunks]                 */
+    Rec5* rec;           /* [tiles][k5RecCap]        */
+};
+__host__ __device__ inline uint64_t ws5_chunks(uint64_t tiles) { return (tiles + k5ChunkTiles - 1) / k5ChunkTiles; }
+__host__ __device__ inline Ws5 ws5_carve(void* base, uint64_t tiles)
+{
+    uint8_t* p = static_cast<uint8_t*>(base);
+    Ws5 w;
+    const uint64_t ch = ws5_chunks(tiles);
+    w.rec = reinterpret_cast<Rec5*>(p); p += tiles * k5RecCap * sizeof(Rec5);
+    w.tagg = reinterpret_cast<TileAgg*>(p); p += ((tiles * sizeof(TileAgg) + 255) & ~255ull);
+    w.cagg = reinterpret_cast<TileAgg*>(p); p += ((ch * sizeof(TileAgg) + 255) & ~255ull);
+    w.cpre = reinterpret_cast<Pre5*>(p); p += ((ch * sizeof(Pre5) + 255) & ~255ull);
+    w.nrec = reinterpret_cast<uint32_t*>(p);
+    return w;
+}
+uint64_t scan5_workspace_bytes(uint64_t stream_bytes)
+{
+    const uint64_t tiles = (stream_bytes + k5TileBytes - 1) / k5TileBytes + 1, ch = ws5_chunks(tiles);
+    return tiles * k5RecCap * sizeof(Rec5) + ((tiles * sizeof(TileAgg) + 255) & ~255ull) + ((ch * sizeof(TileAgg) + 255) & ~255ull) +
+           ((ch * sizeof(Pre5) + 255) & ~255ull) + tiles * sizeof(uint32_t) + 256;
+}
+
+/* the streaming half of a tile: its flag words into l.words, one span at a time, the next span's loads in flight meanwhile */
+__device__ __forceinline__ void tile_words(Lds5& l, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t cut, int lane)
+{
+    Span5 cur, nxt;
+    if (base < n) span_load(nxt, stream, n, base, launder_lane(lane));
+#pragma unroll 1
+    for (int sp = 0; sp < k5TileRows / k5SpanRows; ++sp) {
+        const uint64_t sbase = base + (uint64_t)sp * k5SpanBytes;
+        cur = nxt;
+        if (sp + 1 < k5TileRows / k5SpanRows && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
+        unsigned long long w = 0;
+        if (sbase < n) w = span_flags(cur, n, sbase, cut, launder_lane(lane));
+        if (lane < k5SpanRows) l.words[sp * k5SpanRows + lane] = w;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+/* elements of the tile and whether it is walked by rows (16 or more elements per flagged row: zero stuffing, padding) */
+__device__ __forceinline__ uint32_t tile_census(Lds5& l, int lane, bool& by_rows)
+{
+    uint32_t mycnt = 0, myrows = 0;
+#pragma unroll
+    for (int j = 0; j < k5WordsPerLane; ++j) {
+        const unsigned long long w = l.words[lane * k5WordsPerLane + j];
+        mycnt += (uint32_t)__builtin_popcountll(w);
+        myrows += w != 0ull ? 1u : 0u;
+    }
+    const uint32_t inc = wave_incl_scan32(mycnt, lane);
+    l.lane_pre[lane] = inc - mycnt;
+    const uint32_t nelem = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t flagged_rows = wave_sum32(myrows);
+    by_rows = nelem > 128u && nelem >= 16u * flagged_rows;
+    return nelem;
+}
+
+__device__ __forceinline__ void rec_store(Rec5* r, const Elem& el, uint64_t base)
+{
+    const ElemPacked p = elem_pack(el.m, el.s);
+    u32x4 a, b;
+    a.x = (uint32_t)((el.v.g0 - base) >> 4); a.y = el.gap; a.z = p.a; a.w = p.b;
+    b.x = p.c; b.y = el.cls.z; b.z = el.cls.e1; b.w = el.cls.e3;
+    u32x4* q = reinterpret_cast<u32x4*>(r);
+    q[0] = a; q[1] = b;
+}
+__device__ __forceinline__ void rec_load(const Rec5* r, Elem& el, uint64_t base, uint64_t n)
+{
+    const u32x4* q = reinterpret_cast<const u32x4*>(r);
+    const u32x4 a = q[0], b = q[1];
+    ElemPacked p; p.a = a.z; p.b = a.w; p.c = b.x;
+    elem_unpack(p, el.m, el.s);
+    el.cls.z = b.y; el.cls.e1 = b.z; el.cls.e3 = b.w;
+    el.chunk = a.x; el.gap = a.y;
+    el.v.g0 = base + 16ull * a.x; el.v.n = n; el.v.stream = nullptr;
+    el.v.xpp = el.v.xp = el.v.x0 = el.v.x1 = el.v.x2 = el.v.x3 = el.v.xn = 0;      /* bytes: only a copy would want them */
+}
+
 __global__ __launch_bounds__(64)
-void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
-                 hbs_nal_entry* __restrict__ index, uint64_t index_cap,
-                 unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int gate)
+void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
     if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
     __shared__ Lds5 l;
+    const Ws5 w5 = ws5_carve(ws, num_tiles);
     const int lane0 = threadIdx.x;
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
-    EmitTarget tgt;
-    tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
     for (;;) {
         const int lane = launder_lane(lane0);
         uint32_t tk = 0;
@@ -181,47 +291,11 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
         if (tile >= num_tiles) break;
         const uint64_t base = tile * k5TileBytes;
         const uint64_t tile_end = base + k5TileBytes;
-        const bool last_tile = tile == num_tiles - 1;
-        __builtin_amdgcn_s_setprio(3);
-
-        /* stream the tile: flag words into LDS, one span at a time, the next span's loads in flight meanwhile */
-        {
-            Span5 cur, nxt;
-            if (base < n) span_load(nxt, stream, n, base, launder_lane(lane));
-#pragma unroll 1
-            for (int sp = 0; sp < k5TileRows / k5SpanRows; ++sp) {
-                const uint64_t sbase = base + (uint64_t)sp * k5SpanBytes;
-                cur = nxt;
-                if (sp + 1 < k5TileRows / k5SpanRows && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
-                unsigned long long w = 0;
-                if (sbase < n) w = span_flags(cur, n, sbase, cut, launder_lane(lane));
-                if (lane < k5SpanRows) l.words[sp * k5SpanRows + lane] = w;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        /* my words; how many elements in front of them */
-        uint32_t mycnt = 0;
-#pragma unroll
-        for (int j = 0; j < k5WordsPerLane; ++j) mycnt += (uint32_t)__builtin_popcountll(l.words[lane * k5WordsPerLane + j]);
-        const uint32_t inc = wave_incl_scan32(mycnt, lane);
-        l.lane_pre[lane] = inc - mycnt;
-        const uint32_t nelem = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-        /* rows that hold a flag: by rows, or by elements? */
-        uint32_t myrows = 0;
-#pragma unroll
-        for (int j = 0; j < k5WordsPerLane; ++j) myrows += l.words[lane * k5WordsPerLane + j] != 0ull ? 1u : 0u;
-        const uint32_t flagged_rows = wave_sum32(myrows);
-        const bool by_rows = nelem > 128u && nelem >= 16u * flagged_rows;
-
-        /* elements -> tile aggregate, 64 at a time */
+        tile_words(l, stream, n, base, cut, lane);
+        bool by_rows;
+        const uint32_t nelem = tile_census(l, lane, by_rows);
         const uint32_t npass = (nelem + 63u) >> 6;
-        /* up to 128 elements (a 1 MiB tile of coded video has ~100) are walked once and kept: two per lane */
-        Elem el, el2;
-        TileAgg acc = agg_identity(), e = agg_identity(), e2 = agg_identity();
+        TileAgg acc = agg_identity();
         uint64_t prev_end = base;
         if (by_rows) {
             RowWalk5 w;
@@ -239,68 +313,144 @@ void k_scan_index5(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
                 }
             }
         } else {
+            const bool record = nelem <= k5RecCap;
 #pragma unroll 1
-        for (uint32_t p = 0; p < npass; ++p) {
-            TileAgg ea;
-            if (p == 1u) ea = make_batch(el2, l, 64u, nelem, lane, stream, base, n, prev_end);
-            else ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+            for (uint32_t p = 0; p < npass; ++p) {
+                Elem el;
+                TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+                if (record && 64u * p + (uint32_t)lane < nelem) rec_store(&w5.rec[tile * k5RecCap + 64u * p + (uint32_t)lane], el, base);
+                ea = wave_scan_combine(ea, lane);
+                acc = combine(acc, agg_readlane(ea, 63));
+            }
+        }
+        const TileAgg tagg = combine(acc, gap_agg(span_bytes(prev_end, tile_end, n)));
+        if (lane == 0) {
+            w5.tagg[tile] = tagg;
+            w5.nrec[tile] = (by_rows || nelem > k5RecCap) ? k5Rewalk : nelem;
+        }
+        __builtin_amdgcn_wave_barrier();                       /* l is reused by the next tile */
+    }
+}
+
+__device__ __forceinline__ TileAgg agg_load_or_identity(const TileAgg* a, uint64_t i, uint64_t count)
+{
+    TileAgg r = agg_identity();
+    if (i < count) r = a[i];
+    return r;
+}
+
+__global__ __launch_bounds__(64)
+void k_index5_chunks(uint64_t num_tiles, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate == kGateIfSparse && probe_dense_dev(const_cast<RunHeader*>(hdr))) return;
+    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const int lane = threadIdx.x;
+    const uint64_t c = blockIdx.x;
+    const TileAgg a = wave_scan_combine(agg_load_or_identity(w5.tagg, c * k5ChunkTiles + (uint64_t)lane, num_tiles), lane);
+    if (lane == 63) w5.cagg[c] = a;
+}
+
+__global__ __launch_bounds__(64)
+void k_index5_prefix(uint64_t num_tiles, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate == kGateIfSparse && probe_dense_dev(const_cast<RunHeader*>(hdr))) return;
+    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const int lane = threadIdx.x;
+    const uint64_t chunks = ws5_chunks(num_tiles);
+    Prefix carry; carry.kept = 0; carry.nals = 0; carry.inside = 0;
+    TileAgg nxt = agg_load_or_identity(w5.cagg, (uint64_t)lane, chunks);
+#pragma unroll 1
+    for (uint64_t c0 = 0; c0 < chunks; c0 += 64) {
+        const TileAgg mine = nxt;
+        nxt = agg_load_or_identity(w5.cagg, c0 + 64 + (uint64_t)lane, chunks);        /* the next step's, under this step's scan */
+        const TileAgg inc = wave_scan_combine(mine, lane);
+        TileAgg ex = agg_shfl_up(inc, 1);
+        if (lane == 0) ex = agg_identity();
+        const Prefix p = fold(carry, ex);
+        if (c0 + (uint64_t)lane < chunks) {
+            Pre5 o; o.kept = p.kept; o.nals = p.nals; o.inside = p.inside; o.pad = 0;
+            w5.cpre[c0 + (uint64_t)lane] = o;
+        }
+        carry = prefix_uniform4(fold(carry, agg_readlane(inc, 63)));
+    }
+}
+
+__global__ __launch_bounds__(64)
+void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
+                   hbs_nal_entry* __restrict__ index, uint64_t index_cap, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
+    __shared__ Lds5 l;
+    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const int lane = threadIdx.x;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t base = tile * k5TileBytes, tile_end = base + k5TileBytes;
+    EmitTarget tgt;
+    tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
+    /* the prefix in front of my tile: in front of its chunk, then the tiles of the chunk in front of it */
+    const uint64_t c = tile / k5ChunkTiles, t0 = c * k5ChunkTiles;
+    TileAgg mine = agg_identity();
+    if (t0 + (uint64_t)lane < tile) mine = w5.tagg[t0 + (uint64_t)lane];
+    const TileAgg infront = agg_readlane(wave_scan_combine(mine, lane), 63);
+    const Pre5 cp = w5.cpre[c];
+    Prefix ex; ex.kept = cp.kept; ex.nals = cp.nals; ex.inside = cp.inside;
+    const Prefix excl = prefix_uniform4(fold(ex, infront));
+    if (lane == 0 && tile == num_tiles - 1) {
+        const Prefix incl = fold(excl, w5.tagg[tile]);
+        hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
+    }
+    const uint32_t nrec = w5.nrec[tile];
+    if (nrec != k5Rewalk) {
+        TileAgg acc = agg_identity();
+#pragma unroll 1
+        for (uint32_t p0 = 0; p0 < nrec; p0 += 64u) {
+            Elem el;
+            const bool have = p0 + (uint32_t)lane < nrec;
+            TileAgg ea = agg_identity();
+            if (have) { rec_load(&w5.rec[tile * k5RecCap + p0 + (uint32_t)lane], el, base, n); ea = elem_agg(el.gap, el.s); }
             ea = wave_scan_combine(ea, lane);
             TileAgg up = agg_shfl_up(ea, 1);
             if (lane == 0) up = agg_identity();
-            if (p == 1u) e2 = combine(acc, up); else e = combine(acc, up);
+            const TileAgg e = combine(acc, up);
             acc = combine(acc, agg_readlane(ea, 63));
+            if (have) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
         }
-        }
-        const TileAgg tagg = combine(acc, gap_agg(span_bytes(prev_end, tile_end, n)));
-
-        Prefix ex;
-        uint32_t it, stl;
-        const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
-        __builtin_amdgcn_s_setprio(0);
-        if (!ok) return;
-        if (lane == 0 && last_tile) {
-            const Prefix incl = fold(ex, tagg);
-            hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
-        }
-        const Prefix excl = prefix_uniform4(ex);
-
-        /* index entries: one or two batches -> the elements are still in registers; more -> walk them again */
-        if (by_rows) {
-            TileAgg accb = agg_identity();
-            prev_end = base;
-            RowWalk5 w;
-            rows_begin(w, stream, n, base, tile_end, lane);
+        return;
+    }
+    /* the tile again, the prefix known: by rows, or its elements 64 at a time */
+    const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
+    tile_words(l, stream, n, base, cut, lane);
+    bool by_rows;
+    const uint32_t nelem = tile_census(l, lane, by_rows);
+    TileAgg accb = agg_identity();
+    uint64_t prev_end = base;
+    if (by_rows) {
+        RowWalk5 w;
+        rows_begin(w, stream, n, base, tile_end, lane);
 #pragma unroll 1
-            for (int r = 0; r < k5TileRows; ++r) {
-                DenseRow d;
-                if (!rows_step(w, d, l, r, stream, n, base, lane, prev_end)) continue;
-                const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
-                TileAgg up = agg_shfl_up(ea, 1);
-                if (lane == 0) up = agg_identity();
-                const TileAgg eb = combine(accb, up);
-                accb = combine(accb, agg_readlane(ea, 63));
-                if (d.el.v.g0 < n) elem_emit(d.el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-            }
-        } else if (npass == 1u) {
-            if ((uint32_t)lane < nelem) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-        } else if (npass == 2u) {
-            elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-            if (64u + (uint32_t)lane < nelem) elem_emit(el2, e2, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-        } else if (npass > 2u) {
-            TileAgg accb = agg_identity();
-            prev_end = base;
-#pragma unroll 1
-            for (uint32_t p = 0; p < npass; ++p) {
-                TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
-                ea = wave_scan_combine(ea, lane);
-                TileAgg up = agg_shfl_up(ea, 1);
-                if (lane == 0) up = agg_identity();
-                const TileAgg eb = combine(accb, up);
-                accb = combine(accb, agg_readlane(ea, 63));
-                if (64u * p + (uint32_t)lane < nelem) elem_emit(el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-            }
+        for (int r = 0; r < k5TileRows; ++r) {
+            DenseRow d;
+            if (!rows_step(w, d, l, r, stream, n, base, lane, prev_end)) continue;
+            const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
+            TileAgg up = agg_shfl_up(ea, 1);
+            if (lane == 0) up = agg_identity();
+            const TileAgg eb = combine(accb, up);
+            accb = combine(accb, agg_readlane(ea, 63));
+            if (d.el.v.g0 < n) elem_emit(d.el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
         }
-        __builtin_amdgcn_wave_barrier();                       /* l is reused by the next tile */
+    } else {
+        const uint32_t npass = (nelem + 63u) >> 6;
+#pragma unroll 1
+        for (uint32_t p = 0; p < npass; ++p) {
+            Elem el;
+            TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+            ea = wave_scan_combine(ea, lane);
+            TileAgg up = agg_shfl_up(ea, 1);
+            if (lane == 0) up = agg_identity();
+            const TileAgg eb = combine(accb, up);
+            accb = combine(accb, agg_readlane(ea, 63));
+            if (64u * p + (uint32_t)lane < nelem) elem_emit(el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+        }
     }
 }
 
@@ -312,10 +462,17 @@ void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStre
 {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    uint64_t waves = (uint64_t)cus * 20u;                       /* what fits: ~95 VGPRs per lane, 8.5 KiB of LDS per wavefront */
+    static const int per_cu = [] {                             /* what is resident: 165 VGPRs per lane -> 3 wavefronts per SIMD (8 or 16 per CU measured slower) */
+        const char* e = getenv("HBS5_WAVES_PER_CU");            /* debugging aid */
+        return e && atoi(e) > 0 && atoi(e) <= 32 ? atoi(e) : 12;
+    }();
+    uint64_t waves = (uint64_t)cus * (uint64_t)per_cu;
     if (waves > num_tiles) waves = num_tiles;
     if (waves < 1) waves = 1;
-    k_scan_index5<<<dim3((unsigned)waves), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, a.desc, a.hdr, gate);
+    k_index5_stream<<<dim3((unsigned)waves), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.ws5, a.hdr, gate);
+    k_index5_chunks<<<dim3((unsigned)ws5_chunks(num_tiles)), dim3(64), 0, st>>>(num_tiles, a.ws5, a.hdr, gate);
+    k_index5_prefix<<<dim3(1), dim3(64), 0, st>>>(num_tiles, a.ws5, a.hdr, gate);
+    k_index5_emit<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, a.ws5, a.hdr, gate);
 }
 
 } // namespace hbs

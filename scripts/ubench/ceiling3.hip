@@ -144,6 +144,69 @@ void k_skel(SkelArgs a)
     if (lane == 0 && wave == 0 && a.stats) { atomicAdd(&a.stats[0], polls); atomicAdd(&a.stats[1], tiles); }
 }
 
+// ---- reads (index-only scan, hbs_scan5.hip): who reads what, with non-temporal loads -------------------------------
+// tile:  a wavefront (alone in its workgroup) takes a TILE_KB tile by ticket and streams it SPAN KiB at a time, the next span in flight
+// coop:  a workgroup of WAVES wavefronts takes a tile by ticket; its spans are dealt to the wavefronts round-robin
+// sweep: no tiles: spans dealt grid-wide round-robin (the fastest read pattern of profiles/r02/ceiling2.txt)
+template <int SPAN, int TILE_KB, int WAVES, int DEPTH2>
+__global__ __launch_bounds__(64 * WAVES)
+void k_read_coop(const uint8_t* __restrict__ src, uint32_t* __restrict__ out, size_t ntiles, unsigned* ticket)
+{
+    __shared__ unsigned tk;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t acc = 0;
+    constexpr int spans = TILE_KB / SPAN, mine = spans / WAVES;
+    static_assert(spans % WAVES == 0, "whole spans per wavefront");
+    for (;;) {
+        if (WAVES > 1) __syncthreads();
+        if (threadIdx.x == 0) tk = atomicAdd(ticket, 1u);
+        if (WAVES > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        const size_t t = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+        if (t >= ntiles) break;
+        const uint8_t* base = src + t * (size_t)TILE_KB * 1024 + 16 * lane;
+        u32x4 cur[SPAN], nxt[SPAN];
+#pragma unroll
+        for (int r = 0; r < SPAN; ++r) nxt[r] = ld_nt(base + ((size_t)wave * SPAN + r) * 1024);
+#pragma unroll 1
+        for (int i = 0; i < mine; ++i) {
+#pragma unroll
+            for (int r = 0; r < SPAN; ++r) cur[r] = nxt[r];
+            if (i + 1 < mine) {
+#pragma unroll
+                for (int r = 0; r < SPAN; ++r) nxt[r] = ld_nt(base + ((size_t)((i + 1) * WAVES + wave) * SPAN + r) * 1024);
+            }
+#pragma unroll
+            for (int r = 0; r < SPAN; ++r) acc += cur[r].x ^ cur[r].y ^ cur[r].z ^ cur[r].w;
+        }
+    }
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+template <int SPAN>
+__global__ __launch_bounds__(256)
+void k_read_sweep(const uint8_t* __restrict__ src, uint32_t* __restrict__ out, size_t nspans)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    const size_t stride = (size_t)gridDim.x * 4;
+    size_t s = (size_t)blockIdx.x * 4 + wave;
+    u32x4 cur[SPAN], nxt[SPAN];
+    if (s < nspans) {
+#pragma unroll
+        for (int r = 0; r < SPAN; ++r) nxt[r] = ld_nt(src + (s * SPAN + r) * 1024 + 16 * lane);
+    }
+    for (; s < nspans; s += stride) {
+#pragma unroll
+        for (int r = 0; r < SPAN; ++r) cur[r] = nxt[r];
+        if (s + stride < nspans) {
+#pragma unroll
+            for (int r = 0; r < SPAN; ++r) nxt[r] = ld_nt(src + ((s + stride) * SPAN + r) * 1024 + 16 * lane);
+        }
+#pragma unroll
+        for (int r = 0; r < SPAN; ++r) acc += cur[r].x ^ cur[r].y ^ cur[r].z ^ cur[r].w;
+    }
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 template <class F> float time_ms(F f, int reps = 4)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -196,6 +259,26 @@ int main(int argc, char** argv)
         snprintf(ex, 64, "polls/tile %.2f", st[1] ? (double)st[0] / (double)st[1] : 0.0);
         rw(nm, ms, ex);
     };
+    if (argc > 2 && !strcmp(argv[2], "read")) {
+        uint32_t* outp; hipMalloc(&outp, 4096);
+        auto ro = [&](const char* name, float ms) { printf("read %-44s %7.0f GB/s  (%.3f ms)\n", name, 1.0 * n / ms / 1e6, ms); fflush(stdout); };
+        for (int rep = 0; rep < 2; ++rep) {
+            ro("tile 1 MiB span16, 1 wave, x5120", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<16, 1024, 1, 0><<<5120, 64>>>(src, outp, n >> 20, ticket); }));
+            ro("tile 256 KiB span16, 1 wave, x5120", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<16, 256, 1, 0><<<5120, 64>>>(src, outp, n >> 18, ticket); }));
+            ro("tile 1 MiB span8, 1 wave, x8192", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<8, 1024, 1, 0><<<8192, 64>>>(src, outp, n >> 20, ticket); }));
+            ro("tile 1 MiB span16, 4 waves coop, x1280", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<16, 1024, 4, 0><<<1280, 256>>>(src, outp, n >> 20, ticket); }));
+            ro("tile 1 MiB span16, 16 waves coop, x256", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<16, 1024, 16, 0><<<256, 1024>>>(src, outp, n >> 20, ticket); }));
+            ro("tile 1 MiB span16, 8 waves coop, x512", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<16, 1024, 8, 0><<<512, 512>>>(src, outp, n >> 20, ticket); }));
+            ro("tile 4 MiB span16, 16 waves coop, x256", time_ms([&] { hipMemsetAsync(ticket, 0, 4); k_read_coop<16, 4096, 16, 0><<<256, 1024>>>(src, outp, n >> 22, ticket); }));
+            ro("sweep span16 grid 1024", time_ms([&] { k_read_sweep<16><<<1024, 256>>>(src, outp, n >> 14); }));
+            ro("sweep span16 grid 1280", time_ms([&] { k_read_sweep<16><<<1280, 256>>>(src, outp, n >> 14); }));
+            ro("sweep span16 grid 2048", time_ms([&] { k_read_sweep<16><<<2048, 256>>>(src, outp, n >> 14); }));
+            ro("sweep span8 grid 2048", time_ms([&] { k_read_sweep<8><<<2048, 256>>>(src, outp, n >> 13); }));
+            ro("sweep span4 grid 2048", time_ms([&] { k_read_sweep<4><<<2048, 256>>>(src, outp, n >> 12); }));
+        }
+        hipDeviceSynchronize();
+        return 0;
+    }
 #define GEO(W, R, PC, MINW, PROG, TL, TS, ...) run("prog " #PROG " thr ld " #TL " st " #TS, k_skel<W, R, 0, PROG, MINW, TL, TS>, W, R, PC, __VA_ARGS__)
     for (int rep = 0; rep < 2; ++rep) {
         // store depth 3, load depth swept
