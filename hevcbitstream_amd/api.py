@@ -26,11 +26,11 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_ctx_get_stream",
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_index_extract_host", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_write_headers", "hbs_parse_headers_trace", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
-           "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_grid",
+           "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_kernel_ms_back", "hbs_ctx_grid",
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
-           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world",
+           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_gather_parts",
            "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps"]
 
 
@@ -80,6 +80,7 @@ def load_library():
     lib.hbs_ctx_synchronize.argtypes = [C.c_void_p]
     lib.hbs_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.hbs_ctx_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.hbs_ctx_kernel_ms_back.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     lib.hbs_ctx_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hbs_ctx_set_kernel.argtypes = [C.c_void_p, C.c_int]
     lib.hbs_ctx_get_kernel.argtypes = [C.c_void_p]
@@ -176,6 +177,12 @@ class Context:
         """Duration of the last fused scan/extract kernel (HIP events on its own stream)."""
         ms = C.c_float()
         self._check(self.lib.hbs_ctx_kernel_ms(self.h, C.byref(ms)), "hbs_ctx_kernel_ms")
+        return ms.value
+
+    def kernel_ms_back(self, back):
+        """Duration of the timed call `back` calls ago (0 = the last one; the library keeps the last 64)."""
+        ms = C.c_float()
+        self._check(self.lib.hbs_ctx_kernel_ms_back(self.h, back, C.byref(ms)), "hbs_ctx_kernel_ms_back")
         return ms.value
 
     def grid(self):

@@ -20,6 +20,8 @@
 #define HBS_DEFAULT_SCHED 1
 #endif
 
+constexpr int kTimingRing = 64;       /* timed calls whose event pairs are kept (hbs_ctx_kernel_ms_back) */
+
 struct hbs_ctx {
     int device;
     hipStream_t own_stream;
@@ -46,7 +48,9 @@ struct hbs_ctx {
     void* ws; uint64_t ws_bytes;
     uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
     /* optional timing of the dominant kernel */
-    int timing; hipEvent_t ev0, ev1; int ev_valid;
+    int timing; hipEvent_t ev0, ev1; int ev_valid;        /* ev0 / ev1: the slot of the ring the last call used */
+    hipEvent_t ring0[kTimingRing], ring1[kTimingRing];    /* event pairs of the last kTimingRing timed calls */
+    unsigned long long timed_calls;
     char err[256];
 };
 
@@ -143,7 +147,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->tail) (void)hipFree(c->tail);
     if (c->ws) (void)hipFree(c->ws);
     if (c->zeros) (void)hipFree(c->zeros);
-    if (c->ev0) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
+    if (c->ring0[0]) for (int i = 0; i < kTimingRing; ++i) { (void)hipEventDestroy(c->ring0[i]); (void)hipEventDestroy(c->ring1[i]); }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -167,12 +171,26 @@ int hbs_ctx_set_stream(hbs_ctx* c, void* s)
 int hbs_ctx_enable_timing(hbs_ctx* c, int on)
 {
     if (!c) return HBS_E_ARG;
-    if (on && !c->ev0) {
-        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return HBS_E_HIP;
+    if (on && !c->ring0[0]) {
+        if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+        for (int i = 0; i < kTimingRing; ++i)
+            if (hipEventCreate(&c->ring0[i]) != hipSuccess || hipEventCreate(&c->ring1[i]) != hipSuccess) return HBS_E_HIP;
     }
     c->timing = on ? 1 : 0;
     c->ev_valid = 0;
+    c->timed_calls = 0;
     return 0;
+}
+
+/* the timed call `back` calls ago (0 = the last one); the ring keeps kTimingRing of them */
+int hbs_ctx_kernel_ms_back(hbs_ctx* c, int back, float* ms)
+{
+    if (!c || !ms || !c->ev_valid || back < 0 || back >= kTimingRing || (unsigned long long)back >= c->timed_calls) return HBS_E_ARG;
+    const int slot = (int)((c->timed_calls - 1 - (unsigned long long)back) % kTimingRing);
+    hipError_t e = hipEventSynchronize(c->ring1[slot]);
+    if (e != hipSuccess) return fail(c, e, "hipEventSynchronize");
+    e = hipEventElapsedTime(ms, c->ring0[slot], c->ring1[slot]);
+    return e == hipSuccess ? 0 : fail(c, e, "hipEventElapsedTime");
 }
 
 int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
@@ -293,9 +311,14 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4;
     c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
     if (hbs::scan_takes_small_path(n, index_cap, c->variant)) { c->probe_pending = 0; c->last_variant = 2; }
-    a.ev_begin = c->timing ? c->ev0 : nullptr;
-    a.ev_end = c->timing ? c->ev1 : nullptr;
-    c->ev_valid = (c->timing && n) ? 1 : 0;
+    if (c->timing && n) {                                     /* this call's slot of the ring */
+        const int slot = (int)(c->timed_calls % kTimingRing);
+        c->ev0 = c->ring0[slot]; c->ev1 = c->ring1[slot];
+        c->timed_calls += 1;
+    }
+    a.ev_begin = (c->timing && n) ? c->ev0 : nullptr;
+    a.ev_end = (c->timing && n) ? c->ev1 : nullptr;
+    c->ev_valid = (c->timing && n) ? 1 : (c->ev_valid && c->timing);
     hipError_t e = hbs::launch_scan_extract(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_scan_extract");
 }

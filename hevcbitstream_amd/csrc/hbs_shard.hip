@@ -21,6 +21,7 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include "hbs_common.h"
 
@@ -48,8 +49,11 @@ Rccl g_rccl;
 bool load_rccl()
 {
     if (g_rccl.so) return true;
-    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    /* HBS_RCCL_LIB: another library with RCCL's entry points (tests/sim/fake_rccl.c: a transport between processes that
+     * share ONE GPU, which RCCL itself refuses; the product never sets it) */
+    const char* alt = getenv("HBS_RCCL_LIB");
+    void* so = alt && *alt ? dlopen(alt, RTLD_NOW | RTLD_GLOBAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so && !(alt && *alt)) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!so) { fprintf(stderr, "hevcbitstream_amd: RCCL not found (%s)\n", dlerror()); return false; }
     Rccl r;
     r.so = so;
@@ -73,10 +77,16 @@ __global__ void k_rebase(const hbs_nal_entry* __restrict__ in, uint64_t n, uint6
 
 } // namespace
 
+/* What every rank tells the others before a byte of payload moves: kGatherWords words per rank, all-gathered.  With them
+ * every rank takes the SAME decision -- go on, or return an error -- so that nobody is left waiting in a collective the
+ * others never enter (round 2's advice: a receiver that found its buffer too small used to return alone). */
+enum : int { kGwCount = 0, kGwCap = 1, kGwStatus = 2, kGwStopped = 3, kGatherWords = 4 };
+constexpr int kMaxWorld = 1024;
+
 struct hbs_comm {
     ncclComm_t comm;
     int rank, world, owned, device;
-    unsigned long long* d_counts;      /* world + 1 words: [0, world) everybody's, [world] mine */
+    unsigned long long* d_counts;      /* (world + 1) x kGatherWords words: [0, world) everybody's, [world] mine */
     hbs_nal_entry* d_stage;            /* rebased copy of the local entries */
     uint64_t stage_cap;
 };
@@ -100,7 +110,7 @@ static int comm_new(hbs_ctx* ctx, ncclComm_t c, int owned, int rank, int world, 
     if (!h) return HBS_E_HIP;
     h->comm = c; h->rank = rank; h->world = world; h->owned = owned; h->device = hbs_ctx_device(ctx);
     h->d_stage = nullptr; h->stage_cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_counts), (size_t)(world + 1) * sizeof(unsigned long long)) != hipSuccess) { delete h; return HBS_E_HIP; }
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_counts), (size_t)(world + 1) * kGatherWords * sizeof(unsigned long long)) != hipSuccess) { delete h; return HBS_E_HIP; }
     *out = h;
     return 0;
 }
@@ -140,45 +150,66 @@ void hbs_comm_destroy(hbs_comm* h)
 int hbs_comm_rank(const hbs_comm* h) { return h ? h->rank : HBS_E_ARG; }
 int hbs_comm_world(const hbs_comm* h) { return h ? h->world : HBS_E_ARG; }
 
-int hbs_gather_index(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, uint64_t n_local,
-                     uint64_t stream_base, uint64_t rbsp_base, int root,
-                     hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out)
+static int gather_impl(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, uint64_t n_local, int stopped,
+                       uint64_t stream_base, uint64_t rbsp_base, int root,
+                       hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out)
 {
-    if (!ctx || !h || (n_local && !d_index) || root >= h->world || !counts_out) return HBS_E_ARG;
+    /* argument errors are the same on every rank or a bug of the caller: nothing collective has happened yet */
+    if (!ctx || !h || (n_local && !d_index) || root >= h->world || !counts_out || h->world > kMaxWorld) return HBS_E_ARG;
     if (hipSetDevice(h->device) != hipSuccess) return HBS_E_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(hbs_ctx_get_stream(ctx));
     const int W = h->world;
-    /* 1. the counts: 8 bytes per rank, to everybody */
-    unsigned long long mine = n_local;
-    if (hipMemcpyAsync(h->d_counts + W, &mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess) return HBS_E_HIP;
-    if (g_rccl.AllGather(h->d_counts + W, h->d_counts, 1, ncclUint64, h->comm, st) != ncclSuccess) return HBS_E_HIP;
-    unsigned long long counts[1024];
-    if (W > 1024) return HBS_E_ARG;
-    if (hipMemcpyAsync(counts, h->d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) return HBS_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return HBS_E_HIP;        /* the sizes of the receives are host values */
-    uint64_t total = 0;
-    for (int r = 0; r < W; ++r) { counts_out[r] = counts[r]; total += counts[r]; }
     const bool receiver = root < 0 || root == h->rank;
-    if (receiver && (total > cap_all || (total && !d_all))) return HBS_E_CAPACITY;
-    /* 2. my entries with global offsets (only when a base is given: independent shards keep theirs) */
+    /* 0. everything that can fail locally happens BEFORE the first collective, and its outcome travels with the counts */
+    unsigned long long status = 0;
+    const bool rebase = n_local && (stream_base || rbsp_base);
+    if (rebase && h->stage_cap < n_local) {
+        if (h->d_stage) (void)hipFree(h->d_stage);
+        h->d_stage = nullptr; h->stage_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&h->d_stage), n_local * sizeof(hbs_nal_entry)) != hipSuccess) status = 1;
+        else h->stage_cap = n_local;
+    }
+    /* 1. {count, capacity, status, stopped}: 32 bytes per rank, to everybody */
+    unsigned long long mine[kGatherWords];
+    mine[kGwCount] = n_local;
+    mine[kGwCap] = receiver ? (d_all ? cap_all : 0ull) : ~0ull;         /* a rank that receives nothing has room for anything */
+    mine[kGwStatus] = status;
+    mine[kGwStopped] = stopped ? 1ull : 0ull;
+    unsigned long long* d_mine = h->d_counts + (size_t)W * kGatherWords;
+    if (hipMemcpyAsync(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess) return HBS_E_HIP;
+    if (g_rccl.AllGather(d_mine, h->d_counts, kGatherWords, ncclUint64, h->comm, st) != ncclSuccess) return HBS_E_HIP;
+    static thread_local unsigned long long words[kMaxWorld * kGatherWords];
+    if (hipMemcpyAsync(words, h->d_counts, (size_t)W * sizeof(mine), hipMemcpyDeviceToHost, st) != hipSuccess) return HBS_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return HBS_E_HIP;        /* the sizes of the receives are host values */
+    /* 2. the same decision on every rank.  Parts of ONE stream (hbs_gather_parts): the whole-stream walk ends at the first empty
+     * NAL (hevc_analyze.c:135), so the parts behind the first one that stopped there contribute nothing. */
+    uint64_t total = 0, min_cap = ~0ull;
+    bool failed = false, cut = false;
+    for (int r = 0; r < W; ++r) {
+        unsigned long long* w = words + (size_t)r * kGatherWords;
+        if (cut) w[kGwCount] = 0;
+        if (w[kGwStopped]) cut = true;
+        counts_out[r] = w[kGwCount];
+        total += w[kGwCount];
+        if (w[kGwCap] < min_cap) min_cap = w[kGwCap];
+        if (w[kGwStatus]) failed = true;
+    }
+    if (failed) return HBS_E_HIP;
+    if (total > min_cap) return HBS_E_CAPACITY;                          /* on EVERY rank: some receiver's d_all is too small */
+    const uint64_t n_send = counts_out[h->rank];                         /* n_local, or 0 behind a part that stopped */
+    /* 3. my entries with global offsets (only when a base is given: independent shards keep theirs) */
     const hbs_nal_entry* src = d_index;
-    if (n_local && (stream_base || rbsp_base)) {
-        if (h->stage_cap < n_local) {
-            if (h->d_stage) (void)hipFree(h->d_stage);
-            h->d_stage = nullptr; h->stage_cap = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&h->d_stage), n_local * sizeof(hbs_nal_entry)) != hipSuccess) return HBS_E_HIP;
-            h->stage_cap = n_local;
-        }
-        uint64_t blocks = (n_local + 255) / 256;
+    if (n_send && rebase) {
+        uint64_t blocks = (n_send + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        k_rebase<<<dim3((unsigned)blocks), 256, 0, st>>>(d_index, n_local, stream_base, rbsp_base, h->d_stage);
+        k_rebase<<<dim3((unsigned)blocks), 256, 0, st>>>(d_index, n_send, stream_base, rbsp_base, h->d_stage);
         src = h->d_stage;
     }
-    /* 3. exactly count x 32 bytes per rank */
+    /* 4. exactly count x 32 bytes per rank */
     uint64_t off = 0;
     ncclResult_t rr = g_rccl.GroupStart();
     for (int r = 0; r < W && rr == ncclSuccess; ++r) {
-        const size_t bytes = (size_t)counts[r] * sizeof(hbs_nal_entry);
+        const size_t bytes = (size_t)counts_out[r] * sizeof(hbs_nal_entry);
         if (bytes) {
             if (root < 0) {
                 rr = g_rccl.Broadcast(r == h->rank ? (const void*)src : (const void*)(d_all + off), d_all + off, bytes, ncclUint8, r, h->comm, st);
@@ -189,7 +220,7 @@ int hbs_gather_index(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, ui
                 rr = g_rccl.Send(src, bytes, ncclUint8, root, h->comm, st);
             }
         }
-        off += counts[r];
+        off += counts_out[r];
     }
     const ncclResult_t re = g_rccl.GroupEnd();
     if (rr != ncclSuccess || re != ncclSuccess) {
@@ -197,6 +228,20 @@ int hbs_gather_index(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, ui
         return HBS_E_HIP;
     }
     return 0;
+}
+
+int hbs_gather_index(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, uint64_t n_local,
+                     uint64_t stream_base, uint64_t rbsp_base, int root,
+                     hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out)
+{
+    return gather_impl(ctx, h, d_index, n_local, 0, stream_base, rbsp_base, root, d_all, cap_all, counts_out);
+}
+
+int hbs_gather_parts(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, uint64_t n_local, int stopped,
+                     uint64_t stream_base, uint64_t rbsp_base, int root,
+                     hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out)
+{
+    return gather_impl(ctx, h, d_index, n_local, stopped, stream_base, rbsp_base, root, d_all, cap_all, counts_out);
 }
 
 /* ---- one stream, several parts ---------------------------------------------------------------------------- */

@@ -3,11 +3,13 @@ gather of the NAL index -- counts first, then exactly count x 32 bytes per rank.
 stream bytes and RBSP arenas stay on their GPUs.
 
 Two carriers of the same exchange:
-  * LibraryComm -- the C ABI (include/hevcbitstream_amd.h: hbs_comm_*, hbs_gather_index; RCCL over xGMI, looked up by the
-    library at run time).  torch.distributed only carries the 128-byte communicator id to the ranks.  What a C caller uses,
-    and what bench.py uses on GPUs.
-  * gather_index / IndexGatherer -- torch.distributed collectives (`nccl` = RCCL on GPU tensors, `gloo` on CPU tensors in the
-    world-size-2 CPU tests, which exercise the host-side protocol without a GPU).
+  * LibraryComm -- the C ABI (include/hevcbitstream_amd.h: hbs_comm_*, hbs_gather_index / hbs_gather_parts; RCCL over xGMI,
+    looked up by the library at run time).  torch.distributed only carries the 128-byte communicator id to the ranks.  What a
+    C caller uses, and what `bench.py --gpus N` times (PipelinedLibraryGather below keeps the exchange of one step under the
+    scan of the next).
+  * gather_index / IndexGatherer -- the same exchange over torch.distributed collectives, padded to the largest count
+    (`gloo` on CPU tensors in the world-size-2 CPU tests, which exercise the host-side protocol without a GPU; `nccl` on GPU
+    tensors).  Not what the benchmark measures.
 Also: parts of ONE stream (cut_points / part_ranges over hbs_find_cut_host)."""
 import ctypes as C
 
@@ -22,7 +24,8 @@ HALO_BYTES = 8                      # bytes of the next part scanned behind a pa
 class LibraryComm:
     """hbs_comm of the C ABI.  Collective: every rank constructs it; rank 0's id travels through `dist` (any backend)."""
 
-    def __init__(self, ctx, dist, rank, world, group=None):
+    def __init__(self, ctx, dist, rank, world, group=None, ident=None):
+        """ident: the 128-byte id when the caller carries it to the ranks by its own means (then `dist` is not used)"""
         self.ctx, self.lib, self.rank, self.world = ctx, load_library(), rank, world
         lib = self.lib
         lib.hbs_comm_unique_id.argtypes = [C.c_char_p]
@@ -31,29 +34,48 @@ class LibraryComm:
         lib.hbs_comm_destroy.restype = None
         lib.hbs_gather_index.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                          C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
-        ident = C.create_string_buffer(128)
-        if rank == 0 and lib.hbs_comm_unique_id(ident) != 0:
-            raise HbsError("hbs_comm_unique_id failed (RCCL not found?)")
-        box = [bytes(ident.raw)]
-        if world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
+        lib.hbs_gather_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.hbs_comm_world.argtypes = [C.c_void_p]
+        if ident is None:
+            buf = C.create_string_buffer(128)
+            if rank == 0 and lib.hbs_comm_unique_id(buf) != 0:
+                raise HbsError("hbs_comm_unique_id failed (RCCL not found?)")
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+        else:
+            box = [bytes(ident)]
         h = C.c_void_p()
         rc = lib.hbs_comm_create(ctx.h, box[0], rank, world, C.byref(h))
         if rc != 0:
             raise HbsError("hbs_comm_create(rank %d of %d) failed: %d" % (rank, world, rc))
         self.h = h
 
-    def gather_index(self, local_index, n_local, all_index, stream_base=0, rbsp_base=0, root=-1):
+    def gather_index(self, local_index, n_local, all_index, stream_base=0, rbsp_base=0, root=-1, stopped=None):
         """Enqueue the exchange on the context's stream.  local_index / all_index: device uint8 tensors of entries.  Returns the
-        per-rank counts (list of int); the payload lands in all_index (receiving ranks) in stream order."""
+        per-rank counts (list of int); the payload lands in all_index (receiving ranks) in stream order.
+        stopped (parts of ONE stream, hbs_gather_parts): this part's scan ended at an empty NAL -- the parts behind it then
+        contribute nothing, as in the reference's walk of the whole stream."""
         self.ctx._bind_stream()
         counts = (C.c_uint64 * self.world)()
-        rc = self.lib.hbs_gather_index(self.ctx.h, self.h, C.c_void_p(local_index.data_ptr()), n_local, stream_base, rbsp_base, root,
-                                       C.c_void_p(all_index.data_ptr()) if all_index is not None else None,
-                                       (all_index.numel() // ENTRY_BYTES) if all_index is not None else 0, counts)
+        d_all = C.c_void_p(all_index.data_ptr()) if all_index is not None else None
+        cap = (all_index.numel() // ENTRY_BYTES) if all_index is not None else 0
+        if stopped is None:
+            rc = self.lib.hbs_gather_index(self.ctx.h, self.h, C.c_void_p(local_index.data_ptr()), n_local, stream_base, rbsp_base, root,
+                                           d_all, cap, counts)
+        else:
+            rc = self.lib.hbs_gather_parts(self.ctx.h, self.h, C.c_void_p(local_index.data_ptr()), n_local, 1 if stopped else 0,
+                                           stream_base, rbsp_base, root, d_all, cap, counts)
         if rc != 0:
-            raise HbsError("hbs_gather_index failed: %d" % rc)
+            e = HbsError("hbs_gather_index failed: %d" % rc)
+            e.code = rc
+            raise e
         return [int(c) for c in counts]
+
+    def world_seen(self):
+        """the communicator's own idea of its size"""
+        return int(self.lib.hbs_comm_world(self.h))
 
     def close(self):
         if getattr(self, "h", None):

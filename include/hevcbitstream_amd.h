@@ -108,10 +108,14 @@ void* hbs_ctx_get_stream(hbs_ctx* ctx);
 int  hbs_ctx_synchronize(hbs_ctx* ctx);
 /* Measurement aid: when enabled, hbs_index_extract records HIP events on the
  * context's stream around its dominant kernel (the fused scan/extract kernel)
- * only; hbs_ctx_kernel_ms waits for the last such launch and returns its
- * duration.  hbs_ctx_grid reports the persistent grid used. */
+ * only (for an index-only call: its four kernels); hbs_ctx_kernel_ms waits for the
+ * last such launch and returns its duration, hbs_ctx_kernel_ms_back(back) that of the
+ * call `back` calls earlier (the event pairs of the last 64 timed calls are kept, so a
+ * benchmark can read every step of its timed loop after the loop, without a wait
+ * inside it).  hbs_ctx_grid reports the persistent grid used. */
 int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
 int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
+int  hbs_ctx_kernel_ms_back(hbs_ctx* ctx, int back, float* ms);
 int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
 /* Three implementations of the scan kernel exist, with identical results:
  * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
@@ -348,7 +352,15 @@ int hbs_write_headers(hbs_ctx* ctx, const hbs_parsed_nal* d_parsed, uint64_t n_n
  *                        stream_base / rbsp_base: added to start, end / rbsp_off of this rank's entries on the way out (0 for
  *                        independent streams; the part's cut offset for parts of ONE stream); d_all (cap_all entries; receivers
  *                        only): the ranks' entries back to back in rank order; counts_out[world] (host): entries per rank.
- *                        HBS_E_CAPACITY if cap_all is too small on a receiving rank.
+ *                        Errors are collective: every rank first learns every rank's count, the capacity of every receiver
+ *                        and whether its local preparations succeeded (32 bytes per rank, one all-gather), and all take the
+ *                        same decision -- HBS_E_CAPACITY on EVERY rank if the entries do not fit some receiver's d_all,
+ *                        HBS_E_HIP on every rank if one of them failed -- before any payload call is posted, so that no rank
+ *                        is left inside a collective the others never enter.  world <= 1024.
+ *   hbs_gather_parts     the same for parts of ONE stream (below): `stopped` = this part's scan ended at an empty NAL
+ *                        (hbs_summary.stop_reason == 1).  The reference's loop over the whole stream ends there
+ *                        (hevc_analyze.c:135), so the parts behind the first one that stopped contribute no entries
+ *                        (counts_out says 0 for them) and the gathered index is the whole stream's.
  */
 #define HBS_COMM_ID_BYTES 128
 typedef struct hbs_comm hbs_comm;
@@ -361,6 +373,9 @@ int  hbs_comm_world(const hbs_comm* comm);
 int  hbs_gather_index(hbs_ctx* ctx, hbs_comm* comm, const hbs_nal_entry* d_index, uint64_t n_local,
                       uint64_t stream_base, uint64_t rbsp_base, int root,
                       hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out);
+int  hbs_gather_parts(hbs_ctx* ctx, hbs_comm* comm, const hbs_nal_entry* d_index, uint64_t n_local, int stopped,
+                      uint64_t stream_base, uint64_t rbsp_base, int root,
+                      hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out);
 int  hbs_ctx_device(hbs_ctx* ctx);
 /*
  * ONE stream over several GPUs.  A part begins at the first start code (00 00 01) at or after its nominal boundary:
@@ -369,8 +384,9 @@ int  hbs_ctx_device(hbs_ctx* ctx);
  * agree without a collective.  A rank uploads its part [cut_r, cut_r+1) FOLLOWED BY the next 8 bytes of the stream (they
  * terminate its last NAL as they do in the whole stream, h264_nal.c:64-72), runs hbs_index_extract on that, and drops the NAL the
  * halo opens with hbs_trim_part(part_bytes = cut_r+1 - cut_r): n_kept entries and rbsp_kept arena bytes are the part's.  The last
- * part has no halo and nothing to trim.  hbs_gather_index(stream_base = cut_r, rbsp_base = RBSP bytes of the parts in front or 0)
- * then yields the whole stream's index; RBSP arenas stay where they are.
+ * part has no halo and nothing to trim.  hbs_gather_parts(stopped = (stop_reason == 1), stream_base = cut_r, rbsp_base = RBSP bytes
+ * of the parts in front or 0) then yields the whole stream's index, empty NALs in the stream included; RBSP arenas stay where they are.
+ * (A part whose scan stopped at an empty NAL has nothing to trim either: its walk never reached the halo.)
  */
 uint64_t hbs_find_cut_host(const uint8_t* bytes, uint64_t n, uint64_t from);
 int  hbs_trim_part(hbs_ctx* ctx, const hbs_nal_entry* d_index, uint64_t nal_count, uint64_t rbsp_bytes, uint64_t part_bytes,

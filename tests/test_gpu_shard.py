@@ -102,3 +102,48 @@ def test_library_gather_and_parts_of_one_stream(orc):
     finally:
         comm.close()
         ctx.close()
+
+
+def test_two_ranks_share_one_gpu(orc, tmp_path):
+    """hbs_gather_index / hbs_gather_parts with world = 2 and 3 on ONE GPU (tests/tools/shard_worker.py, one process per rank):
+    to all and to every root with ranks of different (and zero) counts; a receiver whose buffer is too small -- EVERY rank gets
+    HBS_E_CAPACITY and the communicator stays usable (round 2's advice: the receiver used to return alone, the others hung);
+    one stream in parts with an empty NAL in the first or the last part (the whole-stream walk ends there).  RCCL refuses two
+    ranks on one device: the library is pointed at tests/sim/libfake_rccl.so, a shared-memory stand-in that turns what real
+    RCCL would answer with a hang (a send nobody receives, a rank that left the protocol) into an error."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    from multiprocessing import shared_memory
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = os.path.join(root, "tests", "sim", "libfake_rccl.so")
+    assert os.path.exists(fake), "make -C tests/sim"
+    base, idx, _ = orc.gen_stream(0x77, 300, 0, want_arena=False)
+    streams = []
+    for frac in (None, 0.3, 0.8):
+        s = base
+        if frac is not None:
+            k = int(len(idx) * frac)
+            cut = int(idx["start"][k]) - 3                        # in front of NAL k's 00 00 01: an empty NAL in front of it
+            s = np.concatenate([base[:cut], np.array([0, 0, 1], dtype=np.uint8), base[cut:]])
+            assert len(orc.index_stream(s)[0]) == k
+        p = str(tmp_path / ("stream_%s.npy" % frac))
+        np.save(p, s)
+        streams.append(p)
+    lib = C.CDLL(fake)
+    lib.fake_rccl_segment_bytes.restype = C.c_uint64
+    lib.fake_rccl_segment_bytes.argtypes = [C.c_int, C.c_uint64]
+    slot = 4 << 20
+    for world in (2, 3):
+        shm = shared_memory.SharedMemory(create=True, size=int(lib.fake_rccl_segment_bytes(world, slot)))
+        try:
+            env = dict(os.environ, HBS_RCCL_LIB=fake, HBS_FAKE_RCCL_SHM="/" + shm.name.lstrip("/"), HBS_FAKE_RCCL_SLOT=str(slot))
+            procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "tools", "shard_worker.py"), str(r), str(world)] + streams,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+            outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+            for r, (p, o) in enumerate(zip(procs, outs)):
+                assert p.returncode == 0 and ("rank %d ok" % r) in o, "world %d rank %d:\n%s" % (world, r, o[-3000:])
+        finally:
+            shm.close()
+            shm.unlink()
