@@ -10,8 +10,9 @@ stream per GPU.  One "step" = one pass of the hot path -- start-code scan + NAL
 index + RBSP extraction (hbs_index_extract, the fused K12 kernel plus its
 end-of-stream fix-up) -- over a stream that is already resident in HBM; with
 N > 1 each rank owns an independent 16 GiB shard (weak scaling) and the step
-ends with the one real exchange of the path, the RCCL all-gather of the NAL
-index.  Rank 0 prints ONE JSON line.
+ends with the one real exchange of the path, the gather of the NAL index to
+every rank through the C ABI (hbs_gather_index, RCCL), reported by itself as
+"gather".  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline      the fused kernel against the 8 TB/s HBM3E peak: algorithmic bytes
@@ -284,7 +285,7 @@ def other_kernels(torch, hbs, ctx, g, n):
     ms = sum(kms) / len(kms)
     res["index_only"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4),
                          "read_frac_of_hbm_peak": round((sb + 32 * n) / ms / 1e6 / HBM_PEAK_GBS, 4),
-                         "kernel": {4: "hbs::k_scan_extract4", 5: "hbs::k_scan_index5", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?"),
+                         "kernel": {4: "hbs::k_scan_extract4", 5: "hbs::k_index5_stream (+ k_index5_chunks, k_index5_prefix, k_index5_emit)", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?"),
                          "workload": "the bench stream, index only (find_nal_unit over the stream, no arena)"}
     del index
     res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
@@ -385,12 +386,12 @@ def main():
     index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
 
     from hevcbitstream_amd import shard
-    # N > 1: the one exchange of the path is the all-gather of the NAL index (counts, then the padded entry
-    # arrays; RCCL).  It runs on the collective's stream while the next step's scan fills the other index buffer.
+    # N > 1: the one exchange of the path is the gather of the NAL index -- the C ABI's hbs_gather_index (counts, then exactly
+    # count x 32 bytes per rank, RCCL).  It runs on a stream of its own while the next step's scan fills the other index buffer.
     indexes = [index, torch.empty_like(index)] if multi else [index]
-    gatherer = shard.IndexGatherer(torch, dist, cap, index.device, depth=2) if multi else None
+    gatherer = shard.PipelinedLibraryGather(torch, hbs, local_rank, dist, rank, world, cap, depth=2) if multi else None
     counter = [0]
-    last_slot = [None]
+    pending = [None]
 
     def step():
         k = counter[0] % len(indexes)
@@ -400,32 +401,38 @@ def main():
             gatherer.release(k)          # the gather of two steps ago still reads (and the scan's prologue clears) this buffer
         ctx.index_extract_async(stream, buf, cap, rbsp, summary)
         if gatherer is not None:
-            last_slot[0] = gatherer.submit(buf, n, sb, rb)
+            gatherer.mark_scan(k)
+            if pending[0] is not None:   # the previous step's gather: its host side waits for that scan, this one is already queued
+                gatherer.submit(pending[0], indexes[pending[0]], n)
+            pending[0] = k
 
     def fence():
         if gatherer is not None:
+            if pending[0] is not None:
+                gatherer.submit(pending[0], indexes[pending[0]], n)
+                pending[0] = None
             gatherer.drain()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if gatherer is not None:            # RCCL builds its communicator on first use: not inside anybody's timed region, whatever --warmup says
-        gatherer.submit(indexes[0], 0, 0, 0)
+    if gatherer is not None:            # RCCL builds its rings on first use: not inside anybody's timed region, whatever --warmup says
+        gatherer.mark_scan(0)
+        gatherer.submit(0, indexes[0], 0)
         gatherer.drain()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
-    kms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    # kernel duration of the last launch per step needs a sync, so sample it in a separate short loop
-    for _ in range(min(args.steps, 5)):
-        ctx.index_extract_async(stream, index, cap, rbsp, summary)
-        kms.append(ctx.kernel_ms())
+    # the kernel's duration in EVERY step of the timed loop: the library records an event pair per call (a ring of 64) on the
+    # stream the kernel runs on; they are read here, behind the fence -- no wait inside the loop, and kernel_ms <= ms_per_step
+    kms = [ctx.kernel_ms_back(b) for b in range(min(args.steps, 64))]
+    gms = gatherer.gather_ms(args.steps) if gatherer is not None else []
     s = ctx.read_summary(summary)
 
     # parity properties at full size (outside the timed region)
@@ -436,14 +443,14 @@ def main():
     b = gen_index[: n * 32].view(torch.int64).view(n, 4)
     assert torch.equal(a[:, :3], b[:, :3]), "NAL index != generator's index"
 
-    if multi and last_slot[0] is not None:
-        # what the exchange delivered: every rank's rows of the last step, against that rank's own index (the gathered copy of MY
-        # rows must be my index; the others are checked by their owners, and all ranks hold the same bytes)
-        all_index, meta = gatherer.result(last_slot[0])
-        assert [int(x) for x in meta[rank].tolist()] == [n, sb, rb], meta
-        mine = all_index[rank, : n * 32].view(torch.int64).view(n, 4)
+    if multi:
+        # what the exchange delivered in the last step: every rank's rows back to back in rank order; MY rows must be my index
+        # (the others are checked by their owners, and all ranks hold the same bytes)
+        last_k = (counter[0] - 1) % len(indexes)
+        all_index, counts = gatherer.result(last_k)
+        assert counts == [n] * world, counts
+        mine = all_index[rank * n * 32: (rank + 1) * n * 32].view(torch.int64).view(n, 4)
         assert torch.equal(mine[:, :3], b[:, :3]), "gathered index rows of this rank != its index"
-        assert int(meta[:, 0].sum().item()) == n * world
     if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -451,8 +458,14 @@ def main():
         tot = torch.tensor([float(sb), float(n)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bytes, total_nals = float(tot[0].item()), float(tot[1].item())
+        # every rank's own kernel and gather times, for the per-rank lines
+        mine_t = torch.tensor([sum(kms) / len(kms), (sum(gms) / len(gms)) if gms else 0.0, float(sb + rb + 32 * n)], dtype=torch.float64, device="cuda")
+        per_rank_t = torch.empty(world * 3, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(per_rank_t, mine_t)
+        per_rank_t = per_rank_t.view(world, 3).cpu().tolist()
     else:
         total_bytes, total_nals = float(sb), float(n)
+        per_rank_t = None
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -483,7 +496,8 @@ def main():
                                    "resident in HBM%s" % (n, "uniform" if args.mode == 0 else "zero-heavy", sb / 2**30,
                                                           "; + RCCL all-gather of the NAL index" if multi else ""),
                        "stream_bytes_per_gpu": sb, "nals_per_gpu": n,
-                       "parallelism": "%d independent shard(s), one per GPU" % world,
+                       "parallelism": "%d independent shard(s), one per GPU%s" % (world, "; index gathered to every rank by hbs_gather_index "
+                                       "(C ABI, RCCL world %d as the communicator reports it), pipelined under the next step's scan" % gatherer.comm.world_seen() if multi else ""),
                        "grid": "%d persistent workgroups (%d per CU) x %s" % (blocks, per_cu, geometry)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -492,6 +506,17 @@ def main():
                          "note": "bytes = stream read once + RBSP written once + 32 B/NAL index; "
                                  "read-only fraction = %.4f" % (sb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
         }
+        if multi:
+            # the exchange reported by itself -- events on its own stream around hbs_gather_index (all-gather of
+            # the counts, the host's wait for them, count x 32 B per rank to every rank), mean over the timed steps, rank 0's
+            # and the slowest rank's; it overlaps the next step's kernel, so it adds to ms_per_step only where it is longer
+            out["gather"] = {"gather_ms": round(sum(gms) / len(gms), 4) if gms else None,
+                             "gather_ms_max_over_ranks": round(max(r[1] for r in per_rank_t), 4),
+                             "bytes_received_per_rank_per_step": int(total_nals) * 32,
+                             "api": "hbs_gather_index (include/hevcbitstream_amd.h), root = -1", "rccl_world": gatherer.comm.world_seen(),
+                             "kernel_ms": round(k_ms, 4)}
+            out["per_rank"] = [{"rank": r, "kernel_ms": round(t[0], 4), "gather_ms": round(t[1], 4),
+                                "roofline_frac": round(t[2] / (t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for r, t in enumerate(per_rank_t)]
         # HBM bytes per launch by PMC (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes): counters cannot be read from
         # inside this process, so the figure of the committed profile of this very workload and kernel is quoted
         tr = pmc_traffic(kernel_name, algo_bytes)
@@ -514,6 +539,7 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if multi:
+        gatherer.close()
         dist.barrier()
         dist.destroy_process_group()
 

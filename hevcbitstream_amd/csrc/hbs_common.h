@@ -87,7 +87,10 @@ static_assert(sizeof(RunHeader) == 768, "RunHeader layout");
  * kernel handles flagged chunks 64 at a time on one wavefront, so once more than one chunk in
  * kDenseOneIn may hold a zero pair the LDS-image kernel, whose cost does not depend on the data,
  * is the faster of the two. */
-constexpr uint32_t kDenseOneIn = 100;   /* measured crossover: ~1.1 % of chunks flagged (scripts/density_sweep.py) */
+constexpr uint32_t kDenseOneIn = 40;    /* measured crossover: ~2.5-3.5 % of chunks flagged (scripts/density_sweep.py, round 3: 1.7 % -> 1.71 against
+                                           1.37 TB/s, 4.4 % -> 0.49 against 1.41; on streams of small NALs the two meet at ~512-byte NALs,
+                                           scripts/experiments/pin_kernel_by_nal_size.py).  Round 2's 1 % dates from before the event-sparse
+                                           kernel walked the batches of a tile's elements in one go (hbs_scan4.hip) */
 HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged) { return (uint64_t)flagged * kDenseOneIn > (uint64_t)chunks; }
 enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2 };
 #ifdef __HIPCC__

@@ -102,7 +102,7 @@ constexpr uint32_t kDenseElems = 512;      /* a tile with more elements than thi
 struct Lds4 {
     uint32_t wave_tot[k4Waves];            /* elements per wavefront                        */
     uint16_t list[kDenseElems];            /* flagged chunks of the tile, in stream order (a tile with more takes the dense path) */
-    uint32_t seg[k4ElemPass + 1];          /* segment words: [0] tile start, [i+1] element i of the pass */
+    uint32_t seg[kDenseElems + 1];         /* segment words: [0] tile start, [i+1] element i of the tile */
     Deposit dep[k4Waves][kDepCap];         /* bytes of the first elements of each wavefront, left by the flag pass */
     u32x4 park[kParkRows][64];             /* rows of wavefront 0 while it handles elements and looks back */
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
@@ -480,9 +480,28 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 }
             }
             HBS4_T_MARK(3)
-            /* one pass (nearly always): the elements are still in registers */
-            if (ok && npass == 1u && (uint32_t)lane < nflag)
-                elem_emit(el, e, ex, can, rbsp + ex.kept, tgt, &l.seg[lane + 1]);
+            /* one pass (nearly always): the elements are still in registers.  More (a tile of small NALs, a stretch of zero pairs):
+             * the batches again, 64 elements at a time, each leaving its segment words -- all of them before anybody copies, so that
+             * the rows stay parked once and the copy below runs once (until round 3 every batch was followed by a copy pass of its
+             * own over all 48 rows: 28 k cycles a batch; profiles/r03/nal_sweep_*.txt) */
+            if (ok && npass == 1u) {
+                if ((uint32_t)lane < nflag) elem_emit(el, e, ex, can, rbsp + ex.kept, tgt, &l.seg[lane + 1]);
+            } else if (ok) {
+                const Prefix exu = prefix_uniform4(ex);
+                TileAgg accb = agg_identity();
+#pragma unroll 1
+                for (uint32_t p = 0; p < npass; ++p) {
+                    const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
+                    TileAgg ea = agg_identity();
+                    if (i < nflag) ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                    ea = wave_scan_combine(ea, lane);
+                    TileAgg up = agg_shfl_up(ea, 1);
+                    if (lane == 0) up = agg_identity();
+                    const TileAgg eb = combine(accb, up);
+                    accb = combine(accb, agg_readlane(ea, 63));
+                    if (i < nflag) elem_emit(el, eb, exu, can, rbsp + exu.kept, tgt, &l.seg[i + 1]);
+                }
+            }
 #define HBS_UNPARK(i, r) R.q##r = l.park[i][lane];
             HBS_PARKED(HBS_UNPARK)
 #undef HBS_UNPARK
@@ -501,86 +520,54 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         uint8_t* const out = rbsp + excl.kept;
         HBS4_T_MARK(4)
 
-        /* ---- 5. copy everything that is not an element; tiles dense in elements take the
-         *         elements 64 at a time, wavefront 0 redoing each batch before its copy ------- */
-        TileAgg accb = agg_identity();     /* wavefront 0: aggregate of the batches done so far */
-        const uint32_t np = npass ? npass : 1u;
-#pragma unroll 1
-        for (uint32_t p = 0; p < np; ++p) {
-            tid = launder_lane(tid0); lane = tid & 63;
-            const uint32_t pbase = p * (uint32_t)k4ElemPass;
-            if (npass > 1u) {
-                if (wv == 0) {
-#define HBS_PARK(i, r) l.park[i][lane] = R.q##r;
-                    HBS_PARKED(HBS_PARK)
-#undef HBS_PARK
-                    Elem el;
-                    const uint32_t i = pbase + (uint32_t)lane;
-                    TileAgg ea = agg_identity();
-                    if (i < nflag) ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
-                    ea = wave_scan_combine(ea, lane);
-                    TileAgg up = agg_shfl_up(ea, 1);
-                    if (lane == 0) up = agg_identity();
-                    const TileAgg e = combine(accb, up);
-                    accb = combine(accb, agg_readlane(ea, 63));
-                    if (i < nflag) elem_emit(el, e, excl, can_store, out, tgt, &l.seg[lane + 1]);
-#define HBS_UNPARK(i, r) R.q##r = l.park[i][lane];
-                    HBS_PARKED(HBS_UNPARK)
-#undef HBS_UNPARK
-                }
-                __syncthreads();
-            }
-            if (can_store) {
-                const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
-                const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
-                /* lane j: segment word j of this batch (j = 0..63), word 64 apart: a row without
-                 * elements needs one word, picked with a readlane instead of an LDS round trip */
-                const uint32_t segv = l.seg[lane];
-                const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[k4ElemPass]);
-                /* Straight-line over the named rows.  A chunk with k elements in front of it is
-                 * served by the batch that holds element k-1 (k = 0: the tile start, batch 0). */
-                /* At most kCopyDepth stores of a wavefront in flight (see the flag pass: a short memory queue on the CU is what
-                 * lets the other workgroup's look-back through; depth 3 is the model's optimum, 5 and more lose all of it). */
+        /* ---- 5. copy everything that is not an element ------------------------------------------------------------- */
+        tid = launder_lane(tid0); lane = tid & 63;
+        if (can_store) {
+            const uint32_t whole = (uint32_t)(span_bytes(base, tile_end, n) >> 4);   /* chunks of the tile that are complete */
+            const uint32_t cc0 = (uint32_t)(64 * k4Rows * wv + lane);
+            /* lane j: segment word j (j = 0..63), word 64 apart: a row without elements needs ONE word (that of the last element
+             * in front of it), picked with a readlane instead of an LDS round trip; words past 64 (tiles with several batches of
+             * elements) come from LDS, one broadcast read per row */
+            const uint32_t segv = l.seg[lane];
+            const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[k4ElemPass]);
+            /* At most HBS4_COPY_DEPTH stores of a wavefront in flight (see the flag pass: a short memory queue on the CU is what
+             * lets the other workgroup's look-back through; depth 3 is the model's optimum, 5 and more lose all of it). */
 #if HBS4_COPY_DEPTH >= 0
 #define HBS_COPY_THROTTLE asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS4_COPY_DEPTH) : "memory");
 #else
 #define HBS_COPY_THROTTLE
 #endif
+            /* Straight-line over the named rows.  A chunk with k elements in front of it goes where segment word k says. */
 #define HBS_COPY(r) { \
-                    const uint32_t cc = cc0 + 64u * r; \
-                    if (!((rowmask >> r) & 1ull)) {          /* no element in this row: one k, one word for all lanes */ \
-                        const uint32_t k = HBS_ROW_PRE(r); \
-                        const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
-                        if (served) { \
-                            const uint32_t j = k - pbase; \
-                            const uint32_t w = (j == (uint32_t)k4ElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(j & 63u)); \
-                            if (seg_inside(w) && cc < whole) \
-                                arena_store16(out + (int64_t)seg_bias(w) + 16u * cc, R.q##r); \
-                        } \
-                    } else { \
-                        const uint64_t f = HBS_ROW_FM(r); \
-                        const uint32_t k = HBS_ROW_PRE(r) + lanes_below(f); \
-                        const bool served = p == 0u ? k <= (uint32_t)k4ElemPass : (k > pbase && k <= pbase + (uint32_t)k4ElemPass); \
-                        if (!((f >> lane) & 1ull) && served && cc < whole) { \
-                            const uint32_t w = l.seg[k - pbase]; \
-                            if (seg_inside(w)) arena_store16(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)), R.q##r); \
-                        } \
+                const uint32_t cc = cc0 + 64u * r; \
+                if (!((rowmask >> r) & 1ull)) {          /* no element in this row: one k, one word for all lanes */ \
+                    const uint32_t k = HBS_ROW_PRE(r); \
+                    const uint32_t w = (k < (uint32_t)k4ElemPass) ? (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(k & 63u)) \
+                                     : (k == (uint32_t)k4ElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[k]); \
+                    if (seg_inside(w) && cc < whole) \
+                        arena_store16(out + (int64_t)seg_bias(w) + 16u * cc, R.q##r); \
+                } else { \
+                    const uint64_t f = HBS_ROW_FM(r); \
+                    const uint32_t k = HBS_ROW_PRE(r) + lanes_below(f); \
+                    if (!((f >> lane) & 1ull) && cc < whole) { \
+                        const uint32_t w = l.seg[k]; \
+                        if (seg_inside(w)) arena_store16(out + (int64_t)(seg_bias(w) + (int32_t)(16u * cc)), R.q##r); \
                     } \
-                    HBS_COPY_THROTTLE }
-                HBS_ROWS(HBS_COPY)
+                } \
+                HBS_COPY_THROTTLE }
+            HBS_ROWS(HBS_COPY)
 #undef HBS_COPY
 #undef HBS_COPY_THROTTLE
-            }
-            /* The next tile is claimed only now: tiles are looked back in ticket order, and a ticket
-             * taken before the copy (whose duration varies with memory load) makes successors wait for
-             * a tile that has not even been started (measured: 2.1 instead of 3.6 polls per tile).  Tiles dealt
-             * out in stripes instead (tile = workgroup + k x grid, no atomic, no drain of this wavefront's stores
-             * in front of it) ran 8.6 ms against 7.06 on the 16 GiB bench stream: workgroups do not progress
-             * evenly, and with stripes the fast ones wait in their look-backs for the slow ones. */
-            if (p + 1 == np && tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
-            __syncthreads();
-            HBS4_T_MARK(5)
         }
+        /* The next tile is claimed only now: tiles are looked back in ticket order, and a ticket
+         * taken before the copy (whose duration varies with memory load) makes successors wait for
+         * a tile that has not even been started (measured: 2.1 instead of 3.6 polls per tile).  Tiles dealt
+         * out in stripes instead (tile = workgroup + k x grid, no atomic, no drain of this wavefront's stores
+         * in front of it) ran 8.6 ms against 7.06 on the 16 GiB bench stream: workgroups do not progress
+         * evenly, and with stripes the fast ones wait in their look-backs for the slow ones. */
+        if (tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+        __syncthreads();
+        HBS4_T_MARK(5)
 #undef HBS_ROW_PRE
 #undef HBS_ROW_FM
     }

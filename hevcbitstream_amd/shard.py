@@ -83,6 +83,77 @@ class LibraryComm:
             self.h = None
 
 
+class PipelinedLibraryGather:
+    """hbs_gather_index (the C ABI's exchange) kept off the scan's critical path: the gather of step i runs on a stream of its
+    own, on a second context, while the scan of step i + 1 is already running on the caller's stream.  The host side of
+    hbs_gather_index waits for the 8-byte counts -- that is, for scan i -- so the caller enqueues scan i + 1 BEFORE it
+    submits gather i: the GPU always has the next scan queued.  `depth` index buffers alternate; release(k) makes the caller's
+    stream wait for the gather that still reads buffer k.  Every gather is bracketed by events on its stream: gather_ms()."""
+
+    def __init__(self, torch, hbs_module, device_index, dist, rank, world, capacity_per_rank, depth=2):
+        self.torch = torch
+        self.ctx = hbs_module.Context(device_index)                  # supplies the stream and the device of the exchange
+        self.stream = torch.cuda.Stream(device=device_index)
+        self.comm = LibraryComm(self.ctx, dist, rank, world)
+        self.world, self.depth = world, depth
+        dev = torch.device("cuda", device_index)
+        self.recv = [torch.empty(world * capacity_per_rank * ENTRY_BYTES, dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.scan_done = [torch.cuda.Event() for _ in range(depth)]
+        self.gather_done = [None] * depth
+        self.t0 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]
+        self.t1 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]
+        self.ms = []
+        self.counts = [None] * depth
+        self.timed = [False] * depth
+
+    def mark_scan(self, k):
+        """the scan that fills buffer k has just been enqueued on the current stream"""
+        self.scan_done[k].record()
+
+    def submit(self, k, local_index, n_local):
+        """gather buffer k (host: returns once the counts are known, i.e. once scan k is done; payload asynchronous)"""
+        self._collect(k)
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.scan_done[k])
+            self.t0[k].record()
+            self.counts[k] = self.comm.gather_index(local_index, n_local, self.recv[k])
+            self.t1[k].record()
+            ev = torch.cuda.Event()
+            ev.record()
+            self.gather_done[k] = ev
+            self.timed[k] = True
+        return self.counts[k]
+
+    def _collect(self, k):
+        if self.timed[k]:
+            self.t1[k].synchronize()
+            self.ms.append(self.t0[k].elapsed_time(self.t1[k]))
+            self.timed[k] = False
+
+    def release(self, k):
+        """before buffer k is written again: the current stream waits for the gather that reads it"""
+        if self.gather_done[k] is not None:
+            self.torch.cuda.current_stream().wait_event(self.gather_done[k])
+
+    def drain(self):
+        self.stream.synchronize()
+        for k in range(self.depth):
+            self._collect(k)
+
+    def gather_ms(self, last):
+        """durations of the last `last` gathers (events on the exchange's stream: counts all-gather, the wait for them, payload)"""
+        return self.ms[-last:]
+
+    def result(self, k):
+        self.stream.synchronize()
+        return self.recv[k], self.counts[k]
+
+    def close(self):
+        self.comm.close()
+        self.ctx.close()
+
+
 def find_cut_host(host_bytes, start):
     """hbs_find_cut_host: offset of the first start code (00 00 01) at or after `start` that has 8 bytes behind it, or None"""
     lib = load_library()
