@@ -1005,7 +1005,7 @@ struct LdsT {
     uint32_t gaps[kTMaxStarts];                      /* bytes in front of each (zeros + 01)                  */
     uint32_t lens[kTMaxStarts];                      /* their rbsp_len (for the output index)                */
     uint16_t list[kTChunks];                         /* the tile's elements, in order                        */
-    uint32_t seg[kTElemPass + 1];                    /* bytes inserted in the tile up to and including element i of the batch; [0]: before the batch */
+    uint32_t seg[kTDenseLimit + 1];                  /* bytes inserted in the tile up to and including element i; [0]: in front of the first (0) */
     u32x4 park[kTParkRows][64];
     uint32_t wave_tot[kTWaves];
     unsigned long long before;                       /* bytes inserted in front of the tile                  */
@@ -1385,15 +1385,18 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         uint8_t* const tout = out + t.tile_lo + l.before;            /* where byte 0 of the tile goes when nothing is inserted in it */
         const uint32_t whole = (uint32_t)(tile_bytes >> 4);           /* chunks of the tile that are complete */
 
-        /* ---- the bytes: elements by wavefront 0, 64 at a time, each batch followed by the copy of the chunks behind it ---- */
-        uint32_t ins_run = 0;                                       /* wavefront 0: bytes inserted by the batches done */
-        const uint32_t np = npass ? npass : 1u;
-#pragma unroll 1
-        for (uint32_t p = 0; p < np; ++p) {
-            const uint32_t pbase = p * (uint32_t)kTElemPass;
-            if (wv == 0) {
+        /* ---- the bytes: the elements by wavefront 0, 64 at a time -- every batch before anybody copies (its rows parked once;
+         * until round 3 each batch was followed by a copy pass of its own over all 48 rows) -- then one copy of the chunks between
+         * them: a chunk with k elements in front of it goes to its arena offset + seg[k] ----------------------------------- */
+        if (wv == 0) {
 #pragma unroll
-                for (int i = 0; i < kTParkRows; ++i) l.park[i][lane] = q[kTRows - kTParkRows + i];
+            for (int i = 0; i < kTParkRows; ++i) l.park[i][lane] = q[kTRows - kTParkRows + i];
+            uint32_t ins_run = 0;                                   /* bytes inserted by the batches done */
+            if (lane == 0) l.seg[0] = 0;
+            const uint32_t np = npass ? npass : 1u;
+#pragma unroll 1
+            for (uint32_t p = 0; p < np; ++p) {
+                const uint32_t pbase = p * (uint32_t)kTElemPass;
                 const uint32_t i = pbase + (uint32_t)lane;
                 uint32_t e = 0, c = 0;
                 u32x4 qe = q_first;
@@ -1403,41 +1406,35 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 const uint32_t mine_before = ins_run + inc_e - e;
                 if (i < nflag && (can_store || idx_out))
                     (void)tile_element<true>(t, l, c, tout, t.tile_lo + l.before, 16ull * (c & kTListChunk) + mine_before, can_store, idx_out, qe, je, true);
-                if (lane == 0) l.seg[0] = ins_run;
-                l.seg[lane + 1] = ins_run + inc_e;
+                if (i < nflag) l.seg[i + 1] = ins_run + inc_e;
                 ins_run += (uint32_t)__builtin_amdgcn_readlane((int)inc_e, 63);
+            }
 #pragma unroll
-                for (int i2 = 0; i2 < kTParkRows; ++i2) q[kTRows - kTParkRows + i2] = l.park[i2][lane];
-            }
-            __syncthreads();
-            if (can_store) {
-                const int lane = launder_lane(tid0) & 63;          /* the store addresses are formed here, not in front of the element code */
-                const uint32_t cc0 = (uint32_t)(64 * kTRows * wv + lane);
-                const uint32_t segv = l.seg[lane];
-                const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[kTElemPass]);
-                t_for_n<kTRows>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    const uint32_t cc = cc0 + 64u * r;
-                    const uint32_t rowpre = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
-                    if (!((rowmask >> r) & 1ull)) {             /* no element in this row: one word for all lanes */
-                        const uint32_t k = rowpre;
-                        const bool served = p == 0u ? k <= (uint32_t)kTElemPass : (k > pbase && k <= pbase + (uint32_t)kTElemPass);
-                        if (served) {
-                            const uint32_t j = k - pbase;
-                            const uint32_t w = (j == (uint32_t)kTElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(j & 63u));
-                            if (cc < whole) arena_store16(tout + w + 16u * cc, q[r]);
-                        }
-                    } else {
-                        const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, r);
-                        const uint32_t k = rowpre + lanes_below(f);
-                        const bool served = p == 0u ? k <= (uint32_t)kTElemPass : (k > pbase && k <= pbase + (uint32_t)kTElemPass);
-                        if (!((f >> lane) & 1ull) && served && cc < whole) arena_store16(tout + l.seg[k - pbase] + 16u * cc, q[r]);
-                    }
-                    /* at most kTCopyDepth stores of a wavefront in flight: see the fetch */
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS3T_COPY_DEPTH) : "memory");
-                });
-            }
-            if (p + 1 < np) __syncthreads();                       /* the batch's words are read: the next batch may write them */
+            for (int i2 = 0; i2 < kTParkRows; ++i2) q[kTRows - kTParkRows + i2] = l.park[i2][lane];
+        }
+        __syncthreads();
+        if (can_store) {
+            const int lane = launder_lane(tid0) & 63;          /* the store addresses are formed here, not in front of the element code */
+            const uint32_t cc0 = (uint32_t)(64 * kTRows * wv + lane);
+            const uint32_t segv = l.seg[lane];
+            const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[kTElemPass]);
+            t_for_n<kTRows>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const uint32_t cc = cc0 + 64u * r;
+                const uint32_t rowpre = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
+                if (!((rowmask >> r) & 1ull)) {             /* no element in this row: one word for all lanes */
+                    const uint32_t k = rowpre;
+                    const uint32_t w = (k < (uint32_t)kTElemPass) ? (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)(k & 63u))
+                                     : (k == (uint32_t)kTElemPass) ? seg64 : (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[k]);
+                    if (cc < whole) arena_store16(tout + w + 16u * cc, q[r]);
+                } else {
+                    const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, r);
+                    const uint32_t k = rowpre + lanes_below(f);
+                    if (!((f >> lane) & 1ull) && cc < whole) arena_store16(tout + l.seg[k] + 16u * cc, q[r]);
+                }
+                /* at most HBS3T_COPY_DEPTH stores of a wavefront in flight: see the fetch */
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS3T_COPY_DEPTH) : "memory");
+            });
         }
         HBS3_T_MARK(6)
     }

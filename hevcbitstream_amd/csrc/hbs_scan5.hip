@@ -172,7 +172,7 @@ __device__ __forceinline__ bool rows_step(RowWalk5& w, DenseRow& d, const Lds5& 
  * An index-only scan does not need one: nothing a tile does while it streams depends on the tiles in front of it.  So:
  *
  *   k_index5_stream   tile by ticket: flag words, elements, the tile's aggregate -- and the elements themselves (what the
- *                     emit half needs of each: 32 bytes) into the workspace, up to 1024 per tile (the bench stream has ~145 per
+ *                     emit half needs of each: 32 bytes) into the workspace, up to 2048 per tile (the bench stream has ~145 per
  *                     MiB).  No waiting anywhere.
  *   k_index5_chunks   aggregate of every 64 consecutive tiles (one wavefront each)
  *   k_index5_prefix   one wavefront: the prefix in front of every chunk of 64 tiles, 64 chunks per step
@@ -185,7 +185,7 @@ __device__ __forceinline__ bool rows_step(RowWalk5& w, DenseRow& d, const Lds5& 
 struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
 static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
 struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
-constexpr uint32_t k5RecCap = 1024;                                       /* elements recorded per tile */
+constexpr uint32_t k5RecCap = 2048;                                       /* elements recorded per tile */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
 constexpr int k5ChunkTiles = 64;
 
