@@ -30,7 +30,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
-           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_gather_parts",
+           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_gather_parts", "hbs_index_parse",
            "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps"]
 
 
@@ -366,6 +366,23 @@ class Context:
                                         C.c_void_p(structs.data_ptr()) if structs is not None else None,
                                         structs.numel() if structs is not None else 0, C.c_void_p(summary.data_ptr()))
         self._check(rc, "hbs_parse_headers")
+
+    def index_parse_async(self, stream, index, index_cap, parsed, structs, scan_summary, parse_summary, window=0, payload_off=None):
+        """hbs_index_parse: index-only scan + header parse without an RBSP arena.  All arguments are device tensors
+        (structs may be None: plan only; payload_off: optional int64 tensor, one per index entry).  Returns the NAL count
+        (the call waits for the scan; the parse is enqueued behind it)."""
+        self._bind_stream()
+        self.lib.hbs_index_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        n = C.c_uint64(0)
+        rc = self.lib.hbs_index_parse(self.h, C.c_void_p(stream.data_ptr() if stream.numel() else None), stream.numel(),
+                                      C.c_void_p(index.data_ptr()), index_cap, window, C.c_void_p(parsed.data_ptr()),
+                                      C.c_void_p(structs.data_ptr()) if structs is not None else None,
+                                      structs.numel() if structs is not None else 0,
+                                      C.c_void_p(payload_off.data_ptr()) if payload_off is not None else None,
+                                      C.c_void_p(scan_summary.data_ptr()), C.c_void_p(parse_summary.data_ptr()), C.byref(n))
+        self._check(rc, "hbs_index_parse")
+        return int(n.value)
 
     def parse_extended(self, rbsp, index, n_nals, parsed_dev):
         """The NAL types the reference never dispatches (AUD, EOS, EOB, filler data, SEI), behind parse_headers on the same

@@ -13,6 +13,7 @@
 #include "hbs_emit_launch.h"
 #include "hbs_emit.h"
 #include "hbs_parse_launch.h"
+#include "hbs_hdrwin.h"
 #include "hbs_parse.h"
 
 #ifndef HBS_DEFAULT_KERNEL
@@ -46,6 +47,7 @@ struct hbs_ctx {
     uint8_t* tail;                      /* padded copy of the stream's last tile (event-sparse kernel) */
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
+    void* ws2; uint64_t ws2_bytes;   /* hbs_index_parse: header windows and the index that points into them (alive across the parse, which carves ws) */
     uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
     /* optional timing of the dominant kernel */
     int timing; hipEvent_t ev0, ev1; int ev_valid;        /* ev0 / ev1: the slot of the ring the last call used */
@@ -147,6 +149,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->tail) (void)hipFree(c->tail);
     if (c->ws) (void)hipFree(c->ws);
     if (c->zeros) (void)hipFree(c->zeros);
+    if (c->ws2) (void)hipFree(c->ws2);
     if (c->ring0[0]) for (int i = 0; i < kTimingRing; ++i) { (void)hipEventDestroy(c->ring0[i]); (void)hipEventDestroy(c->ring1[i]); }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -467,6 +470,46 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.sequential = c->parse_sequential;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
+}
+
+int hbs_index_parse(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
+                    hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
+                    hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
+                    hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out)
+{
+    if (!c || !d_scan_summary || !d_parse_summary || !d_index || !index_cap || !d_parsed) return HBS_E_ARG;
+    if (header_window == 0) header_window = 512;
+    if (header_window < 64 || header_window > (1u << 16) || (header_window & 15u)) return HBS_E_ARG;
+    /* 1. find_nal_unit over the stream: no arena */
+    int rc = hbs_index_extract(c, d_stream, stream_bytes, d_index, index_cap, nullptr, 0, d_scan_summary);
+    if (rc) return rc;
+    /* the parse's launches are sized by the number of NALs: the one wait of the call */
+    hbs_summary s;
+    rc = hbs_read_summary(c, d_scan_summary, &s);
+    if (rc) return rc;
+    if (nal_count_out) *nal_count_out = s.nal_count;
+    if (s.error) return s.error;
+    const uint64_t nals = s.nal_count;
+    /* 2. the bytes the parse can look at, stripped into windows */
+    hbs::HdrWinArgs a;
+    a.stream = d_stream; a.index = d_index; a.nals = nals; a.index_cap = index_cap; a.window = header_window;
+    a.arena_bytes = hbs::hdrwin_arena_bytes(index_cap, header_window, stream_bytes);
+    const uint64_t b_arena = round256(a.arena_bytes + 64), b_idx = round256(index_cap * sizeof(hbs_nal_entry));
+    if (b_arena + b_idx + 256 > c->ws2_bytes) {
+        if (c->ws2) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
+        const hipError_t e = hipMalloc(&c->ws2, b_arena + b_idx + 256);
+        if (e != hipSuccess) return fail(c, e, "hipMalloc(header windows)");
+        c->ws2_bytes = b_arena + b_idx + 256;
+    }
+    uint8_t* w = static_cast<uint8_t*>(c->ws2);
+    a.arena = w; a.idx2 = reinterpret_cast<hbs_nal_entry*>(w + b_arena); a.bump = reinterpret_cast<unsigned long long*>(w + b_arena + b_idx);
+    hipError_t e = hbs::launch_hdr_strip(a, c->stream);
+    if (e != hipSuccess) return fail(c, e, "launch_hdr_strip");
+    /* 3. K4 on the windows, 4. slice_data_size against the real lengths, windows that were too small reported */
+    rc = hbs_parse_headers(c, a.arena, a.idx2, nals, d_parsed, d_structs, structs_cap, d_parse_summary);
+    if (rc) return rc;
+    e = hbs::launch_hdr_fix(a, d_parsed, d_parse_summary, reinterpret_cast<unsigned long long*>(d_payload_off), c->stream);
+    return e == hipSuccess ? 0 : fail(c, e, "launch_hdr_fix");
 }
 
 int hbs_write_headers(hbs_ctx* c, const hbs_parsed_nal* d_parsed, uint64_t n_nals, uint8_t* d_structs,

@@ -13,6 +13,8 @@
  *   hbs_parse_headers   replaces  read_hevc_nal_unit() per NAL
  *                       reference: hevc_stream.c:155-240 and the readers it
  *                       dispatches to (:243-1218)
+ *   hbs_index_parse     find_nal_unit over the stream + read_hevc_nal_unit per NAL without
+ *                       an RBSP arena (each header is stripped from the stream by itself)
  *   hbs_parse_headers_trace   the same with the per-field trace read_debug_hevc_nal_unit
  *                       prints (hevc_stream.c:2343-3434)
  *   hbs_write_headers   replaces  write_hevc_nal_unit() per NAL up to rbsp_to_nal
@@ -271,6 +273,26 @@ typedef struct hbs_ext_nal {
 } hbs_ext_nal;
 int hbs_parse_extended(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                        hbs_parsed_nal* d_parsed, hbs_ext_nal* d_ext);
+
+/*
+ * hbs_index_parse: BASELINE config 3 without an RBSP arena -- find_nal_unit over the whole stream (the index-only scan:
+ * start / end / rbsp_off / rbsp_len / status exactly as hbs_index_extract with d_rbsp = NULL), then read_hevc_nal_unit's
+ * parse of every NAL, reading each NAL's header straight from the stream: only the bytes the readers can look at are
+ * stripped of their emulation prevention bytes (nal_to_rbsp's rule, hevc_stream.c:161-179 / h264_nal.c:147-200) into a
+ * small window per NAL -- `header_window` RBSP bytes of a slice segment (0 = 512; 64 ... 65536, a multiple of 16), all of
+ * a VPS / SPS / PPS -- instead of the whole stream into an arena.  d_parsed and d_structs come out exactly as from
+ * hbs_index_extract + hbs_parse_headers (slice_data_off / slice_data_size still describe the NAL's RBSP, which is not
+ * materialised); d_payload_off (optional, one uint64 per NAL) receives the STREAM offset of the first payload byte of
+ * every parsed slice (~0 for other NALs).  A slice header that does not end at least 8 bytes inside its window -- hundreds
+ * of entry points -- is reported, never guessed: d_parse_summary->error = HBS_E_CAPACITY and that NAL's rc = INT32_MIN;
+ * call again with a larger window, or take the arena path.  The call waits once, for the scan's NAL count (returned in
+ * *nal_count_out when not NULL); the parse is enqueued behind it.  On the 2.1 GiB 4K30 sequence of bench.py: scan 1 B/B
+ * + ~3 % for the windows, against 2 B/B for the arena.
+ */
+int hbs_index_parse(hbs_ctx* ctx, const uint8_t* d_stream, uint64_t stream_bytes,
+                    hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
+                    hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
+                    hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out);
 
 /* Same, for a batch that continues an earlier one: d_initial_sps_slot (an SPS
  * slot = hevc_sps_t followed at hbs_sps_tables_offset() by its derived RPS
