@@ -495,14 +495,16 @@ int hbs_index_parse(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
     a.stream = d_stream; a.index = d_index; a.nals = nals; a.index_cap = index_cap; a.window = header_window;
     a.arena_bytes = hbs::hdrwin_arena_bytes(index_cap, header_window, stream_bytes);
     const uint64_t b_arena = round256(a.arena_bytes + 64), b_idx = round256(index_cap * sizeof(hbs_nal_entry));
-    if (b_arena + b_idx + 256 > c->ws2_bytes) {
+    const uint64_t b_notes = round256(index_cap * 16);
+    if (b_arena + b_idx + b_notes + 256 > c->ws2_bytes) {
         if (c->ws2) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
-        const hipError_t e = hipMalloc(&c->ws2, b_arena + b_idx + 256);
+        const hipError_t e = hipMalloc(&c->ws2, b_arena + b_idx + b_notes + 256);
         if (e != hipSuccess) return fail(c, e, "hipMalloc(header windows)");
-        c->ws2_bytes = b_arena + b_idx + 256;
+        c->ws2_bytes = b_arena + b_idx + b_notes + 256;
     }
     uint8_t* w = static_cast<uint8_t*>(c->ws2);
     a.arena = w; a.idx2 = reinterpret_cast<hbs_nal_entry*>(w + b_arena); a.bump = reinterpret_cast<unsigned long long*>(w + b_arena + b_idx);
+    a.notes = w + b_arena + b_idx + 256;
     hipError_t e = hbs::launch_hdr_strip(a, c->stream);
     if (e != hipSuccess) return fail(c, e, "launch_hdr_strip");
     /* 3. K4 on the windows, 4. slice_data_size against the real lengths, windows that were too small reported */

@@ -20,6 +20,7 @@ struct HdrWinArgs {
     uint64_t arena_bytes;
     hbs_nal_entry* idx2;             /* index_cap entries: the index K4 parses, pointing into the arena */
     unsigned long long* bump;        /* 16 bytes: the bump counter, then flags */
+    void* notes;                     /* index_cap x 16 bytes: where each window's first emulation prevention bytes were */
 };
 
 uint64_t hdrwin_arena_bytes(uint64_t index_cap, uint32_t window, uint64_t stream_bytes);

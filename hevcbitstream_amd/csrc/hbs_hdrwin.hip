@@ -33,18 +33,32 @@ constexpr uint32_t kOtherBytes = 16;
 
 __device__ __forceinline__ bool is_pset(int t) { return t >= 32 && t <= 34; }
 
-/* one wavefront per NAL, 64 raw bytes a step */
+/* One wavefront per NAL, 512 raw bytes a step (8 per lane): a slice's window is one step, two when it holds emulation
+ * prevention bytes.  The first kEpbNote of them are noted -- as the number of RBSP bytes in front of each -- so that k_hdr_fix
+ * can turn an RBSP offset inside the window into a stream offset without walking the bytes again. */
+constexpr int kEpbNote = 6;
+struct EpbNote { uint16_t n; uint16_t at[kEpbNote]; uint16_t pad; };        /* 16 bytes per NAL */
+
 __global__ __launch_bounds__(256)
 void k_hdr_strip(const uint8_t* __restrict__ stream, const hbs_nal_entry* __restrict__ index, uint64_t nals, uint32_t window,
                  uint8_t* __restrict__ arena, uint64_t slots_bytes, uint64_t arena_bytes, unsigned long long* __restrict__ bump,
-                 hbs_nal_entry* __restrict__ idx2, uint32_t* __restrict__ flags)
+                 hbs_nal_entry* __restrict__ idx2, EpbNote* __restrict__ notes, uint32_t* __restrict__ flags)
 {
+    struct __attribute__((packed, aligned(1))) U8 { uint64_t v; };
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4u;
     for (uint64_t k = wave; k < nals; k += nwaves) {
         const hbs_nal_entry e = index[k];
         const uint64_t raw = e.end - e.start;
-        const int type = raw > 0 ? (int)((stream[e.start] >> 1) & 0x3Fu) : 63;
+        /* this lane's 8 bytes of the first step, asked for before anything else (the type is in the first of them) */
+        const uint8_t* const src = stream + e.start;
+        uint64_t v = ~0ull;
+        {
+            const uint64_t j = 8ull * (uint64_t)lane;
+            if (j + 8 <= raw) v = reinterpret_cast<const U8*>(src + j)->v;
+            else for (uint32_t t = 0; t < 8 && j + t < raw; ++t) v = (v & ~(0xFFull << (8 * t))) | ((uint64_t)src[j + t] << (8 * t));
+        }
+        const int type = raw > 0 ? (int)(((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) >> 1) & 0x3Fu) : 63;
         uint32_t want = type < 32 ? window : is_pset(type) ? kPsetCap : kOtherBytes;
         if (want > e.rbsp_len) want = e.rbsp_len;
         uint64_t dst_off = k * (uint64_t)window;
@@ -59,20 +73,66 @@ void k_hdr_strip(const uint8_t* __restrict__ stream, const hbs_nal_entry* __rest
             }
         }
         uint8_t* const dst = arena + dst_off;
-        uint32_t out = 0, p1 = 0xFF, p2 = 0xFF;                  /* the two bytes in front of this step's first */
-        for (uint64_t j0 = 0; j0 < raw && out < want; j0 += 64) {
-            const uint64_t j = j0 + (uint64_t)lane;
-            const uint32_t b = j < raw ? stream[e.start + j] : 0xFFu;
-            uint32_t q1 = (uint32_t)__shfl_up((int)b, 1, 64), q2 = (uint32_t)__shfl_up((int)b, 2, 64);
-            if (lane == 0) { q1 = p1; q2 = p2; }
-            if (lane == 1) q2 = p1;
-            const bool keep = j < raw && !(b == 3u && q1 == 0u && q2 == 0u);
-            const uint64_t m = __ballot(keep);
-            const uint32_t rank = out + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (keep && rank < want) dst[rank] = (uint8_t)b;
-            out += (uint32_t)__builtin_popcountll(m);
-            p2 = (uint32_t)__builtin_amdgcn_readlane((int)b, 62);
-            p1 = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+        uint32_t out = 0, tail2 = 0xFFFFu;                       /* the two bytes in front of this step's first (low byte = the nearer) */
+        uint32_t noted = 0;
+        EpbNote note;
+        note.n = 0; note.pad = 0;
+#pragma unroll
+        for (int i = 0; i < kEpbNote; ++i) note.at[i] = 0xFFFFu;
+        for (uint64_t j0 = 0; j0 < raw && out < want; j0 += 512) {
+            if (j0) {
+                const uint64_t j = j0 + 8ull * (uint64_t)lane;
+                v = ~0ull;
+                if (j + 8 <= raw) v = reinterpret_cast<const U8*>(src + j)->v;
+                else for (uint32_t t = 0; t < 8 && j + t < raw; ++t) v = (v & ~(0xFFull << (8 * t))) | ((uint64_t)src[j + t] << (8 * t));
+            }
+            /* the two bytes in front of my eight: the previous lane's last two, or what the previous step left */
+            const uint32_t hi = (uint32_t)(v >> 48);                                         /* my bytes 6, 7 */
+            uint32_t prev = (uint32_t)__shfl_up((int)hi, 1, 64);
+            if (lane == 0) prev = ((tail2 & 0xFFu) << 8) | (tail2 >> 8);                     /* byte -2 low, byte -1 high: as bytes 6, 7 */
+            /* x = bytes -2, -1, 0 .. 7 as a 10-byte little-endian number */
+            const uint64_t lo10 = (v << 16) | (uint64_t)(prev & 0xFFFFu);
+            const uint32_t top2 = (uint32_t)(v >> 48);
+            uint32_t keep = 0, epbs = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint64_t w = t < 6 ? (lo10 >> (8 * t)) & 0xFFFFFFull
+                                         : ((lo10 >> (8 * t)) | ((uint64_t)top2 << (64 - 8 * t))) & 0xFFFFFFull;   /* bytes t-2, t-1, t */
+                const bool in = j0 + 8ull * (uint64_t)lane + (uint64_t)t < raw;
+                const bool epb = in && w == 0x030000ull;
+                if (in && !epb) keep |= 1u << t;
+                if (epb) epbs |= 1u << t;
+            }
+            const uint32_t cnt = (uint32_t)__builtin_popcount(keep);
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += t2; }
+            uint32_t pos = out + inc - cnt;
+            /* rare: note where (as RBSP bytes in front of it), lanes in order */
+            uint64_t em = __ballot(epbs != 0u);
+            while (em) {
+                const int l = (int)__builtin_ctzll(em);
+                em &= em - 1;
+                const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)epbs, l), kp = (uint32_t)__builtin_amdgcn_readlane((int)keep, l);
+                const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)pos, l);
+                for (uint32_t m = eb; m; m &= m - 1) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(m);
+                    const uint32_t at = ps + (uint32_t)__builtin_popcount(kp & ((1u << t) - 1u));
+#pragma unroll
+                    for (int i = 0; i < kEpbNote; ++i) if ((uint32_t)i == noted && at <= 0xFFFEu) note.at[i] = (uint16_t)at;     /* (no dynamic index: registers) */
+                    ++noted;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if ((keep >> t) & 1u) {
+                    if (pos < want) dst[pos] = (uint8_t)(v >> (8 * t));
+                    ++pos;
+                }
+            }
+            out += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+            tail2 = ((last & 0xFFu) << 8) | (last >> 8);         /* byte 7 low (the nearer), byte 6 high */
         }
         if (out > want) out = want;
         if (lane == 0) {
@@ -80,16 +140,18 @@ void k_hdr_strip(const uint8_t* __restrict__ stream, const hbs_nal_entry* __rest
             o.rbsp_off = dst_off;
             o.rbsp_len = out;                                    /* = min(rbsp_len, want): the bit reader's `size` */
             idx2[k] = o;
+            note.n = (uint16_t)(noted > 0xFFFFu ? 0xFFFFu : noted);
+            notes[k] = note;
         }
     }
 }
 
 /* behind the parse: slice_data_size counts to the end of the REAL RBSP; a header that came within 8 bytes of the end of a
- * window that does not hold the whole NAL is reported */
+ * window that does not hold the whole NAL is reported; the payload's place in the stream */
 __global__ __launch_bounds__(256)
 void k_hdr_fix(const hbs_nal_entry* __restrict__ index, const hbs_nal_entry* __restrict__ idx2, uint64_t nals,
                ParsedWin* __restrict__ parsed, const uint32_t* __restrict__ flags, hbs_summary* __restrict__ summary,
-               const uint8_t* __restrict__ stream, unsigned long long* __restrict__ payload_off)
+               const uint8_t* __restrict__ stream, const EpbNote* __restrict__ notes, unsigned long long* __restrict__ payload_off)
 {
     bool overflow = false;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nals; k += (uint64_t)gridDim.x * blockDim.x) {
@@ -111,19 +173,27 @@ void k_hdr_fix(const hbs_nal_entry* __restrict__ index, const hbs_nal_entry* __r
             }
         }
         if (payload_off && slice && p.slice_data_off != 0u && p.slice_data_off <= full) {
-            /* the stream offset of RBSP byte slice_data_off: walk the NAL's first bytes once more (a few hundred at most) */
-            const uint64_t s = index[k].start, raw = index[k].end - s;
-            uint32_t kept = 0, z = 0;
-            uint64_t j = 0;
-            for (; j < raw && kept < p.slice_data_off; ++j) {
-                const uint32_t b = stream[s + j];
-                if (b == 3u && z >= 2u) { z = 0; continue; }
-                z = b == 0u ? z + 1u : 0u;
-                ++kept;
+            /* RBSP byte slice_data_off in the stream: its index plus the emulation prevention bytes in front of it */
+            const EpbNote nt = notes[k];
+            const uint64_t s = index[k].start;
+            if (p.slice_data_off <= have && nt.n <= (uint16_t)kEpbNote) {
+                uint32_t e = 0;
+#pragma unroll
+                for (int i = 0; i < kEpbNote; ++i) e += (i < (int)nt.n && (uint32_t)nt.at[i] <= p.slice_data_off) ? 1u : 0u;
+                payload_off[k] = s + p.slice_data_off + e;
+            } else {                                             /* more of them than were noted, or behind the window: walk */
+                const uint64_t raw = index[k].end - s;
+                uint32_t kept = 0, z = 0;
+                uint64_t j = 0;
+                for (; j < raw && kept < p.slice_data_off; ++j) {
+                    const uint32_t b = stream[s + j];
+                    if (b == 3u && z >= 2u) { z = 0; continue; }
+                    z = b == 0u ? z + 1u : 0u;
+                    ++kept;
+                }
+                if (j < raw && stream[s + j] == 3u && z >= 2u) ++j;
+                payload_off[k] = s + j;
             }
-            /* an emulation prevention byte right in front of the payload's first byte belongs to the gap */
-            if (j < raw && stream[s + j] == 3u && z >= 2u) ++j;
-            payload_off[k] = s + j;
         }
     }
     if (__syncthreads_or(overflow ? 1 : 0) && threadIdx.x == 0) summary->error = HBS_E_CAPACITY;
@@ -147,7 +217,7 @@ hipError_t launch_hdr_strip(const HdrWinArgs& a, hipStream_t st)
         uint64_t blocks = (a.nals + 3) / 4;
         if (blocks > 8192) blocks = 8192;
         k_hdr_strip<<<dim3((unsigned)blocks), 256, 0, st>>>(a.stream, a.index, a.nals, a.window, a.arena, a.index_cap * (uint64_t)a.window,
-                                                             a.arena_bytes, a.bump, a.idx2, reinterpret_cast<uint32_t*>(a.bump + 1));
+                                                             a.arena_bytes, a.bump, a.idx2, static_cast<EpbNote*>(a.notes), reinterpret_cast<uint32_t*>(a.bump + 1));
     }
     return hipGetLastError();
 }
@@ -158,7 +228,7 @@ hipError_t launch_hdr_fix(const HdrWinArgs& a, void* parsed, hbs_summary* summar
         uint64_t blocks = (a.nals + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         k_hdr_fix<<<dim3((unsigned)blocks), 256, 0, st>>>(a.index, a.idx2, a.nals, static_cast<ParsedWin*>(parsed),
-                                                           reinterpret_cast<const uint32_t*>(a.bump + 1), summary, a.stream, payload_off);
+                                                           reinterpret_cast<const uint32_t*>(a.bump + 1), summary, a.stream, static_cast<const EpbNote*>(a.notes), payload_off);
     }
     return hipGetLastError();
 }
