@@ -305,6 +305,54 @@ __device__ __forceinline__ void dense_row(DenseRow& d, const u32x4& qp, const u3
     d.row_has_event = __ballot(d.el.s.last != kKindNone) != 0ull;
 }
 
+/* A row of a dense tile, asked two things only: does a terminator (00 00 00 or 00 00 01) end in bytes [0, 18) of any of its
+ * chunks, and if none does, how many of its bytes are kept?  Without a terminator no chunk of the row holds an event, so
+ * the row's aggregate is a gap of "kept bytes" (elem_walk: cnt 0, known 0, last none, carry = the bytes that are not
+ * emulation prevention bytes) -- and that needs two byte-flag words per dword instead of elem_walk's class masks and walk:
+ * ~100 instructions a row against ~300.  Rows of 00 00 03 padding (cabac_zero_words) are exactly this case, and the time a
+ * dense tile takes to publish its aggregate is what every tile behind it waits for (mixed streams).
+ * The test is conservative (any 00 00 00 counts, not only the first of a run); a row that fails it takes the exact walk.
+ * Valid for rows that end at least 64 bytes in front of the stream's end (the caller checks).
+ * kept = kept bytes of this lane's chunk; returns true when some lane of the wavefront saw a terminator. */
+template <bool kErrToo>
+__device__ __forceinline__ bool dense_row_quick(const u32x4& qp, const u32x4& qc, const u32x4& qn, int r, int nrows,
+                                                uint32_t before, uint32_t after, uint32_t& kept)
+{
+    const uint32_t e_prev_w = r == 0 ? before : (uint32_t)__builtin_amdgcn_readlane((int)qp.w, 63);
+    const uint32_t e_next_x = r == nrows - 1 ? after : (uint32_t)__builtin_amdgcn_readlane((int)qn.x, 0);
+    const uint32_t xp = from_prev_lane(qc.w, e_prev_w), xn = from_next_lane(qc.x, e_next_x);
+    /* 0x80 per byte: zero, one, three */
+    const uint32_t zp = zero_bytes(xp), z0 = zero_bytes(qc.x), z1 = zero_bytes(qc.y), z2 = zero_bytes(qc.z), z3 = zero_bytes(qc.w), zn = zero_bytes(xn);
+    const uint32_t o0 = zero_bytes(qc.x ^ 0x01010101u), o1 = zero_bytes(qc.y ^ 0x01010101u), o2 = zero_bytes(qc.z ^ 0x01010101u),
+                   o3 = zero_bytes(qc.w ^ 0x01010101u), on = zero_bytes(xn ^ 0x01010101u);
+    const uint32_t t0 = zero_bytes(qc.x ^ 0x03030303u), t1 = zero_bytes(qc.y ^ 0x03030303u), t2 = zero_bytes(qc.z ^ 0x03030303u),
+                   t3 = zero_bytes(qc.w ^ 0x03030303u);
+    /* "the two bytes in front are zero", per byte: the zero flags moved up by one and by two bytes */
+#define HBS_ZZ(cur, prev) (__builtin_amdgcn_alignbyte((cur), (prev), 3) & __builtin_amdgcn_alignbyte((cur), (prev), 2))
+    const uint32_t zz0 = HBS_ZZ(z0, zp), zz1 = HBS_ZZ(z1, z0), zz2 = HBS_ZZ(z2, z1), zz3 = HBS_ZZ(z3, z2), zzn = HBS_ZZ(zn, z3);
+    const uint32_t term = (zz0 & (z0 | o0)) | (zz1 & (z1 | o1)) | (zz2 & (z2 | o2)) | (zz3 & (z3 | o3)) | (zzn & (zn | on) & 0x00008080u);
+    const uint32_t epb = (uint32_t)__builtin_popcount(zz0 & t0) + (uint32_t)__builtin_popcount(zz1 & t1) +
+                         (uint32_t)__builtin_popcount(zz2 & t2) + (uint32_t)__builtin_popcount(zz3 & t3);
+    kept = 16u - epb;
+    uint32_t bad = term;
+    if (kErrToo) {
+        /* what sets HBS_ST_ERROR (elem_walk: m.err): 00 00 02, or 00 00 03 followed by a byte above 3 -- kErrToo: such a row is
+         * not "quick" either (the index-only emit pass skips quick rows altogether: no terminator, no entry; no error, no mark) */
+        const uint32_t w0 = zero_bytes(qc.x ^ 0x02020202u), w1 = zero_bytes(qc.y ^ 0x02020202u), w2 = zero_bytes(qc.z ^ 0x02020202u),
+                       w3 = zero_bytes(qc.w ^ 0x02020202u);
+        /* 0x80 where the NEXT byte is above 3 */
+        const uint32_t g0 = ~zero_bytes(qc.x & 0xFCFCFCFCu) & 0x80808080u, g1 = ~zero_bytes(qc.y & 0xFCFCFCFCu) & 0x80808080u,
+                       g2 = ~zero_bytes(qc.z & 0xFCFCFCFCu) & 0x80808080u, g3 = ~zero_bytes(qc.w & 0xFCFCFCFCu) & 0x80808080u,
+                       gn = ~zero_bytes(xn & 0xFCFCFCFCu) & 0x80808080u;
+        const uint32_t n0 = __builtin_amdgcn_alignbyte(g1, g0, 1), n1 = __builtin_amdgcn_alignbyte(g2, g1, 1),
+                       n2 = __builtin_amdgcn_alignbyte(g3, g2, 1), n3 = __builtin_amdgcn_alignbyte(gn, g3, 1);
+        bad |= (zz0 & (w0 | (t0 & n0))) | (zz1 & (w1 | (t1 & n1))) | (zz2 & (w2 | (t2 & n2))) | (zz3 & (w3 | (t3 & n3)));
+    }
+#undef HBS_ZZ
+    return __ballot(bad != 0u) != 0ull;
+}
+
+
 __device__ __forceinline__ u32x4 dense_fetch(const uint8_t* src, uint64_t wseg, int r, int lane)
 {
     return *reinterpret_cast<const u32x4*>(src + wseg + 1024ull * (uint64_t)r + 16ull * (uint64_t)lane);    /* the padded copy / the stream: always there */

@@ -121,15 +121,46 @@ struct Lds4 {
  * registers does not exist, and unrolled the walk would be 150 KB of code).  Rows without any terminator, which is
  * what padding looks like, fold with one add per chunk; only rows that hold an event pay for the ordered scan. */
 
+/* The rows of a wavefront's segment again, in order, for the two halves of a dense tile: f(r, previous row, row, next row).
+ * They are read back from memory (the cache, mostly) kDenseAhead rows at a time, the next batch's loads in flight while
+ * this one is walked: with one row in flight -- round 2 -- every row of the aggregate half cost a memory round trip, and that
+ * half is what every tile behind a dense one waits for. */
+constexpr int kDenseAhead = 8;
+static_assert(k4Rows % kDenseAhead == 0, "whole batches of rows");
+template <class F>
+__device__ __forceinline__ void dense_rows(const uint8_t* src, uint64_t wseg, int lane, F&& f)
+{
+    u32x4 cur[kDenseAhead + 2];                                   /* rows b - 1 .. b + kDenseAhead */
+#pragma unroll
+    for (int i = 0; i <= kDenseAhead; ++i) cur[i + 1] = dense_fetch(src, wseg, i < k4Rows ? i : k4Rows - 1, lane);
+    cur[0] = cur[1];
+#pragma unroll 1
+    for (int b = 0; b < k4Rows; b += kDenseAhead) {
+        u32x4 nxt[kDenseAhead];                                   /* rows b + kDenseAhead + 1 .. b + 2 kDenseAhead */
+#pragma unroll
+        for (int i = 0; i < kDenseAhead; ++i) {
+            const int r = b + kDenseAhead + 1 + i;
+            nxt[i] = dense_fetch(src, wseg, r < k4Rows ? r : k4Rows - 1, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < kDenseAhead; ++i) f(b + i, cur[i], cur[i + 1], cur[i + 2]);
+        cur[0] = cur[kDenseAhead]; cur[1] = cur[kDenseAhead + 1];
+#pragma unroll
+        for (int i = 0; i < kDenseAhead; ++i) cur[i + 2] = nxt[i];
+    }
+}
+
 /* first half: the aggregate of this wavefront's rows */
 __device__ __forceinline__ TileAgg dense_aggregate(const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
                                                    uint32_t chunk0, int lane)
 {
     TileAgg acc = agg_identity();
-    u32x4 qp = dense_fetch(src, wseg, 0, lane), qc = qp, qn;
-#pragma unroll 1
-    for (int r = 0; r < k4Rows; ++r) {
-        qn = dense_fetch(src, wseg, r + 1 < k4Rows ? r + 1 : r, lane);
+    dense_rows(src, wseg, lane, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
+        uint32_t kept;
+        if (wseg + 1024ull * (uint64_t)(r + 1) + 64ull <= n && !dense_row_quick<false>(qp, qc, qn, r, k4Rows, before, after, kept)) {
+            acc = combine(acc, gap_agg(wave_sum32(kept)));               /* no terminator anywhere in the row: kept bytes, state-dependent */
+            return;
+        }
         DenseRow d;
         dense_row(d, qp, qc, qn, r, k4Rows, before, before2, after, src, wseg, n, chunk0, lane);
         if (!d.row_has_event) {
@@ -138,8 +169,7 @@ __device__ __forceinline__ TileAgg dense_aggregate(const uint8_t* src, uint64_t 
             const TileAgg ea = wave_scan_combine(elem_agg(0u, d.el.s), lane);
             acc = combine(acc, agg_readlane(ea, 63));
         }
-        qp = qc; qc = qn;
-    }
+    });
     return acc;
 }
 
@@ -149,10 +179,7 @@ __device__ __forceinline__ void dense_emit(const uint8_t* src, uint64_t wseg, ui
                                            const EmitTarget& tgt, uint32_t* scratch_word)
 {
     TileAgg acc = acc0;
-    u32x4 qp = dense_fetch(src, wseg, 0, lane), qc = qp, qn;
-#pragma unroll 1
-    for (int r = 0; r < k4Rows; ++r) {
-        qn = dense_fetch(src, wseg, r + 1 < k4Rows ? r + 1 : r, lane);
+    dense_rows(src, wseg, lane, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
         DenseRow d;
         dense_row(d, qp, qc, qn, r, k4Rows, before, before2, after, src, wseg, n, chunk0, lane);
         const TileAgg ea = wave_scan_combine(elem_agg(0u, d.el.s), lane);
@@ -161,11 +188,8 @@ __device__ __forceinline__ void dense_emit(const uint8_t* src, uint64_t wseg, ui
         const TileAgg e = combine(acc, up);
         acc = combine(acc, agg_readlane(ea, 63));
         if (d.el.v.g0 < n) elem_emit(d.el, e, excl, can_store, out, tgt, scratch_word);
-        qp = qc; qc = qn;
-    }
+    });
 }
-
-
 
 
 /* lane `l` of v <- the wave-uniform value s.  The s_nop covers gfx950's wait states between a

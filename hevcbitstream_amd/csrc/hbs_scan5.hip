@@ -134,33 +134,63 @@ __device__ __forceinline__ TileAgg make_batch(Elem& el, const Lds5& l, uint32_t 
  * 1 % of such bytes ran 14.6 times slower than without (scripts/mixed_time.py).  When the flagged rows of a tile hold 16
  * or more elements each on average, the tile is walked by ROWS instead: every KiB row that has a flag is one batch, all 64
  * of its chunks elements (no gaps inside the row), read with one coalesced load that is issued a row ahead. */
-struct RowWalk5 {
-    u32x4 qp, qc, qn;
-    uint32_t before, before2, after;
-};
-__device__ __forceinline__ void rows_begin(RowWalk5& w, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t tile_end, int lane)
+/* The rows of a tile again, in order, kRowsAhead at a time (the next batch's loads in flight while this one is walked: with
+ * one row in flight every row cost a memory round trip): f(r, previous row, row, next row) for the rows that hold a flag. */
+constexpr int kRowsAhead = 8;
+static_assert(k5TileRows % kRowsAhead == 0, "whole batches of rows");
+struct RowEdges5 { uint32_t before, before2, after; };
+__device__ __forceinline__ RowEdges5 rows_edges(const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t tile_end)
 {
-    w.before = load_dword_guarded(stream, (int64_t)base - 4, n);
-    w.before2 = load_dword_guarded(stream, (int64_t)base - 8, n);
-    w.after = load_dword_guarded(stream, (int64_t)tile_end, n);
-    w.qc = load_chunk_guarded(stream, base + 16ull * (uint64_t)lane, n);
-    w.qp = w.qc;
+    RowEdges5 e;
+    e.before = load_dword_guarded(stream, (int64_t)base - 4, n);
+    e.before2 = load_dword_guarded(stream, (int64_t)base - 8, n);
+    e.after = load_dword_guarded(stream, (int64_t)tile_end, n);
+    return e;
 }
-/* row r as a batch: its elements in d, the gap in front of it on lane 0; false: the row holds no flag (skipped).  The next
- * row's load is issued first (a ring of four rows ahead was tried: slower, 5.2 against 4.2 ms on the mixed stream). */
-__device__ __forceinline__ bool rows_step(RowWalk5& w, DenseRow& d, const Lds5& l, int r, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base,
-                                          int lane, uint64_t& prev_end)
+template <class F>
+__device__ __forceinline__ void tile_rows(const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int lane, const Lds5& l, F&& f)
 {
-    w.qn = load_chunk_guarded(stream, base + 1024ull * (uint64_t)(r + 1 < k5TileRows ? r + 1 : r) + 16ull * (uint64_t)lane, n);
-    const bool flagged = l.words[r] != 0ull;
-    if (flagged) {
-        dense_row(d, w.qp, w.qc, w.qn, r, k5TileRows, w.before, w.before2, w.after, stream, base, n, 0u, lane);
-        const uint64_t row_lo = base + 1024ull * (uint64_t)r;
-        d.el.gap = lane == 0 ? span_bytes(prev_end, row_lo, n) : 0u;
-        prev_end = row_lo + 1024ull;
+    const bool whole = base + k5TileBytes <= n;                  /* every row of the tile is there: plain loads */
+    auto fetch = [&](int r) -> u32x4 {
+        const uint64_t g = base + 1024ull * (uint64_t)(r < k5TileRows ? r : k5TileRows - 1) + 16ull * (uint64_t)lane;
+        return whole ? *reinterpret_cast<const u32x4*>(stream + g) : load_chunk_guarded(stream, g, n);
+    };
+    u32x4 cur[kRowsAhead + 2];                                    /* rows b - 1 .. b + kRowsAhead */
+#pragma unroll
+    for (int i = 0; i <= kRowsAhead; ++i) cur[i + 1] = fetch(i);
+    cur[0] = cur[1];
+#pragma unroll 1
+    for (int b = 0; b < k5TileRows; b += kRowsAhead) {
+        u32x4 nxt[kRowsAhead];
+#pragma unroll
+        for (int i = 0; i < kRowsAhead; ++i) nxt[i] = fetch(b + kRowsAhead + 1 + i);
+#pragma unroll
+        for (int i = 0; i < kRowsAhead; ++i)
+            if (l.words[b + i] != 0ull) f(b + i, cur[i], cur[i + 1], cur[i + 2]);
+        cur[0] = cur[kRowsAhead]; cur[1] = cur[kRowsAhead + 1];
+#pragma unroll
+        for (int i = 0; i < kRowsAhead; ++i) cur[i + 2] = nxt[i];
     }
-    w.qp = w.qc; w.qc = w.qn;
-    return flagged;
+}
+
+/* One flagged row.  1: no terminator ends in it (kErrToo: and nothing that marks an error): all it adds is `quick_bytes`
+ * state-dependent bytes (the gap in front of it + its kept bytes), found with dense_row_quick's ~100 instructions instead of
+ * the walk's ~300 -- rows of 00 00 03 padding; 2: d holds the row's 64 elements */
+template <bool kErrToo>
+__device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32x4& qc, const u32x4& qn, int r, const RowEdges5& e,
+                                         const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int lane, uint64_t& prev_end, uint32_t& quick_bytes)
+{
+    const uint64_t row_lo = base + 1024ull * (uint64_t)r;
+    const uint32_t gap0 = span_bytes(prev_end, row_lo, n);
+    prev_end = row_lo + 1024ull;
+    uint32_t kept;
+    if (row_lo + 1024ull + 64ull <= n && !dense_row_quick<kErrToo>(qp, qc, qn, r, k5TileRows, e.before, e.after, kept)) {
+        quick_bytes = gap0 + wave_sum32(kept);
+        return 1;
+    }
+    dense_row(d, qp, qc, qn, r, k5TileRows, e.before, e.before2, e.after, stream, base, n, 0u, lane);
+    d.el.gap = lane == 0 ? gap0 : 0u;
+    return 2;
 }
 
 /* ---- two passes, no look-back (round 3) ---------------------------------------------------------------------------
@@ -298,12 +328,11 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         TileAgg acc = agg_identity();
         uint64_t prev_end = base;
         if (by_rows) {
-            RowWalk5 w;
-            rows_begin(w, stream, n, base, tile_end, lane);
-#pragma unroll 1
-            for (int r = 0; r < k5TileRows; ++r) {
+            const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
+            tile_rows(stream, n, base, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
                 DenseRow d;
-                if (!rows_step(w, d, l, r, stream, n, base, lane, prev_end)) continue;
+                uint32_t quick = 0;
+                if (row_visit<false>(d, qp, qc, qn, r, edges, stream, n, base, lane, prev_end, quick) == 1) { acc = combine(acc, gap_agg(quick)); return; }
                 const uint32_t gap0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.el.gap);
                 if (!d.row_has_event) {
                     acc = combine(acc, gap_agg(gap0 + wave_sum32(d.el.s.carry)));      /* nothing but state-dependent bytes */
@@ -311,7 +340,7 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                     const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
                     acc = combine(acc, agg_readlane(ea, 63));
                 }
-            }
+            });
         } else {
             const bool record = nelem <= k5RecCap;
 #pragma unroll 1
@@ -425,19 +454,18 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
     TileAgg accb = agg_identity();
     uint64_t prev_end = base;
     if (by_rows) {
-        RowWalk5 w;
-        rows_begin(w, stream, n, base, tile_end, lane);
-#pragma unroll 1
-        for (int r = 0; r < k5TileRows; ++r) {
+        const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
+        tile_rows(stream, n, base, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
             DenseRow d;
-            if (!rows_step(w, d, l, r, stream, n, base, lane, prev_end)) continue;
+            uint32_t quick = 0;
+            if (row_visit<true>(d, qp, qc, qn, r, edges, stream, n, base, lane, prev_end, quick) == 1) { accb = combine(accb, gap_agg(quick)); return; }   /* nothing to write for such a row */
             const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
             TileAgg up = agg_shfl_up(ea, 1);
             if (lane == 0) up = agg_identity();
             const TileAgg eb = combine(accb, up);
             accb = combine(accb, agg_readlane(ea, 63));
             if (d.el.v.g0 < n) elem_emit(d.el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-        }
+        });
     } else {
         const uint32_t npass = (nelem + 63u) >> 6;
 #pragma unroll 1
