@@ -103,6 +103,8 @@ struct Lds4 {
     uint32_t wave_tot[k4Waves];            /* elements per wavefront                        */
     uint16_t list[kDenseElems];            /* flagged chunks of the tile, in stream order (a tile with more takes the dense path) */
     uint32_t seg[kDenseElems + 1];         /* segment words: [0] tile start, [i+1] element i of the tile */
+    u32x4 rec[kDenseElems][3];             /* tiles with several batches of elements: what the first walk found out about each
+                                              (marks, summary, classes, its bytes), so that the second half does not walk it again */
     Deposit dep[k4Waves][kDepCap];         /* bytes of the first elements of each wavefront, left by the flag pass */
     u32x4 park[kParkRows][64];             /* rows of wavefront 0 while it handles elements and looks back */
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
@@ -198,6 +200,27 @@ __device__ __forceinline__ void dense_emit(const uint8_t* src, uint64_t wseg, ui
 #define write_lane(v, s, l) asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, " #l : "+v"(v) : "s"(s))
 
 
+
+__device__ __forceinline__ void rec4_store(u32x4* r, const Elem& el)
+{
+    const ElemPacked p = elem_pack(el.m, el.s);
+    u32x4 a, b, c;
+    a.x = el.chunk; a.y = el.gap; a.z = p.a; a.w = p.b;
+    b.x = p.c; b.y = el.cls.z; b.z = el.cls.e1; b.w = el.cls.e3;
+    c.x = el.v.x0; c.y = el.v.x1; c.z = el.v.x2; c.w = el.v.x3;
+    r[0] = a; r[1] = b; r[2] = c;
+}
+__device__ __forceinline__ void rec4_load(const u32x4* r, Elem& el, const uint8_t* src, uint64_t base, uint64_t n)
+{
+    const u32x4 a = r[0], b = r[1], c = r[2];
+    ElemPacked p; p.a = a.z; p.b = a.w; p.c = b.x;
+    elem_unpack(p, el.m, el.s);
+    el.cls.z = b.y; el.cls.e1 = b.z; el.cls.e3 = b.w;
+    el.chunk = a.x; el.gap = a.y;
+    el.v.x0 = c.x; el.v.x1 = c.y; el.v.x2 = c.z; el.v.x3 = c.w;
+    el.v.xpp = el.v.xp = el.v.xn = 0;                    /* the second half looks at the chunk's own bytes only */
+    el.v.stream = src; el.v.g0 = base + 16ull * a.x; el.v.n = n;
+}
 
 /* Element i of the tile (lane = i mod 64 of wavefront 0): its bytes come from the deposit its
  * flagging lane left in LDS, or from the stream when there is none; then the exact window rules. */
@@ -473,7 +496,10 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             for (uint32_t p = 0; p < npass; ++p) {
                 const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
                 TileAgg ea = agg_identity();
-                if (i < nflag) ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                if (i < nflag) {
+                    ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                    if (npass > 1u) rec4_store(l.rec[i], el);
+                }
                 ea = wave_scan_combine(ea, lane);
                 TileAgg up = agg_shfl_up(ea, 1);
                 if (lane == 0) up = agg_identity();
@@ -517,7 +543,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 for (uint32_t p = 0; p < npass; ++p) {
                     const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
                     TileAgg ea = agg_identity();
-                    if (i < nflag) ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                    if (i < nflag) { rec4_load(l.rec[i], el, src, base, n); ea = elem_agg(el.gap, el.s); }
                     ea = wave_scan_combine(ea, lane);
                     TileAgg up = agg_shfl_up(ea, 1);
                     if (lane == 0) up = agg_identity();
