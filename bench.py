@@ -289,6 +289,28 @@ def mixed_stream_line(torch, ctx, stream, sb, n_cap, uniform_ms):
                         "density probe's windows (the probe says sparse; the dense tiles take the per-tile dense path)" % (100.0 * dense_bytes / sb)}
 
 
+def mixed_index_only(torch, ctx, stream, sb, n_cap, uniform_ms):
+    """the index-only scan on the same mixed stream (start / end of every NAL against the extract path's index)"""
+    mixed, _ = make_mixed(torch, stream, sb)
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_cap)
+    ctx.index_extract_async(mixed, index, cap, rbsp, summary)
+    m = int(ctx.read_summary(summary)["nal_count"])
+    del rbsp
+    index2 = torch.empty_like(index)
+    ks = []
+    for i in range(4):
+        ctx.index_extract_async(mixed, index2, cap, None, summary)
+        if i:
+            ks.append(ctx.kernel_ms())
+    s = ctx.read_summary(summary)
+    a = index[: m * 32].view(torch.int64).view(m, 4)
+    b = index2[: m * 32].view(torch.int64).view(m, 4)
+    assert int(s["error"]) == 0 and int(s["nal_count"]) == m and torch.equal(a[:, :3], b[:, :3]), "mixed stream, index only: differs from the extract path's index"
+    ks.sort()
+    ms = ks[len(ks) // 2]
+    return {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4), "over_uniform": round(ms / uniform_ms, 3)}
+
+
 def other_kernels(torch, hbs, ctx, g, n):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
@@ -316,6 +338,7 @@ def other_kernels(torch, hbs, ctx, g, n):
                          "workload": "the bench stream, index only (find_nal_unit over the stream, no arena)"}
     del index
     res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
+    res["mixed_stream"]["index_only"] = mixed_index_only(torch, ctx, g["stream"][:sb], sb, n + 64, ms)
     out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
@@ -364,6 +387,14 @@ def other_kernels(torch, hbs, ctx, g, n):
     torch.cuda.synchronize()
     ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(4))
     res["write_headers"] = {"value": round(m / ms / 1e3, 1), "unit": "M NAL/s", "ms": round(ms, 3), "workload": "the structs of that parse"}
+    # stream shape: extract / index only / emit against the mean NAL size (2 GiB of random payload each, 3- and 4-byte start
+    # codes), every result checked (scripts/nal_sweep.py); the fractions are of the 8 TB/s peak, at a size where the launches
+    # and the last partial wave of tiles still cost a few points against the 16 GiB figures above
+    del parsed_dev, wout, wr, structs, rbsp, index, d
+    torch.cuda.empty_cache()
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import nal_sweep
+    res["nal_size_sweep"] = nal_sweep.sweep(torch, hbs, ctx, [512, 1024, 2048, 4096, 10240, 65536, 524288], 2.0)
     return res
 
 
