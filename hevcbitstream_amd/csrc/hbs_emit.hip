@@ -935,15 +935,15 @@ void k_synth_fill(uint64_t seed, uint64_t n, int mode, const unsigned long long*
  * store at (its arena offset + bytes inserted in front of it).  Same bytes as the other paths (h264_nal.c:92-132 per NAL).
  *
  * Eligibility is decided on the device (k3t_check): NALs contiguous and in order, first byte 16-byte aligned, gaps below
- * 1 MiB, no 192 KiB window with more than 256 NAL starts, workspace large enough; otherwise k3_fused runs as before. */
+ * 1 MiB, no 192 KiB window with more than 512 NAL starts, workspace large enough; otherwise k3_fused runs as before. */
 constexpr int kTRows = 48, kTWaves = 4, kTThreads = 64 * kTWaves;
 constexpr uint32_t kTWaveBytes = (uint32_t)kTRows * 1024u, kTTileBytes = (uint32_t)kTWaves * kTWaveBytes;
 constexpr int kTChunks = (int)(kTTileBytes / 16u);
 constexpr int kTParkRows = 28;
-constexpr uint32_t kTMaxStarts = 256, kTMaxGap = 1u << 20;
+constexpr uint32_t kTMaxStarts = 512, kTMaxGap = 1u << 20;     /* two NAL starts per thread of the workgroup */
 constexpr uint64_t kTMinArena = 192ull << 20;      /* below, the kernel by NALs is as fast or faster (0.12 against 0.115 ms at 128 MiB, 0.173 against 0.186 at 256 MiB) */
 constexpr int kTElemPass = 64;
-constexpr uint32_t kTDenseLimit = 512;        /* a tile with more elements than this: wavefront 0 would walk them 64 at a time while every tile
+constexpr uint32_t kTDenseLimit = 1024;       /* a tile with more elements than this: wavefront 0 would walk them 64 at a time while every tile
                                                  behind waits (~5 us a batch) -- the call is handed to the kernel by NALs instead, whose cost
                                                  grows gently with the density of zero pairs */
 /* an entry of the tile's element list: chunk number | why it is one */
@@ -1238,9 +1238,11 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         HBS3_T_MARK(1)
         /* ---- flags: chunks a 03 may have to go into (four rows per branch, as in K12) ----------------------------- */
         uint32_t fm_lo = 0, fm_hi = 0;
-        uint64_t nk_off = 0, nk_prev = 0;                          /* this thread's NAL of the tile: its rbsp_off; the NAL in front of the tile */
-        uint64_t nk_start = 0, nk_pend = 0;                        /* ... its start in the caller's stream and the end of the NAL in front (gap_of) */
-        uint32_t nk_len = 0;
+        uint64_t nk_prev = 0;                                      /* rbsp_off of the NAL in front of the tile */
+        uint64_t nk_off[2] = {0, 0};                               /* this thread's two NALs of the tile (numbers tid and tid + 256): rbsp_off */
+        uint64_t nk_start[2] = {0, 0}, nk_pend[2] = {0, 0};        /* ... start in the caller's stream and the end of the NAL in front (gap_of) */
+        uint32_t nk_len[2] = {0, 0};
+        static_assert(kTMaxStarts == 2 * kTThreads, "two per thread");
         t_for_n<kTRows / 4>([&](auto gc) {
             constexpr int g0 = 4 * decltype(gc)::value;
             uint64_t fmask[4];
@@ -1263,27 +1265,35 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 t.m = (uint32_t)(k_hi - t.k_lo);
                 /* without a branch (clamped entry numbers; gap_of() by hand): a load inside a branch makes the compiler wait for
                  * everything in flight where the paths meet */
-                const uint64_t kk = t.k_lo + (uint32_t)tid < n ? t.k_lo + (uint32_t)tid : n - 1;
                 nk_prev = idx[t.k_lo > 0 ? t.k_lo - 1 : 0].rbsp_off;
-                nk_off = idx[kk].rbsp_off;
-                nk_len = idx[kk].rbsp_len;
-                nk_start = idx[kk].start;
-                nk_pend = idx[kk > 0 ? kk - 1 : 0].end;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint64_t want = t.k_lo + (uint32_t)tid + (uint64_t)(h * kTThreads);
+                    const uint64_t kk = want < n ? want : n - 1;
+                    nk_off[h] = idx[kk].rbsp_off;
+                    nk_len[h] = idx[kk].rbsp_len;
+                    nk_start[h] = idx[kk].start;
+                    nk_pend[h] = idx[kk > 0 ? kk - 1 : 0].end;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (g0 / 4 + 2 < kTRows / 4) load_group(std::integral_constant<int, g0 / 4 + 2>{});
             if constexpr (g0 == 4 || kTRows == 4) {
                 /* every loaded register stays live up to here: one that is dead earlier (the upper half of an offset of which
                  * only the lower is used) is handed out as a temporary at once, and writing it waits for the load */
-                asm volatile("" :: "v"(nk_off), "v"(nk_start), "v"(nk_pend), "v"(nk_len));
+                asm volatile("" :: "v"(nk_off[0]), "v"(nk_start[0]), "v"(nk_pend[0]), "v"(nk_len[0]), "v"(nk_off[1]), "v"(nk_start[1]), "v"(nk_pend[1]), "v"(nk_len[1]));
                 t.prev_begin = t.k_lo > 0 ? nk_prev - t.a0 : 0ull;
-                if ((uint32_t)tid < t.m) {
-                    const uint32_t rel = (uint32_t)(nk_off - t.a0 - t.tile_lo);
-                    l.starts[tid] = rel;
-                    const uint64_t k = t.k_lo + (uint32_t)tid;
-                    l.gaps[tid] = (uint32_t)(gap_mode == 1 ? synth_gap(k) : nk_start - (k ? nk_pend : 0ull));
-                    l.lens[tid] = nk_len;
-                    atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t j = (uint32_t)tid + (uint32_t)(h * kTThreads);
+                    if (j < t.m) {
+                        const uint32_t rel = (uint32_t)(nk_off[h] - t.a0 - t.tile_lo);
+                        l.starts[j] = rel;
+                        const uint64_t k = t.k_lo + j;
+                        l.gaps[j] = (uint32_t)(gap_mode == 1 ? synth_gap(k) : nk_start[h] - (k ? nk_pend[h] : 0ull));
+                        l.lens[j] = nk_len[h];
+                        atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+                    }
                 }
                 if (last_tile && tid == 0 && (t.arena_len & 15ull) != 0) {  /* the arena's last, partial chunk is written bytewise */
                     const uint32_t rel = (uint32_t)(t.arena_len - t.tile_lo);
