@@ -311,7 +311,7 @@ def mixed_index_only(torch, ctx, stream, sb, n_cap, uniform_ms):
     return {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4), "over_uniform": round(ms / uniform_ms, 3)}
 
 
-def other_kernels(torch, hbs, ctx, g, n):
+def other_kernels(torch, hbs, ctx, g, n, sweep=True):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
     import numpy as np
@@ -392,9 +392,10 @@ def other_kernels(torch, hbs, ctx, g, n):
     # and the last partial wave of tiles still cost a few points against the 16 GiB figures above
     del parsed_dev, wout, wr, structs, rbsp, index, d
     torch.cuda.empty_cache()
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    import nal_sweep
-    res["nal_size_sweep"] = nal_sweep.sweep(torch, hbs, ctx, [512, 1024, 2048, 4096, 10240, 65536, 524288], 2.0)
+    if sweep:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import nal_sweep
+        res["nal_size_sweep"] = nal_sweep.sweep(torch, hbs, ctx, [512, 1024, 2048, 4096, 10240, 65536, 524288], 2.0)
     return res
 
 
@@ -407,6 +408,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 uniform payload (headline), 1 zero-heavy")
     ap.add_argument("--cpu-sample-nals", type=int, default=1_000_000, help="0 disables the CPU baseline leg")
     ap.add_argument("--other-kernels", type=int, default=1, help="0 skips the emit / parse / write measurements (N = 1 only)")
+    ap.add_argument("--sweep", type=int, default=1, help="0 skips other_kernels' NAL-size sweep (profiling passes)")
     ap.add_argument("--exercise-gather", action="store_true",
                     help="dev aid: run the N > 1 code path (RCCL group, pipelined index gather) with a one-rank group on one GPU")
     args = ap.parse_args()
@@ -586,7 +588,7 @@ def main():
         if world == 1 and args.other_kernels:
             g["uniform_kernel_ms"] = k_ms
             del rbsp, index
-            out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n)
+            out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n, sweep=bool(args.sweep))
         # RCCL writes a version banner to C stdout, which is block-buffered when piped: push it out first, so that the JSON
         # line is the LAST line of rank 0's stdout
         try:
