@@ -24,6 +24,14 @@
 #include "hbs_emit.h"
 #include "hbs_emit_launch.h"
 
+#ifndef HBS_K3F_COPY_DEPTH
+#define HBS_K3F_COPY_DEPTH -1     /* k3_fused: stores / loads of a wavefront in flight (-1: no limit).  Round 3 tried 3 / 8 and 3 / 4,
+                                     the recipe that took k3_tiles from 6.9 to 6.1 ms: nothing here (8.7-8.9 ms either way, scripts/experiments/k3f_ab.sh) */
+#endif
+#ifndef HBS_K3F_LOAD_DEPTH
+#define HBS_K3F_LOAD_DEPTH -1
+#endif
+
 namespace hbs {
 
 /* Which of the two ways?  The single-pass kernel (k3_fused) sends every row that holds a flagged chunk through
@@ -528,6 +536,9 @@ __device__ __forceinline__ void load_rows(u32x4 (&R)[kEmitRows], const uint8_t* 
                  * and phases (they are all the same expression) they would fill the register file */
                 const uint32_t off = 1024u * (r0 + (uint32_t)r) + 16u * (uint32_t)launder_lane(lane);
                 R[r] = k3_load16(base + (off < lim ? off : lim));
+#if HBS_K3F_LOAD_DEPTH >= 0
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS_K3F_LOAD_DEPTH) : "memory");
+#endif
             }
         }
     }
@@ -629,6 +640,11 @@ __device__ __forceinline__ void emit_batch(const u32x4 (&R)[kEmitRows], const ui
                 if (off == last_off) store_bytes(dst, R[r], len - last_off);
             }
         }
+#if HBS_K3F_COPY_DEPTH >= 0
+        /* at most that many stores of a wavefront in flight: a short memory queue on the CU keeps the other workgroups'
+         * look-back polls quick (hbs_scan4.hip, round 3) */
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS_K3F_COPY_DEPTH) : "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);                     /* one row at a time: interleaving rows only costs registers */
     }
 }
