@@ -34,11 +34,13 @@ def ld4(first):
 def body():
     """the fetch and the flag pass, interleaved: group g is flagged with the rows up to 4g+7 issued, so 3 to 7 loads of the
     wavefront are in flight at any time (scripts/ubench/ceiling3.hip: deeper queues delay the other workgroup's look-back polls)"""
-    out = [ld4(0)] + ([ld4(4)] if rows > 4 else [])
+    ahead = int(os.environ.get("AHEAD", 1))        # groups of loads issued beyond the one a flag group's neighbour row is in (1: shipped)
+    assert ahead >= 1, "a group's last row needs the first row of the next group: at least one group ahead"
+    out = [ld4(4 * i) for i in range(ahead + 1) if 4 * i < rows]
     for g in range(0, rows, 4):
         out.append(group(g))
-        if g + 8 < rows:
-            out.append(ld4(g + 8))
+        if g + 4 * (ahead + 1) < rows:
+            out.append(ld4(g + 4 * (ahead + 1)))
     return out
 
 

@@ -259,6 +259,17 @@ int main(int argc, char** argv)
         snprintf(ex, 64, "polls/tile %.2f", st[1] ? (double)st[0] / (double)st[1] : 0.0);
         rw(nm, ms, ex);
     };
+    if (argc > 2 && !strcmp(argv[2], "shift")) {
+        // what alignment of the destination costs a copy: bytes, 16-byte granules, 64-byte sectors, 128-byte lines
+        for (int rep = 0; rep < 2; ++rep)
+            for (int shift : {0, 1, 7, 16, 32, 48, 64, 96, 128, 144, 256, 1024, 1031}) {
+                char nm[96];
+                snprintf(nm, 96, "simple nt-both shift %d", shift);
+                rw(nm, time_ms([&] { k_copy_simple<<<(unsigned)(nc / 256), 256>>>(src, dst, nc, shift); }));
+            }
+        hipDeviceSynchronize();
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[2], "read")) {
         uint32_t* outp; hipMalloc(&outp, 4096);
         auto ro = [&](const char* name, float ms) { printf("read %-44s %7.0f GB/s  (%.3f ms)\n", name, 1.0 * n / ms / 1e6, ms); fflush(stdout); };
