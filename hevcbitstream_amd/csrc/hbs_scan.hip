@@ -27,6 +27,10 @@
 #include "hbs_tile.h"
 #include "hbs_scan.h"
 
+#ifndef HBS2_COPY_DEPTH
+#define HBS2_COPY_DEPTH -1
+#endif
+
 namespace hbs {
 
 /* Diagnostic build only (-DHBS_PHASE_TIMING, tests/tools/phase_timing.py): per-phase
@@ -493,6 +497,9 @@ void scan_tiles(TileLds& l, const uint8_t* __restrict__ stream, uint64_t n, uint
                     if (d.sub == 0xFFFFu) {
                         const Quad qd = view.quad((int32_t)(16u * c));
                         store16_unaligned(out + d.rank, qd);
+#if HBS2_COPY_DEPTH >= 0
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HBS2_COPY_DEPTH) : "memory");     /* a short memory queue on the CU: hbs_scan4.hip, round 3 */
+#endif
                     } else if (d.sub != 0u) {
                         const uint32_t slot = atomicAdd(&l.slow_cnt, 1u);
                         if (slot < (uint32_t)kSlowCap) l.slow[slot] = (uint16_t)c;
