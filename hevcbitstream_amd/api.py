@@ -212,7 +212,10 @@ class Context:
         return worst if stream_bytes <= (64 << 20) else min(worst, stream_bytes // 64 + 4096)
 
     def index_extract_async(self, stream, index, index_cap, rbsp, summary):
-        """Enqueue K12 on the current torch stream.  All arguments are device tensors."""
+        """Enqueue K12 on the current torch stream.  All arguments are device tensors.  A stream with more NALs than
+        index_cap reports HBS_E_CAPACITY in its summary (nal_found = the entries it needs): alloc_outputs() defaults to
+        default_index_cap(), which is NOT the worst case above 64 MiB -- index_extract() retries with a larger index,
+        callers of this method do that themselves."""
         self._bind_stream()
         rc = self.lib.hbs_index_extract(self.h, C.c_void_p(stream.data_ptr() if stream.numel() else None),
                                         stream.numel(), C.c_void_p(index.data_ptr()), index_cap,
@@ -234,8 +237,12 @@ class Context:
         self.index_extract_async(stream, index, cap, rbsp, summary)
         s = self.read_summary(summary)
         if index_cap is None and int(s["error"]) == -4 and int(s["nal_found"]) > cap:      # HBS_E_CAPACITY: the default was too small
+            # only the index grows: the arena and the summary of the first attempt are used again (a second arena next to the
+            # first would double the peak for exactly the large streams the reduced default is for)
             del index
-            index, rbsp, summary, cap = self.alloc_outputs(stream.numel(), int(s["nal_found"]) + 8, want_rbsp)
+            cap = int(s["nal_found"]) + 8
+            index = self.torch.empty(cap * NAL_ENTRY.itemsize, dtype=self.torch.uint8, device=summary.device)
+            summary.zero_()
             self.index_extract_async(stream, index, cap, rbsp, summary)
             s = self.read_summary(summary)
         n = int(s["nal_count"])
