@@ -237,3 +237,33 @@ def test_calls_capture_into_a_hip_graph(orc):
         tot = int(want_idx["rbsp_off"][-1] + want_idx["rbsp_len"][-1]) if len(want_idx) else 0
         assert np.array_equal(rbsp[:tot].cpu().numpy(), want_arena[:tot])
     ctx.close()
+
+
+def test_timing_ring_keeps_the_last_calls(ctx, orc):
+    """hbs_ctx_kernel_ms_back: the event pairs of the last 64 timed calls stay readable (bench.py reads every step of its timed
+    loop behind the loop's fence); calls further back, or before timing was enabled, are refused"""
+    import torch
+    import hevcbitstream_amd as hbs
+    stream, _, _ = orc.gen_stream(0x55, 400, 0)
+    d = torch.from_numpy(stream).cuda()
+    index, rbsp, summary, cap = ctx.alloc_outputs(d.numel())
+    ctx.enable_timing(True)
+    try:
+        with pytest.raises(hbs.HbsError):
+            ctx.kernel_ms_back(0)                          # nothing timed yet
+        for _ in range(5):
+            ctx.index_extract_async(d, index, cap, rbsp, summary)
+        torch.cuda.synchronize()
+        ms = [ctx.kernel_ms_back(b) for b in range(5)]
+        assert all(0.0 < x < 50.0 for x in ms), ms
+        assert abs(ctx.kernel_ms() - ms[0]) < 1e-6         # the last call is slot 0
+        with pytest.raises(hbs.HbsError):
+            ctx.kernel_ms_back(5)                          # only five calls were timed
+        for _ in range(70):
+            ctx.index_extract_async(d, index, cap, rbsp, summary)
+        torch.cuda.synchronize()
+        assert all(0.0 < ctx.kernel_ms_back(b) < 50.0 for b in range(64))
+        with pytest.raises(hbs.HbsError):
+            ctx.kernel_ms_back(64)                         # the ring holds 64
+    finally:
+        ctx.enable_timing(False)
