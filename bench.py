@@ -419,6 +419,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_shard.py runs this file with 2 ranks on ONE GPU): every rank on one device, torch.distributed over
+    # gloo (RCCL refuses two ranks on a device; the library's own exchange then goes through HBS_RCCL_LIB's stand-in)
+    if os.environ.get("HBS_BENCH_ONE_DEVICE"):
+        local_rank = int(os.environ["HBS_BENCH_ONE_DEVICE"])
+    backend = os.environ.get("HBS_BENCH_DIST_BACKEND", "nccl")
+    cdev = "cuda" if backend == "nccl" else "cpu"          # where the tensors of the few host-side collectives live
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
@@ -431,9 +437,9 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
     ctx = hbs.Context(local_rank)
     ctx.enable_timing(True)
@@ -512,15 +518,15 @@ def main():
         mine = all_index[rank * n * 32: (rank + 1) * n * 32].view(torch.int64).view(n, 4)
         assert torch.equal(mine[:, :3], b[:, :3]), "gathered index rows of this rank != its index"
     if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([float(sb), float(n)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(sb), float(n)], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bytes, total_nals = float(tot[0].item()), float(tot[1].item())
         # every rank's own kernel and gather times, for the per-rank lines
-        mine_t = torch.tensor([sum(kms) / len(kms), (sum(gms) / len(gms)) if gms else 0.0, float(sb + rb + 32 * n)], dtype=torch.float64, device="cuda")
-        per_rank_t = torch.empty(world * 3, dtype=torch.float64, device="cuda")
+        mine_t = torch.tensor([sum(kms) / len(kms), (sum(gms) / len(gms)) if gms else 0.0, float(sb + rb + 32 * n)], dtype=torch.float64, device=cdev)
+        per_rank_t = torch.empty(world * 3, dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(per_rank_t, mine_t)
         per_rank_t = per_rank_t.view(world, 3).cpu().tolist()
     else:

@@ -147,3 +147,47 @@ def test_two_ranks_share_one_gpu(orc, tmp_path):
         finally:
             shm.close()
             shm.unlink()
+
+
+def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's whole N > 1 path with world = 2 on this one GPU: the pipelined C-ABI gather (over the stand-in for RCCL), the
+    max-over-ranks timing, the per-rank lines and the checks of the gathered rows -- so that the line is right the first time a
+    node with several GPUs runs it (torch.distributed over gloo here: RCCL refuses two ranks on one device)"""
+    import ctypes as C
+    import json
+    import os
+    import subprocess
+    import sys
+    from multiprocessing import shared_memory
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = os.path.join(root, "tests", "sim", "libfake_rccl.so")
+    assert os.path.exists(fake), "make -C tests/sim"
+    lib = C.CDLL(fake)
+    lib.fake_rccl_segment_bytes.restype = C.c_uint64
+    lib.fake_rccl_segment_bytes.argtypes = [C.c_int, C.c_uint64]
+    world, nals, slot = 2, 40000, 8 << 20
+    shm = shared_memory.SharedMemory(create=True, size=int(lib.fake_rccl_segment_bytes(world, slot)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, HBS_RCCL_LIB=fake, HBS_FAKE_RCCL_SHM="/" + shm.name.lstrip("/"), HBS_FAKE_RCCL_SLOT=str(slot),
+                       HBS_BENCH_ONE_DEVICE="0", HBS_BENCH_DIST_BACKEND="gloo", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+                                           "--nals", str(nals)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
+        outs = [p.communicate(timeout=600) for p in procs]
+        for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0, "rank %d:\n%s" % (r, e.decode()[-3000:])
+        line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["gather"]["rccl_world"] == 2 and len(line["per_rank"]) == 2
+        assert line["gather"]["bytes_received_per_rank_per_step"] == 2 * nals * 32
+        assert line["gather"]["gather_ms"] > 0 and all(r["kernel_ms"] > 0 for r in line["per_rank"])
+        assert line["value"] > 0 and line["config"]["nals_per_gpu"] == nals
+        assert outs[1][0].decode().strip() == "" or "metric" not in outs[1][0].decode()      # one JSON line, from rank 0
+    finally:
+        shm.close()
+        shm.unlink()
