@@ -113,3 +113,26 @@ def test_a_window_that_is_too_small_is_reported(ctx):
         hits += int(too_long.sum())
         same(a, both_ways(ctx, stream, window=1024)[1])
     assert hits > 0, "no header of the test streams was longer than 56 bytes"
+
+
+def test_streams_without_nals_and_small_index(ctx):
+    """no start code at all, an empty stream, and an index that is too small (the scan's HBS_E_CAPACITY comes back as the call's error)"""
+    import torch
+    import hevcbitstream_amd as hbs
+    from hevcbitstream_amd.api import PARSED, SUMMARY
+    for data in (np.full(5000, 0x55, dtype=np.uint8), np.zeros(0, dtype=np.uint8)):
+        d = torch.from_numpy(data).cuda()
+        index = torch.zeros(64 * 32, dtype=torch.uint8, device="cuda")
+        parsed = torch.zeros(64 * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+        s1 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+        s2 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+        assert ctx.index_parse_async(d, index, 64, parsed, None, s1, s2) == 0
+        assert int(ctx.read_summary(s1)["nal_count"]) == 0 and int(ctx.read_summary(s2)["error"]) == 0
+    stream = np.frombuffer(annexb(sequence(2)), dtype=np.uint8).copy()
+    d = torch.from_numpy(stream).cuda()
+    index = torch.zeros(2 * 32, dtype=torch.uint8, device="cuda")
+    parsed = torch.zeros(64 * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+    s1 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+    s2 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+    with pytest.raises(hbs.HbsError):
+        ctx.index_parse_async(d, index, 2, parsed, None, s1, s2)
