@@ -443,6 +443,9 @@ def main():
 
     ctx = hbs.Context(local_rank)
     ctx.enable_timing(True)
+    if multi:
+        # the scan's persistent workgroups fill the GPU; RCCL's kernels need somewhere to run beside it
+        ctx.reserve_workgroups(int(os.environ.get("HBS_BENCH_SPARE_WGS", "32")))
     n = args.nals
     from hevcbitstream_amd.shard import shard_seed
     g = ctx.synth_stream(shard_seed(SEED, rank), n, args.mode)   # independent shard per rank, generated in HBM

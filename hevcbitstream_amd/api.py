@@ -30,7 +30,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
-           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_gather_parts", "hbs_index_parse",
+           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
            "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps"]
 
 
@@ -178,6 +178,11 @@ class Context:
         ms = C.c_float()
         self._check(self.lib.hbs_ctx_kernel_ms(self.h, C.byref(ms)), "hbs_ctx_kernel_ms")
         return ms.value
+
+    def reserve_workgroups(self, spare):
+        """leave `spare` workgroup slots of the persistent scan kernels free (for RCCL's kernels beside the scan)"""
+        self.lib.hbs_ctx_reserve_workgroups.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.hbs_ctx_reserve_workgroups(self.h, int(spare)), "hbs_ctx_reserve_workgroups")
 
     def kernel_ms_back(self, back):
         """Duration of the timed call `back` calls ago (0 = the last one; the library keeps the last 64)."""

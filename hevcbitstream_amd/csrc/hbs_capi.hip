@@ -30,6 +30,7 @@ struct hbs_ctx {
     int grid_blocks;
     int blocks_per_cu;
     int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
+    int grid_full, grid_full4;          /* ... what the GPU holds; grid_blocks / grid_blocks4 may be cut (hbs_ctx_reserve_workgroups) */
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
@@ -126,6 +127,7 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks4 = hbs::scan4_grid_blocks(device, &c->blocks_per_cu4);
     if (c->grid_blocks4 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    c->grid_full = c->grid_blocks; c->grid_full4 = c->grid_blocks4;
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
@@ -203,6 +205,17 @@ int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
     if (e != hipSuccess) return fail(c, e, "hipEventSynchronize");
     e = hipEventElapsedTime(ms, c->ev0, c->ev1);
     return e == hipSuccess ? 0 : fail(c, e, "hipEventElapsedTime");
+}
+
+/* The scan kernels are persistent: their workgroups fill the GPU (the event-sparse kernel's 512 use every register), so a kernel
+ * of another stream -- RCCL's, in the index gather of the multi-GPU path -- finds no CU until the scan ends, and a "pipelined"
+ * exchange runs in the gaps between scans.  Leaving a few workgroup slots free lets it run beside the scan. */
+int hbs_ctx_reserve_workgroups(hbs_ctx* c, int spare)
+{
+    if (!c || spare < 0) return HBS_E_ARG;
+    c->grid_blocks = c->grid_full - spare > 1 ? c->grid_full - spare : 1;
+    c->grid_blocks4 = c->grid_full4 - spare > 1 ? c->grid_full4 - spare : 1;
+    return 0;
 }
 
 int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)

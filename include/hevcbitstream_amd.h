@@ -119,6 +119,11 @@ int  hbs_ctx_enable_timing(hbs_ctx* ctx, int on);
 int  hbs_ctx_kernel_ms(hbs_ctx* ctx, float* ms);
 int  hbs_ctx_kernel_ms_back(hbs_ctx* ctx, int back, float* ms);
 int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
+/* The scan + extract kernels are persistent and fill the GPU: a kernel of another stream (RCCL's, in hbs_gather_index running
+ * beside the next scan) finds no CU before the scan ends.  `spare` workgroup slots are left free from now on (0 = none, the
+ * default; a multi-GPU caller that overlaps the index gather with the next scan wants ~32 of the 512: with 8 or 16 RCCL still
+ * waited for the scan to end, with 32 a one-rank gather of 54 MB took 0.14 ms beside the scan instead of 5.3 ms behind it). */
+int  hbs_ctx_reserve_workgroups(hbs_ctx* ctx, int spare);
 /* Three implementations of the scan kernel exist, with identical results:
  * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
  *     pairs are rare, and the slowest on zero-heavy data),
