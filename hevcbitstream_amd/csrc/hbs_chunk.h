@@ -58,6 +58,15 @@ HBS_HD uint32_t chunk_patterns(uint32_t xp, uint32_t x0, uint32_t x1, uint32_t x
     return movemask4(p0) | (movemask4(p1) << 4) | (movemask4(p2) << 8) | (movemask4(p3) << 12) | ((movemask4(pn) & 3u) << 16);
 }
 
+/* chunk_patterns() != 0 without forming the mask: does a pattern 00 00 {<=3} end in bytes [0, 18) of the chunk? */
+HBS_HD bool chunk_pattern_any(uint32_t xp, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t xn)
+{
+    uint32_t z = zero_bytes(xp);
+    const uint32_t p0 = pattern_marks(x0, z), p1 = pattern_marks(x1, z), p2 = pattern_marks(x2, z), p3 = pattern_marks(x3, z);
+    const uint32_t pn = pattern_marks(xn, z);
+    return (p0 | p1 | p2 | p3 | (pn & 0x00008080u)) != 0u;
+}
+
 /* kept bytes of a chunk with holes, packed low-to-high into lo/hi, straight from registers */
 HBS_HD uint32_t compact_chunk_regs(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t keep16, uint64_t& lo, uint64_t& hi)
 {

@@ -61,6 +61,15 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #ifndef HBS4_PROGRESSIVE
 #define HBS4_PROGRESSIVE 1     /* the fetch inside the flag pass, four rows at a time */
 #endif
+#ifndef HBS4_EXACT_FLAG
+#define HBS4_EXACT_FLAG 1      /* rows with a zero pair are asked again, exactly: only chunks a pattern 00 00 {<=3} touches become elements */
+#endif
+#ifndef HBS4_ELEM_WAVES
+#define HBS4_ELEM_WAVES 2      /* wavefronts that share the batches of a tile with more than 64 elements (each parks kParkRows rows in LDS) */
+#endif
+#ifndef HBS4_EXACT_MIN
+#define HBS4_EXACT_MIN 2       /* ... when the row has more flagged chunks than this */
+#endif
 #ifndef HBS4_COPY_DEPTH
 #define HBS4_COPY_DEPTH 3      /* stores of a wavefront in flight during the copy (-1: no limit) */
 #endif
@@ -101,16 +110,18 @@ constexpr uint32_t kDenseElems = 512;      /* a tile with more elements than thi
 
 struct Lds4 {
     uint32_t wave_tot[k4Waves];            /* elements per wavefront                        */
-    uint16_t list[kDenseElems];            /* flagged chunks of the tile, in stream order (a tile with more takes the dense path) */
+    uint16_t wlist[k4Waves][kDenseElems];  /* flagged chunks of each wavefront's rows, in stream order, written during the flag pass (a tile with more than
+                                              kDenseElems takes the dense path); element i of the tile = entry i - (elements of the wavefronts in front) */
     uint32_t seg[kDenseElems + 1];         /* segment words: [0] tile start, [i+1] element i of the tile */
     u32x4 rec[kDenseElems][3];             /* tiles with several batches of elements: what the first walk found out about each
                                               (marks, summary, classes, its bytes), so that the second half does not walk it again */
     Deposit dep[k4Waves][kDepCap];         /* bytes of the first elements of each wavefront, left by the flag pass */
-    u32x4 park[kParkRows][64];             /* rows of wavefront 0 while it handles elements and looks back */
+    u32x4 park[HBS4_ELEM_WAVES][kParkRows][64];   /* rows of the wavefronts that handle elements (wavefront 0 always, and it looks back) meanwhile */
     unsigned long long ex_kept, ex_nals;   /* the tile's exclusive prefix, from wavefront 0 */
     uint32_t ex_inside, ex_ok;
     uint32_t ticket;
     TileAgg wagg[k4Waves];                 /* dense tiles: the aggregate of each wavefront's rows */
+    TileAgg bagg[kDenseElems / k4ElemPass];/* tiles with several batches of elements: the aggregate of each batch */
 };
 
 /* ---- dense tiles -------------------------------------------------------------------------------------
@@ -222,16 +233,24 @@ __device__ __forceinline__ void rec4_load(const u32x4* r, Elem& el, const uint8_
     el.v.stream = src; el.v.g0 = base + 16ull * a.x; el.v.n = n;
 }
 
+/* chunk number of element i of the tile; wb1..wb3 = elements in front of wavefronts 1..3 */
+__device__ __forceinline__ uint32_t list_at(const Lds4& l, uint32_t i, uint32_t wb1, uint32_t wb2, uint32_t wb3)
+{
+    const uint32_t ew = (i >= wb1 ? 1u : 0u) + (i >= wb2 ? 1u : 0u) + (i >= wb3 ? 1u : 0u);
+    const uint32_t ej = i - (ew == 0u ? 0u : ew == 1u ? wb1 : ew == 2u ? wb2 : wb3);
+    return l.wlist[ew][ej < kDenseElems ? ej : 0u];
+}
+
 /* Element i of the tile (lane = i mod 64 of wavefront 0): its bytes come from the deposit its
  * flagging lane left in LDS, or from the stream when there is none; then the exact window rules. */
 __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i, uint32_t wb1, uint32_t wb2, uint32_t wb3,
                                              const uint8_t* __restrict__ src, uint64_t base, uint64_t n, bool padded)
 {
-    const uint32_t c = l.list[i];
-    const uint64_t prev_end = (i > 0) ? base + 16ull * ((uint32_t)l.list[i - 1] + 1u) : base;
     /* which wavefront flagged it, and as its how-manieth element */
     const uint32_t ew = (i >= wb1 ? 1u : 0u) + (i >= wb2 ? 1u : 0u) + (i >= wb3 ? 1u : 0u);
     const uint32_t ej = i - (ew == 0u ? 0u : ew == 1u ? wb1 : ew == 2u ? wb2 : wb3);
+    const uint32_t c = l.wlist[ew][ej < kDenseElems ? ej : 0u];
+    const uint64_t prev_end = (i > 0) ? base + 16ull * (list_at(l, i - 1u, wb1, wb2, wb3) + 1u) : base;
     /* field by field: a conditional copy of the whole struct ends up in scratch memory, and every later use of the
      * element's bytes then waits for all outstanding memory operations (s_waitcnt vmcnt(0)) to read them back */
     const bool have_dep = ej < (uint32_t)kDepCap && l.dep[ew < (uint32_t)k4Waves ? ew : 0u][ej < (uint32_t)kDepCap ? ej : 0u].chunk == c;
@@ -319,7 +338,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
     uint32_t d_before = 0, d_before2 = 0, d_after = 0;
     uint64_t d_tile = 0;
     for (;;) {
-    bool dense_pending = false;
+    int pending = 0;                   /* 1: a dense tile -- handled below the tile loop, where no row is live */
     for (;;) {
         int tid = launder_lane(tid0);
         int lane = tid & 63;
@@ -365,19 +384,30 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 const bool f##r = chunk_flag(xp##r, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn##r); \
                 const uint64_t fmask##r = __ballot(f##r);
 #define HBS_FLAG_KEEP(r, e_prev_z) \
-                if (fmask##r != 0) {     /* stash the mask, leave the chunk's surroundings for its element thread */ \
-                    write_lane(fm_lo, (uint32_t)fmask##r, r); \
-                    write_lane(fm_hi, (uint32_t)(fmask##r >> 32), r); \
-                    const uint32_t xpp = from_prev_lane(R.q##r.z, (e_prev_z)); \
-                    const uint32_t slot = wslot + lanes_below(fmask##r); \
-                    if (f##r && slot < (uint32_t)kDepCap) { \
-                        Deposit d; \
-                        d.xpp = xpp; d.xp = xp##r; d.x0 = R.q##r.x; d.x1 = R.q##r.y; d.x2 = R.q##r.z; d.x3 = R.q##r.w; d.xn = xn##r; \
-                        d.chunk = (uint32_t)(64 * (k4Rows * wv + r) + lane); \
-                        l.dep[wv][slot] = d; \
+                if (fmask##r != 0) {     /* a zero pair somewhere: now the exact question -- does a pattern 00 00 {<=3} end in bytes [0, 18)? */ \
+                    bool g##r = f##r; \
+                    uint64_t gmask##r = fmask##r; \
+                    if (HBS4_EXACT_FLAG && __builtin_popcountll(fmask##r) > HBS4_EXACT_MIN) {   /* one or two: a start code, most likely -- nothing to gain */ \
+                        g##r = f##r && chunk_pattern_any(xp##r, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn##r); \
+                        gmask##r = __ballot(g##r); \
                     } \
-                    wslot += (uint32_t)__builtin_popcountll(fmask##r); \
-                }
+                    if (gmask##r != 0) { /* stash the mask, leave the chunk's surroundings for its element thread */ \
+                    write_lane(fm_lo, (uint32_t)gmask##r, r); \
+                    write_lane(fm_hi, (uint32_t)(gmask##r >> 32), r); \
+                    const uint32_t xpp = from_prev_lane(R.q##r.z, (e_prev_z)); \
+                    const uint32_t slot = wslot + lanes_below(gmask##r); \
+                    if (g##r && slot < kDenseElems) { \
+                        const uint32_t ch = (uint32_t)(64 * (k4Rows * wv + r) + lane); \
+                        l.wlist[wv][slot] = (uint16_t)ch; \
+                        if (slot < (uint32_t)kDepCap) { \
+                            Deposit d; \
+                            d.xpp = xpp; d.xp = xp##r; d.x0 = R.q##r.x; d.x1 = R.q##r.y; d.x2 = R.q##r.z; d.x3 = R.q##r.w; d.xn = xn##r; \
+                            d.chunk = ch; \
+                            l.dep[wv][slot] = d; \
+                        } \
+                    } \
+                    wslot += (uint32_t)__builtin_popcountll(gmask##r); \
+                } }
 #define HBS_FLAG_GROUP(a, wa, xa, za, b, wb, xb, zb, c, wc, xc, zc, d, wd, xd, zd) { \
                 HBS_FLAG_EVAL(a, wa, xa) HBS_FLAG_EVAL(b, wb, xb) HBS_FLAG_EVAL(c, wc, xc) HBS_FLAG_EVAL(d, wd, xd) \
                 if ((fmask##a | fmask##b | fmask##c | fmask##d) != 0) { \
@@ -439,6 +469,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 /* not flagged by its bytes: nothing was deposited for it; it is the wavefront's last
                  * element, and its thread must read the stream itself */
                 if (lane == 0 && wslot < (uint32_t)kDepCap) l.dep[wv][wslot].chunk = 0xFFFFFFFFu;
+                if (lane == 0 && wslot < kDenseElems) l.wlist[wv][wslot] = (uint16_t)(64 * k4Rows * wv + (int)cut);
                 if (lane == cr) { if (cl < 32) fm_lo |= 1u << cl; else fm_hi |= 1u << (cl - 32); }
             }
         }
@@ -465,60 +496,71 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             /* ---- dense tile: every chunk an element, every wavefront its own rows (dense_tile).  The call is made OUTSIDE the
              * tile loop, where nothing of a tile is live: inside it, what has to survive the call is spilled on the common path. */
             d_before = R.before; d_before2 = R.before2; d_after = R.after; d_tile = tile;
-            dense_pending = true;
+            pending = 1;
             break;
         }
         /* readlanes: only in wave-uniform control flow */
 #define HBS_ROW_PRE(r) (wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, (r)))
 #define HBS_ROW_FM(r) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, (r)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, (r)))
-        for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
-            const int r = __builtin_ctzll(rm);
-            const uint32_t rp = HBS_ROW_PRE(r);
-            const uint64_t f = HBS_ROW_FM(r);
-            if ((f >> lane) & 1ull)
-                l.list[rp + lanes_below(f)] = (uint16_t)(64 * (k4Rows * wv + r) + lane);
-        }
-        __syncthreads();
-        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < (int)kDenseElems; i += k4Threads) g_dbg4[256 + i] = l.list[i]; })
+        HBS4_DBG(if (tile == 0) { if (tid == 0) { g_dbg4[0] = nflag; } for (int i = tid; i < (int)kDenseElems; i += k4Threads) g_dbg4[256 + i] = list_at(l, (uint32_t)i, wb1, wb2, wb3); })
         HBS4_T_MARK(1)
 
         /* ---- 2..4 on wavefront 0: elements -> tile aggregate -> look-back -> emit ----------- */
         const uint32_t npass = (nflag + (uint32_t)k4ElemPass - 1u) / (uint32_t)k4ElemPass;
-        if (wv == 0) {
+        /* Several batches (a tile of small NALs, a stretch of zero pairs): wavefront 1 parks rows too and takes every other
+         * batch, in both halves; what a batch found out about its elements waits in LDS (rec) between the halves, the batch
+         * aggregates meet in LDS (bagg), and all segment words are out before anybody copies.  (Until round 3 wavefront 0 walked
+         * all batches alone, ~10 k cycles each, the other three waiting; all FOUR on the elements would need 80 KiB of parked
+         * rows, or the rows read again: tried as a function of its own, it lost to this below five batches and gained 4 % above.) */
+        const bool multi = npass > 1u;
+        const bool elem_wave = wv == 0 || (multi && wv < HBS4_ELEM_WAVES);
+        if (elem_wave) {
             /* this code needs ~100 registers of its own: part of this wavefront's rows wait in LDS */
-#define HBS_PARK(i, r) l.park[i][lane] = R.q##r;
-            HBS_PARKED(HBS_PARK)
-#undef HBS_PARK
             Elem el;
             TileAgg acc = agg_identity(), e = agg_identity();
+            Prefix ex;
+            bool ok = true, can = false;
+#define HBS_PARK(i, r) l.park[wv][i][lane] = R.q##r;
+            HBS_PARKED(HBS_PARK)
+#undef HBS_PARK
             el.gap = 0; el.chunk = 0;
-#pragma unroll 1
-            for (uint32_t p = 0; p < npass; ++p) {
-                const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
+            if (!multi) {
                 TileAgg ea = agg_identity();
-                if (i < nflag) {
-                    ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
-                    if (npass > 1u) rec4_store(l.rec[i], el);
-                }
+                if ((uint32_t)lane < nflag) ea = elem_make(el, l, (uint32_t)lane, wb1, wb2, wb3, src, base, n, last_tile);
                 ea = wave_scan_combine(ea, lane);
-                TileAgg up = agg_shfl_up(ea, 1);
-                if (lane == 0) up = agg_identity();
-                e = combine(acc, up);
-                acc = combine(acc, agg_readlane(ea, 63));
+                e = agg_shfl_up(ea, 1);
+                if (lane == 0) e = agg_identity();
+                acc = agg_readlane(ea, 63);
+            } else {
+#pragma unroll 1
+                for (uint32_t p = (uint32_t)wv; p < npass; p += (uint32_t)HBS4_ELEM_WAVES) {
+                    const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
+                    TileAgg ea = agg_identity();
+                    if (i < nflag) {
+                        ea = elem_make(el, l, i, wb1, wb2, wb3, src, base, n, last_tile);
+                        rec4_store(l.rec[i], el);
+                    }
+                    ea = wave_scan_combine(ea, lane);
+                    if (lane == 63) l.bagg[p] = ea;
+                }
             }
-            const uint64_t last_end = (nflag > 0) ? base + 16ull * ((uint32_t)l.list[nflag - 1] + 1u) : base;
+            if (multi) __syncthreads();                    /* the other wavefronts: below */
+            if (wv == 0) {
+            if (multi) {
+#pragma unroll 1
+                for (uint32_t p = 0; p < npass; ++p) acc = combine(acc, l.bagg[p]);
+            }
+            const uint64_t last_end = (nflag > 0) ? base + 16ull * (list_at(l, nflag - 1u, wb1, wb2, wb3) + 1u) : base;
             const TileAgg tagg = combine(acc, gap_agg(span_bytes(last_end, tile_end, n)));
             HBS4_T_MARK(2)
 
-            Prefix ex;
             uint32_t it, stl;
-            bool ok;
             HBS4_DBG(if (g_fake_lb4) { ok = true; it = 0; stl = 0; ex.kept = tile * (uint64_t)(k4TileBytes - 4096); ex.nals = tile * 16; ex.inside = 1; } else)
             ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
             HBS4_T_COUNT(7, ((unsigned long long)stl << 32) | it)
             HBS4_PRIO(0);
             const uint32_t tile_kept = tagg.known + (ex.inside ? tagg.sig : 0u);
-            const bool can = rbsp != nullptr && ex.kept + tile_kept <= rbsp_cap;
+            can = rbsp != nullptr && ex.kept + tile_kept <= rbsp_cap;
             if (lane == 0) {
                 l.ex_kept = ex.kept; l.ex_nals = ex.nals; l.ex_inside = ex.inside;
                 l.ex_ok = !ok ? 0u : (rbsp != nullptr && !can) ? 2u : 1u;
@@ -530,17 +572,23 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 }
             }
             HBS4_T_MARK(3)
-            /* one pass (nearly always): the elements are still in registers.  More (a tile of small NALs, a stretch of zero pairs):
-             * the batches again, 64 elements at a time, each leaving its segment words -- all of them before anybody copies, so that
-             * the rows stay parked once and the copy below runs once (until round 3 every batch was followed by a copy pass of its
-             * own over all 48 rows: 28 k cycles a batch; profiles/r03/nal_sweep_*.txt) */
-            if (ok && npass == 1u) {
-                if ((uint32_t)lane < nflag) elem_emit(el, e, ex, can, rbsp + ex.kept, tgt, &l.seg[lane + 1]);
-            } else if (ok) {
-                const Prefix exu = prefix_uniform4(ex);
-                TileAgg accb = agg_identity();
+            } else {
+                HBS4_PRIO(0);
+            }
+            if (multi) __syncthreads();
+            if (!multi) {
+                /* one batch (nearly always): the elements are still in registers */
+                if (ok && (uint32_t)lane < nflag) elem_emit(el, e, ex, can, rbsp + ex.kept, tgt, &l.seg[lane + 1]);
+            } else if (l.ex_ok != 0u) {
+                Prefix exl;
+                exl.kept = l.ex_kept; exl.nals = l.ex_nals; exl.inside = l.ex_inside;
+                const Prefix exu = prefix_uniform4(exl);
+                const bool canu = rbsp != nullptr && l.ex_ok == 1u;
 #pragma unroll 1
-                for (uint32_t p = 0; p < npass; ++p) {
+                for (uint32_t p = (uint32_t)wv; p < npass; p += (uint32_t)HBS4_ELEM_WAVES) {
+                    TileAgg accb = agg_identity();
+#pragma unroll 1
+                    for (uint32_t q = 0; q < p; ++q) accb = combine(accb, l.bagg[q]);
                     const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
                     TileAgg ea = agg_identity();
                     if (i < nflag) { rec4_load(l.rec[i], el, src, base, n); ea = elem_agg(el.gap, el.s); }
@@ -548,15 +596,16 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                     TileAgg up = agg_shfl_up(ea, 1);
                     if (lane == 0) up = agg_identity();
                     const TileAgg eb = combine(accb, up);
-                    accb = combine(accb, agg_readlane(ea, 63));
-                    if (i < nflag) elem_emit(el, eb, exu, can, rbsp + exu.kept, tgt, &l.seg[i + 1]);
+                    if (i < nflag) elem_emit(el, eb, exu, canu, rbsp + exu.kept, tgt, &l.seg[i + 1]);
                 }
             }
-#define HBS_UNPARK(i, r) R.q##r = l.park[i][lane];
+#define HBS_UNPARK(i, r) R.q##r = l.park[wv][i][lane];
             HBS_PARKED(HBS_UNPARK)
 #undef HBS_UNPARK
         } else {
+            /* (a barrier counts wavefronts, wherever they are in the code: these two meet the two above) */
             HBS4_PRIO(0);
+            if (multi) { __syncthreads(); __syncthreads(); }
         }
         __syncthreads();
         if (l.ex_ok == 0u) return;
@@ -621,7 +670,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 #undef HBS_ROW_PRE
 #undef HBS_ROW_FM
     }
-    if (!dense_pending) break;
+    if (pending == 0) break;
     {
         const uint64_t base = d_tile * (uint64_t)k4TileBytes;
         const bool last_tile = d_tile == num_tiles - 1;
@@ -686,7 +735,8 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
                 bool f = false;
                 if (in) {
                     const Quad q = *reinterpret_cast<const Quad*>(stream + off);
-                    f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+                    f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) &&
+                        (!HBS4_EXACT_FLAG || chunk_pattern_any(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu));
                 }
                 chunks += (uint32_t)__builtin_popcountll(__ballot(in));
                 flagged += (uint32_t)__builtin_popcountll(__ballot(f));

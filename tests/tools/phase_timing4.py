@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
-so = "build/diag/libhbs_diag.so"      # built by `make diag` in the dev container
+so = os.environ.get("HBS_DIAG_LIB", "build/diag/libhbs_diag.so")      # built by `make diag` in the dev container
 assert os.path.exists(so), "run `make diag` first"
 import hevcbitstream_amd.api as api
 api.library_path = lambda: so
@@ -11,13 +11,21 @@ from tests import _orc
 orc = _orc.oracle()
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 want_rbsp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
-rep = int(os.environ.get('HBS4_REPEAT', 64))
-d = torch.from_numpy(base).cuda().repeat(rep)
 ctx = hbs.Context(0)
+if os.environ.get('HBS4_NAL_MEAN'):          # a stream of random payload cut into NALs of that mean size (scripts/nal_sweep.py)
+    sys.path.insert(0, "scripts")
+    import nal_sweep
+    _, _, _, nn, sbuf, sb = nal_sweep.make_stream(torch, np, ctx, int(os.environ['HBS4_NAL_MEAN']), 1 << 30)
+    d = sbuf[:sb]
+    ncap = nn + 64
+else:
+    base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
+    rep = int(os.environ.get('HBS4_REPEAT', 64))
+    d = torch.from_numpy(base).cuda().repeat(rep)
+    ncap = 1600 * rep + 16
 ctx.set_kernel(4)
 blocks, per_cu = ctx.grid()
-index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * rep + 16)
+index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=ncap)
 lib = api.load_library()
 if os.environ.get('HBS4_FAKE_LB'):
     assert lib.hbs_debug_fake_lb4(C.c_int(1)) == 0
