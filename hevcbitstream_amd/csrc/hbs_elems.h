@@ -27,14 +27,33 @@ __device__ __forceinline__ TileAgg agg_shfl_up(const TileAgg& a, int d)
     return t;
 }
 
-/* inclusive scan with combine(): lane l <- elements of lanes 0..l in order */
-__device__ __forceinline__ TileAgg wave_scan_combine(TileAgg a, int lane)
+/* the aggregate of the lane in front (lane 0: the identity) */
+__device__ __forceinline__ TileAgg agg_prev_lane(const TileAgg& a)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const TileAgg t = agg_shfl_up(a, d);
-        if (lane >= d) a = combine(t, a);
-    }
+    TileAgg t;
+    t.cnt = dpp_or_zero<kDppWaveShr1, 0xF>(a.cnt); t.known = dpp_or_zero<kDppWaveShr1, 0xF>(a.known);
+    t.sig = dpp_or_zero<kDppWaveShr1, 0xF>(a.sig); t.last = dpp_or_zero<kDppWaveShr1, 0xF>(a.last);
+    return t;
+}
+
+/* inclusive scan with combine(): lane l <- elements of lanes 0..l in order.  Six DPP steps (hbs_wave.h): lanes without a source
+ * read the identity, and combine(identity, a) = a. */
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ TileAgg agg_dpp(const TileAgg& a)
+{
+    TileAgg t;
+    t.cnt = dpp_or_zero<kCtrl, kRowMask>(a.cnt); t.known = dpp_or_zero<kCtrl, kRowMask>(a.known);
+    t.sig = dpp_or_zero<kCtrl, kRowMask>(a.sig); t.last = dpp_or_zero<kCtrl, kRowMask>(a.last);
+    return t;
+}
+__device__ __forceinline__ TileAgg wave_scan_combine(TileAgg a, int /*lane*/)
+{
+    a = combine(agg_dpp<kDppRowShr1, 0xF>(a), a);
+    a = combine(agg_dpp<kDppRowShr2, 0xF>(a), a);
+    a = combine(agg_dpp<kDppRowShr4, 0xF>(a), a);
+    a = combine(agg_dpp<kDppRowShr8, 0xF>(a), a);
+    a = combine(agg_dpp<kDppBcast15, 0xA>(a), a);
+    a = combine(agg_dpp<kDppBcast31, 0xC>(a), a);
     return a;
 }
 

@@ -67,6 +67,9 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #ifndef HBS4_ELEM_WAVES
 #define HBS4_ELEM_WAVES 2      /* wavefronts that share the batches of a tile with more than 64 elements (each parks kParkRows rows in LDS) */
 #endif
+#ifndef HBS4_EMIT_WAVES
+#define HBS4_EMIT_WAVES 2      /* wavefronts that share the second half (emission) of those batches (4: the other two with all their rows in place -- spills 45 registers, some on every tile's path) */
+#endif
 #ifndef HBS4_EXACT_MIN
 #define HBS4_EXACT_MIN 2       /* ... when the row has more flagged chunks than this */
 #endif
@@ -196,7 +199,7 @@ __device__ __forceinline__ void dense_emit(const uint8_t* src, uint64_t wseg, ui
         DenseRow d;
         dense_row(d, qp, qc, qn, r, k4Rows, before, before2, after, src, wseg, n, chunk0, lane);
         const TileAgg ea = wave_scan_combine(elem_agg(0u, d.el.s), lane);
-        TileAgg up = agg_shfl_up(ea, 1);
+        TileAgg up = agg_prev_lane(ea);
         if (lane == 0) up = agg_identity();
         const TileAgg e = combine(acc, up);
         acc = combine(acc, agg_readlane(ea, 63));
@@ -231,6 +234,33 @@ __device__ __forceinline__ void rec4_load(const u32x4* r, Elem& el, const uint8_
     el.v.x0 = c.x; el.v.x1 = c.y; el.v.x2 = c.z; el.v.x3 = c.w;
     el.v.xpp = el.v.xp = el.v.xn = 0;                    /* the second half looks at the chunk's own bytes only */
     el.v.stream = src; el.v.g0 = base + 16ull * a.x; el.v.n = n;
+}
+
+/* second half of the batches first, first + HBS4_EMIT_WAVES, ... of a tile with several: index entries, the elements' own
+ * bytes, a segment word each; the tile's exclusive prefix is in LDS by now */
+__device__ __forceinline__ void emit_batches(Lds4& l, uint32_t first, uint32_t npass, uint32_t nflag, int lane,
+                                             const uint8_t* src, uint64_t base, uint64_t n, uint8_t* rbsp, const EmitTarget& tgt)
+{
+    Prefix exl;
+    exl.kept = l.ex_kept; exl.nals = l.ex_nals; exl.inside = l.ex_inside;
+    const Prefix exu = prefix_uniform4(exl);
+    const bool canu = rbsp != nullptr && l.ex_ok == 1u;
+#pragma unroll 1
+    for (uint32_t p = first; p < npass; p += (uint32_t)HBS4_EMIT_WAVES) {
+        TileAgg accb = agg_identity();
+#pragma unroll 1
+        for (uint32_t q = 0; q < p; ++q) accb = combine(accb, l.bagg[q]);
+        const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
+        TileAgg ea = agg_identity();
+        Elem el;
+        el.gap = 0; el.chunk = 0;
+        if (i < nflag) { rec4_load(l.rec[i], el, src, base, n); ea = elem_agg(el.gap, el.s); }
+        ea = wave_scan_combine(ea, lane);
+        TileAgg up = agg_prev_lane(ea);
+        if (lane == 0) up = agg_identity();
+        const TileAgg eb = combine(accb, up);
+        if (i < nflag) elem_emit(el, eb, exu, canu, rbsp + exu.kept, tgt, &l.seg[i + 1]);
+    }
 }
 
 /* chunk number of element i of the tile; wb1..wb3 = elements in front of wavefronts 1..3 */
@@ -528,7 +558,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 TileAgg ea = agg_identity();
                 if ((uint32_t)lane < nflag) ea = elem_make(el, l, (uint32_t)lane, wb1, wb2, wb3, src, base, n, last_tile);
                 ea = wave_scan_combine(ea, lane);
-                e = agg_shfl_up(ea, 1);
+                e = agg_prev_lane(ea);
                 if (lane == 0) e = agg_identity();
                 acc = agg_readlane(ea, 63);
             } else {
@@ -580,24 +610,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 /* one batch (nearly always): the elements are still in registers */
                 if (ok && (uint32_t)lane < nflag) elem_emit(el, e, ex, can, rbsp + ex.kept, tgt, &l.seg[lane + 1]);
             } else if (l.ex_ok != 0u) {
-                Prefix exl;
-                exl.kept = l.ex_kept; exl.nals = l.ex_nals; exl.inside = l.ex_inside;
-                const Prefix exu = prefix_uniform4(exl);
-                const bool canu = rbsp != nullptr && l.ex_ok == 1u;
-#pragma unroll 1
-                for (uint32_t p = (uint32_t)wv; p < npass; p += (uint32_t)HBS4_ELEM_WAVES) {
-                    TileAgg accb = agg_identity();
-#pragma unroll 1
-                    for (uint32_t q = 0; q < p; ++q) accb = combine(accb, l.bagg[q]);
-                    const uint32_t i = p * (uint32_t)k4ElemPass + (uint32_t)lane;
-                    TileAgg ea = agg_identity();
-                    if (i < nflag) { rec4_load(l.rec[i], el, src, base, n); ea = elem_agg(el.gap, el.s); }
-                    ea = wave_scan_combine(ea, lane);
-                    TileAgg up = agg_shfl_up(ea, 1);
-                    if (lane == 0) up = agg_identity();
-                    const TileAgg eb = combine(accb, up);
-                    if (i < nflag) elem_emit(el, eb, exu, canu, rbsp + exu.kept, tgt, &l.seg[i + 1]);
-                }
+                emit_batches(l, (uint32_t)wv, npass, nflag, lane, src, base, n, rbsp, tgt);
             }
 #define HBS_UNPARK(i, r) R.q##r = l.park[wv][i][lane];
             HBS_PARKED(HBS_UNPARK)
@@ -605,7 +618,14 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         } else {
             /* (a barrier counts wavefronts, wherever they are in the code: these two meet the two above) */
             HBS4_PRIO(0);
-            if (multi) { __syncthreads(); __syncthreads(); }
+            if (multi) {
+                __syncthreads(); __syncthreads();
+#if HBS4_EMIT_WAVES > HBS4_ELEM_WAVES
+                /* the second half needs fewer registers than the first (no window rules: what they found is in LDS): these
+                 * wavefronts take their share of it with all their rows in place */
+                if (l.ex_ok != 0u) emit_batches(l, (uint32_t)wv, npass, nflag, lane, src, base, n, rbsp, tgt);
+#endif
+            }
         }
         __syncthreads();
         if (l.ex_ok == 0u) return;

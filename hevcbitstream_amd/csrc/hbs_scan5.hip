@@ -438,7 +438,7 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             TileAgg ea = agg_identity();
             if (have) { rec_load(&w5.rec[tile * k5RecCap + p0 + (uint32_t)lane], el, base, n); ea = elem_agg(el.gap, el.s); }
             ea = wave_scan_combine(ea, lane);
-            TileAgg up = agg_shfl_up(ea, 1);
+            TileAgg up = agg_prev_lane(ea);
             if (lane == 0) up = agg_identity();
             const TileAgg e = combine(acc, up);
             acc = combine(acc, agg_readlane(ea, 63));
@@ -460,7 +460,7 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             uint32_t quick = 0;
             if (row_visit<true>(d, qp, qc, qn, r, edges, stream, n, base, lane, prev_end, quick) == 1) { accb = combine(accb, gap_agg(quick)); return; }   /* nothing to write for such a row */
             const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
-            TileAgg up = agg_shfl_up(ea, 1);
+            TileAgg up = agg_prev_lane(ea);
             if (lane == 0) up = agg_identity();
             const TileAgg eb = combine(accb, up);
             accb = combine(accb, agg_readlane(ea, 63));
@@ -473,7 +473,7 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             Elem el;
             TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
             ea = wave_scan_combine(ea, lane);
-            TileAgg up = agg_shfl_up(ea, 1);
+            TileAgg up = agg_prev_lane(ea);
             if (lane == 0) up = agg_identity();
             const TileAgg eb = combine(accb, up);
             accb = combine(accb, agg_readlane(ea, 63));

@@ -104,20 +104,30 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t edge)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v, int lane)
+/* DPP moves for scans over the 64 lanes (gfx9: rows of 16 lanes; row_shr within a row, row_bcast15 / row_bcast31 across rows):
+ * a lane without a source, or in a row outside kRowMask, reads 0 -- the identity of a sum, and of the tile algebra (kKindNone = 0).
+ * One VALU instruction each, where __shfl_up is address arithmetic plus an LDS permute. */
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v, int /*lane*/)
+{
+    v += dpp_or_zero<kDppRowShr1, 0xF>(v);
+    v += dpp_or_zero<kDppRowShr2, 0xF>(v);
+    v += dpp_or_zero<kDppRowShr4, 0xF>(v);
+    v += dpp_or_zero<kDppRowShr8, 0xF>(v);
+    v += dpp_or_zero<kDppBcast15, 0xA>(v);       /* rows 1 and 3 <- the total of the row in front */
+    v += dpp_or_zero<kDppBcast31, 0xC>(v);       /* rows 2 and 3 <- the total of the first half   */
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan32(v, 0), 63);
 }
 
 struct __attribute__((packed, aligned(1))) Unaligned16_3 { u32x4 v; };
