@@ -67,20 +67,32 @@ HBS_HD bool chunk_pattern_any(uint32_t xp, uint32_t x0, uint32_t x1, uint32_t x2
     return (p0 | p1 | p2 | p3 | (pn & 0x00008080u)) != 0u;
 }
 
-/* kept bytes of a chunk with holes, packed low-to-high into lo/hi, straight from registers */
+/* Kept bytes of a chunk with holes, packed low-to-high into lo/hi, straight from registers (bytes past the count: undefined).
+ * By RUNS of dropped bytes, from the top: a run [a, t] goes by moving everything above it down over it.  A chunk with one
+ * emulation prevention byte, or the end of a NAL, is one run -- ~25 instructions where a loop over the kept bytes (round 2) took
+ * 15 turns of a dozen, and a batch of elements takes as long as its slowest lane. */
 HBS_HD uint32_t compact_chunk_regs(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t keep16, uint64_t& lo, uint64_t& hi)
 {
-    const uint64_t src_lo = ((uint64_t)x1 << 32) | x0, src_hi = ((uint64_t)x3 << 32) | x2;
-    lo = 0; hi = 0;
-    uint32_t o = 0;
-    for (uint32_t r = keep16; r != 0; r &= r - 1, ++o) {
-        const uint32_t pos = (uint32_t)__builtin_ctz(r);
-        const uint64_t b = (((pos < 8) ? src_lo : src_hi) >> (8u * (pos & 7u))) & 0xFFull;
-        const uint64_t val = b << (8u * (o & 7u));
-        lo |= (o < 8) ? val : 0ull;
-        hi |= (o < 8) ? 0ull : val;
+    uint64_t l = ((uint64_t)x1 << 32) | x0, h = ((uint64_t)x3 << 32) | x2;
+    keep16 &= 0xFFFFu;
+    uint32_t drop = ~keep16 & 0xFFFFu;
+    while (drop != 0) {
+        const uint32_t t = 31u - (uint32_t)__builtin_clz(drop);                 /* the highest dropped byte ...              */
+        const uint32_t below = ~drop & ((1u << t) - 1u);
+        const uint32_t a = below ? 32u - (uint32_t)__builtin_clz(below) : 0u;   /* ... and where its run begins              */
+        const uint32_t s = 8u * (t - a + 1u);                                    /* bits to move down: 8 .. 128               */
+        uint64_t sl, sh;
+        if (s >= 64u) { sl = (s >= 128u) ? 0ull : (h >> (s - 64u)); sh = 0ull; }
+        else { sl = (l >> s) | (h << (64u - s)); sh = h >> s; }
+        uint64_t ml, mh;                                                         /* bytes below a stay                        */
+        if (a >= 8u) { ml = ~0ull; mh = (1ull << (8u * (a - 8u))) - 1ull; }
+        else { ml = (1ull << (8u * a)) - 1ull; mh = 0ull; }
+        l = (l & ml) | (sl & ~ml);
+        h = (h & mh) | (sh & ~mh);
+        drop &= (1u << a) - 1u;
     }
-    return o;
+    lo = l; hi = h;
+    return (uint32_t)__builtin_popcount(keep16);
 }
 
 } // namespace hbs

@@ -418,7 +418,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                     bool g##r = f##r; \
                     uint64_t gmask##r = fmask##r; \
                     if (HBS4_EXACT_FLAG && __builtin_popcountll(fmask##r) > HBS4_EXACT_MIN) {   /* one or two: a start code, most likely -- nothing to gain */ \
-                        g##r = f##r && chunk_pattern_any(xp##r, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn##r); \
+                        g##r = f##r && chunk_pattern_any_dev(xp##r, R.q##r.x, R.q##r.y, R.q##r.z, R.q##r.w, xn##r); \
                         gmask##r = __ballot(g##r); \
                     } \
                     if (gmask##r != 0) { /* stash the mask, leave the chunk's surroundings for its element thread */ \

@@ -62,8 +62,13 @@ __device__ __forceinline__ unsigned long long span_flags(const Span5& s, uint64_
         const uint32_t xn = from_next_lane(s.q[r].x, e_next);
         const uint64_t g0 = base + 1024u * r + 16u * lane;
         /* the chunk cut by the stream end is always an element */
-        const bool f = g0 < n && (chunk_flag(xp, s.q[r].x, s.q[r].y, s.q[r].z, s.q[r].w, xn) || (g0 >> 4) == cut);
-        const unsigned long long m = __ballot(f);
+        bool f = g0 < n && chunk_flag(xp, s.q[r].x, s.q[r].y, s.q[r].z, s.q[r].w, xn);
+        unsigned long long m = __ballot(f);
+        if (__builtin_popcountll(m) > 2) {           /* many zero pairs in this KiB: which of them are followed by a byte <= 3? (as hbs_scan4.hip) */
+            f = f && chunk_pattern_any_dev(xp, s.q[r].x, s.q[r].y, s.q[r].z, s.q[r].w, xn);
+            m = __ballot(f);
+        }
+        m |= __ballot(g0 < n && (g0 >> 4) == cut);
         if (lane == r) mine = m;
     }
     return mine;

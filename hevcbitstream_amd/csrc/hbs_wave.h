@@ -115,6 +115,28 @@ __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, true);
 }
 
+/* chunk_pattern_any() (hbs_chunk.h) in half the instructions: does a pattern 00 00 {<=3} end in bytes [0, 18) of the chunk?
+ * For each of the 18 places p in [-2, 16) one v_perm_b32 forms b[p] << 16 | b[p+1] << 8 | b[p+2] from the two dwords the three
+ * bytes lie in; a pattern is a value of at most 3, so the minimum over the places (v_min3_u32, two places an instruction)
+ * is the whole test. */
+__device__ __forceinline__ bool chunk_pattern_any_dev(uint32_t xp, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t xn)
+{
+#define HBS_P(hi, lo, p) __builtin_amdgcn_perm((hi), (lo), 0x0C000102u + 0x00010101u * (p))   /* bytes p, p+1, p+2 of lo:hi, first byte on top */
+#define HBS_MIN3(a, b, c) __builtin_elementwise_min(__builtin_elementwise_min((a), (b)), (c))
+    uint32_t m = HBS_MIN3(HBS_P(x0, xp, 2u), HBS_P(x0, xp, 3u), HBS_P(x1, x0, 0u));
+    m = HBS_MIN3(m, HBS_P(x1, x0, 1u), HBS_P(x1, x0, 2u));
+    m = HBS_MIN3(m, HBS_P(x1, x0, 3u), HBS_P(x2, x1, 0u));
+    m = HBS_MIN3(m, HBS_P(x2, x1, 1u), HBS_P(x2, x1, 2u));
+    m = HBS_MIN3(m, HBS_P(x2, x1, 3u), HBS_P(x3, x2, 0u));
+    m = HBS_MIN3(m, HBS_P(x3, x2, 1u), HBS_P(x3, x2, 2u));
+    m = HBS_MIN3(m, HBS_P(x3, x2, 3u), HBS_P(xn, x3, 0u));
+    m = HBS_MIN3(m, HBS_P(xn, x3, 1u), HBS_P(xn, x3, 2u));
+    m = __builtin_elementwise_min(m, HBS_P(xn, x3, 3u));
+#undef HBS_MIN3
+#undef HBS_P
+    return m <= 3u;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v, int /*lane*/)
 {
     v += dpp_or_zero<kDppRowShr1, 0xF>(v);
