@@ -87,10 +87,16 @@ static_assert(sizeof(RunHeader) == 768, "RunHeader layout");
  * kernel handles flagged chunks 64 at a time on one wavefront, so once more than one chunk in
  * kDenseOneIn may hold a zero pair the LDS-image kernel, whose cost does not depend on the data,
  * is the faster of the two. */
-constexpr uint32_t kDenseOneIn = 40;    /* measured crossover: ~2.5-3.5 % of chunks flagged (scripts/density_sweep.py, round 3: 1.7 % -> 1.71 against
-                                           1.37 TB/s, 4.4 % -> 0.49 against 1.41; on streams of small NALs the two meet at ~512-byte NALs,
-                                           scripts/experiments/pin_kernel_by_nal_size.py).  Round 2's 1 % dates from before the event-sparse
-                                           kernel walked the batches of a tile's elements in one go (hbs_scan4.hip) */
+#ifndef HBS_DENSE_ONE_IN
+#define HBS_DENSE_ONE_IN 26
+#endif
+constexpr uint32_t kDenseOneIn = HBS_DENSE_ONE_IN;    /* Round 3: the probe counts ELEMENTS (chunks a pattern 00 00 {<=3} ends in, neighbours seen), and the event-sparse
+                                           kernel keeps 0.42-0.53 of peak up to the density at which tiles pass kDenseElems = 512 of 12288 chunks
+                                           (4.2 %; 512-byte NALs: 3.7 %, zero-heavy data: 2-3 %), against 0.30-0.34 for the LDS-image kernel; beyond,
+                                           its tiles are walked chunk by chunk (0.12 at 384-byte NALs).  1 in 26 = 3.85 % leaves the spread of a
+                                           tile's count below the limit.  (Round 2: 1 in 40 of the chunks with a zero PAIR, i.e. ~6 x fewer elements.) */
+constexpr int kExactFlagMin = 2;        /* rows of 1 KiB with more flagged chunks than this are asked again, exactly (chunk_pattern_any_dev): one or two
+                                           are a start code, most likely, and the second test would buy nothing */
 HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged) { return (uint64_t)flagged * kDenseOneIn > (uint64_t)chunks; }
 enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2 };
 #ifdef __HIPCC__

@@ -41,12 +41,23 @@ namespace hbs {
  * arena and both ways are enqueued; the one it rules out returns at once. */
 constexpr uint32_t kEmitDenseOneIn = 800;
 __device__ __forceinline__ bool emit_probe_dense(const uint32_t* probe) { return (uint64_t)probe[1] * kEmitDenseOneIn > (uint64_t)probe[0]; }
+/* The arena-tile kernel walks a tile's elements 64 at a time without looking at the rows between them, so it keeps its pace up
+ * to the density at which tiles pass its element limit (kTDenseLimit of 12288 chunks): round 3, with the probe counting exact
+ * patterns, a zero-heavy arena (2-3 % of the chunks) is its case, not the three steps'. */
+constexpr uint32_t kEmitTilesDenseOneIn = 20;
+__device__ __forceinline__ bool emit_probe_dense_tiles(const uint32_t* probe) { return (uint64_t)probe[1] * kEmitTilesDenseOneIn > (uint64_t)probe[0]; }
 
 /* the arena-tile kernel (k3_tiles, below) takes the sparse case when k3t_check found the index eligible: tflag[0] = a
  * violation was seen, tflag[1] = the global conditions hold */
 __device__ __forceinline__ bool tile_path_on(const uint32_t* tflag) { return tflag && tflag[1] == 1u && tflag[0] == 0u && tflag[3] == 0u; }
 /* tflag[2]: the tile kernel met a tile dense in elements and gave up -- the kernel by NALs, enqueued behind it, does the call */
 __device__ __forceinline__ bool tile_path_done(const uint32_t* tflag) { return tile_path_on(tflag) && tflag[2] == 0u; }
+
+/* the three steps are for what the probe calls dense -- unless the tile kernel, in front of them, has done the call */
+__device__ __forceinline__ bool three_steps_run(const uint32_t* probe, const uint32_t* tflag)
+{
+    return !probe || (emit_probe_dense(probe) && !(!emit_probe_dense_tiles(probe) && tile_path_done(tflag)));
+}
 
 /* tflag[3] (k3t_check, in front of everything that follows the index into the arena): an entry of the index lies outside the
  * caller's RBSP buffer.  The call then ends with HBS_E_ARG and nothing is read through the index. */
@@ -90,7 +101,7 @@ void k3_probe(const uint8_t* __restrict__ rbsp, uint64_t bytes, uint32_t* __rest
         bool f = false;
         if (in) {
             const u32x4 q = reinterpret_cast<const U16*>(rbsp + off)->v;
-            f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+            f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) && chunk_pattern_any_dev(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
         }
         chunks += (uint32_t)__builtin_popcountll(__ballot(in));
         flagged += (uint32_t)__builtin_popcountll(__ballot(f));
@@ -180,6 +191,10 @@ __device__ __forceinline__ RowFlags row_flags(const u32x4& q, uint32_t e_prev, u
     r.xp = xp;
     r.mine = off < len && chunk_flag(xp, q.x, q.y, q.z, q.w, xn);
     r.mask = __ballot(r.mine);
+    if (__builtin_popcountll(r.mask) > kExactFlagMin) {      /* many zero pairs in this KiB: which are followed by a byte <= 3? */
+        r.mine = r.mine && chunk_pattern_any_dev(xp, q.x, q.y, q.z, q.w, xn);
+        r.mask = __ballot(r.mine);
+    }
     return r;
 }
 
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(256)
 void k3_count(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
               unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ probe, const uint32_t* __restrict__ vflag)
 {
-    if ((probe && !emit_probe_dense(probe)) || index_bad(vflag)) return;
+    if (!three_steps_run(probe, vflag) || index_bad(vflag)) return;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -384,7 +399,7 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
              uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
              const uint32_t* __restrict__ probe, const uint32_t* __restrict__ vflag)
 {
-    if ((probe && !emit_probe_dense(probe)) || index_bad(vflag)) return;
+    if (!three_steps_run(probe, vflag) || index_bad(vflag)) return;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -563,7 +578,8 @@ __device__ __forceinline__ void flag_batch(const u32x4 (&R)[kEmitRows], uint32_t
             const uint32_t off = row_lo + 16u * (uint32_t)launder_lane(lane);
             /* a 03 goes in front of byte i only if bytes i-2, i-1 are zero: the chunk behind does not matter */
             const uint32_t xp = from_prev_lane(R[r].w, e_prev);
-            const bool mine = off < len && chunk_flag(xp, R[r].x, R[r].y, R[r].z, R[r].w, 0xFFFFFFFFu);
+            bool mine = off < len && chunk_flag(xp, R[r].x, R[r].y, R[r].z, R[r].w, 0xFFFFFFFFu);
+            if (__builtin_popcountll(__ballot(mine)) > kExactFlagMin) mine = mine && chunk_pattern_any_dev(xp, R[r].x, R[r].y, R[r].z, R[r].w, 0xFFFFFFFFu);
             if (__ballot(mine) != 0) rowmask |= 1u << r;
             myflags |= (mine ? 1u : 0u) << r;
             e_prev = (uint32_t)__builtin_amdgcn_readlane((int)R[r].w, 63);
@@ -894,10 +910,10 @@ int emit_grid_blocks(int device)
 }
 
 __global__ void k3_summary(const unsigned long long* total, uint64_t n, uint64_t rbsp_bytes, const uint32_t* err, hbs_summary* sum,
-                           const unsigned long long* total_dense = nullptr, const uint32_t* probe = nullptr)
+                           const unsigned long long* total_dense = nullptr, const uint32_t* probe = nullptr, const uint32_t* tflag = nullptr)
 {
     sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes;
-    sum->stream_bytes = (probe && emit_probe_dense(probe)) ? *total_dense : *total;
+    sum->stream_bytes = (probe && three_steps_run(probe, tflag)) ? *total_dense : *total;
     sum->stop_reason = n ? -1 : 0; sum->error = -(int32_t)*err;
     sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
 }
@@ -959,6 +975,7 @@ constexpr int kTParkRows = 28;
 constexpr uint32_t kTMaxStarts = 512, kTMaxGap = 1u << 20;     /* two NAL starts per thread of the workgroup */
 constexpr uint64_t kTMinArena = 192ull << 20;      /* below, the kernel by NALs is as fast or faster (0.12 against 0.115 ms at 128 MiB, 0.173 against 0.186 at 256 MiB) */
 constexpr int kTElemPass = 64;
+constexpr int kTElemWaves = 2;                  /* a tile with several batches of elements: wavefront 1 parks rows too and takes every other batch (as hbs_scan4.hip) */
 constexpr uint32_t kTDenseLimit = 1024;       /* a tile with more elements than this: wavefront 0 would walk them 64 at a time while every tile
                                                  behind waits (~5 us a batch) -- the call is handed to the kernel by NALs instead, whose cost
                                                  grows gently with the density of zero pairs */
@@ -1005,7 +1022,7 @@ __global__ __launch_bounds__(256)
 void k3t_first(const hbs_nal_entry* __restrict__ idx, uint64_t n, unsigned long long* __restrict__ first_k,
                const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    if ((probe && emit_probe_dense(probe)) || !tile_path_on(tflag)) return;
+    if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
     const uint64_t a0 = idx[0].rbsp_off;
     const uint64_t ntiles = (idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0) / kTTileBytes + 1;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k <= n; k += (uint64_t)gridDim.x * blockDim.x) {
@@ -1020,9 +1037,10 @@ struct LdsT {
     uint32_t starts[kTMaxStarts];                    /* where the tile's NALs begin, tile-relative, in order */
     uint32_t gaps[kTMaxStarts];                      /* bytes in front of each (zeros + 01)                  */
     uint32_t lens[kTMaxStarts];                      /* their rbsp_len (for the output index)                */
-    uint16_t list[kTChunks];                         /* the tile's elements, in order                        */
+    uint16_t list[kTDenseLimit];                     /* the tile's elements, in order (a tile with more gives the call up) */
+    uint32_t bsum[kTDenseLimit / kTElemPass];        /* tiles with several batches of elements: bytes inserted by each batch */
     uint32_t seg[kTDenseLimit + 1];                  /* bytes inserted in the tile up to and including element i; [0]: in front of the first (0) */
-    u32x4 park[kTParkRows][64];
+    u32x4 park[kTElemWaves][kTParkRows][64];         /* rows of the wavefronts that handle elements, meanwhile */
     uint32_t wave_tot[kTWaves];
     unsigned long long before;                       /* bytes inserted in front of the tile                  */
     uint32_t ok;
@@ -1186,7 +1204,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err,
               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    if ((probe && emit_probe_dense(probe)) || !tile_path_on(tflag)) return;
+    if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
     __shared__ LdsT l;
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -1271,6 +1289,11 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             if ((fmask[0] | fmask[1] | fmask[2] | fmask[3]) != 0) {
                 t_for_n<4>([&](auto kc) {
                     constexpr int k = decltype(kc)::value, r = g0 + k;
+                    if (__builtin_popcountll(fmask[k]) > kExactFlagMin) {      /* many zero pairs in this KiB: which are followed by a byte <= 3? */
+                        const uint32_t e_prev = (r == 0) ? before : (uint32_t)__builtin_amdgcn_readlane((int)q[r ? r - 1 : 0].w, 63);
+                        const uint32_t xp = from_prev_lane(q[r].w, e_prev);
+                        fmask[k] = __ballot(((fmask[k] >> lane) & 1ull) != 0 && chunk_pattern_any_dev(xp, q[r].x, q[r].y, q[r].z, q[r].w, 0xFFFFFFFFu));
+                    }
                     if (fmask[k] != 0) { write_lane_c<r>(fm_lo, (uint32_t)fmask[k]); write_lane_c<r>(fm_hi, (uint32_t)(fmask[k] >> 32)); }
                 });
             }
@@ -1370,74 +1393,92 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         u32x4 q_first = u32x4{0u, 0u, 0u, 0u};
         uint32_t j_first = 0;
         const uint64_t tile_bytes = t.arena_len - t.tile_lo < (uint64_t)kTTileBytes ? t.arena_len - t.tile_lo : (uint64_t)kTTileBytes;
-        if (wv == 0) {
+        const bool multi = npass > 1u;
+        const uint32_t stride = multi ? (uint32_t)kTElemWaves : 1u;
+        if (wv == 0 || (multi && wv < kTElemWaves)) {
 #pragma unroll
-            for (int i = 0; i < kTParkRows; ++i) l.park[i][lane] = q[kTRows - kTParkRows + i];
+            for (int i = 0; i < kTParkRows; ++i) l.park[wv][i][lane] = q[kTRows - kTParkRows + i];
             unsigned long long tile_ins = 0;
 #pragma unroll 1
-            for (uint32_t p = 0; p < npass; ++p) {
+            for (uint32_t p = (uint32_t)wv; p < npass; p += stride) {
                 const uint32_t i = p * (uint32_t)kTElemPass + (uint32_t)lane;
                 uint32_t e = 0;
                 u32x4 qtmp;
                 uint32_t jtmp;
-                if (i < nflag) e = tile_element<false>(t, l, l.list[i], nullptr, 0, 0, false, nullptr, p == 0 ? q_first : qtmp, p == 0 ? j_first : jtmp, false);
-                if (p == 0) e_first = e;                         /* the first batch (nearly always the only one) is not counted again */
-                tile_ins += wave_sum32(e);
+                const bool first = p == (uint32_t)wv;
+                if (i < nflag) e = tile_element<false>(t, l, l.list[i], nullptr, 0, 0, false, nullptr, first ? q_first : qtmp, first ? j_first : jtmp, false);
+                if (first) e_first = e;                          /* a wavefront's first batch (nearly always the only one) is not counted again */
+                const uint32_t bs = wave_sum32(e);
+                tile_ins += bs;
+                if (multi && lane == 0) l.bsum[p] = bs;
             }
             HBS3_T_MARK(3)
-            if (lane == 0 && tile != 0) st_desc3(desc + tile, (tile_ins << 2) | 1ull);
-            __builtin_amdgcn_s_setprio(0);
-            const unsigned long long bf = k3_look_back(desc, tile, lane, err);
-            HBS3_T_MARK(4)
-            if (lane == 0) {
-                st_desc3(desc + tile, ((bf + tile_ins) << 2) | 2ull);
-                const uint64_t end_pos = t.tile_lo + tile_bytes + bf + tile_ins;       /* output offset behind the tile */
-                l.before = bf;
-                l.ok = end_pos <= out_cap ? 1u : 0u;
-                if (end_pos > out_cap) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
-                if (last_tile) {
-                    *total = end_pos;
-                    if (idx_out) idx_out[n - 1].end = end_pos;
+            if (multi) __syncthreads();                          /* (the wavefronts without elements: below) */
+            if (wv == 0) {
+                if (multi) {
+                    tile_ins = 0;
+#pragma unroll 1
+                    for (uint32_t p = 0; p < npass; ++p) tile_ins += l.bsum[p];
                 }
+                if (lane == 0 && tile != 0) st_desc3(desc + tile, (tile_ins << 2) | 1ull);
+                __builtin_amdgcn_s_setprio(0);
+                const unsigned long long bf = k3_look_back(desc, tile, lane, err);
+                HBS3_T_MARK(4)
+                if (lane == 0) {
+                    st_desc3(desc + tile, ((bf + tile_ins) << 2) | 2ull);
+                    const uint64_t end_pos = t.tile_lo + tile_bytes + bf + tile_ins;       /* output offset behind the tile */
+                    l.before = bf;
+                    l.ok = end_pos <= out_cap ? 1u : 0u;
+                    if (end_pos > out_cap) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+                    if (last_tile) {
+                        *total = end_pos;
+                        if (idx_out) idx_out[n - 1].end = end_pos;
+                    }
+                    l.seg[0] = 0;
+                }
+            } else {
+                __builtin_amdgcn_s_setprio(0);
             }
-#pragma unroll
-            for (int i = 0; i < kTParkRows; ++i) q[kTRows - kTParkRows + i] = l.park[i][lane];
-        } else {
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-        HBS3_T_MARK(5)
-        const bool can_store = l.ok != 0u;
-        uint8_t* const tout = out + t.tile_lo + l.before;            /* where byte 0 of the tile goes when nothing is inserted in it */
-        const uint32_t whole = (uint32_t)(tile_bytes >> 4);           /* chunks of the tile that are complete */
-
-        /* ---- the bytes: the elements by wavefront 0, 64 at a time -- every batch before anybody copies (its rows parked once;
-         * until round 3 each batch was followed by a copy pass of its own over all 48 rows) -- then one copy of the chunks between
-         * them: a chunk with k elements in front of it goes to its arena offset + seg[k] ----------------------------------- */
-        if (wv == 0) {
-#pragma unroll
-            for (int i = 0; i < kTParkRows; ++i) l.park[i][lane] = q[kTRows - kTParkRows + i];
-            uint32_t ins_run = 0;                                   /* bytes inserted by the batches done */
-            if (lane == 0) l.seg[0] = 0;
+            __syncthreads();
+            HBS3_T_MARK(5)
+            /* ---- the bytes: the elements, 64 at a time -- every batch before anybody copies (the rows parked once; until round 3
+             * each batch was followed by a copy pass of its own over all 48 rows) -- then one copy of the chunks between them: a
+             * chunk with k elements in front of it goes to its arena offset + seg[k] ------------------------------------- */
+            const bool can_store_e = l.ok != 0u;
+            uint8_t* const tout_e = out + t.tile_lo + l.before;
+            uint32_t ins_run = 0;                                   /* bytes inserted by the batches in front */
             const uint32_t np = npass ? npass : 1u;
 #pragma unroll 1
-            for (uint32_t p = 0; p < np; ++p) {
+            for (uint32_t p = (uint32_t)wv; p < np; p += stride) {
+                if (multi) {
+                    ins_run = 0;
+#pragma unroll 1
+                    for (uint32_t qq = 0; qq < p; ++qq) ins_run += l.bsum[qq];
+                }
                 const uint32_t pbase = p * (uint32_t)kTElemPass;
                 const uint32_t i = pbase + (uint32_t)lane;
                 uint32_t e = 0, c = 0;
                 u32x4 qe = q_first;
                 uint32_t je = j_first;
-                if (i < nflag) { c = l.list[i]; e = p == 0u ? e_first : tile_element<false>(t, l, c, nullptr, 0, 0, false, nullptr, qe, je, false); }
+                if (i < nflag) { c = l.list[i]; e = p == (uint32_t)wv ? e_first : tile_element<false>(t, l, c, nullptr, 0, 0, false, nullptr, qe, je, false); }
                 const uint32_t inc_e = wave_incl_scan32(e, lane);
                 const uint32_t mine_before = ins_run + inc_e - e;
-                if (i < nflag && (can_store || idx_out))
-                    (void)tile_element<true>(t, l, c, tout, t.tile_lo + l.before, 16ull * (c & kTListChunk) + mine_before, can_store, idx_out, qe, je, true);
+                if (i < nflag && (can_store_e || idx_out))
+                    (void)tile_element<true>(t, l, c, tout_e, t.tile_lo + l.before, 16ull * (c & kTListChunk) + mine_before, can_store_e, idx_out, qe, je, true);
                 if (i < nflag) l.seg[i + 1] = ins_run + inc_e;
-                ins_run += (uint32_t)__builtin_amdgcn_readlane((int)inc_e, 63);
             }
 #pragma unroll
-            for (int i2 = 0; i2 < kTParkRows; ++i2) q[kTRows - kTParkRows + i2] = l.park[i2][lane];
+            for (int i2 = 0; i2 < kTParkRows; ++i2) q[kTRows - kTParkRows + i2] = l.park[wv][i2][lane];
+        } else {
+            /* (a barrier counts wavefronts, wherever they are in the code: these meet the ones above) */
+            __builtin_amdgcn_s_setprio(0);
+            if (multi) __syncthreads();
+            __syncthreads();
         }
+        __syncthreads();
+        const bool can_store = l.ok != 0u;
+        uint8_t* const tout = out + t.tile_lo + l.before;            /* where byte 0 of the tile goes when nothing is inserted in it */
+        const uint32_t whole = (uint32_t)(tile_bytes >> 4);           /* chunks of the tile that are complete */
         __syncthreads();
         if (can_store) {
             const int lane = launder_lane(tid0) & 63;          /* the store addresses are formed here, not in front of the element code */
@@ -1472,7 +1513,7 @@ __global__ __launch_bounds__(256)
 void k3t_reset(unsigned long long* __restrict__ desc, uint64_t words, uint32_t* __restrict__ ticket, unsigned long long* __restrict__ total,
                const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    if ((probe && emit_probe_dense(probe)) || !tile_path_on(tflag) || tflag[2] == 0u) return;
+    if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag) || tflag[2] == 0u) return;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) desc[i] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) { *ticket = 0u; *total = 0ull; }
 }
@@ -1532,7 +1573,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe, a.tflag);
     }
     if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
-    else k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary, a.total_dense, probe);
+    else k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary, a.total_dense, probe, a.tflag);
     return hipGetLastError();
 }
 

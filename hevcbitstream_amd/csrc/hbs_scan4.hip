@@ -71,7 +71,7 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #define HBS4_EMIT_WAVES 2      /* wavefronts that share the second half (emission) of those batches (4: the other two with all their rows in place -- spills 45 registers, some on every tile's path) */
 #endif
 #ifndef HBS4_EXACT_MIN
-#define HBS4_EXACT_MIN 2       /* ... when the row has more flagged chunks than this */
+#define HBS4_EXACT_MIN kExactFlagMin       /* ... when the row has more flagged chunks than this */
 #endif
 #ifndef HBS4_COPY_DEPTH
 #define HBS4_COPY_DEPTH 3      /* stores of a wavefront in flight during the copy (-1: no limit) */
@@ -754,9 +754,12 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
                 const bool in = off + 16 <= n;
                 bool f = false;
                 if (in) {
+                    /* with the dwords around the chunk, as the kernels see it (round 3: a start code across two chunks makes two
+                     * elements, and on streams of 384-byte NALs a probe blind to that was 25 % low -- on the wrong side of the rule) */
                     const Quad q = *reinterpret_cast<const Quad*>(stream + off);
-                    f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) &&
-                        (!HBS4_EXACT_FLAG || chunk_pattern_any(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu));
+                    const uint32_t xp = off >= 4 ? *reinterpret_cast<const uint32_t*>(stream + off - 4) : 0xFFFFFFFFu;
+                    const uint32_t xn = off + 20 <= n ? *reinterpret_cast<const uint32_t*>(stream + off + 16) : 0xFFFFFFFFu;
+                    f = chunk_flag(xp, q.x, q.y, q.z, q.w, xn) && (!HBS4_EXACT_FLAG || chunk_pattern_any_dev(xp, q.x, q.y, q.z, q.w, xn));
                 }
                 chunks += (uint32_t)__builtin_popcountll(__ballot(in));
                 flagged += (uint32_t)__builtin_popcountll(__ballot(f));

@@ -64,7 +64,7 @@ __device__ __forceinline__ unsigned long long span_flags(const Span5& s, uint64_
         /* the chunk cut by the stream end is always an element */
         bool f = g0 < n && chunk_flag(xp, s.q[r].x, s.q[r].y, s.q[r].z, s.q[r].w, xn);
         unsigned long long m = __ballot(f);
-        if (__builtin_popcountll(m) > 2) {           /* many zero pairs in this KiB: which of them are followed by a byte <= 3? (as hbs_scan4.hip) */
+        if (__builtin_popcountll(m) > kExactFlagMin) {           /* many zero pairs in this KiB: which of them are followed by a byte <= 3? (as hbs_scan4.hip) */
             f = f && chunk_pattern_any_dev(xp, s.q[r].x, s.q[r].y, s.q[r].z, s.q[r].w, xn);
             m = __ballot(f);
         }
