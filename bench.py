@@ -136,7 +136,7 @@ def pmc_traffic(kernel_name, algo_bytes):
     short = kernel_name.split("::")[-1]
     digest = hbs.source_digest()
     stale = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s.json" % short)), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%s*.json" % short)), reverse=True):      # ..._zero_heavy.json: the same kernel on the stress workload
         try:
             d = json.load(open(f))
         except (OSError, ValueError):

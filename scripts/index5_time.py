@@ -3,15 +3,23 @@
 HBS_LIB picks a development build, HBS5_WAVES_PER_CU the grid."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import hevcbitstream_amd as hbs
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 ctx = hbs.Context(0)
 ctx.enable_timing(True)
-n = 1_677_000
-g = ctx.synth_stream(0x1234, n, 0)
-sb = g["stream_bytes"]
-stream = g["stream"][:sb]
+if os.environ.get("HBS5_NAL_MEAN"):            # 2 GiB of random payload in NALs of that mean size (scripts/nal_sweep.py) instead: no index to compare with
+    import numpy as np
+    import nal_sweep
+    _, _, _, n, sbuf, sb = nal_sweep.make_stream(torch, np, ctx, int(os.environ["HBS5_NAL_MEAN"]), 2 << 30)
+    stream = sbuf[:sb]
+    os.environ["HBS5_NOCHECK"] = "1"
+else:
+    n = 1_677_000
+    g = ctx.synth_stream(0x1234, n, 0)
+    sb = g["stream_bytes"]
+    stream = g["stream"][:sb]
 index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
 del rbsp
 ks = []

@@ -12,6 +12,14 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch0 -- $
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write0 -- $P --other-kernels 0 > $O/pmc_write0_line.json 2> $O/pmc_write0.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $P --sweep 0 > $O/pmc_fetch_line.json 2> $O/pmc_fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $P --sweep 0 > $O/pmc_write_line.json 2> $O/pmc_write.err
+# the zero-heavy stress workload: since round 3 the same kernel
+Z="python3 bench.py --mode 1 --steps 2 --warmup 1 --cpu-sample-nals 0 --other-kernels 0"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetchz -- $Z > $O/pmc_fetchz_line.json 2> $O/pmc_fetchz.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_writez -- $Z > $O/pmc_writez_line.json 2> $O/pmc_writez.err
+ZALGO=$(python3 -c "import json,sys; print(json.loads(open('$O/pmc_fetchz_line.json').read().strip().splitlines()[-1])['roofline']['algorithmic_bytes'])")
+python3 scripts/pmc_traffic.py $O/pmc_fetchz $O/pmc_writez k_scan_extract4 $ZALGO $O/traffic_k_scan_extract4_zero_heavy.json | tail -14
+for p in fetch write; do f=$(find $O/pmc_${p}z -name "*counter_collection.csv" | head -1); (head -1 $f; grep "k_scan_extract4" $f) > $O/pmc_${p}_k_scan_extract4_zero_heavy.csv; done
+find $O/pmc_fetchz $O/pmc_writez -type f -delete
 python3 scripts/pmc_traffic.py $O/pmc_fetch0 $O/pmc_write0 k_scan_extract4 34403064115 $O/traffic_k_scan_extract4.json | tail -14
 python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write k_index5_stream 17231091218 $O/traffic_k_index5_stream.json near_max | tail -14
 python3 scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write k3_tiles 34403064115 $O/traffic_k3_tiles.json near_max | tail -14
