@@ -2,7 +2,7 @@
  * hbs_scan5.hip -- index only (find_nal_unit over a whole stream, no RBSP arena).
  *
  * Without an arena to fill nothing has to stay in registers, so the event-sparse scan turns into
- * a STREAMING kernel: a wavefront takes a tile of 1 MiB by ticket, reads it 16 KiB at a time
+ * a STREAMING kernel: a wavefront takes a tile of 256 KiB by ticket, reads it 16 KiB at a time
  * (the next 16 KiB already in flight), keeps only each chunk's chunk_flag() -- one 64-bit
  * word per KiB, in LDS -- and then treats the flagged chunks exactly as hbs_scan4.hip treats its
  * elements: the window rules on the chunk's bytes [-8, 20) (fetched again from the stream: a few
@@ -23,7 +23,7 @@ namespace hbs {
 
 #ifndef HBS5_SPAN_ROWS
 #define HBS5_SPAN_ROWS 16
-#define HBS5_TILE_ROWS 1024
+#define HBS5_TILE_ROWS 256
 #endif
 constexpr int k5SpanRows = HBS5_SPAN_ROWS;                    /* rows of 1 KiB a wavefront flags per step */
 constexpr uint64_t k5SpanBytes = (uint64_t)k5SpanRows * 1024u;
@@ -220,7 +220,7 @@ __device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32
 struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
 static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
 struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
-constexpr uint32_t k5RecCap = 2048;                                       /* elements recorded per tile */
+constexpr uint32_t k5RecCap = 2u * (uint32_t)k5TileRows;                  /* elements recorded per tile: two a KiB (6 % of the stream's size as workspace) */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
 constexpr int k5ChunkTiles = 64;
 

@@ -131,7 +131,7 @@ int  hbs_ctx_reserve_workgroups(hbs_ctx* ctx, int spare);
  * 5 = index only (no RBSP arena asked for): nothing has to stay in registers, so the bytes are
  *     streamed and only the flagged chunks are looked at again (hbs_scan5.hip); with an arena it means 4,
  * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and kernel 4 (5
- *     when no arena is asked for and the stream is 0.75 GiB or more) or kernel 2 is picked from it on the
+ *     when no arena is asked for and the stream is 1 GiB or more) or kernel 2 is picked from it on the
  *     device, without a host round trip.
  * Environment HBS_KERNEL=0|2|3|4|5 sets the default.  hbs_ctx_last_kernel waits for the last
  * hbs_index_extract and says which kernel ran it. */
