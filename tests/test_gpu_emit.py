@@ -144,6 +144,37 @@ def test_emit_arena_tile_edges(ctx, orc):
         assert np.array_equal(idx_tiles, idx_nals), (lens[:6], "output index")
 
 
+@pytest.mark.parametrize("shape", ["zeros-10-percent", "nals-600", "insertions-every-500"])
+def test_emit_arena_tiles_with_several_batches_of_elements(ctx, orc, shape):
+    """65 to 1024 elements per 192 KiB tile of the arena (round 3: exact flags, wavefront 1 takes every other batch, batch sums in
+    LDS): zero-heavy payload, NALs of ~600 bytes, a 03 to insert every ~500 bytes.  Arena tiles (pinned), the automatic choice and
+    the kernel by NALs against the oracle; the output indexes against each other."""
+    rng = np.random.RandomState({"zeros-10-percent": 41, "nals-600": 42, "insertions-every-500": 43}[shape])
+    total = 2 * (1 << 20) + 777
+    if shape == "nals-600":
+        lens = []
+        while sum(lens) < total:
+            lens.append(int(rng.randint(400, 800)))
+    else:
+        lens = [int(x) for x in rng.randint(3000, 40000, size=total // 21500)]
+    arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+    if shape == "zeros-10-percent":
+        arena[rng.random_sample(len(arena)) < 0.10] = 0
+    elif shape == "insertions-every-500":
+        for q in rng.randint(0, len(arena) - 8, size=len(arena) // 500):
+            arena[q:q + 3] = (0, 0, rng.randint(0, 4))
+    idx = fake_index(lens, [int(rng.randint(3, 5)) for _ in lens])
+    want = orc.emit_annexb(arena, idx)
+    outs = {}
+    for path in (0, 2, -1):
+        ctx.set_emit_path(path)
+        outs[path] = ctx.emit_annexb(dev(arena), idx)
+    ctx.set_emit_path(-1)
+    for path, (got, got_idx) in outs.items():
+        assert np.array_equal(got, want), (shape, path)
+        assert np.array_equal(got_idx, outs[0][1]), (shape, path, "output index")
+
+
 def test_emit_arena_tiles_give_up_on_dense_tiles(ctx, orc):
     """an arena that is sparse but for one stretch of 00 00 03 padding (cabac_zero_words): the tile holding it has thousands of
     elements, the arena-tile kernel gives the call up (hbs_emit.hip: kTDenseLimit) and the kernel by NALs, enqueued behind it,

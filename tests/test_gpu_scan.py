@@ -174,6 +174,34 @@ def test_dense_patterns(ctx, orc, pattern):
     check(ctx, orc, s)
 
 
+@pytest.mark.parametrize("shape", ["nals-500", "nals-1k-epb", "zeros-10-percent", "zeros-and-starts"])
+def test_tiles_with_several_batches_of_elements(ctx, orc, shape):
+    """65 to 512 elements per 192 KiB tile (round 3: exact flags, per-wavefront element lists, two element wavefronts, the batch
+    aggregates and records in LDS): streams of small NALs, NALs full of emulation prevention bytes, zero-heavy bytes."""
+    rng = np.random.RandomState({"nals-500": 11, "nals-1k-epb": 12, "zeros-10-percent": 13, "zeros-and-starts": 14}[shape])
+    n = 3 * (1 << 20) + 4321
+    if shape.startswith("nals"):
+        s = rng.randint(1, 256, size=n).astype(np.uint8)
+        lo, hi = (300, 700) if shape == "nals-500" else (700, 1400)
+        at = 0
+        while at + 8 < n:
+            sc = (0, 0, 1) if rng.randint(3) else (0, 0, 0, 1)
+            s[at:at + len(sc)] = sc
+            s[at + len(sc)] = 0x40
+            at += int(rng.randint(lo, hi))
+        if shape == "nals-1k-epb":
+            for p in rng.randint(8, n - 8, size=n // 500):
+                s[p:p + 4] = (0, 0, 3, rng.randint(0, 4))
+    else:
+        s = rng.randint(1, 256, size=n).astype(np.uint8)
+        s[rng.random_sample(n) < 0.10] = 0
+        s[0:4] = (0, 0, 1, 0x40)
+        if shape == "zeros-and-starts":
+            for p in rng.randint(8, n - 8, size=n // 3000):
+                s[p:p + 4] = (0, 0, 1, 0x42)
+    check(ctx, orc, s)
+
+
 def test_automatic_choice_follows_density(orc):
     """the default mode picks the event-sparse kernel for coded-video-like bytes and the LDS-image kernel for
     zero-heavy ones, on the device; the answer is the oracle's either way"""
