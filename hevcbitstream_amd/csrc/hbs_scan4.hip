@@ -7,28 +7,36 @@
  * hevc_analyze.c:135-177).  What differs is who does the exact work:
  *
  *   1. A workgroup is 4 wavefronts of 256 VGPRs; wavefront w holds 48 rows of
- *      1 KiB in named registers (a tile = 192 KiB).  Per 16-byte chunk,
- *      chunk_flag() (hbs_sparse.h) decides that no pattern 00 00 {<=3} can
- *      touch it; the row's ballot is its flag mask.  Flagged chunks -- a start
- *      code per NAL, a few emulation prevention bytes, a few false alarms: ~15
- *      of 12288 -- are listed in LDS in stream order, and their lanes leave the
- *      chunk's surroundings in LDS.
+ *      1 KiB in named registers (a tile = 192 KiB), fetched inside the flag
+ *      pass, a few rows ahead.  Per 16-byte chunk, chunk_flag() (hbs_sparse.h)
+ *      decides that no two adjacent zero bytes touch it; a row with more than
+ *      two such chunks is asked again, exactly: does a pattern 00 00 {<=3} end
+ *      in the chunk (chunk_pattern_any_dev, hbs_wave.h)?  The row's ballot is
+ *      its flag mask.  Flagged chunks -- a start code per NAL, a few emulation
+ *      prevention bytes, a few false alarms: ~15 of 12288 in coded video --
+ *      are listed in LDS per wavefront, in stream order, as they are found, and
+ *      their lanes leave the chunk's surroundings in LDS.
  *   2. Wavefront 0 takes the listed chunks as "elements", one per lane: exact
  *      window logic of hbs_tile.h on bytes [-8, 20) of the chunk.  A wave scan
- *      with combine() over (gap, chunk) elements gives the tile aggregate.
+ *      (DPP) with combine() over (gap, chunk) elements gives the tile aggregate.
+ *      A tile with more than 64 elements (small NALs, zero-heavy data) has
+ *      several batches: wavefront 1 takes every other one.
  *   3. Wavefront 0 runs the decoupled look-back, 256 predecessors per step;
- *      the others wait at a barrier.  Part of wavefront 0's rows are parked in
- *      LDS during 2 and 3, which need ~100 registers of their own.
+ *      the others wait at a barrier.  Part of an element wavefront's rows are
+ *      parked in LDS during 2-4, which need ~100 registers of their own.
  *   4. With the carried state known the elements emit index entries, write
  *      their own kept bytes, and leave one segment word each; every other chunk
  *      finds the word of the nearest element in front of it and, if inside a
- *      NAL, is one byte-aligned 16-byte store straight from its registers.
+ *      NAL, is one byte-aligned 16-byte store straight from its registers
+ *      (at most three stores of a wavefront in flight: the CU's memory queue
+ *      is shared with the other workgroup's look-back polls).
  *
  * Tiles are handed out by an atomic ticket in arrival order, so a workgroup
  * only ever waits for tiles that are already being worked on: no co-residency
  * requirement, and a slow workgroup delays its successors, not a whole round.
- * Tiles dense in zero pairs (every chunk an element) stay exact: elements are
- * taken 64 at a time, each batch followed by the copy of the chunks behind it.
+ * Tiles with more than kDenseElems elements (padding, zero stuffing) stay
+ * exact the other way round: every chunk is an element, every wavefront walks
+ * its own rows (dense_tile).
  */
 #include <hip/hip_runtime.h>
 #include "hbs_wave.h"
