@@ -571,6 +571,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4),
+                         "kernel_ms_steps": [round(x, 3) for x in reversed(kms)],      # every timed step, first to last; kernel_ms is their mean
                          "algorithmic_bytes": algo_bytes,
                          "note": "bytes = stream read once + RBSP written once + 32 B/NAL index; "
                                  "read-only fraction = %.4f" % (sb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
