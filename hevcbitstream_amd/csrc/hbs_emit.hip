@@ -64,9 +64,13 @@ __device__ __forceinline__ bool three_steps_run(const uint32_t* probe, const uin
 __device__ __forceinline__ bool index_bad(const uint32_t* vflag) { return vflag[3] != 0u; }
 
 enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2 };
-__device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when)
+/* the helper kernels of the two fall-back chains: those of the kernel by NALs (its item list) run when the data is sparse and
+ * the tile kernel, in front of them since round 3, has not done the call; those of the three steps when these run */
+__device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when, const uint32_t* tflag)
 {
-    return probe && when != kWhenAlways && (emit_probe_dense(probe) != (when == kWhenDense));
+    if (when == kWhenAlways) return false;
+    if (when == kWhenSparse) return (probe && emit_probe_dense(probe)) || tile_path_done(tflag);
+    return !three_steps_run(probe, tflag);
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
@@ -88,12 +92,14 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uin
     return x - v;
 }
 
-__global__ __launch_bounds__(256)
-void k3_probe(const uint8_t* __restrict__ rbsp, uint64_t bytes, uint32_t* __restrict__ probe)
+/* the density probe: kProbeBlocks workgroups, each a window of the arena (role of the workgroups behind the first kCheckBlocks
+ * of k3t_check: one launch for the two things every call needs before anything else) */
+constexpr unsigned kCheckBlocks = 1024, kProbeBlocks = 64;
+__device__ __forceinline__ void probe_window(const uint8_t* __restrict__ rbsp, uint64_t bytes, uint32_t* __restrict__ probe, unsigned block)
 {
     struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
-    const uint64_t stride = (bytes / gridDim.x) & ~15ull;
-    const uint64_t base = (uint64_t)blockIdx.x * stride;
+    const uint64_t stride = (bytes / kProbeBlocks) & ~15ull;
+    const uint64_t base = (uint64_t)block * stride;
     uint32_t chunks = 0, flagged = 0;
     for (int k = 0; k < 4; ++k) {
         const uint64_t off = base + (uint64_t)(k * 256 + (int)threadIdx.x) * 16u;
@@ -269,9 +275,9 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
 
 __global__ __launch_bounds__(256)
 void k_scan_reduce(const unsigned long long* __restrict__ v, uint64_t n, unsigned long long* __restrict__ part,
-                   const uint32_t* __restrict__ probe, int when)
+                   const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
 {
-    if (emit_skip(probe, when)) return;
+    if (emit_skip(probe, when, tflag)) return;
     __shared__ unsigned long long wsum[4];
     const uint64_t per = (n + kScanBlocks - 1) / kScanBlocks;
     const uint64_t lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
@@ -284,9 +290,9 @@ void k_scan_reduce(const unsigned long long* __restrict__ v, uint64_t n, unsigne
 
 __global__ __launch_bounds__(kScanBlocks)
 void k_scan_parts(unsigned long long* __restrict__ part, unsigned long long* __restrict__ total,
-                  const uint32_t* __restrict__ probe, int when)
+                  const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
 {
-    if (emit_skip(probe, when)) return;
+    if (emit_skip(probe, when, tflag)) return;
     __shared__ unsigned long long sh[kScanBlocks];
     const int tid = threadIdx.x;
     const unsigned long long s = part[tid];
@@ -304,9 +310,9 @@ void k_scan_parts(unsigned long long* __restrict__ part, unsigned long long* __r
 
 __global__ __launch_bounds__(256)
 void k_scan_apply(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
-                  const unsigned long long* __restrict__ part, const uint32_t* __restrict__ probe, int when)
+                  const unsigned long long* __restrict__ part, const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
 {
-    if (emit_skip(probe, when)) return;
+    if (emit_skip(probe, when, tflag)) return;
     __shared__ unsigned long long wsum[4];
     const uint64_t per = (n + kScanBlocks - 1) / kScanBlocks;
     const uint64_t lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
@@ -321,13 +327,45 @@ void k_scan_apply(const unsigned long long* __restrict__ v, unsigned long long* 
     }
 }
 
+/* the same scan by ONE workgroup, for up to kScanOneMax values: a thread sums its slice, the 1024 sums are scanned in LDS, the
+ * thread writes its slice's prefixes.  One launch instead of three -- and an emit call enqueues two scans of which at most one
+ * does anything (round 3: a 1 GiB call was 17 launches around one that matters). */
+constexpr uint64_t kScanOneMax = 1ull << 18;
+__global__ __launch_bounds__(1024)
+void k_scan_one(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
+                unsigned long long* __restrict__ total, const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
+{
+    if (emit_skip(probe, when, tflag)) return;
+    __shared__ unsigned long long sh[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023u) / 1024u;
+    const uint64_t lo = (uint64_t)tid * per < n ? (uint64_t)tid * per : n, hi = lo + per < n ? lo + per : n;
+    unsigned long long s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += v[i];
+    sh[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long t = (tid >= d) ? sh[tid - d] : 0ull;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    unsigned long long carry = sh[tid] - s;
+    for (uint64_t i = lo; i < hi; ++i) { const unsigned long long x = v[i]; out[i] = carry; carry += x; }
+    if (tid == 1023) *total = sh[1023];
+}
+
 static void launch_scan_u64(const unsigned long long* v, unsigned long long* out, uint64_t n, unsigned long long* total,
                             unsigned long long* part /* kScanBlocks entries */, hipStream_t st,
-                            const uint32_t* probe = nullptr, int when = kWhenAlways)
+                            const uint32_t* probe = nullptr, int when = kWhenAlways, const uint32_t* tflag = nullptr)
 {
-    k_scan_reduce<<<kScanBlocks, 256, 0, st>>>(v, n, part, probe, when);
-    k_scan_parts<<<1, kScanBlocks, 0, st>>>(part, total, probe, when);
-    k_scan_apply<<<kScanBlocks, 256, 0, st>>>(v, out, n, part, probe, when);
+    if (n <= kScanOneMax) {
+        k_scan_one<<<1, 1024, 0, st>>>(v, out, n, total, probe, when, tflag);
+        return;
+    }
+    k_scan_reduce<<<kScanBlocks, 256, 0, st>>>(v, n, part, probe, when, tflag);
+    k_scan_parts<<<1, kScanBlocks, 0, st>>>(part, total, probe, when, tflag);
+    k_scan_apply<<<kScanBlocks, 256, 0, st>>>(v, out, n, part, probe, when, tflag);
 }
 
 /* one NAL written by one wavefront: gap bytes at `base`, then the NAL with its 03s; `total` = gap + len + inserted */
@@ -730,9 +768,9 @@ constexpr uint32_t kEmitSegBytes = (uint32_t)kEmitRows * 1024u;
 constexpr int kItemSegBits = 20;                             /* rbsp_len < 2^32: fewer than 2^19 segments */
 
 __global__ void k3_seg_count(const hbs_nal_entry* __restrict__ idx, uint64_t n, unsigned long long* __restrict__ segs,
-                             const uint32_t* __restrict__ probe)
+                             const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    if (probe && emit_probe_dense(probe)) return;
+    if (emit_skip(probe, kWhenSparse, tflag)) return;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t len = idx[k].rbsp_len;
         segs[k] = len <= kEmitSegBytes ? 1ull : (unsigned long long)((len + kEmitSegBytes - 1u) / kEmitSegBytes);
@@ -743,8 +781,7 @@ __global__ void k3_expand(const unsigned long long* __restrict__ segs, const uns
                           const unsigned long long* __restrict__ n_items, unsigned long long* __restrict__ items, uint64_t items_cap,
                           const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
 {
-    (void)tflag;
-    if (probe && emit_probe_dense(probe)) return;
+    if (emit_skip(probe, kWhenSparse, tflag)) return;
     if (*n_items == n || *n_items > items_cap) return;       /* identity: nothing to build; too many: the main kernel reports it */
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long base = item_base[k], m = segs[k];
@@ -988,10 +1025,15 @@ static_assert(kTChunks <= (int)kTListChunk + 1, "a chunk number fits the list en
 
 __global__ __launch_bounds__(256)
 void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-               uint64_t first_cap, uint64_t desc_words, int want_tiles, int pinned, uint32_t* __restrict__ tflag, uint32_t* __restrict__ err)
+               uint64_t first_cap, uint64_t desc_words, int want_tiles, int pinned, uint32_t* __restrict__ tflag, uint32_t* __restrict__ err,
+               uint32_t* __restrict__ probe)
 {
+    if (blockIdx.x >= kCheckBlocks) {                /* launched only when a probe is wanted */
+        probe_window(rbsp, rbsp_bytes, probe, blockIdx.x - kCheckBlocks);
+        return;
+    }
     bool bad = false, outside = false;
-    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)kCheckBlocks * blockDim.x) {
         const uint64_t off = idx[k].rbsp_off;
         if (off > rbsp_bytes || idx[k].rbsp_len > rbsp_bytes - off) outside = true;      /* every kernel behind this one trusts the index */
         if (k > 0 && off != idx[k - 1].rbsp_off + idx[k - 1].rbsp_len) bad = true;
@@ -1540,17 +1582,13 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     /* forced one way (HBS_EMIT_TWO_PASS=1 / =0), or -- the default -- picked on the device from a density probe */
     const uint32_t* probe = a.two_pass < 0 ? a.probe : nullptr;
     const bool want_dense = a.two_pass != 0, want_sparse = a.two_pass <= 0;
-    if (a.n && probe) k3_probe<<<64, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.probe);
     /* arena tiles when the index allows it (decided on the device), the item kernel otherwise; path 0 pins the item kernel */
     const uint32_t* tflag = (a.n && want_sparse && a.tiles != 0 && (a.tiles == 2 || a.rbsp_bytes >= kTMinArena)) ? a.tflag : nullptr;
-    /* always: it is also what checks every entry of the index against rbsp_bytes (tflag[3]) before anything follows one into the arena */
-    if (a.n) k3t_check<<<1024, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap),
-                                             tflag ? 1 : 0, a.tiles == 2 ? 1 : 0, a.tflag, a.err);
+    /* always: it is also what checks every entry of the index against rbsp_bytes (tflag[3]) before anything follows one into the
+     * arena; its last kProbeBlocks workgroups are the density probe */
+    if (a.n) k3t_check<<<kCheckBlocks + (probe ? kProbeBlocks : 0u), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap,
+                                             emit_desc_words(a.items_cap), tflag ? 1 : 0, a.tiles == 2 ? 1 : 0, a.tflag, a.err, a.probe);
     if (a.n && want_sparse) {
-        /* items: segments per NAL, their exclusive scan, the item list (skipped on the device when it is the identity) */
-        k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe);
-        launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse);
-        k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe, tflag);
         if (tflag) {
             /* arena tiles first; the kernel by NALs behind them runs when they do not apply -- or gave up on a tile dense in elements */
             k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.first_k, probe, tflag);
@@ -1561,6 +1599,11 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
                                                               a.index_out, a.total, a.err, probe, tflag);
             k3t_reset<<<256, 256, 0, st>>>(a.desc, emit_desc_words(a.items_cap), a.ticket, a.total, probe, tflag);
         }
+        /* items of the kernel by NALs: segments per NAL, their exclusive scan, the item list (skipped on the device when the tile
+         * kernel has done the call, or when the list is the identity) */
+        k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe, a.tflag);
+        launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse, a.tflag);
+        k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe, a.tflag);
         const uint64_t ngroups = (a.items_cap + kEmitGroup - 1) / kEmitGroup;       /* upper bound */
         uint64_t blocks = (uint64_t)a.grid_blocks;
         if (blocks > ngroups) blocks = ngroups;
@@ -1569,7 +1612,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     }
     if (a.n && want_dense) {
         k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
-        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, probe, kWhenDense);
+        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, probe, kWhenDense, a.tflag);
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe, a.tflag);
     }
     if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
