@@ -2,8 +2,8 @@
 """bench.py -- headline benchmark of the MI355X Annex-B indexer / RBSP extractor.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-             --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    (N > 1: as typed -- this process then starts one child per GPU and relays rank 0's line -- or under
+            python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
 Metric (BASELINE.json): Annex-B GB/s scanned (+ NAL units/s) on a 16 GiB synthetic
 stream per GPU.  One "step" = one pass of the hot path -- start-code scan + NAL
@@ -399,6 +399,69 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True):
     return res
 
 
+def launch_ranks(n, argv, script=None):
+    """One process per GPU on this node, started from a parent that holds no GPU state: `sys.executable bench.py <same
+    arguments>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set;
+    the rendezvous is env:// on 127.0.0.1 -- the container's hostname may not resolve).  Rank 0's stdout is captured and
+    its last line -- the JSON line -- printed last; everything else the ranks print goes to stderr.  Returns the exit code:
+    0 only when every rank exited 0 and rank 0 printed a JSON line; a rank that fails takes the others down (no retry)."""
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode(errors="replace").splitlines()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        # a rank died: the others would wait in a collective for ever -- give them a moment, then end exactly the children started here
+        deadline = time.time() + 10.0
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                try:
+                    codes[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[r] = p.wait()
+    reader.join(timeout=30)
+    line = None
+    for text in out0:
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            print(text, file=sys.stderr)
+    sys.stderr.flush()
+    if failed is not None:
+        print("bench.py launcher: rank %d exited with code %s (all: %s)" % (failed, codes[failed], codes), file=sys.stderr)
+        return codes[failed] if codes[failed] and codes[failed] > 0 else 1
+    if line is None:
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,6 +475,11 @@ def main():
     ap.add_argument("--exercise-gather", action="store_true",
                     help="dev aid: run the N > 1 code path (RCCL group, pipelined index gather) with a one-rank group on one GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` as typed: this process becomes the launcher.  It has not imported torch and never
+        # touches the GPU; the ranks are fresh child processes and rank 0's JSON line is relayed as the last stdout line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import hevcbitstream_amd as hbs
@@ -459,6 +527,8 @@ def main():
     # count x 32 bytes per rank, RCCL).  It runs on a stream of its own while the next step's scan fills the other index buffer.
     indexes = [index, torch.empty_like(index)] if multi else [index]
     gatherer = shard.PipelinedLibraryGather(torch, hbs, local_rank, dist, rank, world, cap, depth=2) if multi else None
+    if gatherer is not None and gatherer.comm.world_seen() != world:
+        raise SystemExit("bench.py: the communicator reports %d ranks, %d were launched" % (gatherer.comm.world_seen(), world))
     counter = [0]
     pending = [None]
 

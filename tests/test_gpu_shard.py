@@ -149,7 +149,8 @@ def test_two_ranks_share_one_gpu(orc, tmp_path):
             shm.unlink()
 
 
-def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("how", ["launcher", "env"])
+def test_bench_with_two_ranks_on_one_gpu(tmp_path, how):
     """bench.py's whole N > 1 path with world = 2 on this one GPU: the pipelined C-ABI gather (over the stand-in for RCCL), the
     max-over-ranks timing, the per-rank lines and the checks of the gathered rows -- so that the line is right the first time a
     node with several GPUs runs it (torch.distributed over gloo here: RCCL refuses two ranks on one device)"""
@@ -172,16 +173,25 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     port = s.getsockname()[1]
     s.close()
     try:
-        procs = []
-        for r in range(world):
-            env = dict(os.environ, HBS_RCCL_LIB=fake, HBS_FAKE_RCCL_SHM="/" + shm.name.lstrip("/"), HBS_FAKE_RCCL_SLOT=str(slot),
-                       HBS_BENCH_ONE_DEVICE="0", HBS_BENCH_DIST_BACKEND="gloo", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
-                                           "--nals", str(nals)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
-        outs = [p.communicate(timeout=600) for p in procs]
-        for r, (p, (o, e)) in enumerate(zip(procs, outs)):
-            assert p.returncode == 0, "rank %d:\n%s" % (r, e.decode()[-3000:])
+        hooks = dict(HBS_RCCL_LIB=fake, HBS_FAKE_RCCL_SHM="/" + shm.name.lstrip("/"), HBS_FAKE_RCCL_SLOT=str(slot),
+                     HBS_BENCH_ONE_DEVICE="0", HBS_BENCH_DIST_BACKEND="gloo")
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1", "--nals", str(nals)]
+        if how == "launcher":
+            # the driver's command as typed: no RANK / WORLD_SIZE in the environment, bench.py starts its ranks itself
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            p = subprocess.Popen(cmd, env=dict(env, **hooks), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+            o, e = p.communicate(timeout=600)
+            assert p.returncode == 0, e.decode()[-3000:]
+            outs = [(o, e), (b"", b"")]
+            assert o.decode().strip().count("\n") == 0, "the launcher's stdout is the JSON line and nothing else"
+        else:
+            procs = []
+            for r in range(world):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **hooks)
+                procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
+            outs = [p.communicate(timeout=600) for p in procs]
+            for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+                assert p.returncode == 0, "rank %d:\n%s" % (r, e.decode()[-3000:])
         line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and line["gather"]["rccl_world"] == 2 and len(line["per_rank"]) == 2
         assert line["gather"]["bytes_received_per_rank_per_step"] == 2 * nals * 32

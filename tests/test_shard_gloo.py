@@ -129,3 +129,54 @@ def test_two_rank_index_gather():
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+_RANK_SCRIPT = '''
+import json, os, sys
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["LOCAL_RANK"]) == rank
+if "--die" in sys.argv and rank == 1:
+    sys.exit(7)
+dist.init_process_group("gloo")
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+print("rank %d chatter" % rank)
+if rank == 0:
+    print(json.dumps({"metric": "m", "n_gpus": world, "sum": t.item(), "argv": sys.argv[1:]}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_bench_launcher_starts_the_ranks_itself(tmp_path):
+    """`python3 bench.py --gpus N` without WORLD_SIZE (the driver's command): bench.launch_ranks starts one child per rank with
+    the torch.distributed.run environment on 127.0.0.1, relays rank 0's JSON line as the LAST and ONLY stdout line, sends the
+    rest to stderr, and exits non-zero when a rank fails (the others are ended, nobody hangs).  The rank script here is a
+    gloo stand-in: bench.py's own ranks need a GPU (tests/test_gpu_shard.py runs the real thing through the same launcher)."""
+    import json
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    drv = ("import sys; sys.path.insert(0, %r); import bench; "
+           "sys.exit(bench.launch_ranks(2, sys.argv[1:], script=%r))" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-c", drv, "--gpus", "2", "--steps", "3"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = p.stdout.decode().strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["sum"] == 3.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert "rank 0 chatter" in p.stderr.decode() and "rank 1 chatter" in p.stderr.decode()
+    t0 = __import__("time").time()
+    p = subprocess.run([sys.executable, "-c", drv, "--die"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 7 and p.stdout.decode().strip() == "", (p.returncode, p.stdout)
+    assert __import__("time").time() - t0 < 120
+
+
+def test_bench_gpus_1_does_not_launch():
+    """--gpus 1 (and a run under torch.distributed.run, WORLD_SIZE set) never goes through the launcher"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ:' in src
+    head = src[: src.index("def launch_ranks")]
+    assert "import torch" not in head, "nothing may touch torch / HIP before the launcher decision"
