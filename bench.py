@@ -43,10 +43,13 @@ N_NALS_16GIB = 1_677_000       # S(seed, n) with ~10 KiB NALs: 16.0 GiB of Annex
 SEED = 0x1234
 
 
-def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
+def cpu_baseline(stream_dev, index_dev, rbsp_dev, n_nals, sample_nals):
     """The reference's own loop (find_nal_unit + nal_to_rbsp per NAL) on one host core over the first `sample_nals`
     NALs of the stream: through the REAL reference library when its prebuilt copy travelled with the tree
-    (oracle/_ref, kind "reference"), else through the oracle's restatement (kind "port")."""
+    (oracle/_ref, kind "reference"), else through the oracle's restatement (kind "port").
+    index_dev / rbsp_dev are what the GPU produced in the timed loop: EVERY entry (start, end, rbsp_off, rbsp_len) of the
+    sample and EVERY byte of its RBSP are compared with what the reference produced here -- the headline run is pinned on the
+    reference, not only on the device generator."""
     import ctypes as C
     import numpy as np
     from tests import _orc
@@ -62,15 +65,25 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
         lib = C.CDLL(drv)
         lib.ref_walk.restype = C.c_int64
         lib.ref_walk.argtypes = [u8p, C.c_int64, u8p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.c_int64]
-        starts = np.zeros(sample_nals + 8, dtype=np.uint64)
+        lib.ref_walk_index.restype = C.c_int64
+        lib.ref_walk_index.argtypes = [u8p, C.c_int64, u8p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        ref_entry = np.dtype([("start", "<u8"), ("end", "<u8"), ("rbsp_off", "<u8"), ("rbsp_len", "<i4"), ("rc_rbsp", "<i4"),
+                              ("rc_find", "<i4"), ("pad", "<i4")])
+        rent = np.zeros(sample_nals + 8, dtype=ref_entry)   # pre-faulted like the arena
         tot = C.c_int64(0)
         t0 = time.perf_counter()
-        n = lib.ref_walk(host.ctypes.data_as(u8p), len(host), arena.ctypes.data_as(u8p), len(arena), C.byref(tot),
-                         starts.ctypes.data_as(C.POINTER(C.c_uint64)), len(starts))
+        # the walk that also writes down what it learns per NAL (40 bytes per ~10 KiB NAL: the same loop, the same time)
+        n = lib.ref_walk_index(host.ctypes.data_as(u8p), len(host), arena.ctypes.data_as(u8p), len(arena), rent.ctypes.data, len(rent), C.byref(tot))
         dt = time.perf_counter() - t0
         # the 4 bytes kept behind the sample are a start code: the reference finds one more, empty-handed NAL there or stops
-        assert n >= sample_nals and np.array_equal(starts[:sample_nals], ent["start"])
-        assert tot.value >= int(ent["rbsp_off"][-1]) + int(ent["rbsp_len"][-1])
+        assert n >= sample_nals
+        r = rent[:sample_nals]
+        for f in ("start", "end", "rbsp_off"):
+            assert np.array_equal(r[f], ent[f]), "GPU index field %s differs from the reference's" % f
+        assert np.array_equal(r["rbsp_len"].astype(np.int64), ent["rbsp_len"].astype(np.int64)), "GPU rbsp_len differs from the reference's"
+        assert int((r["rc_rbsp"] < 0).sum()) == 0
+        ref_rb = int(r["rbsp_off"][-1]) + int(r["rbsp_len"][-1])
+        assert tot.value >= ref_rb
         kind, what = "reference", "the reference's find_nal_unit + nal_to_rbsp (oracle/_ref/libhevcref.so, gcc -O2) driven by oracle/ref_driver.c"
     else:
         orc = _orc.oracle()
@@ -81,8 +94,22 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
         tot = orc.lib.orc_extract_rbsp(host.ctypes.data_as(u8p), idx.ctypes.data, n, arena.ctypes.data_as(u8p), len(arena))
         dt = time.perf_counter() - t0
         assert n >= sample_nals and tot > 0
-        assert np.array_equal(idx["start"][:sample_nals], ent["start"]) and np.array_equal(idx["rbsp_off"][:sample_nals], ent["rbsp_off"])
+        for f in ("start", "end", "rbsp_off", "rbsp_len"):
+            assert np.array_equal(idx[f][:sample_nals], ent[f]), "GPU index field %s differs from the oracle's" % f
+        ref_rb = int(idx["rbsp_off"][sample_nals - 1]) + int(idx["rbsp_len"][sample_nals - 1])
         kind, what = "port", "find_nal_unit loop + nal_to_rbsp per NAL, oracle/hbs_oracle_nal.c, gcc -O2"
+    # every RBSP byte of the sample: the GPU's arena against the CPU's, a piece at a time
+    t1 = time.perf_counter()
+    step = 1 << 29
+    for lo in range(0, ref_rb, step):
+        hi = min(ref_rb, lo + step)
+        piece = rbsp_dev[lo:hi].cpu().numpy()
+        if not np.array_equal(piece, arena[lo:hi]):
+            bad = lo + int(np.flatnonzero(piece != arena[lo:hi])[0])
+            raise AssertionError("GPU RBSP arena differs from the %s's at byte %d of %d" % (kind, bad, ref_rb))
+    t_cmp = time.perf_counter() - t1
+    checked = ("the GPU's index (start, end, rbsp_off, rbsp_len of all %d NALs) and all %d RBSP bytes of the sample compared "
+               "with this walk's: equal (%.1f s)" % (sample_nals, ref_rb, t_cmp))
     cpu_model = "?"
     try:
         for line in open("/proc/cpuinfo"):
@@ -93,7 +120,8 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
         pass
     res = {"value": round(len(host) / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind, "cpu": cpu_model,
            "nal_per_s": round(n / dt, 1),
-           "sample": "first %d NALs (%.2f GiB) of rank 0's stream: %s, 1 thread, %.1f s" % (sample_nals, len(host) / 2**30, what, dt)}
+           "sample": "first %d NALs (%.2f GiB) of rank 0's stream: %s, 1 thread, %.1f s; %s" % (sample_nals, len(host) / 2**30, what, dt, checked),
+           "parity_checked_nals": sample_nals, "parity_checked_rbsp_bytes": ref_rb}
     # the same loop on every host core at once, one contiguous share of the sample per thread (the reference itself is
     # single-threaded; this is what a caller could get out of the host by sharding the file)
     import threading
@@ -125,6 +153,32 @@ def cpu_baseline(stream_dev, index_dev, n_nals, sample_nals):
         res["all_cores"] = {"value": round(len(host) / dtm / 1e9, 3), "unit": "GB/s", "cores": cores,
                             "note": "%d threads, one contiguous share of the same sample each, %.2f s" % (cores, dtm)}
     return res
+
+
+def cpu_baseline_parse(stream_dev, index_dev, rbsp_dev, m, parsed, structs_dev):
+    """The CPU-baseline leg of BASELINE config 3: the reference's read_hevc_nal_unit (hevc_stream.c:155-240) fed the m NALs of
+    the 4K30 sequence in stream order on one host core -- the compiled reference when its prebuilt library travelled with the
+    tree, else the oracle's restatement -- timed, and EVERY NAL's rc, NAL header, struct (every member) and slice payload
+    compared with what the GPU parse produced (tests/_parsecmp.compare)."""
+    import numpy as np
+    from tests import _orc
+    from tests._parsecmp import compare, oracle_pass
+    s = stream_dev.cpu().numpy()
+    idx = index_dev[: m * 32].cpu().numpy().view(_orc.NAL_ENTRY)
+    nals = [bytes(s[int(a):int(b)]) for a, b in zip(idx["start"], idx["end"])]
+    tm = []
+    if _orc.reference() is not None:
+        exp = oracle_pass(nals, parser=_orc.ReferenceHevc(), timing=tm)
+        kind, what = "reference", "the reference's read_hevc_nal_unit (oracle/_ref/libhevcref.so, gcc -O2), one call per NAL through ctypes"
+    else:
+        exp = oracle_pass(nals, timing=tm)
+        kind, what = "port", "orc_read_hevc_nal_unit (oracle/hbs_oracle_parse.c, gcc -O2), one call per NAL through ctypes"
+    arena = rbsp_dev[: int(idx["rbsp_off"][-1]) + int(idx["rbsp_len"][-1])].cpu().numpy()
+    compare(parsed, structs_dev.cpu().numpy(), arena, idx, exp)
+    return {"value": round(m / tm[0], 1), "unit": "NAL/s", "cores": 1, "kind": kind,
+            "sample": "all %d NALs of the sequence: %s, %.2f s inside the calls; the GPU parse's rc, NAL header, every struct member and "
+                      "every slice payload compared with this walk's: equal" % (m, what, tm[0]),
+            "parity_checked_nals": m}
 
 
 def pmc_traffic(kernel_name, algo_bytes):
@@ -311,7 +365,7 @@ def mixed_index_only(torch, ctx, stream, sb, n_cap, uniform_ms):
     return {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4), "over_uniform": round(ms / uniform_ms, 3)}
 
 
-def other_kernels(torch, hbs, ctx, g, n, sweep=True):
+def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
     import numpy as np
@@ -371,7 +425,14 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True):
     ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(5))
     res["parse_headers"] = {"value": round(m / ms / 1e3, 1), "unit": "M NAL/s", "ms": round(ms, 3),
                             "workload": "synthetic 4K30 stream, %d NALs (VPS/SPS/PPS every 60 pictures, 8 slices per picture)" % m}
+    if cpu_parse:
+        # config 3 pinned on the reference: the structs of this sequence against read_hevc_nal_unit on the host, all NALs;
+        # config3_end_to_end below requires the 2.1 GiB pipeline (with and without arena) to produce these same structs
+        res["parse_headers"]["cpu_baseline"] = cpu_baseline_parse(d, index, rbsp, m, parsed, structs)
     res["config3_end_to_end"] = config3_end_to_end(torch, hbs, ctx, d, index, rbsp, m, parsed, structs)
+    if cpu_parse:
+        res["config3_end_to_end"]["parity"] = ("header structs equal to those of parse_headers' sequence, which were compared "
+                                               "with the %s on all %d NALs" % (res["parse_headers"]["cpu_baseline"]["kind"], m))
     parsed_dev = torch.from_numpy(parsed.view(np.uint8).copy()).cuda()
     wcap = 256
     written, wout = ctx.write_headers(parsed_dev, structs, m, wcap)
@@ -664,11 +725,11 @@ def main():
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
         if world == 1 and args.cpu_sample_nals > 0:            # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(stream, gen_index, n, min(args.cpu_sample_nals, n))
+            out["cpu_baseline"] = cpu_baseline(stream, index, rbsp, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:
             g["uniform_kernel_ms"] = k_ms
             del rbsp, index
-            out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n, sweep=bool(args.sweep))
+            out["other_kernels"] = other_kernels(torch, hbs, ctx, g, n, sweep=bool(args.sweep), cpu_parse=args.cpu_sample_nals > 0)
         # RCCL writes a version banner to C stdout, which is block-buffered when piped: push it out first, so that the JSON
         # line is the LAST line of rank 0's stdout
         try:

@@ -31,7 +31,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
            "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
-           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps"]
+           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes"]
 
 
 class HbsError(RuntimeError):
@@ -183,6 +183,12 @@ class Context:
         """leave `spare` workgroup slots of the persistent scan kernels free (for RCCL's kernels beside the scan)"""
         self.lib.hbs_ctx_reserve_workgroups.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.hbs_ctx_reserve_workgroups(self.h, int(spare)), "hbs_ctx_reserve_workgroups")
+
+    def device_bytes(self):
+        """device memory the context itself holds (grow-only scratch; caller-owned buffers are not counted)"""
+        self.lib.hbs_ctx_device_bytes.restype = C.c_uint64
+        self.lib.hbs_ctx_device_bytes.argtypes = [C.c_void_p]
+        return int(self.lib.hbs_ctx_device_bytes(self.h))
 
     def kernel_ms_back(self, back):
         """Duration of the timed call `back` calls ago (0 = the last one; the library keeps the last 64)."""

@@ -31,6 +31,7 @@ struct hbs_ctx {
     int blocks_per_cu;
     int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
     int grid_full, grid_full4;          /* ... what the GPU holds; grid_blocks / grid_blocks4 may be cut (hbs_ctx_reserve_workgroups) */
+    int grid_env, spare_wgs;            /* HBS_GRID_BLOCKS (0: unset); workgroup slots left free for other streams' kernels */
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
@@ -129,6 +130,7 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     if (c->grid_blocks4 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_full = c->grid_blocks; c->grid_full4 = c->grid_blocks4;
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
+    c->grid_env = (g && atoi(g) > 0) ? atoi(g) : 0;
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
     const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 4 event-sparse, 5 index-only streaming */
@@ -157,9 +159,9 @@ void hbs_ctx_destroy(hbs_ctx* c)
     delete c;
 }
 
-/* internal (hbs_ingest.hip): one object kept alive with the context, freed with it */
-void* hbs_ctx_attachment(hbs_ctx* c) { return c ? c->attachment : nullptr; }
-void hbs_ctx_attach(hbs_ctx* c, void* p, void (*free_fn)(void*))
+/* internal (hbs_ingest.hip): one object kept alive with the context, freed with it; not exported */
+__attribute__((visibility("hidden"))) void* hbs_ctx_attachment(hbs_ctx* c) { return c ? c->attachment : nullptr; }
+__attribute__((visibility("hidden"))) void hbs_ctx_attach(hbs_ctx* c, void* p, void (*free_fn)(void*))
 {
     if (!c) return;
     if (c->attachment && c->attachment_free && c->attachment != p) c->attachment_free(c->attachment);
@@ -179,7 +181,16 @@ int hbs_ctx_enable_timing(hbs_ctx* c, int on)
     if (on && !c->ring0[0]) {
         if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
         for (int i = 0; i < kTimingRing; ++i)
-            if (hipEventCreate(&c->ring0[i]) != hipSuccess || hipEventCreate(&c->ring1[i]) != hipSuccess) return HBS_E_HIP;
+            if (hipEventCreate(&c->ring0[i]) != hipSuccess || hipEventCreate(&c->ring1[i]) != hipSuccess) {
+                /* all or nothing: ring0[0] != null means "the whole ring exists" everywhere else */
+                for (int j = 0; j <= i; ++j) {
+                    if (c->ring0[j]) (void)hipEventDestroy(c->ring0[j]);
+                    if (c->ring1[j]) (void)hipEventDestroy(c->ring1[j]);
+                    c->ring0[j] = nullptr; c->ring1[j] = nullptr;
+                }
+                c->timing = 0; c->ev_valid = 0;
+                return HBS_E_HIP;
+            }
     }
     c->timing = on ? 1 : 0;
     c->ev_valid = 0;
@@ -213,8 +224,12 @@ int hbs_ctx_kernel_ms(hbs_ctx* c, float* ms)
 int hbs_ctx_reserve_workgroups(hbs_ctx* c, int spare)
 {
     if (!c || spare < 0) return HBS_E_ARG;
+    c->spare_wgs = spare;
     c->grid_blocks = c->grid_full - spare > 1 ? c->grid_full - spare : 1;
     c->grid_blocks4 = c->grid_full4 - spare > 1 ? c->grid_full4 - spare : 1;
+    /* the HBS_GRID_BLOCKS debugging cap is a ceiling of its own: reserving workgroups never raises it */
+    if (c->grid_env > 0 && c->grid_env < c->grid_blocks) c->grid_blocks = c->grid_env;
+    if (c->grid_env > 0 && c->grid_env < c->grid_blocks4) c->grid_blocks4 = c->grid_env;
     return 0;
 }
 
@@ -292,6 +307,13 @@ int hbs_ctx_synchronize(hbs_ctx* c)
 
 const char* hbs_last_error(hbs_ctx* c) { return c ? c->err : "no context"; }
 
+uint64_t hbs_ctx_device_bytes(hbs_ctx* c)
+{
+    if (!c) return 0;
+    const uint64_t zb = c->zeros ? ((sizeof(hevc_sps_t) + 255) & ~(uint64_t)255) : 0;
+    return c->desc_tiles * 16 + sizeof(hbs::RunHeader) + hbs::scan4_tail_bytes() + c->ws_bytes + c->ws2_bytes + zb;
+}
+
 uint64_t hbs_workspace_bytes(uint64_t stream_bytes)
 {
     return ((stream_bytes + hbs::kTileBytes - 1) / hbs::kTileBytes + 1) * 16 + sizeof(hbs::RunHeader);
@@ -321,10 +343,10 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
         if (rc) return rc;
         a.ws5 = c->ws;
     }
-    c->last_index_only = (!d_rbsp && (c->variant == 5 || (c->variant == 0 && n >= (3ull << 28))) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
+    c->last_index_only = (hbs::scan_uses_index_only(n, c->variant, d_rbsp) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;
     a.sched = c->sched;
-    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4;
+    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4; a.spare_wgs = c->spare_wgs;
     c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
     if (hbs::scan_takes_small_path(n, index_cap, c->variant)) { c->probe_pending = 0; c->last_variant = 2; }
     if (c->timing && n) {                                     /* this call's slot of the ring */
@@ -505,11 +527,14 @@ int hbs_index_parse(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
     const uint64_t nals = s.nal_count;
     /* 2. the bytes the parse can look at, stripped into windows */
     hbs::HdrWinArgs a;
-    a.stream = d_stream; a.index = d_index; a.nals = nals; a.index_cap = index_cap; a.window = header_window;
-    a.arena_bytes = hbs::hdrwin_arena_bytes(index_cap, header_window, stream_bytes);
-    const uint64_t b_arena = round256(a.arena_bytes + 64), b_idx = round256(index_cap * sizeof(hbs_nal_entry));
-    const uint64_t b_notes = round256(index_cap * 16);
-    if (b_arena + b_idx + b_notes + 256 > c->ws2_bytes) {
+    /* everything below is sized by the NALs FOUND (known since the wait above), not by the caller's index capacity: a default
+     * capacity of stream_bytes / 64 entries would ask for 137 GB of windows on a 16 GiB stream (round 3's advice) */
+    const uint64_t slots = nals ? nals : 1;
+    a.stream = d_stream; a.index = d_index; a.nals = nals; a.index_cap = slots; a.window = header_window;
+    a.arena_bytes = hbs::hdrwin_arena_bytes(slots, header_window, stream_bytes);
+    const uint64_t b_arena = round256(a.arena_bytes + 64), b_idx = round256(slots * sizeof(hbs_nal_entry));
+    const uint64_t b_notes = round256(slots * 16);
+    if (b_arena + b_idx + b_notes + 256 > c->ws2_bytes) {                 /* grow-only */
         if (c->ws2) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ws2); c->ws2 = nullptr; c->ws2_bytes = 0; }
         const hipError_t e = hipMalloc(&c->ws2, b_arena + b_idx + b_notes + 256);
         if (e != hipSuccess) return fail(c, e, "hipMalloc(header windows)");

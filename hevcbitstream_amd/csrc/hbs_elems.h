@@ -96,8 +96,8 @@ __device__ __forceinline__ void look_back_publish(unsigned long long* desc, uint
     }
 }
 
-/* second half: fold the tiles in front, publish the inclusive prefix.  May run long after the first (hbs_scan6.hip
- * does other work in between, so that the predecessors have published by the time it asks). */
+/* second half: fold the tiles in front, publish the inclusive prefix.  May run long after the first (an experiment of round 2
+ * did other work in between, so that the predecessors had published by the time it asked). */
 __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
                                                   RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
 {

@@ -17,8 +17,8 @@ extern "C" {
 int hbs_ctx_set_stream(hbs_ctx* ctx, void* hip_stream);
 void* hbs_ctx_get_stream(hbs_ctx* ctx);
 /* internal: an object that lives and dies with the context (hbs_capi.hip) */
-void* hbs_ctx_attachment(hbs_ctx* ctx);
-void hbs_ctx_attach(hbs_ctx* ctx, void* p, void (*free_fn)(void*));
+__attribute__((visibility("hidden"))) void* hbs_ctx_attachment(hbs_ctx* ctx);
+__attribute__((visibility("hidden"))) void hbs_ctx_attach(hbs_ctx* ctx, void* p, void (*free_fn)(void*));
 }
 
 namespace {

@@ -22,6 +22,7 @@ struct ScanArgs {
     hbs_summary* summary;         /* device                                       */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
     int grid_blocks4;                 /* ... of the event-sparse kernel                                        */
+    int spare_wgs;                    /* hbs_ctx_reserve_workgroups: slots (of 256 threads) every scan kernel leaves free     */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
     int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */
     int variant;                  /* 0: automatic (density probe, then event-sparse or LDS-image kernel, decided on the device),
@@ -32,6 +33,13 @@ struct ScanArgs {
 /* persistent grid size for `device` (CUs x co-resident workgroups per CU) */
 int scan_grid_blocks(int device, int* blocks_per_cu_out);
 hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st);
+/* an arena-less call that goes to the streaming index-only kernel (5): pinned, or automatic from 1 GiB up (below, the
+ * event-sparse kernel without an arena is quicker: scripts/experiments/index_only_by_size.py).  ONE rule for the launcher and
+ * for what hbs_ctx_last_kernel reports. */
+inline bool scan_uses_index_only(uint64_t n, int variant, const void* rbsp)
+{
+    return rbsp == nullptr && (variant == 5 || (variant == 0 && n >= (1ull << 30)));
+}
 /* automatic mode, at most one 64 KiB tile and a small index: one launch of one workgroup does the whole call */
 bool scan_takes_small_path(uint64_t n, uint64_t index_cap, int variant);
 

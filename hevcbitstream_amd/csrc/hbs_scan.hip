@@ -645,7 +645,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     /* no arena asked for: the streaming index-only kernel takes the place of the event-sparse one */
     /* (from 1 GiB up: below, the event-sparse kernel without an arena is quicker -- 0.126 against 0.139 ms at 512 MiB, 0.233
      * against 0.227 at 1 GiB, 0.458 against 0.403 at 2 GiB; scripts/experiments/index_only_by_size.py) */
-    const bool index_only = a.rbsp == nullptr && (a.variant == 5 || (automatic && a.n >= (1ull << 30)));
+    const bool index_only = scan_uses_index_only(a.n, a.variant, a.rbsp);
     const int sparse_variant = ((a.variant == 5 && !index_only) || automatic) ? 4 : a.variant;
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
     const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;

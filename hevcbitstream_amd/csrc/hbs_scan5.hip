@@ -500,6 +500,9 @@ void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStre
         return e && atoi(e) > 0 && atoi(e) <= 32 ? atoi(e) : 12;
     }();
     uint64_t waves = (uint64_t)cus * (uint64_t)per_cu;
+    /* hbs_ctx_reserve_workgroups: a reserved slot is four wavefronts' worth of registers (one 256-thread workgroup of the
+     * event-sparse kernel); these one-wavefront workgroups fill every SIMD otherwise */
+    if (a.spare_wgs > 0) waves = waves > 4ull * (uint64_t)a.spare_wgs + 64 ? waves - 4ull * (uint64_t)a.spare_wgs : 64;
     if (waves > num_tiles) waves = num_tiles;
     if (waves < 1) waves = 1;
     k_index5_stream<<<dim3((unsigned)waves), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.ws5, a.hdr, gate);

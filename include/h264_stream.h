@@ -7,8 +7,8 @@
  * runs, the answer comes back.  They exist so that code written against the
  * reference (hevc_analyze.c) links unmodified; throughput work should call
  * hbs_index_extract / hbs_emit_annexb on device-resident streams instead.
- * There is no CPU implementation behind them: without a gfx950 GPU they print a
- * diagnostic and abort().
+ * There is no CPU implementation behind them: without a gfx950 GPU they print one
+ * diagnostic on stderr and return the reference's failure values (-1, or 0 NALs found).
  */
 #ifndef _H264_STREAM_H
 #define _H264_STREAM_H        1

@@ -122,7 +122,9 @@ int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
 /* The scan + extract kernels are persistent and fill the GPU: a kernel of another stream (RCCL's, in hbs_gather_index running
  * beside the next scan) finds no CU before the scan ends.  `spare` workgroup slots are left free from now on (0 = none, the
  * default; a multi-GPU caller that overlaps the index gather with the next scan wants ~32 of the 512: with 8 or 16 RCCL still
- * waited for the scan to end, with 32 a one-rank gather of 54 MB took 0.14 ms beside the scan instead of 5.3 ms behind it). */
+ * waited for the scan to end, with 32 a one-rank gather of 54 MB took 0.14 ms beside the scan instead of 5.3 ms behind it).
+ * Covers every scan kernel: the register-tile and LDS-image kernels launch `spare` workgroups fewer, the index-only streaming
+ * kernel 4 x `spare` one-wavefront workgroups fewer.  An HBS_GRID_BLOCKS debugging cap stays a ceiling of its own. */
 int  hbs_ctx_reserve_workgroups(hbs_ctx* ctx, int spare);
 /* Three implementations of the scan kernel exist, with identical results:
  * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
@@ -439,6 +441,16 @@ int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_
 /* Upper bound of the scratch the context will hold for a stream this long
  * (look-back descriptors; allocated lazily, reused between calls). */
 uint64_t hbs_workspace_bytes(uint64_t stream_bytes);
+
+/* Device memory the context itself holds right now (look-back descriptors, run header, padded last tile, the K3 / K4 /
+ * index-only workspace, the header windows of hbs_index_parse): grow-only scratch, sized by what the calls so far needed --
+ * by the NALs FOUND, never by an index capacity.  Caller-owned buffers (stream, index, arena, structs) are not counted. */
+uint64_t hbs_ctx_device_bytes(hbs_ctx* ctx);
+
+/* Legacy single-NAL symbols (h264_stream.h / hevc_stream.h) only.  The derived short-term RPS tables are process state in
+ * the reference (file-static, zero at program start, hevc_stream.c:26-32) and device state here; this puts them back to
+ * "program start", which the reference can only do by starting a new process.  Not part of the reference's API. */
+void hbs_legacy_reset_tables(void);
 
 #ifdef __cplusplus
 }

@@ -15,12 +15,17 @@ def which_struct(t):
     return {32: "vps", 33: "sps", 34: "pps"}.get(t)
 
 
-def oracle_pass(nals):
-    """Feed the NALs, in order, to the oracle's read_hevc_nal_unit restatement."""
-    o = _orc.OracleHevc()
+def oracle_pass(nals, parser=None, timing=None):
+    """Feed the NALs, in order, to the oracle's read_hevc_nal_unit restatement (or to `parser`, e.g. _orc.ReferenceHevc():
+    the compiled reference itself).  timing: a list that receives the seconds spent inside read() alone."""
+    import time
+    o = parser if parser is not None else _orc.OracleHevc()
     exp = []
+    spent = 0.0
     for nal in nals:
+        t0 = time.perf_counter()
         rc = o.read(nal)
+        spent += time.perf_counter() - t0
         nalhdr = o.v["nal"].copy()
         t = int(nalhdr[1])
         rec = {"rc": rc, "nal": nalhdr}
@@ -32,6 +37,8 @@ def oracle_pass(nals):
                 rec["slice_data"] = o.slice_data()
         exp.append(rec)
     o.close()
+    if timing is not None:
+        timing.append(spent)
     return exp
 
 

@@ -34,6 +34,18 @@ def test_library_exports_everything_declared():
     C.c_void_p.in_dll(lib, "h264_dbgfile")          # data symbol hevc_analyze.c uses
 
 
+def test_nothing_is_exported_that_no_header_declares():
+    """the other direction (round 3's verdict found three undeclared exports): every function the library exports is
+    declared in include/ -- internal hooks are hidden, test hooks are documented where a user can see them"""
+    import subprocess
+    so = os.path.join(ROOT, "hevcbitstream_amd", "libhevcbitstream_amd.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW"}
+    exported = {n for n in exported if not n.startswith(("_Z", "__hip", "_init", "_fini"))}
+    extra = exported - declared_functions()
+    assert not extra, "exported but declared in no header of include/: %s" % sorted(extra)
+
+
 def test_python_binding_lists_the_same_batch_api():
     from hevcbitstream_amd.api import EXPORTS
     for n in EXPORTS:
@@ -58,7 +70,7 @@ def test_struct_sizes_of_public_records():
 
 def test_only_the_checkers_touch_the_oracle():
     """oracle/ is test infrastructure: the product (package sources, the C-ABI library's objects, scripts/) never
-    names it; bench.py does so only inside its cpu_baseline leg, __graft_entry__.py in build() (building the
+    names it; bench.py does so only inside its cpu_baseline leg (the functions named cpu_baseline*), __graft_entry__.py in build() (building the
     checker) and smoke() (checking against it).  Tools that compare against the oracle live in tests/tools/."""
     pat = re.compile(r"\boracle\b|_orc\b|liboracle|hbs_oracle")
     product = []
@@ -74,8 +86,11 @@ def test_only_the_checkers_touch_the_oracle():
                 raise AssertionError("%s:%d includes an oracle header" % (path, ln))
     # bench.py: every use sits inside cpu_baseline()
     src = open(os.path.join(ROOT, "bench.py")).read()
-    body = re.search(r"^def cpu_baseline\(.*?(?=^def |\Z)", src, flags=re.S | re.M).group(0)
-    rest = src.replace(body, "")
+    rest = src
+    bodies = re.findall(r"^def cpu_baseline\w*\(.*?(?=^def |\Z)", src, flags=re.S | re.M)       # cpu_baseline, cpu_baseline_parse
+    assert bodies
+    for body in bodies:
+        rest = rest.replace(body, "")
     for ln, line in enumerate(rest.splitlines(), 1):
         code = line.split("#")[0]
         assert not (pat.search(code) and ("import" in code or "oracle(" in code or "CDLL" in code)), "bench.py outside cpu_baseline: " + line.strip()

@@ -136,3 +136,33 @@ def test_streams_without_nals_and_small_index(ctx):
     s2 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
     with pytest.raises(hbs.HbsError):
         ctx.index_parse_async(d, index, 2, parsed, None, s1, s2)
+
+
+def test_workspace_is_sized_by_the_nals_found_not_by_the_index_capacity():
+    """round 3's advice: with the default index capacity (stream_bytes / 3 entries on a small stream) the header windows
+    used to be sized by it -- 11 GB for a 64 MiB stream.  They are sized by the NALs the scan found."""
+    import torch
+    import hevcbitstream_amd as hbs
+    from hevcbitstream_amd.api import PARSED, SUMMARY
+    c = hbs.Context(0)
+    try:
+        stream, _ = stream_4k30(5, n_pictures=400, slices_per_picture=4, idr_every=30, payload_bytes=(20000, 40000))
+        s = np.frombuffer(stream, dtype=np.uint8).copy()
+        d = torch.from_numpy(s).cuda()
+        cap = c.default_index_cap(d.numel())
+        assert cap > 1_000_000                                    # the capacity is far above the ~1 700 NALs there are
+        index = torch.zeros(cap * 32, dtype=torch.uint8, device="cuda")
+        n_guess = 4000
+        parsed = torch.empty(n_guess * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+        structs = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        s1 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+        s2 = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+        n = c.index_parse_async(d, index, cap, parsed, structs, s1, s2)
+        assert 1000 < n < n_guess and int(c.read_summary(s2)["error"]) == 0
+        held = c.device_bytes()
+        assert held < 64 << 20, "context scratch %d bytes for a %d-byte stream of %d NALs" % (held, d.numel(), n)
+        # and the answer is the arena path's
+        a, b = both_ways(c, stream)
+        same(a, b)
+    finally:
+        c.close()

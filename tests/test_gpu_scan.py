@@ -222,6 +222,39 @@ def test_automatic_choice_follows_density(orc):
         c.close()
 
 
+def test_last_kernel_reports_what_ran_without_an_arena():
+    """arena-less calls in automatic mode: the streaming index-only kernel (5) from 1 GiB up, the register-tile kernel (4)
+    below -- and hbs_ctx_last_kernel says so on both sides of the threshold (round 3's advice: it used its own, older
+    threshold and reported 5 at 0.8 GiB where 4 had run).  Results of the two agree on the same bytes."""
+    import torch
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    try:
+        g = c.synth_stream(0x51, 110_000)                                   # ~1.05 GiB of ~10 KiB NALs
+        sb = g["stream_bytes"]
+        assert sb > (1 << 30)
+        cut = int(0.8 * (1 << 30)) & ~15
+        got = {}
+        for nbytes, want in ((cut, 4), (sb, 5), (cut, 4)):
+            index, _, summary, cap = c.alloc_outputs(nbytes, index_cap=120_000, want_rbsp=False)
+            c.index_extract_async(g["stream"][:nbytes], index, cap, None, summary)
+            s = c.read_summary(summary)
+            assert int(s["error"]) == 0
+            assert c.last_kernel() == want, (nbytes, c.last_kernel())
+            got[nbytes] = (int(s["nal_count"]), index[: int(s["nal_count"]) * 32].clone())
+        # kernel 4 pinned on the whole stream = kernel 5's automatic answer
+        c.set_kernel(4)
+        index, _, summary, cap = c.alloc_outputs(sb, index_cap=120_000, want_rbsp=False)
+        c.index_extract_async(g["stream"][:sb], index, cap, None, summary)
+        n = int(c.read_summary(summary)["nal_count"])
+        assert c.last_kernel() == 4 and n == got[sb][0] == 110_000
+        a = index[: n * 32].view(torch.int64).view(n, 4)
+        b = got[sb][1].view(torch.int64).view(n, 4)
+        assert torch.equal(a[:, :3], b[:, :3])
+    finally:
+        c.close()
+
+
 def test_calls_capture_into_a_hip_graph(orc):
     """hbs_index_extract only enqueues (no allocation after a warm-up call of the same size, no host wait, the
     kernel choice made on the device): captured once in a HIP graph, it is replayed on other bytes in the same
