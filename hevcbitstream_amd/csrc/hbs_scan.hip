@@ -550,23 +550,35 @@ extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] 
 
 /* the run header is initialised by k_scan_prologue (hbs_scan4.hip); k_scan_small below does the same in front of its tile */
 
-__global__ void k_tail_fixup(const uint8_t* __restrict__ stream, uint64_t n,
-                             hbs_nal_entry* index, uint64_t index_cap,
-                             uint8_t* rbsp, uint64_t rbsp_cap, RunHeader* hdr, hbs_summary* sum)
+/* Behind the tiles, ONE launch (round 4; they were two, k_tail_fixup then k_fill_rbsp_len, each waiting for the one before):
+ * thread 0 applies the end-of-stream rules and writes the summary; everybody derives rbsp_len (and drops TRAILING03 from
+ * rejected NALs) for the entries whose successor the tiles already wrote.  The last entry the tiles found, and one the
+ * end-of-stream rules append, are thread 0's -- it is the only thread that touches them, and nothing here writes
+ * hdr->final_nals / final_kept, which every thread reads. */
+constexpr int kFinishBlocks = 128;
+__global__ __launch_bounds__(256)
+void k_scan_finish(const uint8_t* __restrict__ stream, uint64_t n,
+                   hbs_nal_entry* index, uint64_t index_cap,
+                   uint8_t* rbsp, uint64_t rbsp_cap, RunHeader* hdr, hbs_summary* sum)
 {
-    uint8_t tail[8];
-    for (int i = 0; i < 8; ++i) {
-        const int64_t q = (int64_t)n - 8 + i;
-        tail[i] = (q >= 0) ? stream[q] : (uint8_t)0xFF;
+    const uint64_t found0 = hdr->final_nals;
+    const uint64_t lim = found0 < index_cap ? found0 : index_cap;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k + 1 < lim; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t off = index[k].rbsp_off;
+        const int32_t st = index[k].status;
+        index[k].rbsp_len = (uint32_t)(index[k + 1].rbsp_off - off);
+        if ((st & HBS_ST_ERROR) && (st & HBS_ST_TRAILING03)) index[k].status = st & ~HBS_ST_TRAILING03;
     }
-    tail_fixup(hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum);
-}
-
-__global__ void k_fill_rbsp_len(const RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap)
-{
-    const uint64_t found = hdr->final_nals;
-    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < found; k += (uint64_t)gridDim.x * blockDim.x)
-        fill_rbsp_len(hdr, index, index_cap, k);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint8_t tail[8];
+        for (int i = 0; i < 8; ++i) {
+            const int64_t q = (int64_t)n - 8 + i;
+            tail[i] = (q >= 0) ? stream[q] : (uint8_t)0xFF;
+        }
+        const TailOut t = tail_fixup(hdr, index, index_cap, rbsp, rbsp_cap, tail, n, sum, false);
+        if (lim > 0) fill_rbsp_len_v(index, index_cap, lim - 1, t.found, t.kept);
+        if (t.found > t.found0) fill_rbsp_len_v(index, index_cap, t.found0, t.found, t.kept);
+    }
 }
 
 /* A stream of at most one tile (the legacy single-NAL symbols call with a few KiB): everything the
@@ -678,9 +690,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         }
         if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
     }
-    k_tail_fixup<<<1, 1, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);
-    if (a.index_cap)
-        k_fill_rbsp_len<<<256, 256, 0, st>>>(a.hdr, a.index, a.index_cap);
+    k_scan_finish<<<kFinishBlocks, 256, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);
     return hipGetLastError();
 }
 

@@ -786,9 +786,16 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
         if (tail_tile_bytes == 0 || n == 0) return;
         const uint64_t last_base = ((n - 1) / (uint64_t)tail_tile_bytes) * (uint64_t)tail_tile_bytes;
         const uint32_t tail_bytes = (uint32_t)(k4TailLead + tail_tile_bytes + 64);
-        for (uint32_t i = (uint32_t)(b - kProbeBlocks) * 256u + threadIdx.x; i < tail_bytes; i += (uint32_t)kTailBlocks * 256u) {
-            const int64_t q = (int64_t)last_base + (int64_t)i - k4TailLead;
-            tail[i] = (q >= 0 && (uint64_t)q < n) ? stream[q] : (uint8_t)0xFF;
+        /* 16 bytes per thread and step (round 4; byte by byte this copy was the longest thing in the launch): last_base and the lead
+         * are multiples of 16, so chunk c of the copy is an aligned chunk of the stream -- whole, cut by an end of the stream, or outside */
+        static_assert(k4TailLead % 16 == 0 && (k4TailLead + 64) % 16 == 0, "whole chunks");
+        for (uint32_t c = (uint32_t)(b - kProbeBlocks) * 256u + threadIdx.x; c < tail_bytes / 16u; c += (uint32_t)kTailBlocks * 256u) {
+            const int64_t q = (int64_t)last_base + (int64_t)c * 16 - k4TailLead;
+            if (q >= 0 && (uint64_t)q + 16 <= n) {
+                *reinterpret_cast<u32x4*>(tail + 16u * c) = *reinterpret_cast<const u32x4*>(stream + q);
+            } else {
+                for (int j = 0; j < 16; ++j) tail[16u * c + j] = (q + j >= 0 && (uint64_t)(q + j) < n) ? stream[q + j] : (uint8_t)0xFF;
+            }
         }
     } else {
         const uint64_t t0 = (uint64_t)(b - kProbeBlocks - kTailBlocks) * 256u + threadIdx.x;

@@ -515,12 +515,18 @@ HBS_D uint32_t compact_chunk(const TileView& v, uint32_t c, uint32_t sub, uint64
  * tail[] holds the last 8 stream bytes: tail[i] = S[n-8+i], 0xFF before the
  * stream start.  Returns through `sum`; may bump hdr->final_* for an appended NAL.
  */
-HBS_D void tail_fixup(RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap,
-                      uint8_t* rbsp, uint64_t rbsp_cap,
-                      const uint8_t* tail, uint64_t n, hbs_summary* sum)
+struct TailOut { uint64_t found0, kept0, found, kept; };      /* NALs / kept bytes as the tiles left them, and with an appended last NAL */
+
+/* commit = false: hdr->final_nals / final_kept stay as the tiles left them (k_scan_finish: other threads of the same launch
+ * still read them); the caller takes the final values from the return value */
+HBS_D TailOut tail_fixup(RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap,
+                         uint8_t* rbsp, uint64_t rbsp_cap,
+                         const uint8_t* tail, uint64_t n, hbs_summary* sum, bool commit = true)
 {
     uint64_t found = hdr->final_nals;
     uint64_t kept = hdr->final_kept;
+    TailOut ret;
+    ret.found0 = found; ret.kept0 = kept;
     bool inside = hdr->final_inside != 0;
     const uint8_t* e = tail + 8;                 /* e[-1] is the last stream byte */
 
@@ -579,8 +585,11 @@ HBS_D void tail_fixup(RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap,
     if (count > index_cap) { count = index_cap; flag_error(hdr, (uint32_t)(-HBS_E_CAPACITY)); }
     if (rbsp != nullptr && kept > rbsp_cap) flag_error(hdr, (uint32_t)(-HBS_E_CAPACITY));
 
-    hdr->final_nals = found;
-    hdr->final_kept = kept;
+    if (commit) {
+        hdr->final_nals = found;
+        hdr->final_kept = kept;
+    }
+    ret.found = found; ret.kept = kept;
     sum->nal_count = count;
     sum->nal_found = found;
     sum->rbsp_bytes = kept;
@@ -588,17 +597,21 @@ HBS_D void tail_fixup(RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap,
     sum->stop_reason = stop;
     sum->error = -(int32_t)hdr->error;
     sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
+    return ret;
 }
 
-/* rbsp_len of NAL k from the packed arena offsets (grid-stride over NALs) */
-HBS_D void fill_rbsp_len(const RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap, uint64_t k)
+/* rbsp_len of NAL k from the packed arena offsets (grid-stride over NALs); found / final_kept: the finished run's */
+HBS_D void fill_rbsp_len_v(hbs_nal_entry* index, uint64_t index_cap, uint64_t k, uint64_t found, uint64_t final_kept)
 {
-    const uint64_t found = hdr->final_nals;
     if (k >= found || k >= index_cap) return;
-    const uint64_t next = (k + 1 < found && k + 1 < index_cap) ? index[k + 1].rbsp_off : hdr->final_kept;
+    const uint64_t next = (k + 1 < found && k + 1 < index_cap) ? index[k + 1].rbsp_off : final_kept;
     index[k].rbsp_len = (uint32_t)(next - index[k].rbsp_off);
     /* a rejected NAL reports no consumed size (h264_nal.c:158,166 return before :197) */
     if (index[k].status & HBS_ST_ERROR) index[k].status &= ~HBS_ST_TRAILING03;
+}
+HBS_D void fill_rbsp_len(const RunHeader* hdr, hbs_nal_entry* index, uint64_t index_cap, uint64_t k)
+{
+    fill_rbsp_len_v(index, index_cap, k, hdr->final_nals, hdr->final_kept);
 }
 
 } // namespace hbs

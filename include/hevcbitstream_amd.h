@@ -435,6 +435,32 @@ int hbs_host_free(hbs_ctx* ctx, void* p);
 int hbs_copy_to_device_async(hbs_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
 int hbs_copy_device(hbs_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);
 
+/*
+ * Output buffers placed against the input they are written from.
+ *
+ * On MI355X a kernel that reads one large buffer and writes another in long bursts (hbs_index_extract: stream -> RBSP arena;
+ * hbs_emit_annexb: arena -> stream) runs ~4-5 % slower when both buffers lie in the same one of two classes of physical
+ * memory (16 GiB: 6.20 against 5.90 ms; DESIGN.md section 4, profiles/r04/placement_*.txt) -- decided when the buffers are
+ * allocated, the same for every offset inside them, and invisible to HIP.  hbs_pair_alloc allocates `bytes` of device memory
+ * in 1 GiB physical chunks and MEASURES each chunk against the piece of `d_peer` at the same offset (a content-free copy with
+ * the kernels' access pattern, ~1.5 ms per chunk, on the context's stream: `d_peer` must hold its final size and location,
+ * its contents do not matter and are not changed); a chunk that would run in the slow mode is swapped for another one.
+ * The result is an ordinary device pointer (2 MiB-aligned, usable with every call of this header, hipMemcpy, torch via
+ * __cuda_array_interface__), freed with hbs_pair_free.  Buffers below 384 MiB, or with d_peer == NULL, are allocated
+ * without probing.  Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every other time.
+ * No reference counterpart (the reference's buffers are malloc'ed host memory, hevc_analyze.c:100-103).
+ */
+typedef struct hbs_pair_report {
+    uint32_t chunks;                 /* physical chunks the buffer consists of                                        */
+    uint32_t probed;                 /* chunk candidates measured against the peer                                    */
+    uint32_t rejected;               /* candidates put aside because they paired slowly                               */
+    uint32_t accepted_fast;          /* chunks kept BECAUSE they paired fast (the rest: too small to probe, or budget)*/
+    uint32_t unprobed_after_budget;  /* chunks taken unprobed after nchunks + 16 rejections or when memory ran out    */
+    float    mean_ratio;             /* mean (time against the peer) / (time against itself) of the accepted chunks   */
+} hbs_pair_report;
+int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* report /* may be NULL */);
+int hbs_pair_free(hbs_ctx* ctx, void* ptr);
+
 /* Synchronising copy of a device hbs_summary to the host. */
 int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_summary);
 

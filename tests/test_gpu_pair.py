@@ -1,0 +1,73 @@
+"""hbs_pair_alloc / hbs_pair_free: output buffers placed against their input (include/hevcbitstream_amd.h).  What is tested
+here is function -- the memory is ordinary device memory, results through it are the oracle's, the report adds up, freeing
+works; the speed it buys is measured by scripts/r4/pair_time.py and bench.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_small_buffers_are_plain_memory():
+    import torch
+    import hevcbitstream_amd as hbs
+    from tests import _orc
+    orc = _orc.oracle()
+    c = hbs.Context(0)
+    try:
+        stream, want_idx, want_arena = orc.gen_stream(0x99, 300, 0)
+        d = torch.from_numpy(stream).cuda()
+        index, rbsp, summary, cap = c.alloc_outputs(d.numel(), peer=d)
+        rep = c.last_pair_report
+        assert rep["chunks"] == 1 and rep["probed"] == 0 and rep["rejected"] == 0       # far below the probing size
+        assert rbsp.is_cuda and rbsp.dtype == torch.uint8 and rbsp.numel() == d.numel() + 16 and rbsp.data_ptr() % (2 << 20) == 0
+        c.index_extract_async(d, index, cap, rbsp, summary)
+        s = c.read_summary(summary)
+        n = int(s["nal_count"])
+        assert n == len(want_idx)
+        assert np.array_equal(index[: n * 32].cpu().numpy().view(hbs.NAL_ENTRY), want_idx)
+        assert np.array_equal(rbsp[: int(s["rbsp_bytes"])].cpu().numpy(), want_arena)
+        # torch ops work on it like on any tensor; dropping the last reference gives the memory back
+        rbsp.fill_(7)
+        assert int(rbsp.sum().item()) == 7 * rbsp.numel()
+        view = rbsp[100:200]
+        del rbsp
+        assert int(view.sum().item()) == 700                 # a view keeps the memory alive
+        del view
+        torch.cuda.synchronize()
+        assert c.lib.hbs_pair_free(None, None) == 0 and c.lib.hbs_pair_free(None, 12345) == -3
+    finally:
+        c.close()
+
+
+def test_probed_arena_gives_the_same_bytes_and_the_report_adds_up():
+    """2.2 GiB stream: three chunks, the first two large enough to be probed.  The arena through the paired buffer equals the
+    arena through a torch buffer byte for byte (and both equal the generator's)."""
+    import torch
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    try:
+        g = c.synth_stream(0x77, 230_000)
+        sb, rb, n = g["stream_bytes"], g["rbsp_bytes"], 230_000
+        assert sb > (2 << 30)
+        stream = g["stream"][:sb]
+        index, rbsp, summary, cap = c.alloc_outputs(sb, index_cap=n + 8, peer=stream)
+        rep = c.last_pair_report
+        assert rep["chunks"] == 3 and rep["probed"] >= 2 and rep["probed"] == rep["accepted_fast"] + rep["rejected"]
+        assert rep["rejected"] <= rep["chunks"] + 16
+        if rep["accepted_fast"]:
+            assert 0.90 < rep["mean_ratio"] < 0.985
+        c.index_extract_async(stream, index, cap, rbsp, summary)
+        s = c.read_summary(summary)
+        assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["rbsp_bytes"]) == rb
+        assert torch.equal(rbsp[:rb], g["rbsp"][:rb])
+        # the other direction: the re-emitted stream into a buffer placed against the arena
+        out, rep2 = c.pair_alloc(rbsp, sb + 4096)
+        idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        c.emit_annexb_async(rbsp, rb, index, n, 1, out, idx_out, summary)
+        s = c.read_summary(summary)
+        assert int(s["error"]) == 0 and int(s["stream_bytes"]) == sb
+        assert torch.equal(out[:sb], stream)
+        # host copies work (ordinary device memory)
+        assert np.array_equal(out[:4096].cpu().numpy(), stream[:4096].cpu().numpy())
+    finally:
+        c.close()
