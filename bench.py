@@ -319,7 +319,7 @@ def mixed_stream_line(torch, ctx, stream, sb, n_cap, uniform_ms):
     """the automatic mode on the mixed stream against the uniform one; outputs checked against the LDS-image kernel (whose
     cost does not depend on the data) entry by entry and byte by byte on the device"""
     mixed, dense_bytes = make_mixed(torch, stream, sb)
-    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_cap)
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_cap, peer=mixed)      # placed like the uniform run's arena
     ks = []
     for i in range(4):
         ctx.index_extract_async(mixed, index, cap, rbsp, summary)
@@ -393,7 +393,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     del index
     res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
     res["mixed_stream"]["index_only"] = mixed_index_only(torch, ctx, g["stream"][:sb], sb, n + 64, ms)
-    out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
+    out, emit_placement = ctx.pair_alloc(g["rbsp"], sb + 4096)       # the emitted stream placed against the arena it is read from
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -406,7 +406,8 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
     assert torch.equal(out[:sb], g["stream"][:sb]), "emitted stream != generated stream"
     res["emit_annexb"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s emitted", "ms": round(ms, 3),
-                          "hbm_traffic_GBs": round((rb + sb) / ms / 1e6, 1), "workload": "the bench arena: %d NALs, %.2f GiB" % (n, rb / 2**30)}
+                          "hbm_traffic_GBs": round((rb + sb) / ms / 1e6, 1), "workload": "the bench arena: %d NALs, %.2f GiB" % (n, rb / 2**30),
+                          "output_placement": "hbs_pair_alloc against the arena: %s" % json.dumps(emit_placement)}
     del out, idx_out
     stream, _ = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
     d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
@@ -533,6 +534,7 @@ def main():
     ap.add_argument("--cpu-sample-nals", type=int, default=1_000_000, help="0 disables the CPU baseline leg")
     ap.add_argument("--other-kernels", type=int, default=1, help="0 skips the emit / parse / write measurements (N = 1 only)")
     ap.add_argument("--sweep", type=int, default=1, help="0 skips other_kernels' NAL-size sweep (profiling passes)")
+    ap.add_argument("--plain-alloc", type=int, default=0, help="1: the RBSP arena from torch's allocator instead of hbs_pair_alloc (placement left to chance)")
     ap.add_argument("--exercise-gather", action="store_true",
                     help="dev aid: run the N > 1 code path (RCCL group, pipelined index gather) with a one-rank group on one GPU")
     args = ap.parse_args()
@@ -581,7 +583,13 @@ def main():
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
     stream = g["stream"][:sb]
     gen_rbsp, gen_index = g["rbsp"], g["index"]
-    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
+    # the RBSP arena is allocated by the library AGAINST the stream it will be written from (hbs_pair_alloc: on MI355X a
+    # stream / arena pair runs ~5 % slower when both lie in the same one of two classes of physical memory, which plain
+    # allocations hit about every other time -- DESIGN.md section 4); --plain-alloc 1 takes torch's allocator instead
+    t_alloc = time.perf_counter()
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=None if args.plain_alloc else stream)
+    torch.cuda.synchronize()
+    placement = None if args.plain_alloc else dict(ctx.last_pair_report, seconds=round(time.perf_counter() - t_alloc, 3))
 
     from hevcbitstream_amd import shard
     # N > 1: the one exchange of the path is the gather of the NAL index -- the C ABI's hbs_gather_index (counts, then exactly
@@ -698,7 +706,9 @@ def main():
                        "stream_bytes_per_gpu": sb, "nals_per_gpu": n,
                        "parallelism": "%d independent shard(s), one per GPU%s" % (world, "; index gathered to every rank by hbs_gather_index "
                                        "(C ABI, RCCL world %d as the communicator reports it), pipelined under the next step's scan" % gatherer.comm.world_seen() if multi else ""),
-                       "grid": "%d persistent workgroups (%d per CU) x %s" % (blocks, per_cu, geometry)},
+                       "grid": "%d persistent workgroups (%d per CU) x %s" % (blocks, per_cu, geometry),
+                       "arena_placement": ("hbs_pair_alloc against the stream (1 GiB chunks classed by measurement, outside the timed region): %s"
+                                           % json.dumps(placement)) if placement is not None else "torch allocator (placement left to chance)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4),

@@ -35,7 +35,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
 
 
 PAIR_REPORT = np.dtype([("chunks", "<u4"), ("probed", "<u4"), ("rejected", "<u4"), ("accepted_fast", "<u4"),
-                        ("unprobed_after_budget", "<u4"), ("mean_ratio", "<f4")])
+                        ("unprobed_after_budget", "<u4"), ("reserved", "<f4")])
 
 
 class _PairedMemory:
@@ -239,7 +239,7 @@ class Context:
         holder = _PairedMemory(self.lib, ptr.value, nbytes)
         tensor = t.as_tensor(holder, device=t.device("cuda", self.device))       # zero-copy: torch keeps `holder` alive
         assert tensor.data_ptr() == ptr.value
-        return tensor, {k: (float(rep[0][k]) if k == "mean_ratio" else int(rep[0][k])) for k in PAIR_REPORT.names}
+        return tensor, {k: int(rep[0][k]) for k in PAIR_REPORT.names if k != "reserved"}
 
     def alloc_outputs(self, stream_bytes, index_cap=None, want_rbsp=True, peer=None):
         """Device buffers sized for a stream: (index[u8, cap*32], rbsp[u8] or None, summary[u8, 64]).

@@ -159,6 +159,11 @@ void hbs_ctx_destroy(hbs_ctx* c)
     delete c;
 }
 
+/* internal (hbs_place.hip): what hbs_last_error will say; not exported */
+__attribute__((visibility("hidden"))) void hbs_ctx_set_error(hbs_ctx* c, const char* what, int hip_error)
+{
+    if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString((hipError_t)hip_error));
+}
 /* internal (hbs_ingest.hip): one object kept alive with the context, freed with it; not exported */
 __attribute__((visibility("hidden"))) void* hbs_ctx_attachment(hbs_ctx* c) { return c ? c->attachment : nullptr; }
 __attribute__((visibility("hidden"))) void hbs_ctx_attach(hbs_ctx* c, void* p, void (*free_fn)(void*))

@@ -28,6 +28,8 @@
 #include <vector>
 #include "hevcbitstream_amd.h"
 
+extern "C" __attribute__((visibility("hidden"))) void hbs_ctx_set_error(hbs_ctx* c, const char* what, int hip_error);
+
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +38,8 @@ constexpr uint64_t kChunk = 1ull << 30;           /* physical chunks: the classe
 constexpr uint64_t kGran = 2ull << 20;
 constexpr int kRows = 48;                          /* K12's wavefront: 48 rows of 1 KiB in registers */
 constexpr uint64_t kTile = 4ull * kRows * 1024;    /* 192 KiB per workgroup */
-constexpr uint64_t kProbeMin = 384ull << 20;       /* below this a probe does not separate the classes (256 MiB: 2.5 %, 64 MiB: nothing) */
+constexpr double kFastRatio = 0.985;               /* a pairing is "fast" when it takes less than this x the chunk against itself: the classes are 3-4 % apart
+                                                      at half a GiB, repeated measurements 0.3 % (256 MiB: 2.5 % apart, 64 MiB: nothing) */
 
 /* K12's memory side without its logic: a persistent workgroup takes 192 KiB tiles by ticket, every wavefront loads its 48 rows,
  * then stores them.  Content-free, so the same bytes need not be on both sides of a comparison. */
@@ -123,6 +126,19 @@ void release_pair(Pair* p)
 
 extern "C" {
 
+/*
+ * The search.  Physical memory comes in long runs of one class in the order hipMemCreate hands it out (runs of 5-10 chunks seen),
+ * so "reject and ask again" would walk a whole run a GiB at a time.  Instead:
+ *   1. a reference chunk R; every piece of the peer is classed against it (same class as R / the other class);
+ *   2. candidates are created, each in a scratch address slot of its own (an address is never mapped twice: re-mapping one
+ *      left stale translations behind on this stack), and classed against R the same way;
+ *   3. a chunk of the buffer wants a candidate of the class its peer piece is NOT in; candidates nobody wants are put aside
+ *      (they stay allocated, so that the next ones are other memory), and after two of those in a row an unmapped "ballast"
+ *      allocation of 4, 8, 16 ... GiB skips ahead in the run;
+ *   4. the chosen candidates move from their scratch slots to their place in the buffer; pile and ballast are given back.
+ * Bounded: at most nchunks + kExtraCands candidates and kBallastMax of ballast; when memory runs out or the bound is reached,
+ * whatever is at hand is used (the report says how many chunks were placed knowingly).
+ */
 int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
 {
     if (!ctx || !out) return HBS_E_ARG;
@@ -141,71 +157,158 @@ int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64
     hipMemAccessDesc acc;
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipError_t e;
+#define PAIR_FAIL(what) { hbs_ctx_set_error(ctx, "hbs_pair_alloc: " what, (int)e); rc = HBS_E_HIP; }
 
+    /* layout: whole chunks of 1 GiB (probed when the peer allows), then a remainder of its own (< half a chunk: unprobed) */
+    const uint64_t total = up(bytes, kGran);
+    const bool want_probe = d_peer != nullptr && peer_bytes >= kChunk / 2 && total >= kChunk && !getenv("HBS_PAIR_NO_PROBE");
+    uint64_t nfull = want_probe ? total / kChunk : 0;
+    uint64_t rest = total - nfull * kChunk;
+    if (want_probe && rest >= kChunk / 2) { nfull += 1; rest = 0; }
     Pair* p = new (std::nothrow) Pair();
     if (!p) return HBS_E_HIP;
     p->device = device;
-    p->va_bytes = up(bytes, kGran);
-    if (hipMemAddressReserve(&p->va, p->va_bytes, kGran, nullptr, 0) != hipSuccess) { delete p; return HBS_E_HIP; }
-    uint8_t* const base = static_cast<uint8_t*>(p->va);
-
-    /* probing needs the caller's input to be there: everything enqueued on the context's stream so far */
-    const bool want_probe = d_peer != nullptr && peer_bytes >= kProbeMin && bytes >= kProbeMin && !getenv("HBS_PAIR_NO_PROBE");
-    Prober* pr = want_probe ? new (std::nothrow) Prober(st, device) : nullptr;
-    if (pr && !pr->ok) { delete pr; pr = nullptr; }
-    std::vector<hipMemGenericAllocationHandle_t> pile;              /* chunks put aside: kept until the end, so that the next one is other memory */
-    std::vector<uint64_t> pile_sizes;
-    const uint64_t nchunks = (p->va_bytes + kChunk - 1) / kChunk;
-    int budget = (int)nchunks + 16;                                  /* chunks that may be put aside in all */
-    double ratio_sum = 0.0;
+    p->va_bytes = nfull * kChunk + rest;
     int rc = 0;
-    for (uint64_t k = 0; k < nchunks && rc == 0; ++k) {
-        const uint64_t off = k * kChunk;
-        const uint64_t size = std::min(kChunk, p->va_bytes - off);
-        /* the input piece this chunk will be written from (K12: arena offset ~ stream offset; K3: the same the other way) */
-        const uint64_t half = (size / 2) / kTile * kTile;
-        const uint64_t peer_last = peer_bytes > half ? (uint64_t)((peer_bytes - half) & ~(uint64_t)15) : (uint64_t)0;
-        const uint64_t peer_off = std::min(off, peer_last);
-        const bool probe = pr != nullptr && half >= kProbeMin / 2 && peer_bytes >= half;
-        for (;;) {
-            hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, size, &prop, 0) != hipSuccess) {
-                /* out of memory while chunks are on the pile: give one back and take what comes, unprobed */
-                if (pile.empty()) { rc = HBS_E_HIP; break; }
-                (void)hipMemRelease(pile.back()); pile.pop_back(); pile_sizes.pop_back();
-                budget = 0;
-                continue;
-            }
-            if (hipMemMap(base + off, size, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); rc = HBS_E_HIP; break; }
-            if (hipMemSetAccess(base + off, size, &acc, 1) != hipSuccess) { (void)hipMemUnmap(base + off, size); (void)hipMemRelease(h); rc = HBS_E_HIP; break; }
-            bool keep = true;
-            if (probe && budget > 0) {
-                /* the chunk against itself (one class by construction: the slow case), then the input piece against the chunk */
-                const double t_self = pr->copy_ms(base + off, base + off + half, half);
-                const double t_pair = pr->copy_ms(static_cast<const uint8_t*>(d_peer) + peer_off, base + off + half, half);
-                if (t_self > 0 && t_pair > 0) {
-                    r.probed += 1;
-                    keep = t_pair < 0.985 * t_self;              /* the classes are ~3.5 % apart at this size, repeat measurements 0.3 % */
-                    if (keep) ratio_sum += t_pair / t_self;
+    e = hipMemAddressReserve(&p->va, p->va_bytes, kGran, nullptr, 0);
+    if (e != hipSuccess) { PAIR_FAIL("hipMemAddressReserve") delete p; return rc; }
+    uint8_t* const base = static_cast<uint8_t*>(p->va);
+    auto map_at = [&](uint64_t off, uint64_t size, hipMemGenericAllocationHandle_t h) -> bool {
+        e = hipMemMap(base + off, size, 0, h, 0);
+        if (e != hipSuccess) { PAIR_FAIL("hipMemMap") return false; }
+        e = hipMemSetAccess(base + off, size, &acc, 1);
+        if (e != hipSuccess) { PAIR_FAIL("hipMemSetAccess") (void)hipMemUnmap(base + off, size); return false; }
+        p->handles.push_back(h); p->offs.push_back(off); p->sizes.push_back(size);
+        return true;
+    };
+    if (rest) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, rest, &prop, 0);
+        if (e != hipSuccess) { PAIR_FAIL("hipMemCreate") }
+        else if (!map_at(nfull * kChunk, rest, h)) (void)hipMemRelease(h);
+    }
+
+    struct Cand { hipMemGenericAllocationHandle_t h; uint8_t* va; int other; bool used; };     /* other: 1 = not R's class, 0 = R's, -1 = unknown */
+    std::vector<Cand> cands;
+    std::vector<hipMemGenericAllocationHandle_t> ballast;
+    constexpr int kExtraCands = 24;
+    constexpr uint64_t kBallastMax = 96ull << 30;
+    const uint64_t half = (kChunk / 2) / kTile * kTile;
+    void* scratch = nullptr;
+    const uint64_t scratch_slots = nfull + kExtraCands + 1;
+    Prober* pr = nullptr;
+    if (rc == 0 && nfull) {
+        e = hipMemAddressReserve(&scratch, scratch_slots * kChunk, kGran, nullptr, 0);
+        if (e != hipSuccess) { PAIR_FAIL("hipMemAddressReserve(scratch)") }
+        pr = new (std::nothrow) Prober(st, device);
+        if (pr && !pr->ok) { delete pr; pr = nullptr; }
+    }
+    auto new_cand = [&]() -> bool {                      /* false: no more memory (or address slots) */
+        if (cands.size() >= scratch_slots) return false;
+        Cand c; c.other = -1; c.used = false;
+        if (hipMemCreate(&c.h, kChunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        c.va = static_cast<uint8_t*>(scratch) + cands.size() * kChunk;
+        if (hipMemMap(c.va, kChunk, 0, c.h, 0) != hipSuccess || hipMemSetAccess(c.va, kChunk, &acc, 1) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipMemRelease(c.h); return false;
+        }
+        cands.push_back(c);
+        return true;
+    };
+    std::vector<int> want(nfull, -1);                    /* class wanted for chunk k: 1 = not R's, 0 = R's, -1 = no preference */
+    if (rc == 0 && nfull && pr && new_cand()) {
+        Cand& R = cands[0];
+        const double self_r = pr->copy_ms(R.va, R.va + half, half);
+        R.other = 0;
+        const bool dbg = getenv("HBS_PAIR_DEBUG") != nullptr;
+        uint64_t need[2] = {0, 0};
+        for (uint64_t k = 0; k < nfull && self_r > 0; ++k) {
+            const uint64_t peer_last = peer_bytes > half ? (uint64_t)((peer_bytes - half) & ~(uint64_t)15) : (uint64_t)0;
+            const uint64_t peer_off = std::min(k * kChunk, peer_last);
+            const double t = pr->copy_ms(static_cast<const uint8_t*>(d_peer) + peer_off, R.va + half, half);
+            if (t <= 0) break;
+            const int peer_other = t < kFastRatio * self_r ? 1 : 0;          /* the peer piece is in the class R is not in */
+            want[k] = 1 - peer_other;
+            need[want[k]] += 1;
+            r.probed += 1;
+            if (dbg) fprintf(stderr, "hbs_pair_alloc: peer piece %llu against the reference chunk: %.4f / %.4f = %.4f -> chunk wants class %d\n",
+                             (unsigned long long)k, t, self_r, t / self_r, want[k]);
+        }
+        uint64_t have[2] = {1, 0};
+        uint64_t ballast_bytes = 0, next_ballast = 4ull << 30;
+        int unwanted_in_a_row = 0;
+        while ((have[0] < need[0] || have[1] < need[1]) && cands.size() < nfull + (uint64_t)kExtraCands) {
+            if (unwanted_in_a_row >= 2 && ballast_bytes + next_ballast <= kBallastMax) {
+                hipMemGenericAllocationHandle_t b;
+                if (hipMemCreate(&b, next_ballast, &prop, 0) == hipSuccess) {
+                    ballast.push_back(b); ballast_bytes += next_ballast; next_ballast *= 2; unwanted_in_a_row = 0;
+                    if (dbg) fprintf(stderr, "hbs_pair_alloc: ballast %llu GiB\n", (unsigned long long)(ballast_bytes >> 30));
+                } else {
+                    (void)hipGetLastError();
+                    next_ballast /= 2;
+                    if (next_ballast < (1ull << 30)) break;
+                    continue;
                 }
             }
-            if (keep) {
-                p->handles.push_back(h); p->offs.push_back(off); p->sizes.push_back(size);
-                if (probe && budget <= 0) r.unprobed_after_budget += 1;
-                break;
-            }
-            (void)hipMemUnmap(base + off, size);
-            pile.push_back(h); pile_sizes.push_back(size);
-            r.rejected += 1;
-            budget -= 1;
+            if (!new_cand()) break;
+            Cand& X = cands.back();
+            const double self_x = pr->copy_ms(X.va, X.va + half, half);
+            const double t = pr->copy_ms(cands[0].va, X.va + half, half);
+            if (self_x <= 0 || t <= 0) break;
+            X.other = t < kFastRatio * self_x ? 1 : 0;
+            r.probed += 1;
+            const bool wanted = have[X.other] < need[X.other];
+            have[X.other] += 1;
+            unwanted_in_a_row = wanted ? 0 : unwanted_in_a_row + 1;
+            if (!wanted) r.rejected += 1;
+            if (dbg) fprintf(stderr, "hbs_pair_alloc: candidate %zu against the reference chunk: %.4f / %.4f = %.4f -> class %d%s\n",
+                             cands.size() - 1, t, self_x, t / self_x, X.other, wanted ? "" : " (not needed)");
         }
     }
-    for (auto h : pile) (void)hipMemRelease(h);
+    /* hand the candidates out: first to the chunks that want their class, then whatever is left to whoever is left */
+    std::vector<int> pick(nfull, -1);
+    for (int pass = 0; pass < 2 && rc == 0; ++pass)
+        for (uint64_t k = 0; k < nfull; ++k) {
+            if (pick[k] >= 0) continue;
+            for (size_t c = 0; c < cands.size(); ++c) {
+                if (cands[c].used) continue;
+                if (pass == 0 && (want[k] < 0 || cands[c].other != want[k])) continue;
+                pick[k] = (int)c; cands[c].used = true;
+                if (pass == 0) r.accepted_fast += 1; else r.unprobed_after_budget += 1;
+                break;
+            }
+        }
+    for (uint64_t k = 0; k < nfull && rc == 0; ++k) {
+        hipMemGenericAllocationHandle_t h;
+        if (pick[k] >= 0) {
+            Cand& c = cands[(size_t)pick[k]];
+            e = hipMemUnmap(c.va, kChunk);
+            if (e != hipSuccess) { PAIR_FAIL("hipMemUnmap") break; }
+            h = c.h;
+        } else {
+            e = hipMemCreate(&h, kChunk, &prop, 0);
+            if (e != hipSuccess) { PAIR_FAIL("hipMemCreate") break; }
+            r.unprobed_after_budget += 1;
+        }
+        if (!map_at(k * kChunk, kChunk, h)) {
+            if (pick[k] >= 0) { cands[(size_t)pick[k]].used = false; cands[(size_t)pick[k]].va = nullptr; }    /* released with the rest below */
+            else (void)hipMemRelease(h);
+            break;
+        }
+    }
+    /* everything that was not chosen goes back */
+    (void)hipStreamSynchronize(st);
+    for (auto& c : cands) {
+        if (c.used) continue;
+        if (c.va) (void)hipMemUnmap(c.va, kChunk);
+        (void)hipMemRelease(c.h);
+    }
+    for (auto b : ballast) (void)hipMemRelease(b);
+    if (scratch) (void)hipMemAddressFree(scratch, scratch_slots * kChunk);
     delete pr;
+#undef PAIR_FAIL
     if (rc) { release_pair(p); return rc; }
     r.chunks = (uint32_t)p->handles.size();
-    r.accepted_fast = (uint32_t)(r.probed - r.rejected);
-    r.mean_ratio = r.accepted_fast ? (float)(ratio_sum / r.accepted_fast) : 0.f;
     {
         std::lock_guard<std::mutex> g(g_mu);
         g_pairs[p->va] = p;

@@ -442,21 +442,26 @@ int hbs_copy_device(hbs_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes
  * hbs_emit_annexb: arena -> stream) runs ~4-5 % slower when both buffers lie in the same one of two classes of physical
  * memory (16 GiB: 6.20 against 5.90 ms; DESIGN.md section 4, profiles/r04/placement_*.txt) -- decided when the buffers are
  * allocated, the same for every offset inside them, and invisible to HIP.  hbs_pair_alloc allocates `bytes` of device memory
- * in 1 GiB physical chunks and MEASURES each chunk against the piece of `d_peer` at the same offset (a content-free copy with
- * the kernels' access pattern, ~1.5 ms per chunk, on the context's stream: `d_peer` must hold its final size and location,
- * its contents do not matter and are not changed); a chunk that would run in the slow mode is swapped for another one.
+ * in 1 GiB physical chunks and MEASURES where they lie relative to `d_peer` (a content-free copy with the kernels' access
+ * pattern, half a GiB at a time, on the context's stream; `d_peer` must have its final size and location, its contents do
+ * not matter and are not changed): every 1 GiB piece of the peer and every candidate chunk is classed against one reference
+ * chunk, and chunk k of the buffer is taken from the class that piece k of the peer is not in.  Candidates of the wrong class
+ * are held until the end (and the allocator is pushed ahead by up to 96 GiB of unmapped ballast) so that other memory comes
+ * next; all of it is given back before the call returns.  Cost: ~1 ms per GiB when the first candidates fit, up to a few
+ * hundred ms otherwise.  When memory runs short or 24 surplus candidates did not help, the remaining chunks are taken as they
+ * come -- the buffer is always valid, the report says how it was placed.
  * The result is an ordinary device pointer (2 MiB-aligned, usable with every call of this header, hipMemcpy, torch via
- * __cuda_array_interface__), freed with hbs_pair_free.  Buffers below 384 MiB, or with d_peer == NULL, are allocated
- * without probing.  Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every other time.
+ * __cuda_array_interface__), freed with hbs_pair_free.  Buffers below 1 GiB, peers below 512 MiB or d_peer == NULL: no
+ * probing.  Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every other time.
  * No reference counterpart (the reference's buffers are malloc'ed host memory, hevc_analyze.c:100-103).
  */
 typedef struct hbs_pair_report {
-    uint32_t chunks;                 /* physical chunks the buffer consists of                                        */
-    uint32_t probed;                 /* chunk candidates measured against the peer                                    */
-    uint32_t rejected;               /* candidates put aside because they paired slowly                               */
-    uint32_t accepted_fast;          /* chunks kept BECAUSE they paired fast (the rest: too small to probe, or budget)*/
-    uint32_t unprobed_after_budget;  /* chunks taken unprobed after nchunks + 16 rejections or when memory ran out    */
-    float    mean_ratio;             /* mean (time against the peer) / (time against itself) of the accepted chunks   */
+    uint32_t chunks;                 /* physical chunks the buffer consists of (1 GiB each + a remainder)              */
+    uint32_t probed;                 /* measurements taken: peer pieces and candidate chunks against the reference     */
+    uint32_t rejected;               /* candidates of a class no chunk still wanted (held, then given back)            */
+    uint32_t accepted_fast;          /* chunks placed in the class their peer piece is NOT in (the fast pairing)       */
+    uint32_t unprobed_after_budget;  /* chunks taken as they came (no memory / no candidate of the wanted class left)   */
+    float    reserved;
 } hbs_pair_report;
 int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* report /* may be NULL */);
 int hbs_pair_free(hbs_ctx* ctx, void* ptr);

@@ -14,7 +14,7 @@ ctx = hbs.Context(0)
 g = ctx.synth_stream(0x1234, N, mode)          # runs the generator + K3 once
 rb, sb = g["rbsp_bytes"], g["stream_bytes"]
 print("rbsp bytes", rb, "stream bytes", sb)
-out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
+out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda") if os.environ.get("HBS_PLAIN_ALLOC") else ctx.pair_alloc(g["rbsp"], sb + 4096)[0]
 idx_out = torch.empty(N * 32, dtype=torch.uint8, device="cuda")
 summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]

@@ -60,7 +60,8 @@ def sweep(torch, hbs, ctx, sizes, gib, check=True):
     for mean in sizes:
         arena, rb, idx, n, stream_buf, sb = make_stream(torch, np, ctx, mean, int(gib * 2**30))
         stream = stream_buf[:sb]
-        index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 64)
+        plain = bool(os.environ.get("HBS_PLAIN_ALLOC"))          # default: outputs placed against their inputs (hbs_pair_alloc)
+        index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 64, peer=None if plain else stream)
         ctx.set_kernel(0)
         ms_x = best_ms(torch, lambda: ctx.index_extract_async(stream, index, cap, rbsp, summary))
         s = ctx.read_summary(summary)
@@ -83,7 +84,7 @@ def sweep(torch, hbs, ctx, sizes, gib, check=True):
         b = index_b[: n * 32].view(torch.int64).view(n, 4)
         assert int(s["nal_count"]) == n and torch.equal(a[:, :2], b[:, :2]), "mean %d: index-only start / end differ" % mean
         del index_b
-        out = torch.empty(sb + 4096, dtype=torch.uint8, device=stream.device)
+        out = torch.empty(sb + 4096, dtype=torch.uint8, device=stream.device) if plain else ctx.pair_alloc(rbsp, sb + 4096)[0]
         esum = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device=stream.device)
         ctx.set_emit_path(-1)
         ms_e = best_ms(torch, lambda: ctx.emit_annexb_async(rbsp, rb, index, n, 0, out, None, esum))

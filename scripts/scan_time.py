@@ -26,7 +26,7 @@ def main():
     g = ctx.synth_stream(0x1234, n, args.mode)
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
     stream = g["stream"][:sb]
-    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8)
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=None if os.environ.get("HBS_PLAIN_ALLOC") else stream)
     res = {"lib": os.environ.get("HBS_LIB", "default"), "stream_bytes": sb, "nals": n}
     ks = []
     for i in range(args.reps + 1):

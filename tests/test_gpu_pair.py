@@ -40,7 +40,7 @@ def test_small_buffers_are_plain_memory():
 
 
 def test_probed_arena_gives_the_same_bytes_and_the_report_adds_up():
-    """2.2 GiB stream: three chunks, the first two large enough to be probed.  The arena through the paired buffer equals the
+    """2.2 GiB stream: two chunks of 1 GiB, placed by measurement, and a remainder.  The arena through the paired buffer equals the
     arena through a torch buffer byte for byte (and both equal the generator's)."""
     import torch
     import hevcbitstream_amd as hbs
@@ -52,10 +52,9 @@ def test_probed_arena_gives_the_same_bytes_and_the_report_adds_up():
         stream = g["stream"][:sb]
         index, rbsp, summary, cap = c.alloc_outputs(sb, index_cap=n + 8, peer=stream)
         rep = c.last_pair_report
-        assert rep["chunks"] == 3 and rep["probed"] >= 2 and rep["probed"] == rep["accepted_fast"] + rep["rejected"]
-        assert rep["rejected"] <= rep["chunks"] + 16
-        if rep["accepted_fast"]:
-            assert 0.90 < rep["mean_ratio"] < 0.985
+        # two whole chunks (probed) and a remainder of its own
+        assert rep["chunks"] == 3 and rep["probed"] >= 2 and rep["accepted_fast"] + rep["unprobed_after_budget"] == 2
+        assert rep["rejected"] <= 24
         c.index_extract_async(stream, index, cap, rbsp, summary)
         s = c.read_summary(summary)
         assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["rbsp_bytes"]) == rb
