@@ -488,7 +488,10 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     }
     const uint64_t b_n = round256((n_nals + 1) * 8);
     const uint64_t b_rows = round256(hbs::parse_own_rows_bytes(n_nals));
-    int rc = ensure_ws(c, 3 * b_n + 512 + round256(1024 * 24) + b_rows);
+    /* the exact re-walk's records: three words per NAL, a summary word per 256, the temporaries of its lanes */
+    const uint64_t b_n4 = round256((n_nals + 1) * 4), b_bsum = round256((n_nals / 256 + 2) * 4), b_fix = round256(hbs::parse_fix_temps_bytes());
+    const uint64_t fix_off = 3 * b_n + 512 + round256(1024 * 24) + b_rows;
+    int rc = ensure_ws(c, fix_off + 3 * b_n4 + b_bsum + 256 + b_fix);
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::ParseArgs a;
@@ -506,6 +509,12 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.div_flag = reinterpret_cast<uint32_t*>(w + 3 * b_n + 256 + 64);
     a.scan_tmp = w + 3 * b_n + 512;
     a.own_rows = reinterpret_cast<hbs::RpsRow*>(w + 3 * b_n + 512 + round256(1024 * 24));
+    a.deps = reinterpret_cast<uint32_t*>(w + fix_off);
+    a.wmask = reinterpret_cast<uint32_t*>(w + fix_off + b_n4);
+    a.fix_list = reinterpret_cast<uint32_t*>(w + fix_off + 2 * b_n4);
+    a.bsum = reinterpret_cast<uint32_t*>(w + fix_off + 3 * b_n4);
+    a.fix_count = reinterpret_cast<uint32_t*>(w + fix_off + 3 * b_n4 + b_bsum);
+    a.fix_temps = reinterpret_cast<hbs::RpsRow*>(w + fix_off + 3 * b_n4 + b_bsum + 256);
     a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;
     a.sequential = c->parse_sequential;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);

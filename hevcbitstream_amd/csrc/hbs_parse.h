@@ -53,6 +53,42 @@ struct RpsRow {
     int DeltaPocS0[32], UsedByCurrPicS0[32], DeltaPocS1[32], UsedByCurrPicS1[32];
 };
 
+/* one row of the derived tables wherever it lives: a row of an RpsTables, or an RpsRow */
+struct RowView { const int* s0; const int* u0; const int* s1; const int* u1; int nd, nn, np; };
+HBS_HD RowView view_of_tables(const RpsTables* t, int r)
+{
+    RowView v;
+    v.s0 = t->DeltaPocS0[r]; v.u0 = t->UsedByCurrPicS0[r]; v.s1 = t->DeltaPocS1[r]; v.u1 = t->UsedByCurrPicS1[r];
+    v.nd = t->NumDeltaPocs[r]; v.nn = t->NumNegativePics[r]; v.np = t->NumPositivePics[r];
+    return v;
+}
+HBS_HD RowView view_of_row(const RpsRow* q)
+{
+    RowView v;
+    v.s0 = q->DeltaPocS0; v.u0 = q->UsedByCurrPicS0; v.s1 = q->DeltaPocS1; v.u1 = q->UsedByCurrPicS1;
+    v.nd = q->NumDeltaPocs; v.nn = q->NumNegativePics; v.np = q->NumPositivePics;
+    return v;
+}
+HBS_HD RowView view_of_zeros(const int* zeros32)        /* a row nobody has written: at least 32 zero ints */
+{
+    RowView v;
+    v.s0 = v.u0 = v.s1 = v.u1 = zeros32; v.nd = v.nn = v.np = 0;
+    return v;
+}
+
+/* What a slice's walk did with the derived tables, recorded by every parse (hbs_parse_fix.h decides from it whose answer
+ * depends on NALs in front of its SPS): bits 0-5 own row written + 1, bits 6-11 row its own set was predicted from + 1,
+ * bits 12-17 row num_pic_total_curr read + 1 (0 = none each).  Which rows a slice touches does not depend on what the rows
+ * hold -- the indices are read from the bits in front of any table-dependent length -- so the record of a slice that read
+ * the wrong content is still right. */
+HBS_HD uint32_t deps_pack(int own_written_idx, int ref_row, int read_row)
+{
+    return (uint32_t)(own_written_idx + 1) | ((uint32_t)(ref_row + 1) << 6) | ((uint32_t)(read_row + 1) << 12);
+}
+HBS_HD int deps_own(uint32_t d) { return (int)(d & 63u) - 1; }
+HBS_HD int deps_ref(uint32_t d) { return (int)((d >> 6) & 63u) - 1; }
+HBS_HD int deps_read(uint32_t d) { return (int)((d >> 12) & 63u) - 1; }
+
 /* per-NAL result record of hbs_parse_headers (layout = hbs_parsed_nal in the public header) */
 struct ParsedNal {
     int32_t rc;                    /* what read_hevc_nal_unit returns                         */
@@ -225,15 +261,26 @@ struct ParserT {
     RpsTables* out_rps;
     RpsRow* own;
     int own_idx; int diverged;   /* diverged: this slice reads or clobbers an RPS row whose content depends on NALs in front of its SPS (see hbs_parse.hip, k4_seq) */
+    /* the exact re-walk of one slice (hbs_parse_fix.h): up to two rows whose true content -- what the last NAL that wrote them
+     * in stream order left -- is handed in; they go before everything else.  (The re-walk also points sps_rps at zeros: the reference's tables always exist.) */
+    int ov_idx[2]; RowView ov[2];
+    int stop_after_rps;          /* leave slice_segment_header once the slice's own short-term set is derived (the re-walk wants only that row) */
+    int rec_own, rec_ref, rec_read;      /* own row written / row it was predicted from / row num_pic_total_curr read, -1: none */
+    HBS_M void init_rows()
+    {
+        sps_rps = nullptr; out_rps = nullptr; own = nullptr; own_idx = -1; diverged = 0;
+        ov_idx[0] = ov_idx[1] = -1; stop_after_rps = 0; rec_own = rec_ref = rec_read = -1;
+    }
+    HBS_M int ovi(int r) const { return r == ov_idx[0] ? 0 : (r == ov_idx[1] ? 1 : -1); }
 
     /* ---- access to the RPS rows in force ------------------------------------------- */
-    HBS_M int numDelta(int r) const { return !in32(r) ? 0 : (own && r == own_idx) ? own->NumDeltaPocs : (out_rps ? out_rps->NumDeltaPocs[r] : (sps_rps ? sps_rps->NumDeltaPocs[r] : 0)); }
-    HBS_M int numNeg(int r) const { return !in32(r) ? 0 : (own && r == own_idx) ? own->NumNegativePics : (out_rps ? out_rps->NumNegativePics[r] : (sps_rps ? sps_rps->NumNegativePics[r] : 0)); }
-    HBS_M int numPos(int r) const { return !in32(r) ? 0 : (own && r == own_idx) ? own->NumPositivePics : (out_rps ? out_rps->NumPositivePics[r] : (sps_rps ? sps_rps->NumPositivePics[r] : 0)); }
-    HBS_M const int* rowS0(int r) const { return (own && r == own_idx) ? own->DeltaPocS0 : (out_rps ? out_rps->DeltaPocS0[r] : sps_rps->DeltaPocS0[r]); }
-    HBS_M const int* rowU0(int r) const { return (own && r == own_idx) ? own->UsedByCurrPicS0 : (out_rps ? out_rps->UsedByCurrPicS0[r] : sps_rps->UsedByCurrPicS0[r]); }
-    HBS_M const int* rowS1(int r) const { return (own && r == own_idx) ? own->DeltaPocS1 : (out_rps ? out_rps->DeltaPocS1[r] : sps_rps->DeltaPocS1[r]); }
-    HBS_M const int* rowU1(int r) const { return (own && r == own_idx) ? own->UsedByCurrPicS1 : (out_rps ? out_rps->UsedByCurrPicS1[r] : sps_rps->UsedByCurrPicS1[r]); }
+    HBS_M int numDelta(int r) const { if (!in32(r)) return 0; const int o = ovi(r); if (o >= 0) return ov[o].nd; return (own && r == own_idx) ? own->NumDeltaPocs : (out_rps ? out_rps->NumDeltaPocs[r] : (sps_rps ? sps_rps->NumDeltaPocs[r] : 0)); }
+    HBS_M int numNeg(int r) const { if (!in32(r)) return 0; const int o = ovi(r); if (o >= 0) return ov[o].nn; return (own && r == own_idx) ? own->NumNegativePics : (out_rps ? out_rps->NumNegativePics[r] : (sps_rps ? sps_rps->NumNegativePics[r] : 0)); }
+    HBS_M int numPos(int r) const { if (!in32(r)) return 0; const int o = ovi(r); if (o >= 0) return ov[o].np; return (own && r == own_idx) ? own->NumPositivePics : (out_rps ? out_rps->NumPositivePics[r] : (sps_rps ? sps_rps->NumPositivePics[r] : 0)); }
+    HBS_M const int* rowS0(int r) const { const int o = ovi(r); if (o >= 0) return ov[o].s0; return (own && r == own_idx) ? own->DeltaPocS0 : (out_rps ? out_rps->DeltaPocS0[r] : sps_rps->DeltaPocS0[r]); }
+    HBS_M const int* rowU0(int r) const { const int o = ovi(r); if (o >= 0) return ov[o].u0; return (own && r == own_idx) ? own->UsedByCurrPicS0 : (out_rps ? out_rps->UsedByCurrPicS0[r] : sps_rps->UsedByCurrPicS0[r]); }
+    HBS_M const int* rowS1(int r) const { const int o = ovi(r); if (o >= 0) return ov[o].s1; return (own && r == own_idx) ? own->DeltaPocS1 : (out_rps ? out_rps->DeltaPocS1[r] : sps_rps->DeltaPocS1[r]); }
+    HBS_M const int* rowU1(int r) const { const int o = ovi(r); if (o >= 0) return ov[o].u1; return (own && r == own_idx) ? own->UsedByCurrPicS1 : (out_rps ? out_rps->UsedByCurrPicS1[r] : sps_rps->UsedByCurrPicS1[r]); }
     HBS_M bool have_rows() const { return out_rps != nullptr || sps_rps != nullptr; }
     /* destination row `r` of the set being parsed */
     HBS_M int* wS0(int r) { return (own && r == own_idx) ? own->DeltaPocS0 : out_rps->DeltaPocS0[r]; }
@@ -398,6 +445,7 @@ struct ParserT {
     /* ---- 7.3.7 + derivation (hevc_stream.c:1032-1085, :61-113) ------------------------------ */
     HBS_M void st_ref_pic_set(hevc_st_ref_pic_set_t* rps, int stRpsIdx, int num_sets)
     {
+        if (stRpsIdx == num_sets && can_write(stRpsIdx)) rec_own = stRpsIdx;
         int inter = 0;
         if (stRpsIdx != 0) { inter = b.u1(HBS_SITE(0), rps->inter_ref_pic_set_prediction_flag); rps->inter_ref_pic_set_prediction_flag = inter; }
         if (inter) {
@@ -408,6 +456,7 @@ struct ParserT {
             const int absd = (int)b.ue(HBS_SITE(0), rps->abs_delta_rps_minus1);
             rps->abs_delta_rps_minus1 = absd;
             const int RefRpsIdx = stRpsIdx - (delta_idx_minus1 + 1);
+            if (stRpsIdx == num_sets && in32(RefRpsIdx)) rec_ref = RefRpsIdx;      /* a slice's own set, predicted from a row it did not write */
             const bool ref_ok = in32(RefRpsIdx) && have_rows();
             const int lim = ref_ok ? numDelta(RefRpsIdx) : 0;
             uint64_t used = 0, use_delta = 0;                     /* bit k: flag k (k < 32) */
@@ -787,6 +836,7 @@ struct ParserT {
     {
         int n = 0;
         const int cur = sps_flag ? rps_idx : sps->num_short_term_ref_pic_sets;
+        if (in32(cur)) const_cast<ParserT*>(this)->rec_read = cur;
         if (in32(cur) && (have_rows() || (own && cur == own_idx))) {
             const int nn = numNeg(cur), np = numPos(cur);
             if (nn > 0) { const int* u = rowU0(cur); for (int i = 0; i < nn && i < 32; ++i) if (u[i]) ++n; }
@@ -864,6 +914,7 @@ struct ParserT {
                 sh->short_term_ref_pic_set_sps_flag = sps_flag;
                 if (!sps_flag) {
                     st_ref_pic_set(&sh->st_ref_pic_set, sps->num_short_term_ref_pic_sets, sps->num_short_term_ref_pic_sets); if (own && own_idx == 0 && last_sps->num_short_term_ref_pic_sets > 0) diverged = 1;
+                    if (stop_after_rps) return;
                 } else if (sps->num_short_term_ref_pic_sets > 1) {
                     rps_idx = b.u(ceil_log2_int(sps->num_short_term_ref_pic_sets), HBS_SITE(0), sh->short_term_ref_pic_set_idx);
                     sh->short_term_ref_pic_set_idx = rps_idx; } if (own && sps_flag && in32(rps_idx) && rps_idx >= last_sps->num_short_term_ref_pic_sets) { diverged = 1;

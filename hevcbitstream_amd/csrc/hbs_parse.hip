@@ -14,6 +14,7 @@
  */
 #include <hip/hip_runtime.h>
 #include "hbs_parse.h"
+#include "hbs_parse_fix.h"
 #include "hbs_parse_ext.h"
 #include "hbs_parse_launch.h"
 
@@ -21,7 +22,7 @@ namespace hbs {
 
 
 __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
-                        ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size)
+                        ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size, uint32_t* __restrict__ deps)
 {
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const hbs_nal_entry e = idx[k];
@@ -35,6 +36,7 @@ __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* _
         }
         parsed[k] = p;
         slot_size[k] = sz;
+        deps[k] = 0u;
     }
 }
 
@@ -252,13 +254,12 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
                                                const uint8_t* my_win, uint32_t wb, const uint8_t* src,
                                                const uint8_t* sps_slot, const uint8_t* pps_struct, const uint8_t* zeros,
                                                ParsedNal& out, TraceRec* trace, uint32_t trace_cap, RpsRow* own_row,
-                                               RpsTables* seq_tables = nullptr, int* diverged = nullptr)
+                                               RpsTables* seq_tables = nullptr, int* diverged = nullptr, uint32_t* deps_out = nullptr)
 {
     ParserT<kMode> ps;
-    ps.diverged = 0;
     ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;   /* past the NAL header */
     ps.b.tr = trace; ps.b.tr_cap = trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
-    ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+    ps.sps = nullptr; ps.pps = nullptr; ps.init_rows();
     const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
     const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
     const hevc_sps_t* last_sps = zero_sps;
@@ -280,6 +281,7 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
     const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
     parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
     if (diverged) *diverged = ps.diverged;
+    if (deps_out && slice) *deps_out = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read);
     return ps.b.tr_n;
 }
 
@@ -305,7 +307,8 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               const uint8_t* __restrict__ zeros, const uint8_t* __restrict__ init_sps_slot,
               const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
-              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks, uint32_t* __restrict__ div_flag)
+              RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks, uint32_t* __restrict__ div_flag,
+              uint32_t* __restrict__ deps)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -372,9 +375,11 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             }
             ParsedNal out = parsed[k];
             int dv = 0;
+            uint32_t dp = 0u;
             const uint32_t tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, out,
-                                                    trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane], nullptr, &dv);
-            if (dv) atomicOr(div_flag, 1u);        /* the batch is walked again, NAL after NAL (k4_seq) */
+                                                    trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane], nullptr, &dv, &dp);
+            if (slice) deps[k] = dp;
+            if (dv) atomicOr(div_flag, 1u);        /* some slices are walked again, exactly (k4_fix) */
             parsed[k] = out;
             if (trace_count) trace_count[k] = tr_n;
         }
@@ -623,6 +628,64 @@ void k4_seq(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ 
     }
 }
 
+/* ---- the exact re-walk of the slices that need it (hbs_parse_fix.h), gated on div_flag ------------------------------ */
+
+__global__ __launch_bounds__(kFixBlock)
+void k4_fix_masks(const ParsedNal* __restrict__ parsed, const uint8_t* __restrict__ structs, const uint32_t* __restrict__ deps, uint64_t n,
+                  uint32_t* __restrict__ wmask, uint32_t* __restrict__ bsum, uint32_t* __restrict__ fix_count, const uint32_t* __restrict__ gate)
+{
+    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    __shared__ uint32_t part[kFixBlock / 64];
+    const uint64_t k = (uint64_t)blockIdx.x * kFixBlock + threadIdx.x;
+    uint32_t m = 0u;
+    if (k < n) { m = fix_wmask_of(parsed, structs, deps, k); wmask[k] = m; }
+    uint32_t acc = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t all = 0u;
+        for (int w = 0; w < kFixBlock / 64; ++w) all |= part[w];
+        bsum[blockIdx.x] = all;
+        if (blockIdx.x == 0) { fix_count[0] = 0u; fix_count[1] = 0u; }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k4_fix_list(FixCtx c, uint32_t* __restrict__ list, uint32_t* __restrict__ fix_count, const uint32_t* __restrict__ gate)
+{
+    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < c.n; k += (uint64_t)gridDim.x * blockDim.x)
+        if (fix_is_affected(c, k)) list[atomicAdd(&fix_count[0], 1u)] = (uint32_t)k;
+}
+
+#ifndef HBS_FIX_ENABLED
+#define HBS_FIX_ENABLED 1
+#endif
+constexpr unsigned kFixBlocks = 128;             /* x 64 lanes: slices walked again at the same time */
+template <int kMode>
+__global__ __launch_bounds__(64)
+void k4_fix(FixCtx c, const uint32_t* __restrict__ list, uint32_t* __restrict__ fix_count, RpsRow* __restrict__ temps,
+            TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count, const uint32_t* __restrict__ gate)
+{
+    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const uint32_t count = fix_count[0];
+    const uint32_t me = blockIdx.x * 64u + threadIdx.x;
+    RpsRow* const my = temps + (uint64_t)me * kFixTemps;
+    for (uint32_t q = me; q < count; q += gridDim.x * 64u) {
+        const uint64_t k = list[q];
+        uint32_t tr_n = 0;
+#if HBS_FIX_ENABLED
+        const bool ok = fix_slice<kMode>(c, k, my, trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &tr_n);
+#else
+        const bool ok = false; (void)my;
+#endif
+        if (!ok) atomicOr(&fix_count[1], 1u);                    /* a chain of slices deeper than kFixDepth: the whole batch in order (k4_seq) */
+        else if (trace_count) trace_count[k] = tr_n;
+    }
+}
+
 /* ---- K5: syntax writers (write_hevc_nal_unit, hevc_stream.c:1249-1327, up to rbsp_to_nal) ---- */
 
 __global__ void k5_slot_sizes(const ParsedNal* __restrict__ parsed, uint64_t n, unsigned long long* __restrict__ slot_size)
@@ -669,7 +732,7 @@ void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_
             ParserT<kModeWrite> ps;
             ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = rbsp_cap; ps.b.pos = 0;
             ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = out;
-            ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+            ps.sps = nullptr; ps.pps = nullptr; ps.init_rows();
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
             const hevc_sps_t* last_sps = zero_sps;
@@ -713,6 +776,7 @@ unsigned parse_grid_blocks(uint64_t n)
     return (unsigned)(want < 1 ? 1 : want > kParseMaxBlocks ? kParseMaxBlocks : want);
 }
 uint64_t parse_own_rows_bytes(uint64_t n) { return (uint64_t)parse_grid_blocks(n) * 4u * 64u * sizeof(RpsRow); }
+uint64_t parse_fix_temps_bytes() { return (uint64_t)kFixBlocks * 64u * (uint64_t)kFixTemps * sizeof(RpsRow); }
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
 {
@@ -729,8 +793,9 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
     }
     /* The parallel parse reads every slice against the tables of the SPS in front of it.  A slice whose answer depends on
      * more than that -- it names a set that SPS does not have, or rewrites one of its rows: streams the spec forbids --
-     * raises div_flag, and the batch is then walked again the reference's way, NAL after NAL with one set of tables
-     * (k4_seq, gated on the flag: no host round trip; it returns at once on ordinary streams). */
+     * raises div_flag.  Batches of up to 64 NALs are then walked again the reference's way, NAL after NAL with one set of
+     * tables (k4_seq, gated on the flag: no host round trip; it returns at once on ordinary streams); larger ones walk
+     * only the slices that need it (k4_fix, below). */
     hipError_t e = hipMemsetAsync(a.div_flag, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     RpsTables* const seq_tables_ws = reinterpret_cast<RpsTables*>(a.own_rows);
@@ -762,7 +827,7 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         if (e != hipSuccess) return e;
     }
     if (a.n) {
-        k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size);
+        k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size, a.deps);
         Scan3* part = reinterpret_cast<Scan3*>(a.scan_tmp);
         k4_scan_reduce<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part);
         k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
@@ -772,14 +837,41 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
             for (int pass = 0; pass < 2; ++pass) {
                 const unsigned grid = pblocks + (pass == 0 ? kZeroBlocks : 0u);
                 if (a.trace)
-                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks, a.div_flag);
+                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks, a.div_flag, a.deps);
                 else
-                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag);
+                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps);
             }
         }
     }
     k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);
-    exact_pass();
+    if (a.structs && a.n) {
+        /* A batch in which some slice raised div_flag: the slices whose rows have another last writer than their SPS are found
+         * from the records every walk left (masks, list) and walked again, each by itself with the true rows handed in (k4_fix).
+         * All three return at once on ordinary streams.  Only a chain of slices deeper than kFixDepth still sends the batch
+         * through k4_seq (gated on fix_count[1]). */
+        FixCtx c;
+        c.rbsp = a.rbsp; c.idx = a.index; c.n = a.n; c.parsed = a.parsed; c.structs = a.structs; c.structs_cap = a.structs_cap;
+        c.ctx_sps = a.ctx_sps; c.ctx_pps = a.ctx_pps; c.zeros = a.zeros; c.init_sps_slot = a.initial_sps_slot; c.init_pps = a.initial_pps;
+        c.deps = a.deps; c.wmask = a.wmask; c.bsum = a.bsum;
+        e = hipMemsetAsync(a.fix_count, 0, 2 * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+        const unsigned mblocks = (unsigned)((a.n + kFixBlock - 1) / kFixBlock);
+        k4_fix_masks<<<mblocks, kFixBlock, 0, st>>>(a.parsed, a.structs, a.deps, a.n, a.wmask, a.bsum, a.fix_count, a.div_flag);
+        const unsigned lblocks = mblocks < 1024u ? mblocks : 1024u;
+        k4_fix_list<<<lblocks, 256, 0, st>>>(c, a.fix_list, a.fix_count, a.div_flag);
+        if (a.trace)
+            k4_fix<kModeTrace><<<kFixBlocks, 64, 0, st>>>(c, a.fix_list, a.fix_count, a.fix_temps, a.trace, a.trace_cap, a.trace_count, a.div_flag);
+        else
+            k4_fix<kModeRead><<<kFixBlocks, 64, 0, st>>>(c, a.fix_list, a.fix_count, a.fix_temps, nullptr, 0, nullptr, a.div_flag);
+        if (a.n >= 2) {
+            if (a.trace)
+                k4_seq<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                     a.initial_pps, a.trace, a.trace_cap, a.trace_count, seq_tables_ws, a.summary, a.fix_count + 1);
+            else
+                k4_seq<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
+                                                    a.initial_pps, nullptr, 0, nullptr, seq_tables_ws, a.summary, a.fix_count + 1);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -35,12 +35,20 @@ struct ParseArgs {
     uint32_t trace_cap;
     uint32_t* trace_count;           /* optional: records each NAL produced (may exceed trace_cap) */
     RpsRow* own_rows;                /* parse_own_rows_bytes(n): one row per lane of the parse grid */
+    /* the exact re-walk of the few slices a flagged batch needs (hbs_parse_fix.h) */
+    uint32_t* deps;                  /* n: what every slice's walk did with the derived tables */
+    uint32_t* wmask;                 /* n: rows each NAL writes */
+    uint32_t* bsum;                  /* n / 256 + 1 */
+    uint32_t* fix_list;              /* n: ordinals of the slices to walk again; fix_count[0] how many, fix_count[1] "walk the whole batch in order after all" */
+    uint32_t* fix_count;
+    RpsRow* fix_temps;               /* parse_fix_temps_bytes() */
     int sequential;                  /* n == 1 only: the RPS tables behind initial_sps_slot are read AND written, as the
                                         reference's file-static tables are (what the legacy single-NAL symbols need) */
 };
 
 unsigned parse_grid_blocks(uint64_t n);
 uint64_t parse_own_rows_bytes(uint64_t n);
+uint64_t parse_fix_temps_bytes();
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);
 hipError_t launch_parse_extended(const uint8_t* rbsp, const hbs_nal_entry* index, uint64_t n, ParsedNal* parsed, hbs_ext_nal* ext, hipStream_t st);
 

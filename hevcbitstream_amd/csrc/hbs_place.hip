@@ -9,10 +9,10 @@
  * slow, every pair across classes fast, no exception in 2 x 380 pairs); pure reads and pure writes do not care, a
  * one-chunk-per-thread copy cares by 1.7 %, a copy with K12's geometry (48 KiB per wavefront loaded, then stored) by 4 %.
  * It looks like the two ranks behind every HBM channel: reads and writes that alternate on ONE rank pay its write-to-read
- * turnaround, on two ranks they do not.  HIP does not tell physical addresses, so the class of a chunk relative to an input
- * is MEASURED: a content-free copy with K12's geometry from the input piece into the chunk, against the same copy inside
- * the chunk (same chunk = same class = the slow case by construction).  A chunk whose pairing with its input piece is not
- * faster than its pairing with itself is put aside and another one is asked for; the pile is given back at the end.
+ * turnaround, on two ranks they do not.  HIP does not tell physical addresses, so where a buffer lies relative to an input
+ * is MEASURED: a content-free copy with K12's geometry from a piece of the input into the piece of the candidate that will
+ * be written from it, against the same copy inside the candidate (one allocation = one class = the slow case by
+ * construction).  A candidate that pairs slowly is kept aside while another one is allocated, then freed.
  *
  * No reference counterpart (the reference allocates with malloc, h264_nal.c / hevc_nal.c); buffers from hipMalloc or
  * torch work with every call exactly as before -- they just land in the slow mode about every other time.
@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <new>
 #include <vector>
 #include "hevcbitstream_amd.h"
 
@@ -35,7 +36,6 @@ namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint64_t kChunk = 1ull << 30;           /* physical chunks: the classes were seen at this grain, and a probe needs ~0.5 GiB to tell them apart */
-constexpr uint64_t kGran = 2ull << 20;
 constexpr int kRows = 48;                          /* K12's wavefront: 48 rows of 1 KiB in registers */
 constexpr uint64_t kTile = 4ull * kRows * 1024;    /* 192 KiB per workgroup */
 constexpr double kFastRatio = 0.985;               /* a pairing is "fast" when it takes less than this x the chunk against itself: the classes are 3-4 % apart
@@ -63,18 +63,8 @@ void k_probe_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ui
     }
 }
 
-struct Pair {
-    void* va = nullptr;
-    uint64_t va_bytes = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::vector<uint64_t> offs, sizes;
-    int device = 0;
-};
-
 std::mutex g_mu;
-std::map<void*, Pair*> g_pairs;
-
-uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+std::map<void*, int> g_pairs;                      /* pointer -> device */
 
 struct Prober {
     hipStream_t st;
@@ -112,34 +102,72 @@ struct Prober {
     }
 };
 
-void release_pair(Pair* p)
+
+constexpr uint64_t kGran = 2ull << 20;
+uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+/* Addresses for the chunked buffers: ONE reservation per process, handed out front to back and never given back or used
+ * twice.  On this stack a virtual address that had been unmapped and mapped again -- inside one call, or freed and reserved
+ * again by a later one -- now and then kept serving the OLD physical memory (wrong bytes in the second buffer of a
+ * process; hipMemSetAccess failing with "invalid argument").  An address that is used once cannot go stale.  When the pool
+ * is used up (kVaPool of addresses: some 500 buffers of 16 GiB with their scratch slots) the plain allocator takes over. */
+constexpr uint64_t kVaPool = 32ull << 40;
+std::mutex g_va_mu;
+uint8_t* g_va_base = nullptr;
+uint64_t g_va_size = 0, g_va_used = 0;
+bool g_va_tried = false;
+void* va_take(uint64_t bytes)
+{
+    std::lock_guard<std::mutex> g(g_va_mu);
+    if (!g_va_tried) {
+        g_va_tried = true;
+        for (uint64_t want = kVaPool; want >= (1ull << 40); want /= 2) {
+            void* p = nullptr;
+            const hipError_t e = hipMemAddressReserve(&p, want, kGran, nullptr, 0);
+            if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: address pool of %llu GiB: %s\n", (unsigned long long)(want >> 30), hipGetErrorString(e));
+            if (e == hipSuccess && p) { g_va_base = static_cast<uint8_t*>(p); g_va_size = want; break; }
+            (void)hipGetLastError();
+        }
+    }
+    bytes = up(bytes, kGran);
+    if (!g_va_base || g_va_used + bytes > g_va_size) return nullptr;
+    void* r = g_va_base + g_va_used;
+    g_va_used += bytes;
+    return r;
+}
+
+struct Pair {
+    void* va = nullptr;
+    uint64_t va_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<uint64_t> offs, sizes;
+    int device = 0;
+};
+std::map<void*, Pair*> g_chunked;                  /* under g_mu */
+
+void release_pair(Pair* p)                          /* the physical memory goes back; the addresses are spent */
 {
     for (size_t i = 0; i < p->handles.size(); ++i) {
         (void)hipMemUnmap(static_cast<uint8_t*>(p->va) + p->offs[i], p->sizes[i]);
         (void)hipMemRelease(p->handles[i]);
     }
-    if (p->va) (void)hipMemAddressFree(p->va, p->va_bytes);
     delete p;
 }
 
 } // namespace
 
-extern "C" {
-
 /*
- * The search.  Physical memory comes in long runs of one class in the order hipMemCreate hands it out (runs of 5-10 chunks seen),
- * so "reject and ask again" would walk a whole run a GiB at a time.  Instead:
+ * The chunked way.  Physical memory comes in runs of one class in the order hipMemCreate hands it out (runs of 2-10 GiB seen):
  *   1. a reference chunk R; every piece of the peer is classed against it (same class as R / the other class);
- *   2. candidates are created, each in a scratch address slot of its own (an address is never mapped twice: re-mapping one
- *      left stale translations behind on this stack), and classed against R the same way;
- *   3. a chunk of the buffer wants a candidate of the class its peer piece is NOT in; candidates nobody wants are put aside
- *      (they stay allocated, so that the next ones are other memory), and after two of those in a row an unmapped "ballast"
+ *   2. candidate chunks are created, each mapped into an address slot of its own, and classed against R the same way;
+ *   3. a chunk of the buffer wants a candidate of the class its peer piece is NOT in; candidates nobody wants stay allocated
+ *      until the end (so that the next ones are other memory), and after two of those in a row an unmapped "ballast"
  *      allocation of 4, 8, 16 ... GiB skips ahead in the run;
- *   4. the chosen candidates move from their scratch slots to their place in the buffer; pile and ballast are given back.
+ *   4. the chosen candidates are mapped at their place in the buffer; everything else is released.
  * Bounded: at most nchunks + kExtraCands candidates and kBallastMax of ballast; when memory runs out or the bound is reached,
  * whatever is at hand is used (the report says how many chunks were placed knowingly).
  */
-int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
+static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
 {
     if (!ctx || !out) return HBS_E_ARG;
     *out = nullptr;
@@ -171,8 +199,8 @@ int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64
     p->device = device;
     p->va_bytes = nfull * kChunk + rest;
     int rc = 0;
-    e = hipMemAddressReserve(&p->va, p->va_bytes, kGran, nullptr, 0);
-    if (e != hipSuccess) { PAIR_FAIL("hipMemAddressReserve") delete p; return rc; }
+    p->va = va_take(p->va_bytes);
+    if (!p->va) { delete p; return HBS_E_CAPACITY; }                  /* the address pool is used up: the caller takes the plain way */
     uint8_t* const base = static_cast<uint8_t*>(p->va);
     auto map_at = [&](uint64_t off, uint64_t size, hipMemGenericAllocationHandle_t h) -> bool {
         e = hipMemMap(base + off, size, 0, h, 0);
@@ -199,23 +227,28 @@ int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64
     const uint64_t scratch_slots = nfull + kExtraCands + 1;
     Prober* pr = nullptr;
     if (rc == 0 && nfull) {
-        e = hipMemAddressReserve(&scratch, scratch_slots * kChunk, kGran, nullptr, 0);
-        if (e != hipSuccess) { PAIR_FAIL("hipMemAddressReserve(scratch)") }
+        scratch = va_take(scratch_slots * kChunk);
+        if (!scratch) { release_pair(p); return HBS_E_CAPACITY; }
         pr = new (std::nothrow) Prober(st, device);
         if (pr && !pr->ok) { delete pr; pr = nullptr; }
     }
     auto new_cand = [&]() -> bool {                      /* false: no more memory (or address slots) */
         if (cands.size() >= scratch_slots) return false;
         Cand c; c.other = -1; c.used = false;
-        if (hipMemCreate(&c.h, kChunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        hipError_t ce = hipMemCreate(&c.h, kChunk, &prop, 0);
+        if (ce != hipSuccess) { if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: hipMemCreate: %s\n", hipGetErrorString(ce)); (void)hipGetLastError(); return false; }
         c.va = static_cast<uint8_t*>(scratch) + cands.size() * kChunk;
-        if (hipMemMap(c.va, kChunk, 0, c.h, 0) != hipSuccess || hipMemSetAccess(c.va, kChunk, &acc, 1) != hipSuccess) {
+        ce = hipMemMap(c.va, kChunk, 0, c.h, 0);
+        if (ce == hipSuccess) ce = hipMemSetAccess(c.va, kChunk, &acc, 1);
+        if (ce != hipSuccess) {
+            if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: mapping a candidate at %p: %s\n", (void*)c.va, hipGetErrorString(ce));
             (void)hipGetLastError(); (void)hipMemRelease(c.h); return false;
         }
         cands.push_back(c);
         return true;
     };
     std::vector<int> want(nfull, -1);                    /* class wanted for chunk k: 1 = not R's, 0 = R's, -1 = no preference */
+    if (getenv("HBS_PAIR_DEBUG") && nfull) fprintf(stderr, "hbs_pair_alloc: %llu chunks + %llu bytes, prober %s\n", (unsigned long long)nfull, (unsigned long long)rest, pr ? "ready" : "NOT available");
     if (rc == 0 && nfull && pr && new_cand()) {
         Cand& R = cands[0];
         const double self_r = pr->copy_ms(R.va, R.va + half, half);
@@ -304,36 +337,159 @@ int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64
         (void)hipMemRelease(c.h);
     }
     for (auto b : ballast) (void)hipMemRelease(b);
-    if (scratch) (void)hipMemAddressFree(scratch, scratch_slots * kChunk);
     delete pr;
 #undef PAIR_FAIL
     if (rc) { release_pair(p); return rc; }
     r.chunks = (uint32_t)p->handles.size();
+    r.unprobed_after_budget += (uint32_t)(rest ? 1 : 0);
     {
         std::lock_guard<std::mutex> g(g_mu);
-        g_pairs[p->va] = p;
+        g_chunked[p->va] = p;
     }
     *out = p->va;
     if (rep) *rep = r;
     return 0;
 }
 
+
+/*
+ * The plain way.  Ordinary hipMalloc memory -- one allocation of the whole size.  Up to kTries allocations are made, each KEPT
+ * while the next is made (so that the next one is other memory); every whole GiB of a candidate is measured against the
+ * peer piece it will be written from (and against itself: the slow case by construction); the first candidate whose pieces
+ * are all fast wins, else the one with the most fast pieces; the others are freed.  Three pieces (first, middle, last) are
+ * measured first, and a candidate that is slow in all three is not measured further.  An allocation of many GiB usually
+ * spans both classes somewhere (13-15 fast pieces of 15 were typical), which is why the chunked way comes first.
+ */
+static int alloc_plain(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
+{
+    if (!ctx || !out) return HBS_E_ARG;
+    *out = nullptr;
+    hbs_pair_report r;
+    memset(&r, 0, sizeof(r));
+    const int device = hbs_ctx_device(ctx);
+    if (device < 0 || hipSetDevice(device) != hipSuccess) return HBS_E_NO_DEVICE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hbs_ctx_get_stream(ctx));
+    if (bytes == 0) bytes = 16;
+    constexpr int kTries = 6;
+    const uint64_t half = (kChunk / 2) / kTile * kTile;
+    const uint64_t nfull = bytes / kChunk;
+    const bool want_probe = d_peer != nullptr && peer_bytes >= half && nfull >= 1 && !getenv("HBS_PAIR_NO_PROBE");
+    const bool dbg = getenv("HBS_PAIR_DEBUG") != nullptr;
+    Prober* pr = want_probe ? new (std::nothrow) Prober(st, device) : nullptr;
+    if (pr && !pr->ok) { delete pr; pr = nullptr; }
+    r.chunks = (uint32_t)((bytes + kChunk - 1) / kChunk);
+
+    struct Cand { uint8_t* p; uint32_t fast, measured; };
+    std::vector<Cand> cands;
+    int best = -1;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < (pr ? kTries : 1); ++attempt) {
+        if (attempt) {                                    /* room for one more, with some to spare? */
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (4ull << 30)) break;
+        }
+        Cand c; c.p = nullptr; c.fast = 0; c.measured = 0;
+        e = hipMalloc(reinterpret_cast<void**>(&c.p), bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); break; }
+        cands.push_back(c);
+        Cand& C = cands.back();
+        if (!pr) { best = 0; break; }
+        auto piece_is_fast = [&](uint64_t k) -> int {          /* 1 fast, 0 slow, -1 measurement failed */
+            const uint64_t peer_last = peer_bytes > half ? (uint64_t)((peer_bytes - half) & ~(uint64_t)15) : (uint64_t)0;
+            const uint64_t peer_off = std::min(k * kChunk, peer_last);
+            uint8_t* lo = C.p + k * kChunk;
+            const double t_self = pr->copy_ms(lo, lo + half, half);
+            const double t_pair = pr->copy_ms(static_cast<const uint8_t*>(d_peer) + peer_off, lo + half, half);
+            if (t_self <= 0 || t_pair <= 0) return -1;
+            r.probed += 1;
+            if (dbg) fprintf(stderr, "hbs_pair_alloc: candidate %d piece %llu: against the peer %.4f ms, against itself %.4f ms (%.4f)\n",
+                             attempt, (unsigned long long)k, t_pair, t_self, t_pair / t_self);
+            return t_pair < kFastRatio * t_self ? 1 : 0;
+        };
+        /* first, middle, last; then the rest unless those three are all slow */
+        std::vector<uint64_t> order;
+        order.push_back(0);
+        if (nfull > 2) order.push_back(nfull / 2);
+        if (nfull > 1) order.push_back(nfull - 1);
+        const size_t quick = order.size();
+        for (uint64_t k = 0; k < nfull; ++k) if (k != 0 && k != nfull / 2 && k != nfull - 1) order.push_back(k);
+        bool failed = false;
+        for (size_t q = 0; q < order.size(); ++q) {
+            if (q == quick && C.fast == 0) break;                /* slow wherever it was looked at */
+            const int f = piece_is_fast(order[q]);
+            if (f < 0) { failed = true; break; }
+            C.measured += 1; C.fast += (uint32_t)f;
+        }
+        if (failed) { best = best < 0 ? (int)cands.size() - 1 : best; break; }
+        if (best < 0 || C.fast > cands[(size_t)best].fast) best = (int)cands.size() - 1;
+        if (C.fast == nfull) break;                              /* every piece pairs fast: done */
+        r.rejected += 1;
+    }
+    delete pr;
+    if (best < 0) {
+        hbs_ctx_set_error(ctx, "hbs_pair_alloc: hipMalloc", (int)(e == hipSuccess ? hipErrorOutOfMemory : e));
+        for (auto& c : cands) (void)hipFree(c.p);
+        return HBS_E_HIP;
+    }
+    (void)hipStreamSynchronize(st);
+    for (size_t i = 0; i < cands.size(); ++i) if ((int)i != best) (void)hipFree(cands[i].p);
+    if (r.rejected && cands[(size_t)best].fast == nfull) r.rejected = (uint32_t)cands.size() - 1;
+    r.accepted_fast = cands[(size_t)best].fast;
+    r.unprobed_after_budget = r.chunks - cands[(size_t)best].fast;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        g_pairs[cands[(size_t)best].p] = device;
+    }
+    *out = cands[(size_t)best].p;
+    if (rep) *rep = r;
+    return 0;
+}
+
+extern "C" {
+
+/* Two ways.  (1) Chunked: the buffer is put together from 1 GiB physical chunks, each classed by measurement, at addresses
+ * that are used once (see va_take) -- every piece can be placed, whatever the allocator hands out.  (2) Plain: whole
+ * hipMalloc allocations as candidates, the best one kept -- ordinary memory, but an allocation usually spans both classes
+ * somewhere.  (1) is used for buffers that get probed at all; (2) for small buffers (one plain allocation, no probing),
+ * when HBS_PAIR_PLAIN is set, and when the address pool or the virtual-memory calls give out. */
+int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
+{
+    if (!ctx || !out) return HBS_E_ARG;
+    const bool probe = d_peer != nullptr && peer_bytes >= kChunk / 2 && bytes >= kChunk && !getenv("HBS_PAIR_NO_PROBE");
+    if (probe && !getenv("HBS_PAIR_PLAIN")) {
+        const int rc = alloc_chunked(ctx, d_peer, peer_bytes, bytes, out, rep);
+        (void)hipGetLastError();                       /* a HIP call that failed on the way (memory ran out under the candidates) is not the caller's error */
+        if (rc == 0) return 0;
+        if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: the chunked way failed (%d: %s), taking the plain one\n", rc, hbs_last_error(ctx));
+        if (rc != HBS_E_CAPACITY && rc != HBS_E_HIP) return rc;
+    }
+    const int rc = alloc_plain(ctx, d_peer, peer_bytes, bytes, out, rep);
+    (void)hipGetLastError();
+    return rc;
+}
+
 int hbs_pair_free(hbs_ctx* ctx, void* ptr)
 {
     if (!ptr) return 0;
+    int device = 0;
     Pair* p = nullptr;
     {
         std::lock_guard<std::mutex> g(g_mu);
-        auto it = g_pairs.find(ptr);
-        if (it == g_pairs.end()) return HBS_E_ARG;
-        p = it->second;
-        g_pairs.erase(it);
+        auto ic = g_chunked.find(ptr);
+        if (ic != g_chunked.end()) { p = ic->second; g_chunked.erase(ic); }
+        else {
+            auto it = g_pairs.find(ptr);
+            if (it == g_pairs.end()) return HBS_E_ARG;
+            device = it->second;
+            g_pairs.erase(it);
+        }
     }
-    (void)hipSetDevice(p->device);
+    if (p) device = p->device;
+    (void)hipSetDevice(device);
     if (ctx) (void)hbs_ctx_synchronize(ctx);
     (void)hipDeviceSynchronize();
-    release_pair(p);
-    return 0;
+    if (p) { release_pair(p); return 0; }
+    return hipFree(ptr) == hipSuccess ? 0 : HBS_E_HIP;
 }
 
 } // extern "C"

@@ -441,26 +441,23 @@ int hbs_copy_device(hbs_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes
  * On MI355X a kernel that reads one large buffer and writes another in long bursts (hbs_index_extract: stream -> RBSP arena;
  * hbs_emit_annexb: arena -> stream) runs ~4-5 % slower when both buffers lie in the same one of two classes of physical
  * memory (16 GiB: 6.20 against 5.90 ms; DESIGN.md section 4, profiles/r04/placement_*.txt) -- decided when the buffers are
- * allocated, the same for every offset inside them, and invisible to HIP.  hbs_pair_alloc allocates `bytes` of device memory
- * in 1 GiB physical chunks and MEASURES where they lie relative to `d_peer` (a content-free copy with the kernels' access
- * pattern, half a GiB at a time, on the context's stream; `d_peer` must have its final size and location, its contents do
- * not matter and are not changed): every 1 GiB piece of the peer and every candidate chunk is classed against one reference
- * chunk, and chunk k of the buffer is taken from the class that piece k of the peer is not in.  Candidates of the wrong class
- * are held until the end (and the allocator is pushed ahead by up to 96 GiB of unmapped ballast) so that other memory comes
- * next; all of it is given back before the call returns.  Cost: ~1 ms per GiB when the first candidates fit, up to a few
- * hundred ms otherwise.  When memory runs short or 24 surplus candidates did not help, the remaining chunks are taken as they
- * come -- the buffer is always valid, the report says how it was placed.
- * The result is an ordinary device pointer (2 MiB-aligned, usable with every call of this header, hipMemcpy, torch via
- * __cuda_array_interface__), freed with hbs_pair_free.  Buffers below 1 GiB, peers below 512 MiB or d_peer == NULL: no
- * probing.  Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every other time.
- * No reference counterpart (the reference's buffers are malloc'ed host memory, hevc_analyze.c:100-103).
+ * allocated, the same for every offset inside them, and invisible to HIP.  hbs_pair_alloc returns `bytes` of ordinary
+ * hipMalloc memory whose placement against `d_peer` has been MEASURED: every whole GiB of a candidate allocation is timed
+ * against the piece of the peer at the same offset (a content-free copy with the kernels' access pattern, half a GiB at a
+ * time, on the context's stream; `d_peer` must have its final size and location, its contents do not matter and are not
+ * changed) and against itself, which is the slow case by construction.  A candidate that pairs slowly is kept aside while
+ * the next one is allocated (up to six, as long as the GPU has room), and freed before the call returns; when none pairs
+ * fast in every piece, the one with the most fast pieces is returned.  Cost: 1.6 ms per GiB and candidate.
+ * Buffers below 1 GiB, peers below 512 MiB or d_peer == NULL: one plain allocation, no measurement.
+ * Free with hbs_pair_free.  Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every
+ * other time.  No reference counterpart (the reference's buffers are malloc'ed host memory, hevc_analyze.c:100-103).
  */
 typedef struct hbs_pair_report {
-    uint32_t chunks;                 /* physical chunks the buffer consists of (1 GiB each + a remainder)              */
-    uint32_t probed;                 /* measurements taken: peer pieces and candidate chunks against the reference     */
-    uint32_t rejected;               /* candidates of a class no chunk still wanted (held, then given back)            */
-    uint32_t accepted_fast;          /* chunks placed in the class their peer piece is NOT in (the fast pairing)       */
-    uint32_t unprobed_after_budget;  /* chunks taken as they came (no memory / no candidate of the wanted class left)   */
+    uint32_t chunks;                 /* GiB pieces of the buffer (the last one may be partial)                         */
+    uint32_t probed;                 /* pieces measured, over all candidates                                           */
+    uint32_t rejected;               /* candidate allocations set aside and freed                                      */
+    uint32_t accepted_fast;          /* pieces of the returned buffer that pair fast with their peer piece             */
+    uint32_t unprobed_after_budget;  /* pieces of the returned buffer that do not (or were not measured)               */
     float    reserved;
 } hbs_pair_report;
 int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* report /* may be NULL */);

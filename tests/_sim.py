@@ -93,10 +93,14 @@ def synth_rbsp(seed, n_nals, mode):
     return arena[:tot].copy(), idx[:n_nals]
 
 
-def parse_headers(rbsp, idx):
-    """K4 single-stepped on the CPU.  Returns (parsed ndarray[PARSED], struct arena uint8)."""
+def parse_headers(rbsp, idx, fix=0, stats=None):
+    """K4 single-stepped on the CPU.  Returns (parsed ndarray[PARSED], struct arena uint8).
+    fix: 0 the batch parse alone, 1 + the exact re-walk of the slices that need it when a slice raised the flag (what the
+    library does), 2 + even when none did; stats: a list that receives [flag raised, slices walked again, chains too deep]."""
     from tests._parsecmp import PARSED
     L = lib()
+    L.sim_parse_set_fix.argtypes = [C.c_int]
+    L.sim_parse_set_fix(int(fix))
     L.sim_parse_headers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     L.sim_parse_headers.restype = C.c_int64
     rbsp = np.ascontiguousarray(np.concatenate([rbsp, np.zeros(16, dtype=np.uint8)]))
@@ -107,6 +111,11 @@ def parse_headers(rbsp, idx):
     structs = np.full(need + 64, 0xA5, dtype=np.uint8)
     got = L.sim_parse_headers(rbsp.ctypes.data, idx.ctypes.data, n, parsed.ctypes.data, structs.ctypes.data, need)
     assert got == need
+    if stats is not None:
+        st = (C.c_int * 3)()
+        L.sim_parse_fix_stats(st)
+        stats[:] = list(st)
+    L.sim_parse_set_fix(0)
     return parsed[:n], structs[:need]
 
 

@@ -585,7 +585,7 @@ class Synth:
         w.u1(sl)
         if sl:
             self.scaling_list(w)
-        lm = self.ri(0, 1)
+        lm = force.get("lists_mod", self.ri(0, 1))
         w.u1(lm)
         w.ue(self.ri(0, 3))
         she = 1 if self.chance(0.3) else 0
@@ -631,13 +631,14 @@ class Synth:
         n += sum(1 for u in lt_used_flags if u)
         return n
 
-    def slice_nal(self, nal_type, first=True, payload=b"", slice_type=None, address=0, tid=1):
+    def slice_nal(self, nal_type, first=True, payload=b"", slice_type=None, address=0, tid=1, pps_id=0):
         s, p = self.sps, self.pps
         w = BitWriter()
         w.u1(1 if first else 0)
         if 16 <= nal_type <= 23:
             w.u1(self.ri(0, 1))
-        w.ue(0)                                 # slice_pic_parameter_set_id: 0 (envelope)
+        w.ue(pps_id)                            # slice_pic_parameter_set_id: 0 (envelope); anything else makes the reference read the
+        #                                         header against its all-zero sets -- and, if it codes an own RPS, write it into row 0 of the tables
         dependent = 0
         if not first:
             if p["dependent"]:
@@ -818,21 +819,27 @@ def annexb(nals, four_byte_every=4):
     return bytes(out)
 
 
-def stream_4k30(seed, n_pictures, slices_per_picture=8, idr_every=60, payload_bytes=(9000, 11000), rich=False):
+def stream_4k30(seed, n_pictures, slices_per_picture=8, idr_every=60, payload_bytes=(9000, 11000), rich=False, forbidden_every=0):
     """Config 3: synthetic 3840x2160 elementary stream -- VPS+SPS+PPS before each IDR,
     `slices_per_picture` slice segments per picture, P/B pictures using the SPS RPS sets."""
     g = Synth(seed, rich=rich)
     rng = np.random.RandomState(seed + 1)
     nals = []
+    count = 0
     for pic in range(n_pictures):
         idr = pic % idr_every == 0
         if idr:
             nals.append(g.vps())
             nals.append(g.sps_nal(3840, 2160, ctb_log2=6))
-            nals.append(g.pps_nal(force={"tiles": 0}))
+            nals.append(g.pps_nal(force={"tiles": 0, "lists_mod": 1} if forbidden_every else {"tiles": 0}))
         for sl in range(slices_per_picture):
             n = int(rng.randint(payload_bytes[0], payload_bytes[1]))
             payload = rng.randint(0, 256, size=n).astype(np.uint8).tobytes()
+            count += 1
+            bad = forbidden_every and not idr and count % forbidden_every == 0
+            if bad:      # out of spec on purpose: an IDR coded as a P slice asks for the RPS row the last slice with an own set left behind
+                nals.append(g.slice_nal(19, first=(sl == 0), payload=payload, slice_type=1, address=sl * (2040 // slices_per_picture)))
+                continue
             nals.append(g.slice_nal(19 if idr else 1, first=(sl == 0), payload=payload,
                                     address=sl * (2040 // slices_per_picture)))
     return annexb(nals), len(nals)

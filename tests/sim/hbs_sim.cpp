@@ -17,6 +17,7 @@
 #include "../../hevcbitstream_amd/csrc/hbs_sparse.h"
 #include "../../hevcbitstream_amd/csrc/hbs_emit.h"
 #include "../../hevcbitstream_amd/csrc/hbs_parse.h"
+#include "../../hevcbitstream_amd/csrc/hbs_parse_fix.h"
 #include "../../hevcbitstream_amd/csrc/hbs_parse_ext.h"
 #include "../../hevcbitstream_amd/csrc/hbs_ingest.h"
 
@@ -199,6 +200,11 @@ static TraceRec* g_sim_trace = nullptr;       /* set by sim_parse_trace around s
 static uint32_t g_sim_trace_cap = 0;
 static uint32_t* g_sim_trace_count = nullptr;
 
+static int g_sim_fix_mode = 0;                 /* 0: the batch parse alone; 1: + the exact re-walk when a slice raised the flag; 2: + always */
+static int g_sim_fix_stats[3];                 /* a slice raised the flag / slices walked again / chains that were too deep */
+extern "C" void sim_parse_set_fix(int mode) { g_sim_fix_mode = mode; }
+extern "C" void sim_parse_fix_stats(int* out) { out[0] = g_sim_fix_stats[0]; out[1] = g_sim_fix_stats[1]; out[2] = g_sim_fix_stats[2]; }
+
 template <int kMode>
 static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n,
                               ParsedNal* parsed, uint8_t* structs, uint64_t structs_cap)
@@ -207,6 +213,8 @@ static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uin
     uint64_t run = 0;
     long long cs = -1, cp = -1;
     std::vector<long long> ctx_sps(n), ctx_pps(n);
+    std::vector<uint32_t> deps(n + 1, 0u);
+    int any_diverged = 0;
     for (uint64_t k = 0; k < n; ++k) {
         ParsedNal p;
         p.rc = -1; p.nal_unit_type = p.nal_layer_id = p.nal_temporal_id_plus1 = -1;
@@ -239,7 +247,7 @@ static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uin
             ps.b.win = src; ps.b.full = src; ps.b.win_bytes = idx[k].rbsp_len < 512u ? idx[k].rbsp_len : 512u;
             ps.b.size = idx[k].rbsp_len; ps.b.pos = 16;
             ps.b.tr = g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr; ps.b.tr_cap = g_sim_trace_cap; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
-            ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+            ps.sps = nullptr; ps.pps = nullptr; ps.init_rows();
             const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
             const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
             const hevc_sps_t* last_sps = zero_sps;
@@ -262,8 +270,29 @@ static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uin
             ParsedNal out = parsed[k];
             parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
             parsed[k] = out;
+            if (slice) { deps[k] = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read); any_diverged |= ps.diverged; }
             if (g_sim_trace_count) g_sim_trace_count[k] = ps.b.tr_n;
         }
+    /* the exact re-walk of the slices that need it: hbs_parse_fix.h, as k4_fix_masks / k4_fix_list / k4_fix run it */
+    g_sim_fix_stats[0] = any_diverged; g_sim_fix_stats[1] = 0; g_sim_fix_stats[2] = 0;
+    if (g_sim_fix_mode && (any_diverged || g_sim_fix_mode == 2)) {          /* mode 2: look for affected slices even when no slice raised the flag (is the flag complete?) */
+        std::vector<uint32_t> wmask(n + 1, 0u), bsum(n / kFixBlock + 2, 0u);
+        for (uint64_t k = 0; k < n; ++k) { wmask[k] = fix_wmask_of(parsed, structs, deps.data(), k); bsum[k / kFixBlock] |= wmask[k]; }
+        FixCtx c;
+        c.rbsp = rbsp; c.idx = idx; c.n = n; c.parsed = parsed; c.structs = structs; c.structs_cap = structs_cap;
+        c.ctx_sps = ctx_sps.data(); c.ctx_pps = ctx_pps.data(); c.zeros = zeros.data(); c.init_sps_slot = nullptr; c.init_pps = nullptr;
+        c.deps = deps.data(); c.wmask = wmask.data(); c.bsum = bsum.data();
+        std::vector<uint64_t> list;
+        for (uint64_t k = 0; k < n; ++k) if (fix_is_affected(c, k)) list.push_back(k);
+        g_sim_fix_stats[1] = (int)list.size();
+        std::vector<RpsRow> temps(kFixTemps);
+        for (uint64_t k : list) {
+            uint32_t tr_n = 0;
+            const bool ok = fix_slice<kMode>(c, k, temps.data(), g_sim_trace ? g_sim_trace + k * (uint64_t)g_sim_trace_cap : nullptr, g_sim_trace_cap, &tr_n);
+            if (!ok) g_sim_fix_stats[2] += 1;
+            else if (g_sim_trace_count) g_sim_trace_count[k] = tr_n;
+        }
+    }
     return (int64_t)run;
 }
 
@@ -522,7 +551,7 @@ extern "C" int sim_write_nal(int type, int layer, int tid, uint8_t* slot /* stru
     ParserT<kModeWrite> ps;
     ps.b.win = out; ps.b.full = out; ps.b.win_bytes = 0; ps.b.size = cap; ps.b.pos = 0;
     ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = out;
-    ps.sps = nullptr; ps.pps = nullptr; ps.sps_rps = nullptr; ps.out_rps = nullptr; ps.own = nullptr; ps.own_idx = -1;
+    ps.sps = nullptr; ps.pps = nullptr; ps.init_rows();
     const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros.data());
     const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros.data());
     const hevc_sps_t* last_sps = sps_slot ? reinterpret_cast<const hevc_sps_t*>(sps_slot) : zero_sps;

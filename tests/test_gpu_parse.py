@@ -154,6 +154,23 @@ def test_config3_4k30_100k_nals(ctx):
     assert (parsed["slice_data_size"][sl] + parsed["slice_data_off"][sl].astype(np.int64) == idx["rbsp_len"][sl]).all()
 
 
+def test_out_of_spec_slices_are_walked_again_by_themselves(ctx):
+    """A 4K30-style batch of ~16 k NALs in which one slice in a hundred is an IDR coded as a P slice: its header reads the RPS
+    row the last slice with an own set left behind (hevc_stream.c:35-59 on the file-static tables), which the parallel parse
+    does not know.  Only those slices are walked again, each with the true row handed in (hbs_parse_fix.h); every NAL of
+    the batch must equal the oracle's sequential parse -- and the batch parse alone must NOT (the test has teeth)."""
+    stream, n = stream_4k30(21, n_pictures=2000, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120), forbidden_every=100)
+    s, idx, arena, parsed, structs = gpu_parse(ctx, stream)
+    assert len(idx) == n
+    nals = [bytes(s[int(a):int(b)]) for a, b in zip(idx["start"], idx["end"])]
+    exp = oracle_pass(nals)
+    compare(parsed, structs, arena, idx, exp)
+    from tests import _sim
+    p0, s0 = _sim.parse_headers(arena, idx, fix=0)                      # the batch parse alone, single-stepped on the CPU
+    with pytest.raises(AssertionError):
+        compare(p0, s0, arena, idx, exp)
+
+
 def test_write_headers_batch_roundtrip(ctx):
     """K5 over a whole parsed batch (config-3 style stream, ~8k NALs): VPS and PPS come back bit for bit
     (SURVEY: "round-trips VPS/PPS exactly"), an SPS comes back without its trailing bits and unfinished

@@ -111,3 +111,48 @@ def test_bit_io_fast_paths_equal_the_bit_loops():
     L.sim_bitio_check.argtypes = [C.c_uint64, C.c_int64]
     L.sim_bitio_check.restype = C.c_int64
     assert L.sim_bitio_check(12345, 400000) == 0
+
+
+def test_exact_rewalk_of_slices_that_depend_on_earlier_nals():
+    """hbs_parse_fix.h single-stepped: on streams the spec forbids -- parameter sets and slices damaged, sequences glued
+    together, an IDR coded as a P slice every hundred slices -- the batch parse plus the re-walk of the slices whose RPS
+    rows have another last writer than their SPS equals the oracle's sequential parse everywhere; the batch parse alone
+    does not (counted), and no chain of writers is deeper than the re-walk follows."""
+    def one(nals, fix, stats):
+        stream = np.frombuffer(annexb(nals), dtype=np.uint8)
+        idx, arena, s = _sim.index_extract(stream)
+        assert len(idx) == len(nals)
+        parsed, structs = _sim.parse_headers(arena, idx, fix=fix, stats=stats)
+        return parsed, structs, arena, idx
+
+    rewalked = wrong_without = 0
+    streams = []
+    for seed in range(6000, 6120):
+        streams.append(broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True))
+    for seed in (300, 1036, 1320, 5224):
+        nals = []
+        for s2 in range(seed, seed + 8):
+            nals += broken(sequence(s2), np.random.RandomState(7 * s2 + 2), lambda t: True) if s2 % 2 else sequence(s2)
+        streams.append(nals)
+    for nals in streams:
+        exp = oracle_pass(nals)
+        st = []
+        compare(*one(nals, 1, st), exp)
+        assert st[2] == 0
+        rewalked += st[1]
+        if st[1]:
+            try:
+                compare(*one(nals, 0, []), exp)
+            except AssertionError:
+                wrong_without += 1
+    assert rewalked > 10 and wrong_without > 3, (rewalked, wrong_without)
+    # the 4K30-style batch with one out-of-spec slice in a hundred
+    stream, n = stream_4k30(21, n_pictures=400, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120), forbidden_every=100)
+    s = np.frombuffer(stream, dtype=np.uint8)
+    idx, arena, summ = _sim.index_extract(s)
+    nals = [bytes(s[int(a):int(b)]) for a, b in zip(idx["start"], idx["end"])]
+    exp = oracle_pass(nals)
+    st = []
+    parsed, structs = _sim.parse_headers(arena, idx, fix=1, stats=st)
+    compare(parsed, structs, arena, idx, exp)
+    assert st[0] == 1 and 20 <= st[1] <= 40 and st[2] == 0, st
