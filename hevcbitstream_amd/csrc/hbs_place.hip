@@ -188,12 +188,13 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
     hipError_t e;
 #define PAIR_FAIL(what) { hbs_ctx_set_error(ctx, "hbs_pair_alloc: " what, (int)e); rc = HBS_E_HIP; }
 
-    /* layout: whole chunks of 1 GiB (probed when the peer allows), then a remainder of its own (< half a chunk: unprobed) */
+    /* layout: whole chunks of 1 GiB, the size rounded up (a remainder mapped as a chunk of its own size made hipMemSetAccess
+     * fail with "invalid argument" on this stack, so every mapping is one GiB: up to a GiB more than asked for is held) */
     const uint64_t total = up(bytes, kGran);
     const bool want_probe = d_peer != nullptr && peer_bytes >= kChunk / 2 && total >= kChunk && !getenv("HBS_PAIR_NO_PROBE");
-    uint64_t nfull = want_probe ? total / kChunk : 0;
-    uint64_t rest = total - nfull * kChunk;
-    if (want_probe && rest >= kChunk / 2) { nfull += 1; rest = 0; }
+    if (!want_probe) return HBS_E_CAPACITY;                           /* nothing to place: the plain way */
+    const uint64_t nfull = (total + kChunk - 1) / kChunk;
+    const uint64_t rest = 0;
     Pair* p = new (std::nothrow) Pair();
     if (!p) return HBS_E_HIP;
     p->device = device;

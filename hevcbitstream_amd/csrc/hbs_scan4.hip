@@ -311,8 +311,11 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
  * every tile's first barrier (index-only scans ran 23 % slower).  false: a look-back timed out, the workgroup gives up. */
 __device__ __attribute__((noinline))
 bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
-                uint64_t tile, bool last_tile, uint8_t* rbsp, uint64_t rbsp_cap, unsigned long long* desc, RunHeader* hdr, const EmitTarget& tgt)
+                uint64_t tile, bool last_tile, uint8_t* rbsp, uint64_t rbsp_cap, unsigned long long* desc, RunHeader* hdr,
+                hbs_nal_entry* index, uint64_t index_cap)
 {
+    EmitTarget tgt;                      /* built here: handed over by reference it had to live in scratch memory for the whole kernel */
+    tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk0 = (uint32_t)(64 * k4Rows * wv);
@@ -704,7 +707,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         const bool last_tile = d_tile == num_tiles - 1;
         const uint8_t* const src = last_tile
             ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
-        if (!dense_tile(l, src, base + (uint64_t)(wv * k4WaveBytes), n, d_before, d_before2, d_after, d_tile, last_tile, rbsp, rbsp_cap, desc, hdr, tgt)) return;
+        if (!dense_tile(l, src, base + (uint64_t)(wv * k4WaveBytes), n, d_before, d_before2, d_after, d_tile, last_tile, rbsp, rbsp_cap, desc, hdr, index, index_cap)) return;
     }
     }
     HBS4_T_FLUSH
