@@ -474,6 +474,18 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
                             const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
                             hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary)
 {
+    return hbs_parse_headers_state(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, d_initial_sps_slot, d_initial_pps,
+                                   d_trace, trace_cap, d_trace_count, d_summary, nullptr, nullptr);
+}
+
+int hbs_parse_headers_state(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                            hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                            const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                            hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary,
+                            uint8_t* d_state_sps_slot, uint8_t* d_state_pps)
+{
+    if ((d_state_sps_slot == nullptr) != (d_state_pps == nullptr)) return HBS_E_ARG;
+    if (d_state_sps_slot && (!d_structs || !n_nals)) return HBS_E_ARG;
     static_assert(sizeof(hbs_trace_rec) == sizeof(hbs::TraceRec), "public record == kernel record");
     static_assert(sizeof(hbs_parsed_nal) == sizeof(hbs::ParsedNal), "public record == kernel record");
     if (!c || !d_summary || (n_nals && (!d_rbsp || !d_index || !d_parsed))) return HBS_E_ARG;
@@ -516,7 +528,8 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.fix_count = reinterpret_cast<uint32_t*>(w + fix_off + 3 * b_n4 + b_bsum);
     a.fix_temps = reinterpret_cast<hbs::RpsRow*>(w + fix_off + 3 * b_n4 + b_bsum + 256);
     a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;
-    a.sequential = c->parse_sequential;
+    a.state_sps_slot_out = d_state_sps_slot; a.state_pps_out = d_state_pps;
+    a.sequential = d_state_sps_slot ? 0 : c->parse_sequential;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
 }

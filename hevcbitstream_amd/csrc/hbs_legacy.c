@@ -3,10 +3,11 @@
  * the batch C ABI (include/hevcbitstream_amd.h).  Plain C: it only moves the
  * caller's buffers to and from the GPU and calls hbs_*; every byte is scanned,
  * stripped, inserted or parsed by the HIP kernels.  No CPU implementation of
- * the algorithms exists in this file, and without a gfx950 GPU the first call
- * prints a diagnostic and abort()s.  A call is launch and copy latency, so the
- * wrappers keep it to one upload (page-locked staging), the kernels back to
- * back, and one download of a result block (see need_ctx).
+ * the algorithms exists in this file, and without a gfx950 GPU every call returns
+ * its failure value.  A call by itself is launch and copy latency, so a caller's
+ * loop over a buffer is answered from ONE batch per buffer ("one batch per buffer"
+ * below); calls outside such a loop keep to one upload (page-locked staging), the
+ * kernels back to back, and one download of a result block (see need_ctx).
  *
  * Symbols and the reference interface each one replaces:
  *   find_nal_unit               h264_nal.c:38-76       (proto h264_stream.h:54)
@@ -140,8 +141,10 @@ static int need_ctx(void)
     if ((rc = hbs_dev_alloc(g_ctx, sizeof(hevc_pps_t) + 64, (void**)&g_dpps))) die("hbs_dev_alloc", rc);
     if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
     if ((rc = hbs_fill_device(g_ctx, g_dpps, 0, sizeof(hevc_pps_t)))) die("hbs_fill_device", rc);
-    g_sps_shadow = (uint8_t*)malloc(sizeof(hevc_sps_t));
-    g_pps_shadow = (uint8_t*)malloc(sizeof(hevc_pps_t));
+    /* the device-side sets start all-zero, like a fresh hevc_stream_t's (hevc_nal.c:34-57 callocs them) */
+    g_sps_shadow = (uint8_t*)calloc(1, sizeof(hevc_sps_t));
+    g_pps_shadow = (uint8_t*)calloc(1, sizeof(hevc_pps_t));
+    g_sps_shadow_ok = g_pps_shadow_ok = 1;
     return 0;
 }
 
@@ -236,6 +239,170 @@ static void fetch_results(uint64_t bytes, hbs_summary* sum, hbs_nal_entry* ent)
     memcpy(ent, g_hres + RES_INDEX, LEGACY_INDEX_CAP * sizeof(hbs_nal_entry));
 }
 
+/* ---- one batch per buffer (round 4) ------------------------------------------------------------------
+ * The reference's callers walk a buffer NAL by NAL (hevc_analyze.c:135-177: find_nal_unit, read_debug_hevc_nal_unit, on to
+ * the NAL's end); one GPU round trip per call made that loop twenty times slower than the CPU it replaces.  Now the first
+ * find_nal_unit of a buffer of WIN_MIN bytes or more indexes, extracts and PARSES all of it (up to WIN_MAX) as one batch --
+ * from the parameter sets and derived tables in force, with the exact re-walk of hbs_parse_fix.h, so every NAL's answer is
+ * the sequential parser's -- and brings index, records, structs, RBSP and traces to the host.  The calls that follow are
+ * answered from there as long as they are the calls the reference's loop would make: the next NAL, at the address the
+ * previous one ended, the same bytes (memcmp against the copy the batch was made from), the caller's h->sps / h->pps still
+ * what the previous answers put there.  Anything else -- another buffer, changed bytes, a NAL whose trace is longer than
+ * the batch keeps, a read in the other mode -- goes the old way, one call at a time, after the device-side state (the SPS
+ * and PPS in force and the tables) has been brought up to the NALs answered so far (hbs_parse_headers_state over them). */
+#define WIN_MIN (128u << 10)
+#define WIN_MAX (64u << 20)
+#define WIN_TRACE_CAP_MAX 1024u
+static uint32_t g_win_trace_cap = WIN_TRACE_CAP_MAX;     /* trace records the batch keeps per NAL (HBS_LEGACY_TRACE_CAP lowers it: a testing aid) */
+#define WIN_TRACE_CAP g_win_trace_cap
+typedef struct {
+    int valid, trace;
+    const uint8_t* base;             /* the caller's buffer the batch was made from, and a copy of those bytes */
+    uint64_t len;
+    uint8_t* copy; uint64_t copy_cap;
+    uint64_t n;                      /* NALs of the batch: those terminated inside the window */
+    uint64_t find_next;              /* the NAL the next find_nal_unit is expected to ask for */
+    uint64_t served;                 /* NALs read so far, in order */
+    uint64_t synced;                 /* the device-side parser state reflects NALs [0, synced) */
+    hbs_nal_entry* ent; hbs_parsed_nal* parsed; uint64_t ent_cap;
+    uint8_t* structs; uint64_t structs_cap;
+    uint8_t* rbsp; uint64_t rbsp_cap;
+    hbs_trace_rec* tr; uint32_t* trn; uint64_t tr_cap;
+    uint64_t struct_bytes, rbsp_bytes;
+    /* device */
+    uint8_t* d_stream; uint64_t d_stream_cap;
+    uint8_t* d_rbsp; uint64_t d_rbsp_cap;
+    uint8_t* d_index; uint64_t d_index_cap;      /* entries, then records */
+    uint8_t* d_structs; uint64_t d_structs_cap;
+    uint8_t* d_tr; uint64_t d_tr_cap;            /* trace records, then counts */
+    uint8_t* d_misc;                             /* summary (64), end-state SPS slot, end-state PPS */
+} window_t;
+static window_t W;
+static int g_read_mode = 1;          /* 1: the last read was read_debug_hevc_nal_unit -- the mode the next batch is parsed in */
+
+static void grow_dev(uint8_t** p, uint64_t* cap, uint64_t want)
+{
+    int rc;
+    if (want <= *cap) return;
+    if (*p) hbs_dev_free(g_ctx, *p);
+    *cap = want + want / 4 + 4096;
+    if ((rc = hbs_dev_alloc(g_ctx, *cap, (void**)p))) die("hbs_dev_alloc", rc);
+}
+static void grow_host(void** p, uint64_t* cap, uint64_t want)
+{
+    if (want <= *cap) return;
+    free(*p);
+    *cap = want + want / 4 + 4096;
+    *p = malloc((size_t)*cap);
+    if (!*p) { fprintf(stderr, "libhevcbitstream: out of host memory\n"); abort(); }
+}
+#define W_SUM ((hbs_summary*)W.d_misc)
+#define W_END_SPS (W.d_misc + 256)
+#define W_END_PPS (W.d_misc + 256 + ((hbs_sps_slot_bytes() + 255) & ~(uint64_t)255))
+
+/* the device-side parser state (g_dsps_slot, g_dpps) up to the NALs answered from the batch so far */
+static void window_settle(void)
+{
+    int rc;
+    hbs_summary s;
+    if (!W.valid || W.synced >= W.served) return;
+    if (W.synced == 0 && W.served == W.n) {                    /* everything: the state the batch itself computed */
+        if ((rc = hbs_copy_device(g_ctx, g_dsps_slot, W_END_SPS, hbs_sps_slot_bytes()))) die("hbs_copy_device", rc);
+        if ((rc = hbs_copy_device(g_ctx, g_dpps, W_END_PPS, sizeof(hevc_pps_t)))) die("hbs_copy_device", rc);
+    } else {
+        const uint64_t a = W.synced, m = W.served - W.synced;
+        if ((rc = hbs_parse_headers_state(g_ctx, W.d_rbsp, (const hbs_nal_entry*)W.d_index + a, m,
+                                          (hbs_parsed_nal*)(W.d_index + W.ent_cap * sizeof(hbs_nal_entry)) + a, W.d_structs, W.d_structs_cap,
+                                          g_dsps_slot, g_dpps, NULL, 0, NULL, W_SUM, g_dsps_slot, g_dpps))) die("hbs_parse_headers_state", rc);
+        if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
+        if (s.reserved[1] || s.error) {
+            fprintf(stderr, "libhevcbitstream: the parser state behind %llu NALs of a batch could not be derived (error %d)\n", (unsigned long long)W.served, s.error);
+            abort();
+        }
+    }
+    W.synced = W.served;
+}
+
+/* parse (again) the NALs [from, W.n) of the window in the given mode, from the device-side state, and fetch the answers */
+static void window_parse(int trace)
+{
+    int rc;
+    hbs_summary s;
+    const uint64_t n = W.n;
+    hbs_nal_entry* d_ent = (hbs_nal_entry*)W.d_index;
+    hbs_parsed_nal* d_par = (hbs_parsed_nal*)(W.d_index + W.ent_cap * sizeof(hbs_nal_entry));
+    /* how large is the struct arena? (a plan-only pass: sizes and offsets, nothing parsed) */
+    if ((rc = hbs_parse_headers_ctx(g_ctx, W.d_rbsp, d_ent, n, d_par, NULL, 0, g_dsps_slot, g_dpps, W_SUM))) die("hbs_parse_headers_ctx", rc);
+    if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
+    W.struct_bytes = s.reserved[0];
+    grow_dev(&W.d_structs, &W.d_structs_cap, W.struct_bytes + 64);
+    if (trace) grow_dev(&W.d_tr, &W.d_tr_cap, n * ((uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec) + 4) + 64);
+    {
+        hbs_trace_rec* d_tr = trace ? (hbs_trace_rec*)W.d_tr : NULL;
+        uint32_t* d_trn = trace ? (uint32_t*)(W.d_tr + n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec)) : NULL;
+        if ((rc = hbs_parse_headers_state(g_ctx, W.d_rbsp, d_ent, n, d_par, W.d_structs, W.d_structs_cap, g_dsps_slot, g_dpps,
+                                          d_tr, trace ? WIN_TRACE_CAP : 0, d_trn, W_SUM, W_END_SPS, W_END_PPS))) die("hbs_parse_headers_state", rc);
+    }
+    if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
+    if (s.error || s.reserved[1]) { W.valid = 0; return; }      /* (a chain of own sets deeper than the re-walk follows: one call at a time) */
+    grow_host((void**)&W.structs, &W.structs_cap, W.struct_bytes + 64);
+    if ((rc = hbs_copy_to_host(g_ctx, W.parsed, d_par, n * sizeof(hbs_parsed_nal)))) die("hbs_copy_to_host", rc);
+    if (W.struct_bytes && (rc = hbs_copy_to_host(g_ctx, W.structs, W.d_structs, W.struct_bytes))) die("hbs_copy_to_host", rc);
+    if (trace) {
+        free(W.trn); W.trn = (uint32_t*)malloc((size_t)(n * 4 + 64));
+        if ((rc = hbs_copy_to_host(g_ctx, W.trn, W.d_tr + n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec), n * 4))) die("hbs_copy_to_host", rc);
+        free(W.tr); W.tr = (hbs_trace_rec*)malloc((size_t)(n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec) + 64));
+        /* (the records of a NAL sit WIN_TRACE_CAP apart: one copy of the block) */
+        if ((rc = hbs_copy_to_host(g_ctx, W.tr, W.d_tr, n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec)))) die("hbs_copy_to_host", rc);
+    }
+    W.trace = trace;
+}
+
+/* index + extract + parse the first min(size, WIN_MAX) bytes of buf as one batch; 0: no batch (too many NALs, nothing terminated) */
+static int window_build(uint8_t* buf, int size)
+{
+    int rc;
+    hbs_summary s;
+    uint64_t len = (uint64_t)size < WIN_MAX ? (uint64_t)size : WIN_MAX, cap, n;
+    {
+        const char* tc = getenv("HBS_LEGACY_TRACE_CAP");
+        if (tc && atoi(tc) > 0 && (uint32_t)atoi(tc) < WIN_TRACE_CAP_MAX) g_win_trace_cap = (uint32_t)atoi(tc);
+    }
+    window_settle();
+    W.valid = 0;
+    cap = len / 48 + 64;                                        /* NALs of 48 bytes and less: not what this is for */
+    grow_dev(&W.d_stream, &W.d_stream_cap, len + 64);
+    grow_dev(&W.d_rbsp, &W.d_rbsp_cap, len + 64);
+    if (cap > W.ent_cap) {
+        W.ent_cap = cap + cap / 4;
+        grow_dev(&W.d_index, &W.d_index_cap, W.ent_cap * (sizeof(hbs_nal_entry) + sizeof(hbs_parsed_nal)) + 64);
+        free(W.ent); free(W.parsed);
+        W.ent = (hbs_nal_entry*)malloc((size_t)(W.ent_cap * sizeof(hbs_nal_entry)));
+        W.parsed = (hbs_parsed_nal*)malloc((size_t)(W.ent_cap * sizeof(hbs_parsed_nal)));
+    }
+    if (!W.d_misc && (rc = hbs_dev_alloc(g_ctx, 256 + 2 * ((hbs_sps_slot_bytes() + 255) & ~(uint64_t)255) + sizeof(hevc_pps_t), (void**)&W.d_misc))) die("hbs_dev_alloc", rc);
+    need_stage(len);
+    memcpy(g_hstage, buf, (size_t)len);
+    if ((rc = hbs_copy_to_device_async(g_ctx, W.d_stream, g_hstage, len))) die("hbs_copy_to_device_async", rc);
+    if ((rc = hbs_index_extract(g_ctx, W.d_stream, len, (hbs_nal_entry*)W.d_index, W.ent_cap, W.d_rbsp, W.d_rbsp_cap, W_SUM))) die("hbs_index_extract", rc);
+    if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
+    if (s.error || s.nal_count == 0) return 0;
+    n = s.nal_count;
+    if ((rc = hbs_copy_to_host(g_ctx, W.ent, W.d_index, n * sizeof(hbs_nal_entry)))) die("hbs_copy_to_host", rc);
+    /* only NALs that end inside the window, with what terminates them (as find_nal_unit needs to see it) */
+    while (n && ((W.ent[n - 1].status & HBS_ST_UNTERMINATED) || W.ent[n - 1].end + 4 > len)) --n;
+    if (n < 2) return 0;
+    W.n = n; W.len = len; W.base = buf;
+    W.rbsp_bytes = W.ent[n - 1].rbsp_off + W.ent[n - 1].rbsp_len;
+    grow_host((void**)&W.copy, &W.copy_cap, len);
+    memcpy(W.copy, buf, (size_t)len);
+    grow_host((void**)&W.rbsp, &W.rbsp_cap, W.rbsp_bytes + 64);
+    if (W.rbsp_bytes && (rc = hbs_copy_to_host(g_ctx, W.rbsp, W.d_rbsp, W.rbsp_bytes))) die("hbs_copy_to_host", rc);
+    W.valid = 1; W.find_next = 0; W.served = 0; W.synced = 0;
+    window_parse(g_read_mode);
+    return W.valid;
+}
+
 /* ---- byte layer ------------------------------------------------------------------------- */
 
 static int find_nal_unit_unlocked(uint8_t* buf, int size, int* nal_start, int* nal_end)
@@ -245,6 +412,30 @@ static int find_nal_unit_unlocked(uint8_t* buf, int size, int* nal_start, int* n
     *nal_end = 0;
     if (size <= 0) return 0;
     if (need_ctx()) return 0;
+    if (W.valid && W.find_next < W.n) {
+        /* the next NAL of the batch, asked for where the previous one ended, over the same bytes */
+        const uint64_t from = W.find_next ? W.ent[W.find_next - 1].end : 0;
+        const hbs_nal_entry* cur = &W.ent[W.find_next];
+        const uint64_t need = cur->end - from + 4;
+        if (buf == W.base + from && (uint64_t)size >= need && memcmp(buf, W.copy + from, (size_t)need) == 0) {
+            *nal_start = (int)(cur->start - from);
+            *nal_end = (int)(cur->end - from);
+            W.find_next++;
+            return *nal_end - *nal_start;
+        }
+    }
+    if ((uint64_t)size >= WIN_MIN && !getenv("HBS_LEGACY_NO_BATCH")) {
+        /* a buffer worth a batch (not one this call was already answered from: that is the case above) */
+        const int rest_of_old = W.valid && W.find_next >= W.n && buf == W.base + W.ent[W.n - 1].end &&
+                                (uint64_t)size <= W.len - W.ent[W.n - 1].end;     /* what the batch left: its unterminated last NAL */
+        if (!rest_of_old && window_build(buf, size)) {
+            const hbs_nal_entry* cur = &W.ent[0];
+            *nal_start = (int)cur->start;
+            *nal_end = (int)cur->end;
+            W.find_next = 1;
+            return *nal_end - *nal_start;
+        }
+    }
     if (g_fc_next >= 1 && g_fc_next < g_fc_n) {
         const hbs_nal_entry* prev = &g_fc_ent[g_fc_next - 1];
         const hbs_nal_entry* cur = &g_fc_ent[g_fc_next];
@@ -479,6 +670,71 @@ static void print_trace(void)
 
 static int is_slice(int t) { return (t >= 0 && t <= 9) || (t >= 16 && t <= 21); }
 
+static void print_trace_records(const hbs_trace_rec* tr, uint32_t n)
+{
+    uint32_t i;
+    for (i = 0; i < n; i++) {
+        const char* name = trace_name(tr[i].site);
+        printf("%ld.%d: ", (long)(tr[i].pos >> 3), (int)(8 - (tr[i].pos & 7)));
+        if (!name) printf("site_%u: %d \n", tr[i].site, tr[i].value);
+        else if (name[0]) printf("%s: %d \n", name, tr[i].value);
+    }
+}
+
+/* NAL W.served of the batch, checked by the caller to be what is asked for: the answer read_nal would fetch from the GPU,
+ * from the host copies the batch left (same order of side effects on *h as below) */
+static int serve_from_window(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int trace)
+{
+    const uint64_t k = W.served;
+    const hbs_nal_entry* e = &W.ent[k];
+    const hbs_parsed_nal* p = &W.parsed[k];
+    const uint8_t* src;
+    int t;
+    W.served = k + 1;
+    if (e->status & HBS_ST_ERROR) return -1;                             /* hevc_stream.c:167: nothing of *h is touched */
+    *stripped = 1;
+    if (trace) {
+        printf("0.8: forbidden_zero_bit: %d \n", (buf[0] >> 7) & 1);
+        printf("0.7: nal->nal_unit_type: %d \n", (buf[0] >> 1) & 0x3F);
+        printf("0.1: nal->nal_layer_id: %d \n", ((buf[0] & 1) << 5) | ((size > 1 ? buf[1] : 0) >> 3));
+        printf("1.3: nal->nal_temporal_id_plus1: %d \n", (size > 1 ? buf[1] : 0) & 7);
+        print_trace_records(W.tr + k * (uint64_t)WIN_TRACE_CAP, W.trn[k] < WIN_TRACE_CAP ? W.trn[k] : WIN_TRACE_CAP);
+    }
+    t = p->nal_unit_type;
+    h->nal->nal_unit_type = t;
+    h->nal->nal_layer_id = p->nal_layer_id;
+    h->nal->nal_temporal_id_plus1 = p->nal_temporal_id_plus1;
+    if (p->struct_off == ~0ull) return -1;                               /* unsupported type: hevc_stream.c:221 */
+    src = W.structs + p->struct_off;
+    if (t == HEVC_NAL_UNIT_TYPE_VPS_NUT) {
+        memcpy(h->vps, src, sizeof(hevc_vps_t));
+    } else if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
+        memcpy(h->sps, src, sizeof(hevc_sps_t));
+        memcpy(g_sps_shadow, src, sizeof(hevc_sps_t));                   /* what the device-side state will hold once it is brought up to here */
+        if (h->sps->sps_seq_parameter_set_id >= 0 && h->sps->sps_seq_parameter_set_id < 32)
+            memcpy(h->sps_table[h->sps->sps_seq_parameter_set_id], h->sps, sizeof(hevc_sps_t));
+    } else if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) {
+        memcpy(h->pps, src, sizeof(hevc_pps_t));
+        memcpy(g_pps_shadow, src, sizeof(hevc_pps_t));
+        if (h->pps->pic_parameter_set_id >= 0 && h->pps->pic_parameter_set_id < 256)
+            memcpy(h->pps_table[h->pps->pic_parameter_set_id], h->pps, sizeof(hevc_pps_t));
+    } else if (is_slice(t)) {
+        memcpy(h->sh, src, sizeof(hevc_slice_header_t));
+        if (h->slice_data) {
+            free(h->slice_data->rbsp_buf);
+            h->slice_data->rbsp_buf = NULL;
+            h->slice_data->rbsp_size = p->slice_data_size;
+            if (p->slice_data_size >= 0) {
+                h->slice_data->rbsp_buf = (uint8_t*)malloc((size_t)p->slice_data_size + 1);
+                if (p->slice_data_size > 0)
+                    memcpy(h->slice_data->rbsp_buf, W.rbsp + e->rbsp_off + p->slice_data_off, (size_t)p->slice_data_size);
+            }
+        }
+    }
+    if (W.served == W.n) window_settle();                                /* the batch is used up: the state behind it, for whoever comes next */
+    return p->rc;
+}
+
 /* *stripped = 0 when nal_to_rbsp already rejected the NAL (nothing of *h is touched then).
  * One upload, the scan and the parse back to back, one download of summary + index + parsed record +
  * slice-sized struct: the host looks at the scan's answer only afterwards (a parse of a NAL the scan
@@ -493,6 +749,28 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     *stripped = 0;
     if (size < 0) return -1;
     if (need_ctx()) return -1;
+    g_read_mode = trace ? 1 : 0;
+    if (W.valid && W.served < W.n) {
+        const uint64_t k = W.served;
+        const hbs_nal_entry* we = &W.ent[k];
+        const int mine = buf == W.base + we->start && (uint64_t)size == we->end - we->start && memcmp(buf, W.copy + we->start, (size_t)size) == 0 &&
+                         g_sps_shadow_ok && g_pps_shadow_ok && memcmp(g_sps_shadow, h->sps, sizeof(hevc_sps_t)) == 0 &&
+                         memcmp(g_pps_shadow, h->pps, sizeof(hevc_pps_t)) == 0;
+        if (mine && trace != W.trace && k == W.synced) {
+            /* the batch was parsed for the other reader: parse what is left of it again, in this one */
+            window_settle();
+            if (k) {                                            /* (from NAL k on: the window shrinks to its rest) */
+                W.valid = 0;
+            } else window_parse(trace);
+        }
+        if (mine && W.valid && trace == W.trace && (!trace || W.trn[k] <= WIN_TRACE_CAP)) return serve_from_window(h, buf, size, stripped, trace);
+        /* not the call the batch expected, or one it cannot answer: the old way, from the state behind the NALs answered so far */
+        window_settle();
+        if (mine && W.valid) { /* this very NAL, one call at a time; the batch goes on behind it */ }
+        else W.valid = 0;
+    } else if (W.valid) {
+        window_settle();                                        /* everything answered: the old way continues from the state behind the batch */
+    }
     need_bufs((uint64_t)size + 16, 0);
     need_block((uint64_t)size + 16);
     upload_input(sc, 3, buf, (uint64_t)size);
@@ -560,17 +838,32 @@ void hbs_legacy_reset_tables(void)
     int rc;
     legacy_lock();
     if (need_ctx() == 0) {
+        W.valid = 0;
         if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
         g_sps_shadow_ok = 0;
     }
     legacy_unlock();
 }
 
+/* a read that went the old way although it was the batch's next NAL (its trace was too long for the batch): the batch goes on
+ * behind it -- the device-side state now includes it */
+static int read_nal_w(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int trace)
+{
+    const int was_valid = W.valid;
+    const uint64_t k = W.served;
+    const int r = read_nal(h, buf, size, stripped, trace);
+    if (was_valid && W.valid && W.served == k && k < W.n && buf == W.base + W.ent[k].start && (uint64_t)size == W.ent[k].end - W.ent[k].start) {
+        W.served = k + 1;
+        W.synced = k + 1;
+    }
+    return r;
+}
+
 int read_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
     int stripped, r;
     legacy_lock();
-    r = read_nal(h, buf, size, &stripped, 0);
+    r = read_nal_w(h, buf, size, &stripped, 0);
     legacy_unlock();
     return r;
 }
@@ -586,7 +879,7 @@ int read_debug_hevc_nal_unit(hevc_stream_t* h, uint8_t* buf, int size)
 {
     int stripped, r;
     legacy_lock();
-    r = read_nal(h, buf, size, &stripped, 1);
+    r = read_nal_w(h, buf, size, &stripped, 1);
     legacy_unlock();
     return r;
 }
@@ -609,6 +902,8 @@ static int write_hevc_nal_unit_unlocked(hevc_stream_t* h, uint8_t* buf, int size
     static hbs_written_nal* d_written = NULL;
     if (size < 0) return -1;
     if (need_ctx()) return -1;
+    window_settle();                                                     /* the writers read (and an SPS rewrites) the tables in force */
+    W.valid = 0;
     cap = (uint32_t)((long)size * 3 / 4);
     need_bufs(16, (uint64_t)cap + 16);
     need_block(0);

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kFixBlock)
 void k4_fix_masks(const ParsedNal* __restrict__ parsed, const uint8_t* __restrict__ structs, const uint32_t* __restrict__ deps, uint64_t n,
                   uint32_t* __restrict__ wmask, uint32_t* __restrict__ bsum, uint32_t* __restrict__ fix_count, const uint32_t* __restrict__ gate)
 {
-    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     __shared__ uint32_t part[kFixBlock / 64];
     const uint64_t k = (uint64_t)blockIdx.x * kFixBlock + threadIdx.x;
     uint32_t m = 0u;
@@ -683,6 +683,62 @@ void k4_fix(FixCtx c, const uint32_t* __restrict__ list, uint32_t* __restrict__ 
 #endif
         if (!ok) atomicOr(&fix_count[1], 1u);                    /* a chain of slices deeper than kFixDepth: the whole batch in order (k4_seq) */
         else if (trace_count) trace_count[k] = tr_n;
+    }
+}
+
+/* What the reference holds BEHIND the last NAL of the batch (hbs_parse_headers_state; the legacy symbols continue from it):
+ * the SPS and PPS in force, and the 32 rows of the derived tables -- each row what its last writer left, found and evaluated
+ * like the rows an out-of-spec slice reads (hbs_parse_fix.h), a lane per row.  One wavefront. */
+__global__ __launch_bounds__(64)
+void k4_state(FixCtx c, RpsRow* __restrict__ temps, uint8_t* __restrict__ scratch_sh /* 32 slice headers */,
+              uint8_t* __restrict__ sps_slot_out, uint8_t* __restrict__ pps_out, hbs_summary* __restrict__ sum)
+{
+    const int lane = threadIdx.x;
+    const uint64_t n = c.n;
+    /* the parameter sets in force behind NAL n - 1 */
+    long long cs = -1, cp = -1;
+    if (n) {
+        cs = c.ctx_sps[n - 1]; cp = c.ctx_pps[n - 1];
+        const int t = c.parsed[n - 1].nal_unit_type;
+        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) cs = (long long)(n - 1);
+        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) cp = (long long)(n - 1);
+    }
+    const uint64_t tbl_off = round16(sizeof(hevc_sps_t));
+    const uint8_t* sps_src = cs >= 0 ? (c.parsed[cs].struct_off != ~0ull ? c.structs + c.parsed[cs].struct_off : c.zeros) : c.init_sps_slot;
+    const uint8_t* pps_src = cp >= 0 ? (c.parsed[cp].struct_off != ~0ull ? c.structs + c.parsed[cp].struct_off : c.zeros) : c.init_pps;
+    /* rows first (they may read the initial tables, which sps_slot_out may alias): into LDS-free temporaries, then out */
+    RpsRow* const my = temps + (uint64_t)lane * (kFixDepth + 1);
+    bool ok = true;
+    if (lane < 32) {
+        RowView v;
+        ok = fix_resolve_row(c, lane, n, my, reinterpret_cast<hevc_slice_header_t*>(scratch_sh + (uint64_t)lane * round16(sizeof(hevc_slice_header_t))), v);
+        RpsRow* keep = &my[kFixDepth];
+        if (ok) {
+            keep->NumDeltaPocs = v.nd; keep->NumNegativePics = v.nn; keep->NumPositivePics = v.np;
+            for (int j = 0; j < 32; ++j) { keep->DeltaPocS0[j] = v.s0[j]; keep->UsedByCurrPicS0[j] = v.u0[j]; keep->DeltaPocS1[j] = v.s1[j]; keep->UsedByCurrPicS1[j] = v.u1[j]; }
+        }
+    }
+    if (__ballot(!ok) != 0ull && lane == 0) sum->reserved[1] = 1;           /* a chain deeper than the re-walk follows: the rows it could not tell are left as they were */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    /* the structs (when they are not already where they go) */
+    if (sps_src && sps_src != sps_slot_out)
+        for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(hevc_sps_t) / 4); i += 64) reinterpret_cast<uint32_t*>(sps_slot_out)[i] = reinterpret_cast<const uint32_t*>(sps_src)[i];
+    if (!sps_src)
+        for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(hevc_sps_t) / 4); i += 64) reinterpret_cast<uint32_t*>(sps_slot_out)[i] = 0u;
+    if (pps_src && pps_src != pps_out)
+        for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(hevc_pps_t) / 4); i += 64) reinterpret_cast<uint32_t*>(pps_out)[i] = reinterpret_cast<const uint32_t*>(pps_src)[i];
+    if (!pps_src)
+        for (uint32_t i = (uint32_t)lane; i < (uint32_t)(sizeof(hevc_pps_t) / 4); i += 64) reinterpret_cast<uint32_t*>(pps_out)[i] = 0u;
+    if (lane < 32 && ok) {
+        RpsTables* t = reinterpret_cast<RpsTables*>(sps_slot_out + tbl_off);
+        const RpsRow* keep = &my[kFixDepth];
+        t->NumDeltaPocs[lane] = keep->NumDeltaPocs; t->NumNegativePics[lane] = keep->NumNegativePics; t->NumPositivePics[lane] = keep->NumPositivePics;
+        for (int j = 0; j < 32; ++j) {
+            t->DeltaPocS0[lane][j] = keep->DeltaPocS0[j]; t->UsedByCurrPicS0[lane][j] = keep->UsedByCurrPicS0[j];
+            t->DeltaPocS1[lane][j] = keep->DeltaPocS1[j]; t->UsedByCurrPicS1[lane][j] = keep->UsedByCurrPicS1[j];
+        }
     }
 }
 
@@ -808,7 +864,7 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
             k4_seq<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
                                                 a.initial_pps, nullptr, 0, nullptr, seq_tables_ws, a.summary, a.div_flag);
     };
-    if (a.n >= 1 && a.n <= 64) {
+    if (a.n >= 1 && a.n <= 64 && !a.state_sps_slot_out) {
         if (a.trace)
             k4_small<kModeTrace><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
                                                    a.initial_pps, a.trace, a.trace_cap, a.trace_count, a.own_rows, a.summary, a.sequential, a.div_flag);
@@ -856,7 +912,7 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         e = hipMemsetAsync(a.fix_count, 0, 2 * sizeof(uint32_t), st);
         if (e != hipSuccess) return e;
         const unsigned mblocks = (unsigned)((a.n + kFixBlock - 1) / kFixBlock);
-        k4_fix_masks<<<mblocks, kFixBlock, 0, st>>>(a.parsed, a.structs, a.deps, a.n, a.wmask, a.bsum, a.fix_count, a.div_flag);
+        k4_fix_masks<<<mblocks, kFixBlock, 0, st>>>(a.parsed, a.structs, a.deps, a.n, a.wmask, a.bsum, a.fix_count, a.state_sps_slot_out ? nullptr : a.div_flag);
         const unsigned lblocks = mblocks < 1024u ? mblocks : 1024u;
         k4_fix_list<<<lblocks, 256, 0, st>>>(c, a.fix_list, a.fix_count, a.div_flag);
         if (a.trace)
@@ -870,6 +926,12 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
             else
                 k4_seq<kModeRead><<<1, 64, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.structs, a.structs_cap, a.zeros, a.initial_sps_slot,
                                                     a.initial_pps, nullptr, 0, nullptr, seq_tables_ws, a.summary, a.fix_count + 1);
+        }
+        if (a.state_sps_slot_out && a.state_pps_out) {
+            /* (temps: 64 lanes x (kFixDepth + 1) rows at the front of the re-walk's; scratch headers behind them) */
+            static_assert(64 * (kFixDepth + 1) * sizeof(RpsRow) + 32 * ((sizeof(hevc_slice_header_t) + 15) / 16 * 16) <= (size_t)kFixBlocks * 64 * kFixTemps * sizeof(RpsRow), "the state kernel fits the re-walk's temporaries");
+            uint8_t* scratch = reinterpret_cast<uint8_t*>(a.fix_temps) + 64 * (kFixDepth + 1) * sizeof(RpsRow);
+            k4_state<<<1, 64, 0, st>>>(c, a.fix_temps, scratch, a.state_sps_slot_out, a.state_pps_out, a.summary);
         }
     }
     return hipGetLastError();

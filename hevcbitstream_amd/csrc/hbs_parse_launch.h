@@ -42,6 +42,10 @@ struct ParseArgs {
     uint32_t* fix_list;              /* n: ordinals of the slices to walk again; fix_count[0] how many, fix_count[1] "walk the whole batch in order after all" */
     uint32_t* fix_count;
     RpsRow* fix_temps;               /* parse_fix_temps_bytes() */
+    /* optional: the parameter sets in force BEHIND the last NAL of the batch and the derived tables as the reference would
+     * hold them there (hbs_parse_headers_state): an SPS slot (struct + tables) and a hevc_pps_t */
+    uint8_t* state_sps_slot_out;
+    uint8_t* state_pps_out;
     int sequential;                  /* n == 1 only: the RPS tables behind initial_sps_slot are read AND written, as the
                                         reference's file-static tables are (what the legacy single-NAL symbols need) */
 };

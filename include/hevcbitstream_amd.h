@@ -321,6 +321,18 @@ int hbs_parse_headers_trace(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_e
                             const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
                             hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary);
 uint64_t hbs_sps_slot_bytes(void);
+/* The same, and what the reference would hold BEHIND the last NAL of the batch, for a caller that goes on NAL by NAL or with
+ * another batch (the legacy symbols do: they serve the loop of hevc_analyze.c:135-177 from one batch per buffer): the SPS in
+ * force with the 32 rows of the derived RPS tables (hevc_stream.c:26-32) -- each row what the last NAL that wrote it left,
+ * also rows beyond the SPS's own sets -- into d_state_sps_slot (hbs_sps_slot_bytes()), and the PPS in force into d_state_pps
+ * (sizeof(hevc_pps_t)).  Either may be the buffer the initial context came from.  Both NULL: hbs_parse_headers_trace.
+ * summary.reserved[1] != 0: a row depends on a chain of more than three slices' own sets; that row was left untouched.
+ * Needs d_structs and n_nals >= 1. */
+int hbs_parse_headers_state(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                            hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                            const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                            hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary,
+                            uint8_t* d_state_sps_slot, uint8_t* d_state_pps);
 /* One NAL at a time, exactly as the reference does it (what the legacy symbols use): with this on, a call with
  * n_nals == 1 and a d_initial_sps_slot treats the RPS tables behind that SPS as THE tables (hevc_stream.c:26-32):
  * an SPS writes its rows into them and leaves the others, a slice's own set lands in them, and a slice that names a

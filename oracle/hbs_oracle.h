@@ -86,6 +86,7 @@ int orc_read_hevc_nal_unit(orc_hevc* o, const uint8_t* buf, int size);
 /* RBSP of the NAL read last, and where its slice payload copy starts (-1: none) */
 const uint8_t* orc_hevc_rbsp(orc_hevc* o, int* size);
 int orc_hevc_slice_data_off(orc_hevc* o);
+const int* orc_hevc_tables(orc_hevc* o);      /* the derived RPS tables as they stand: 3 x 32 counts, then 4 x 32 x 32 values */
 
 /* ---- the NAL types read_hevc_nal_unit never dispatches (35..40): what their unused readers would read -------
  * hevc_stream.c:573-577 (AUD), :580-587 (EOS / EOB: nothing), :590-597 (filler data), :524-563 (SEI message loop,

@@ -76,6 +76,8 @@ void orc_hevc_free(orc_hevc* o)
 void* orc_hevc_stream_ptr(orc_hevc* o) { return &o->h; }
 const uint8_t* orc_hevc_rbsp(orc_hevc* o, int* size) { *size = o->rbsp_size; return o->rbsp; }
 int orc_hevc_slice_data_off(orc_hevc* o) { return o->slice_data_off; }
+/* the derived tables as they stand (hevc_stream.c:26-32): 3 x 32 counts, then 4 x 32 x 32 values, in the order of the struct above */
+const int* orc_hevc_tables(orc_hevc* o) { return o->NumDeltaPocs; }
 
 static int row_ok(int r) { return r >= 0 && r < ROWS; }
 static int col_ok(int c) { return c >= 0 && c < 32; }

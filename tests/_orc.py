@@ -228,6 +228,13 @@ class OracleHevc(_HevcParser):
         buf = np.frombuffer(bytes(nal) + b"\xff" * 8, dtype=np.uint8).copy()
         return self.L.orc_read_hevc_nal_unit(self.o, _ptr(buf), len(nal))
 
+    def tables(self):
+        """the derived RPS tables as they stand (hevc_stream.c:26-32): int32[3 * 32 + 4 * 32 * 32], the layout of hbs::RpsTables"""
+        self.L.orc_hevc_tables.argtypes = [C.c_void_p]
+        self.L.orc_hevc_tables.restype = C.POINTER(C.c_int32)
+        n = 3 * 32 + 4 * 32 * 32
+        return np.ctypeslib.as_array(self.L.orc_hevc_tables(self.o), shape=(n,)).copy()
+
     def close(self):
         self.L.orc_hevc_free(self.o)
 

@@ -93,6 +93,21 @@ def synth_rbsp(seed, n_nals, mode):
     return arena[:tot].copy(), idx[:n_nals]
 
 
+def parse_state(rbsp, idx):
+    """the derived RPS tables behind the last NAL of the batch, as k4_state computes them (every row from its last writer):
+    (int32 array in the layout of hbs::RpsTables, ok flag)"""
+    L = lib()
+    L.sim_rps_tables_bytes.restype = C.c_uint64
+    L.sim_parse_set_state_out.argtypes = [C.c_void_p]
+    out = np.zeros(int(L.sim_rps_tables_bytes()) // 4, dtype=np.int32)
+    L.sim_parse_set_state_out(out.ctypes.data)
+    try:
+        parse_headers(rbsp, idx, fix=1)
+    finally:
+        L.sim_parse_set_state_out(None)
+    return out, bool(L.sim_parse_state_ok())
+
+
 def parse_headers(rbsp, idx, fix=0, stats=None):
     """K4 single-stepped on the CPU.  Returns (parsed ndarray[PARSED], struct arena uint8).
     fix: 0 the batch parse alone, 1 + the exact re-walk of the slices that need it when a slice raised the flag (what the

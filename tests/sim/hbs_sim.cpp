@@ -200,6 +200,11 @@ static TraceRec* g_sim_trace = nullptr;       /* set by sim_parse_trace around s
 static uint32_t g_sim_trace_cap = 0;
 static uint32_t* g_sim_trace_count = nullptr;
 
+static uint8_t* g_sim_state_out = nullptr;     /* when set: the derived tables behind the last NAL go here (sizeof(RpsTables)) */
+static int g_sim_state_ok = 0;
+extern "C" void sim_parse_set_state_out(uint8_t* p) { g_sim_state_out = p; }
+extern "C" int sim_parse_state_ok() { return g_sim_state_ok; }
+extern "C" uint64_t sim_rps_tables_bytes() { return sizeof(RpsTables); }
 static int g_sim_fix_mode = 0;                 /* 0: the batch parse alone; 1: + the exact re-walk when a slice raised the flag; 2: + always */
 static int g_sim_fix_stats[3];                 /* a slice raised the flag / slices walked again / chains that were too deep */
 extern "C" void sim_parse_set_fix(int mode) { g_sim_fix_mode = mode; }
@@ -273,6 +278,25 @@ static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uin
             if (slice) { deps[k] = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read); any_diverged |= ps.diverged; }
             if (g_sim_trace_count) g_sim_trace_count[k] = ps.b.tr_n;
         }
+    if (g_sim_state_out) {
+        /* what the reference holds behind the last NAL (k4_state): every row of the tables from its last writer */
+        std::vector<uint32_t> wmask(n + 1, 0u), bsum(n / kFixBlock + 2, 0u);
+        for (uint64_t k = 0; k < n; ++k) { wmask[k] = fix_wmask_of(parsed, structs, deps.data(), k); bsum[k / kFixBlock] |= wmask[k]; }
+        FixCtx c;
+        c.rbsp = rbsp; c.idx = idx; c.n = n; c.parsed = parsed; c.structs = structs; c.structs_cap = structs_cap;
+        c.ctx_sps = ctx_sps.data(); c.ctx_pps = ctx_pps.data(); c.zeros = zeros.data(); c.init_sps_slot = nullptr; c.init_pps = nullptr;
+        c.deps = deps.data(); c.wmask = wmask.data(); c.bsum = bsum.data();
+        std::vector<RpsRow> temps(kFixDepth);
+        std::vector<uint8_t> scratch(sizeof(hevc_slice_header_t) + 64);
+        RpsTables* t = reinterpret_cast<RpsTables*>(g_sim_state_out);
+        g_sim_state_ok = 1;
+        for (int r = 0; r < 32; ++r) {
+            RowView v;
+            if (!fix_resolve_row(c, r, n, temps.data(), reinterpret_cast<hevc_slice_header_t*>(scratch.data()), v)) { g_sim_state_ok = 0; continue; }
+            t->NumDeltaPocs[r] = v.nd; t->NumNegativePics[r] = v.nn; t->NumPositivePics[r] = v.np;
+            for (int j = 0; j < 32; ++j) { t->DeltaPocS0[r][j] = v.s0[j]; t->UsedByCurrPicS0[r][j] = v.u0[j]; t->DeltaPocS1[r][j] = v.s1[j]; t->UsedByCurrPicS1[r][j] = v.u1[j]; }
+        }
+    }
     /* the exact re-walk of the slices that need it: hbs_parse_fix.h, as k4_fix_masks / k4_fix_list / k4_fix run it */
     g_sim_fix_stats[0] = any_diverged; g_sim_fix_stats[1] = 0; g_sim_fix_stats[2] = 0;
     if (g_sim_fix_mode && (any_diverged || g_sim_fix_mode == 2)) {          /* mode 2: look for affected slices even when no slice raised the flag (is the flag complete?) */

@@ -211,6 +211,47 @@ def test_reference_cli_full_stdout():
         assert got == want, (v["tag"], [(a, b) for a, b in zip(got, want) if a != b][:3], len(got), len(want))
 
 
+@pytest.mark.parametrize("kind", ["plain-11MB", "out-of-spec", "long-traces", "no-batch"])
+def test_reference_cli_on_large_streams_equals_the_reference_binary(kind, tmp_path):
+    """The loop of hevc_analyze.c:135-177 answered from ONE batch per buffer (hbs_legacy.c, round 4): the unmodified CLI on this
+    library against the same CLI on the compiled reference, whole stdout, on streams large enough for the batch path --
+    an 11 MB / 2 015-NAL sequence; one with an out-of-spec slice every 50 (their headers depend on the tables earlier
+    NALs left: the batch's exact re-walk and the state behind it are what is tested); NALs whose traces
+    are longer than the batch keeps (those NALs go one call at a time, the batch continues behind them); and the old way
+    (HBS_LEGACY_NO_BATCH=1) for comparison."""
+    from tests.hevc_synth import stream_4k30
+    amd = os.path.join(ROOT, "oracle", "_ref", "hevc_analyze_amd")
+    ref = os.path.join(ROOT, "oracle", "_ref", "hevc_analyze_ref")
+    if not (os.path.exists(amd) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref/hevc_analyze_amd / _ref not built (needs /root/reference at build time)")
+    if kind == "plain-11MB":
+        stream, n = stream_4k30(11, n_pictures=250, slices_per_picture=8, idr_every=60, payload_bytes=(2000, 9000))
+    elif kind == "out-of-spec":
+        stream, n = stream_4k30(21, n_pictures=300, slices_per_picture=8, idr_every=60, payload_bytes=(200, 900), forbidden_every=50)
+    elif kind == "long-traces":      # (the batch made to keep 40 trace records per NAL: parameter sets and many slices exceed that)
+        stream, n = stream_4k30(5, n_pictures=200, slices_per_picture=4, idr_every=10, payload_bytes=(400, 1500))
+    else:
+        stream, n = stream_4k30(13, n_pictures=60, slices_per_picture=8, idr_every=20, payload_bytes=(2000, 4000))
+    assert len(stream) > (128 << 10)
+    path = str(tmp_path / "s.hevc")
+    open(path, "wb").write(stream)
+    env = dict(os.environ)
+    env.pop("HBS_LEGACY_NO_BATCH", None)
+    env.pop("HBS_LEGACY_TRACE_CAP", None)
+    if kind == "no-batch":
+        env["HBS_LEGACY_NO_BATCH"] = "1"
+    if kind == "long-traces":
+        env["HBS_LEGACY_TRACE_CAP"] = "40"
+    want = subprocess.run([ref, path], stdout=subprocess.PIPE, check=True).stdout.decode("latin-1").splitlines()
+    got = subprocess.run([amd, path], stdout=subprocess.PIPE, check=True, env=env).stdout.decode("latin-1").splitlines()
+    for lines in (want, got):          # the first hex dump starts 4 bytes in front of the file buffer (heap bytes)
+        for i, l in enumerate(lines):
+            if l.startswith("!! Found NAL"):
+                lines[i + 1] = lines[i + 1][12:]
+                break
+    assert len(got) == len(want) and got == want, (kind, n, [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:3], len(got), len(want))
+
+
 def test_write_hevc_nal_unit_golden():
     """hevc_new + read_hevc_nal_unit + (edit) + write_hevc_nal_unit per NAL against the reference's writer
     (tests/golden/make_golden_write.py): bytes, return value and the slice_data side effect."""

@@ -156,3 +156,38 @@ def test_exact_rewalk_of_slices_that_depend_on_earlier_nals():
     parsed, structs = _sim.parse_headers(arena, idx, fix=1, stats=st)
     compare(parsed, structs, arena, idx, exp)
     assert st[0] == 1 and 20 <= st[1] <= 40 and st[2] == 0, st
+
+
+def test_table_state_behind_a_batch_equals_the_sequential_parsers():
+    """k4_state's arithmetic single-stepped: the 32 rows of the derived tables behind the last NAL of a batch, each taken from
+    the last NAL that wrote it (hbs_parse_fix.h), against the tables the oracle's sequential parser is left with -- on
+    ordinary sequences, damaged ones, and sequences glued together (rows of earlier SPSs with more sets stay alive)."""
+    from tests import _orc
+    checked = 0
+    for seed in range(7000, 7080):
+        variants = [sequence(seed), broken(sequence(seed), np.random.RandomState(7 * seed + 2), lambda t: True)]
+        if seed % 4 == 0:
+            variants.append(sequence(seed) + broken(sequence(seed + 1), np.random.RandomState(seed), lambda t: True) + sequence(seed + 2))
+        for nals in variants:
+            stream = np.frombuffer(annexb(nals), dtype=np.uint8)
+            idx, arena, s = _sim.index_extract(stream)
+            got, ok = _sim.parse_state(arena, idx)
+            if not ok:
+                continue
+            o = _orc.OracleHevc()
+            for nal in nals:
+                o.read(nal)
+            want = o.tables()
+            o.close()
+            # counts exactly; values below the counts (what lies beyond them in a row is never read -- hevc_stream.c:35-59, :1043-1075
+            # loop to the counts -- and keeps whatever an earlier, longer set left there in the reference)
+            g3, w3 = got[:96].reshape(3, 32), want[:96].reshape(3, 32)
+            assert np.array_equal(g3, w3), (seed, g3, w3)
+            g4, w4 = got[96:].reshape(4, 32, 32), want[96:].reshape(4, 32, 32)
+            for r in range(32):
+                nn, npos = int(w3[1][r]), int(w3[2][r])
+                for tbl, cnt in ((0, nn), (1, nn), (2, npos), (3, npos)):
+                    c = max(0, min(cnt, 32))
+                    assert np.array_equal(g4[tbl][r][:c], w4[tbl][r][:c]), (seed, r, tbl)
+            checked += 1
+    assert checked > 150

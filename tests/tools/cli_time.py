@@ -17,3 +17,25 @@ for exe in ("oracle/_ref/hevc_analyze_ref", "oracle/_ref/hevc_analyze_amd"):
         best = min(best, time.perf_counter() - t0)
         out_len = len(r.stdout)
     print("%-32s %d NALs, %.1f MB: %.2f s (%.0f NAL/s), stdout %d bytes, rc %d" % (exe, n, len(stream) / 1e6, best, n / best, out_len, r.returncode))
+
+# what of that is start-up (process, HIP, context): the same binaries on a 10-NAL file
+small = "tests/golden/ten_nal.hevc"
+for exe in ("oracle/_ref/hevc_analyze_ref", "oracle/_ref/hevc_analyze_amd"):
+    if not os.path.exists(exe) or not os.path.exists(small):
+        continue
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        subprocess.run([exe, small], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        best = min(best, time.perf_counter() - t0)
+    print("%-32s 10 NALs (start-up): %.3f s" % (exe, best))
+for mode in ("batch", "HBS_LEGACY_NO_BATCH=1"):
+    env = dict(os.environ)
+    if mode != "batch":
+        env["HBS_LEGACY_NO_BATCH"] = "1"
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        subprocess.run(["oracle/_ref/hevc_analyze_amd", path], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        best = min(best, time.perf_counter() - t0)
+    print("hevc_analyze_amd, %s: %.3f s for %d NALs" % (mode, best, n))
