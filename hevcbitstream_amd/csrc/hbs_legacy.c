@@ -37,6 +37,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <time.h>
 
 #include "../../include/hevcbitstream_amd.h"
 #include "../../include/h264_stream.h"
@@ -119,6 +120,14 @@ static void die(const char* what, int rc)
     abort();
 }
 
+static struct timespec g_t_ready;
+static void report_time(void)
+{
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    fprintf(stderr, "libhevcbitstream: %.4f s between the context being ready and exit\n",
+            (double)(t1.tv_sec - g_t_ready.tv_sec) + 1e-9 * (double)(t1.tv_nsec - g_t_ready.tv_nsec));
+}
 static int g_no_gpu = 0;
 /* 0, or -1: there is no gfx950 GPU to run on (said once; the callers return their failure value) */
 static int need_ctx(void)
@@ -145,6 +154,10 @@ static int need_ctx(void)
     g_sps_shadow = (uint8_t*)calloc(1, sizeof(hevc_sps_t));
     g_pps_shadow = (uint8_t*)calloc(1, sizeof(hevc_pps_t));
     g_sps_shadow_ok = g_pps_shadow_ok = 1;
+    if (getenv("HBS_LEGACY_TIMING")) {                          /* measuring aid: the time from here (GPU start-up done) to exit, on stderr */
+        clock_gettime(CLOCK_MONOTONIC, &g_t_ready);
+        atexit(report_time);
+    }
     return 0;
 }
 
