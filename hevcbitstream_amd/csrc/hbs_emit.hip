@@ -445,6 +445,114 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
         emit_nal(rbsp, idx, k, gap_of(idx, k, gap_mode), out_off[k], nal_total[k], out, out_cap, idx_out, err, lane);
 }
 
+/* ---- arenas of tiny NALs: a LANE per NAL (round 4) ---------------------------------------------------
+ * NALs below 384 bytes -- one slice per CTU row at a low bitrate -- have more than 512 starts per 192 KiB, so the arena
+ * tiles do not apply, and the kernels by NALs give every NAL a wavefront (or a 12 KiB slot): a 64-byte NAL used one lane in
+ * sixteen (0.008 of the HBM peak at 64 bytes, 0.04 at 384).  Here every lane walks its own NAL byte by byte, rbsp_to_nal
+ * as it is written (h264_nal.c:92-132): pass 1 the bytes that go in, an exclusive scan of the NALs' output sizes (the
+ * three steps' own), pass 2 the bytes -- read as unaligned dwords, written as unaligned dwords from a small register
+ * buffer.  Picked on the HOST (mean NAL size = rbsp_bytes / n below kTinyMeanBytes): no device-side gate, no probe. */
+constexpr uint64_t kTinyMeanBytes = 448;         /* (a mean of 384 bytes and more fits the arena tiles in principle -- at most 512 starts per 192 KiB -- but sizes scatter) */
+
+/* a lane's NAL, 16 bytes a load (a dword a load fetched every 128-byte line thirty-two times: 64 lanes x 32 wavefronts of
+ * lines do not stay in a 16 KiB L1) */
+template <class F>
+__device__ __forceinline__ void tiny_bytes(const uint8_t* __restrict__ p, uint32_t len, F&& f)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    uint32_t i = 0;
+#pragma unroll 1
+    for (; i + 16u <= len; i += 16u) {
+        const u32x4 q = reinterpret_cast<const U16*>(p + i)->v;
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { f(w[d] & 0xFFu); w[d] >>= 8; }
+    }
+#pragma unroll 1
+    for (; i < len; ++i) f((uint32_t)p[i]);
+}
+
+__device__ __forceinline__ uint32_t tiny_count(const uint8_t* __restrict__ p, uint32_t len)
+{
+    uint32_t ins = 0, count = 0;
+    tiny_bytes(p, len, [&](uint32_t v) {
+        if (count == 2u && v <= 3u) { ++ins; count = 0u; }
+        count = v == 0u ? count + 1u : 0u;
+    });
+    return ins;
+}
+
+__global__ __launch_bounds__(256)
+void k3_count_tiny(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+                   unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ vflag)
+{
+    if (index_bad(vflag)) return;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t len = idx[k].rbsp_len;
+        nal_total[k] = gap_of(idx, k, gap_mode) + len + tiny_count(rbsp + idx[k].rbsp_off, len);
+    }
+}
+
+/* bytes out through a 128-bit buffer: one (unaligned) 16-byte store whenever sixteen are there */
+struct TinyOut {
+    uint8_t* dst; uint64_t lo, hi; uint32_t have;
+    __device__ __forceinline__ void put(uint32_t v)
+    {
+        struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+        if (have < 8u) lo |= (uint64_t)v << (8u * have); else hi |= (uint64_t)v << (8u * (have - 8u));
+        if (++have == 16u) {
+            u32x4 q; q.x = (uint32_t)lo; q.y = (uint32_t)(lo >> 32); q.z = (uint32_t)hi; q.w = (uint32_t)(hi >> 32);
+            reinterpret_cast<U16*>(dst)->v = q;
+            dst += 16; lo = hi = 0ull; have = 0u;
+        }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        for (uint32_t b = 0; b < have; ++b) dst[b] = (uint8_t)((b < 8u ? lo >> (8u * b) : hi >> (8u * (b - 8u))));
+        dst += have; have = 0u; lo = hi = 0ull;
+    }
+};
+
+__global__ __launch_bounds__(256)
+void k3_emit_tiny(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+                  const unsigned long long* __restrict__ nal_total, const unsigned long long* __restrict__ out_off,
+                  uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
+                  const uint32_t* __restrict__ vflag)
+{
+    if (index_bad(vflag)) return;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t begin = idx[k].rbsp_off;
+        const uint32_t len = idx[k].rbsp_len;
+        const uint64_t gap = gap_of(idx, k, gap_mode), base = out_off[k], total = nal_total[k];
+        const uint64_t nal_start = base + gap, nal_end = base + total;
+        if (idx_out) {
+            hbs_nal_entry e;
+            e.start = nal_start; e.end = nal_end; e.rbsp_off = begin; e.rbsp_len = len; e.status = 0;
+            idx_out[k] = e;
+        }
+        if (nal_end > out_cap) { atomicMax(err, (uint32_t)(-HBS_E_CAPACITY)); continue; }
+        TinyOut o;
+        o.dst = out + base; o.lo = o.hi = 0ull; o.have = 0u;
+        for (uint64_t g = 0; g + 1 < gap; ++g) o.put(0u);                        /* zero_byte / leading zeros, then 01 */
+        if (gap) o.put(1u);
+        uint32_t count = 0;
+        tiny_bytes(rbsp + begin, len, [&](uint32_t v) {
+            if (count == 2u && v <= 3u) { o.put(3u); count = 0u; }
+            o.put(v);
+            count = v == 0u ? count + 1u : 0u;
+        });
+        o.flush();
+    }
+}
+
+bool emit_takes_tiny_path(uint64_t n, uint64_t rbsp_bytes, int two_pass, int tiles)
+{
+    /* automatic mode only (a pinned path stays pinned: the tests and the soak pin every path on every arena) */
+    return two_pass < 0 && tiles == 1 && n > 256 && rbsp_bytes / n < kTinyMeanBytes;      /* (256: k3_small takes what is below) */
+}
+
 /* ---- a handful of small NALs: the whole call in one launch of one workgroup --------------------------
  * (the general path is a dozen launches: what a legacy rbsp_to_nal() of one parameter set or a short
  * batch pays for is their latency).  Wavefront w takes NALs w, w + 4, ...: sizes, a scan across the
@@ -1579,6 +1687,17 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     hipError_t e = hipMemsetAsync(a.desc, 0, a.clear_bytes, st);
     if (e != hipSuccess) return e;
     const unsigned grid = 256 * 16;
+    if (emit_takes_tiny_path(a.n, a.rbsp_bytes, a.two_pass, a.tiles)) {
+        /* the index checked against the arena (tflag[3]), then a lane per NAL: sizes, their scan, the bytes */
+        k3t_check<<<kCheckBlocks, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap), 0, 0, a.tflag, a.err, a.probe);
+        const uint64_t want = (a.n + 255) / 256;
+        const unsigned tgrid = (unsigned)(want < 8192 ? want : 8192);
+        k3_count_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.tflag);
+        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, nullptr, kWhenAlways, a.tflag);
+        k3_emit_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, a.tflag);
+        k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
+        return hipGetLastError();
+    }
     /* forced one way (HBS_EMIT_TWO_PASS=1 / =0), or -- the default -- picked on the device from a density probe */
     const uint32_t* probe = a.two_pass < 0 ? a.probe : nullptr;
     const bool want_dense = a.two_pass != 0, want_sparse = a.two_pass <= 0;

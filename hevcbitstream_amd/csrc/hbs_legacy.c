@@ -394,9 +394,8 @@ static int window_build(uint8_t* buf, int size)
         W.parsed = (hbs_parsed_nal*)malloc((size_t)(W.ent_cap * sizeof(hbs_parsed_nal)));
     }
     if (!W.d_misc && (rc = hbs_dev_alloc(g_ctx, 256 + 2 * ((hbs_sps_slot_bytes() + 255) & ~(uint64_t)255) + sizeof(hevc_pps_t), (void**)&W.d_misc))) die("hbs_dev_alloc", rc);
-    need_stage(len);
-    memcpy(g_hstage, buf, (size_t)len);
-    if ((rc = hbs_copy_to_device_async(g_ctx, W.d_stream, g_hstage, len))) die("hbs_copy_to_device_async", rc);
+    /* straight from the caller's buffer (a pageable copy that waits: page-locking a staging buffer of this size costs more than it saves) */
+    if ((rc = hbs_copy_to_device(g_ctx, W.d_stream, buf, len))) die("hbs_copy_to_device", rc);
     if ((rc = hbs_index_extract(g_ctx, W.d_stream, len, (hbs_nal_entry*)W.d_index, W.ent_cap, W.d_rbsp, W.d_rbsp_cap, W_SUM))) die("hbs_index_extract", rc);
     if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
     if (s.error || s.nal_count == 0) return 0;

@@ -278,6 +278,33 @@ def test_emit_few_small_nals(ctx, orc):
         ctx.emit_annexb(dev(arena), idx, out_cap=310)      # 7 + 300 + 149 inserted bytes do not fit
 
 
+def test_emit_arenas_of_tiny_nals(ctx, orc):
+    """the automatic path on arenas whose NALs are too small for the arena tiles (mean below 448 bytes: a lane per NAL,
+    k3_count_tiny / k3_emit_tiny): zero-heavy and plain bytes, empty NALs, NALs around the 16-byte load and store steps, gaps
+    of 3-6 bytes, the output index; against the oracle's rbsp_to_nal per NAL.  Also a capacity that is too small."""
+    import hevcbitstream_amd as hbs
+    rng = np.random.RandomState(77)
+    for mean, nn, zeros in ((40, 3000, True), (130, 2000, False), (300, 1500, True), (17, 5000, True), (1, 400, True)):
+        lens = [int(x) for x in rng.randint(0, 2 * mean + 1, size=nn)]
+        lens[0] = 15; lens[1] = 16; lens[2] = 17; lens[3] = 0; lens[4] = 33
+        gaps = [int(rng.randint(3, 7)) for _ in lens]
+        total = sum(lens)
+        arena = ALPHA[rng.randint(0, len(ALPHA), size=total)].copy() if zeros else rng.randint(0, 256, size=total).astype(np.uint8)
+        idx = fake_index(lens, gaps)
+        got, got_idx = ctx.emit_annexb(dev(arena), idx)
+        want = orc.emit_annexb(arena, idx)
+        assert np.array_equal(got, want), (mean, nn)
+        pos = 0
+        for k, (n, g) in enumerate(zip(lens, gaps)):
+            assert int(got_idx["start"][k]) == pos + g and int(got_idx["rbsp_len"][k]) == n and int(got_idx["rbsp_off"][k]) == int(idx["rbsp_off"][k])
+            pos = int(got_idx["end"][k])
+        assert pos == len(want)
+    arena = np.zeros(300 * 40, dtype=np.uint8)
+    idx = fake_index([40] * 300, [4] * 300)
+    with pytest.raises(hbs.HbsError):
+        ctx.emit_annexb(dev(arena), idx, out_cap=300 * 44 + 100)      # the inserted 03s do not fit
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_device_generator_matches_oracle(ctx, orc, mode):
     n = 3000
