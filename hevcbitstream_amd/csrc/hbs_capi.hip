@@ -42,6 +42,7 @@ struct hbs_ctx {
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
     int emit_tile_blocks, emit_tiles; /* ... of the arena-tile kernel; 0 never / 1 when eligible / 2 pinned */
     int emit_path_set;                /* hbs_ctx_set_emit_path was called: the environment no longer decides */
+    const uint32_t* last_emit_tflag;  /* the last hbs_emit_annexb's verdict words (device): hbs_ctx_last_emit_by_tiles */
     int sched;
     unsigned long long* desc;
     uint64_t desc_tiles;
@@ -276,6 +277,19 @@ int hbs_ctx_set_emit_path(hbs_ctx* c, int path)
     return 0;
 }
 
+/* 1: the arena-tile kernel did the whole of the last hbs_emit_annexb (eligible index, no tile handed over); 0: another path; waits */
+int hbs_ctx_last_emit_by_tiles(hbs_ctx* c)
+{
+    if (!c) return HBS_E_ARG;
+    if (!c->last_emit_tflag) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return HBS_E_NO_DEVICE;
+    uint32_t f[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(f, c->last_emit_tflag, sizeof(f), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, e, "read-back of the emit verdict");
+    return (f[1] == 1u && f[0] == 0u && f[3] == 0u && f[2] == 0u) ? 1 : 0;
+}
+
 int hbs_ctx_last_kernel(hbs_ctx* c)
 {
     if (!c) return HBS_E_ARG;
@@ -411,6 +425,7 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.tflag = reinterpret_cast<uint32_t*>(tail + 768 + 192);
     a.first_k = reinterpret_cast<unsigned long long*>(tail + 1024); a.first_cap = first_cap;
     a.tiles = c->emit_tiles; a.tile_blocks = c->emit_tile_blocks;
+    c->last_emit_tflag = a.tflag;
     a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);

@@ -1192,6 +1192,8 @@ struct LdsT {
     uint32_t seg[kTDenseLimit + 1];                  /* bytes inserted in the tile up to and including element i; [0]: in front of the first (0) */
     u32x4 park[kTElemWaves][kTParkRows][64];         /* rows of the wavefronts that handle elements, meanwhile */
     uint32_t wave_tot[kTWaves];
+    uint32_t dz_tot[kTWaves][3], dz_out[kTWaves][3]; /* dense tiles: bytes inserted in / count behind each wavefront's rows, per count it is entered with */
+    uint32_t dz_in[kTWaves], dz_base[kTWaves];       /* ... the count each wavefront's rows are entered with, and the bytes inserted in front of them in the tile */
     unsigned long long before;                       /* bytes inserted in front of the tile                  */
     uint32_t ok;
     uint32_t ticket, abort;
@@ -1339,6 +1341,324 @@ __device__ __forceinline__ uint32_t tile_element(const TileCtx& t, const LdsT& l
     return ins;
 }
 
+/* ---- dense tiles (round 4) ------------------------------------------------------------------------------
+ * A tile with more than kTDenseLimit elements -- a stretch of zeros in the arena: what cabac_zero_words or 00 00 03 padding
+ * leave behind -- used to hand the WHOLE call to the kernel by NALs (a 16 GiB arena with 1 % of such bytes: 2.3 x the
+ * uniform time).  Now such a tile is walked by rows, every chunk looked at, by all four wavefronts:
+ *   - what a chunk does depends on the count it is entered with (h264_nal.c:110-116: 0, 1 or 2 zeros seen) only through its
+ *     leading zeros; an all-zero chunk maps 0 -> 2, 1 -> 1, 2 -> 2 and takes 7 / 8 / 8 bytes in; any other chunk leaves a
+ *     count that does not depend on the one it was entered with.  So the count a chunk is entered with comes from the
+ *     nearest chunk in front that is not all zeros (a ballot and a shuffle per row), not from walking the run back;
+ *   - a wavefront does not know the count ITS rows are entered with until the wavefronts in front are done, so the first half
+ *     carries all three possibilities (they coincide behind the first chunk that is not all zeros) and lane 0 picks;
+ *   - the count the TILE is entered with is found by wavefront 0 walking back a KiB at a time (parity of the run of zeros);
+ *   - chunks in which a NAL begins (and the arena's partial last chunk) are walked byte by byte.
+ * The tile then publishes its bytes like any other, resolves its look-back, and writes. */
+__device__ __forceinline__ uint32_t dz_map(uint32_t c) { return c == 1u ? 1u : 2u; }          /* an all-zero chunk: the count behind it */
+__device__ __forceinline__ uint32_t dz_ins(uint32_t c) { return c == 0u ? 7u : 8u; }          /* ... and the 03s that go into it */
+__device__ __forceinline__ uint32_t dz_count_of(uint64_t run) { return run == 0 ? 0u : ((run & 1ull) ? 1u : 2u); }
+__device__ __forceinline__ uint32_t dz_lead_bits(uint32_t c) { return c == 0u ? 0x5554u : (c == 1u ? 0xAAAAu : 0x5555u); }   /* 03s in leading zeros */
+
+/* zero bytes at the top (highest address) end of the chunk, 0..16 */
+__device__ __forceinline__ uint32_t top_zero_bytes(const u32x4& q)
+{
+    if (q.w) return (uint32_t)__builtin_clz(q.w) >> 3;
+    if (q.z) return 4u + ((uint32_t)__builtin_clz(q.z) >> 3);
+    if (q.y) return 8u + ((uint32_t)__builtin_clz(q.y) >> 3);
+    if (q.x) return 12u + ((uint32_t)__builtin_clz(q.x) >> 3);
+    return 16u;
+}
+/* ... at the low end */
+__device__ __forceinline__ uint32_t low_zero_bytes(const u32x4& q)
+{
+    if (q.x) return (uint32_t)__builtin_ctz(q.x) >> 3;
+    if (q.y) return 4u + ((uint32_t)__builtin_ctz(q.y) >> 3);
+    if (q.z) return 8u + ((uint32_t)__builtin_ctz(q.z) >> 3);
+    if (q.w) return 12u + ((uint32_t)__builtin_ctz(q.w) >> 3);
+    return 16u;
+}
+__device__ __forceinline__ uint32_t byte_of(const u32x4& q, uint32_t i)
+{
+    const uint32_t w = i < 4u ? q.x : i < 8u ? q.y : i < 12u ? q.z : q.w;
+    return (w >> (8u * (i & 3u))) & 0xFFu;
+}
+
+/* the count arena byte `pos` is entered with, inside the NAL that begins at `begin` (<= pos): the run of zeros in front of it,
+ * followed back a KiB at a time by the whole wavefront (lane l looks at the 16 bytes that end 16 l in front of the current end) */
+__device__ __forceinline__ uint32_t wave_lead_count(const uint8_t* __restrict__ arena, uint64_t begin, uint64_t pos, int lane)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    uint64_t end = pos, run = 0;
+    for (;;) {
+        if (end <= begin) break;
+        uint32_t tz;                                               /* zeros at the top of my window, counted down to `begin` at most */
+        const int64_t lo = (int64_t)end - 16 * (int64_t)(lane + 1);
+        if (lo >= (int64_t)begin) {
+            tz = top_zero_bytes(reinterpret_cast<const U16*>(arena + lo)->v);
+        } else {
+            tz = 0;
+            const uint64_t top = end - 16u * (uint64_t)lane;       /* one past my window; may already be at or below begin */
+#pragma unroll 1
+            for (uint64_t b = top; b > begin && b + 16u > top && arena[b - 1] == 0; --b) ++tz;
+            if (top <= begin) tz = 0;
+            /* a window cut by `begin` ends the run even when all of its bytes are zeros: mark it "not full" below */
+        }
+        const bool full = tz == 16u && lo >= (int64_t)begin;
+        const uint64_t fm = __ballot(full);
+        const int first = fm == ~0ull ? 64 : (int)__builtin_ctzll(~fm);
+        if (first == 64) { run += 1024u; end -= 1024u; continue; }
+        run += 16u * (uint64_t)first + (uint64_t)(uint32_t)__shfl((int)tz, first, 64);
+        break;
+    }
+    return dz_count_of(run);
+}
+
+/* a chunk in which NALs begin (or the arena's partial last chunk): byte by byte, entered with `count`.  Returns the bytes that go
+ * in (03s and gaps); count_out = the count behind it.  kEmit: writes the chunk at out + pos and the index entries. */
+template <bool kEmit>
+__device__ __forceinline__ uint32_t dz_start_chunk(const TileCtx& t, const LdsT& l, uint32_t c, u32x4 q, uint32_t nb, uint32_t count, uint32_t& count_out,
+                                                   uint8_t* __restrict__ out, uint64_t abs0, uint64_t pos, bool store, hbs_nal_entry* __restrict__ idx_out)
+{
+    const uint32_t p = 16u * c;
+    const uint64_t x0 = t.tile_lo + p;
+    uint32_t j = lower_bound_lds(l.starts, t.m, p);
+    uint32_t ins = 0;
+    uint8_t* dst = out + pos;
+#pragma unroll 1
+    for (uint32_t i = 0; i <= 16u; ++i) {
+        while (j < t.m && l.starts[j] == p + i && i < 16u) {       /* NAL k_lo + j begins in front of byte i (empty NALs: several) */
+            const uint32_t gap = l.gaps[j];
+            if (kEmit) {
+                const uint64_t k = t.k_lo + j;
+                const uint64_t at = abs0 + pos + i + ins;
+                if (store) {
+                    for (uint32_t g = 0; g + 1 < gap; ++g) dst[i + ins + g] = 0;
+                    if (gap) dst[i + ins + gap - 1] = 1;
+                }
+                if (idx_out) {
+                    if (k > 0) idx_out[k - 1].end = at;
+                    idx_out[k].start = at + gap; idx_out[k].rbsp_off = t.a0 + x0 + i; idx_out[k].rbsp_len = l.lens[j]; idx_out[k].status = 0;
+                }
+            }
+            ins += gap;
+            count = 0;
+            ++j;
+        }
+        if (i < nb) {
+            const uint32_t v = q.x & 0xFFu;
+            if (count == 2u && v <= 3u) { if (kEmit && store) dst[i + ins] = 3; ++ins; count = 0; }
+            if (kEmit && store) dst[i + ins] = (uint8_t)v;
+            count = (v == 0u) ? count + 1u : 0u;
+            q.x = (q.x >> 8) | (q.y << 24); q.y = (q.y >> 8) | (q.z << 24); q.z = (q.z >> 8) | (q.w << 24); q.w >>= 8;
+        }
+    }
+    count_out = count;
+    return ins;
+}
+
+/* one row of a dense tile: what lane's chunk is and does.  q = its 16 bytes, xp = the dword in front of it */
+struct DzChunk { uint32_t nb; bool active, start, reset; uint32_t ins[3], out; u32x4 q; uint32_t lz, mask0; bool flagged; };
+__device__ __forceinline__ void dz_classify(DzChunk& d, const TileCtx& t, const LdsT& l, uint32_t c, bool has_start, uint32_t xp)
+{
+    const uint64_t x0 = t.tile_lo + 16ull * c;
+    d.active = x0 < t.arena_len;
+    d.nb = !d.active ? 0u : (t.arena_len - x0 < 16u ? (uint32_t)(t.arena_len - x0) : 16u);
+    d.start = d.active && (has_start || d.nb < 16u);
+    d.lz = 0; d.mask0 = 0; d.flagged = false;
+    d.ins[0] = d.ins[1] = d.ins[2] = 0; d.out = 0;
+    if (!d.active) { d.reset = false; return; }
+    if (d.start) {
+        d.reset = true;
+        for (uint32_t h = 0; h < 3u; ++h) {
+            uint32_t co;
+            d.ins[h] = dz_start_chunk<false>(t, l, c, d.q, d.nb, h, co, nullptr, 0, 0, false, nullptr);
+            d.out = co;                                            /* (the same for every h when a NAL begins in the chunk; the arena's last chunk has nothing behind it) */
+        }
+        return;
+    }
+    d.lz = low_zero_bytes(d.q);
+    if (d.lz == 16u) { d.reset = false; d.ins[0] = 7u; d.ins[1] = 8u; d.ins[2] = 8u; return; }
+    d.reset = true;
+    d.out = dz_count_of(top_zero_bytes(d.q));
+    d.flagged = chunk_flag(xp, d.q.x, d.q.y, d.q.z, d.q.w, 0xFFFFFFFFu);
+    if (!d.flagged) return;                                        /* no two zeros next to each other in or just in front of it: nothing goes in */
+    d.mask0 = insert_mask16(d.q.x, d.q.y, d.q.z, d.q.w, 16u, 0u);
+    const uint32_t v = byte_of(d.q, d.lz);
+    const uint32_t keep = d.mask0 & ~((2u << d.lz) - 1u);          /* behind the first byte that is not zero: the same whatever the count was */
+#pragma unroll
+    for (uint32_t h = 0; h < 3u; ++h) {
+        const uint32_t lead = dz_lead_bits(h) & ((1u << d.lz) - 1u);
+        const uint32_t first = (dz_count_of((uint64_t)h + d.lz) == 2u && v <= 3u) ? (1u << d.lz) : 0u;
+        d.ins[h] = (uint32_t)__builtin_popcount(keep | lead | first);
+    }
+}
+__device__ __forceinline__ uint32_t dz_mask_for(const DzChunk& d, uint32_t c_in)
+{
+    if (d.lz == 16u) return dz_lead_bits(c_in);
+    if (!d.flagged) return 0u;
+    const uint32_t v = byte_of(d.q, d.lz);
+    const uint32_t keep = d.mask0 & ~((2u << d.lz) - 1u);
+    const uint32_t lead = dz_lead_bits(c_in) & ((1u << d.lz) - 1u);
+    const uint32_t first = (dz_count_of((uint64_t)c_in + d.lz) == 2u && v <= 3u) ? (1u << d.lz) : 0u;
+    return keep | lead | first;
+}
+__device__ __forceinline__ uint32_t dz_pick(const uint32_t* a, uint32_t c) { return c == 0u ? a[0] : (c == 1u ? a[1] : a[2]); }
+
+/* the count lane's chunk is entered with, given the row's (row_in), and the count behind the row */
+__device__ __forceinline__ uint32_t dz_count_in(bool reset, uint32_t out, uint32_t row_in, int lane, uint32_t& row_out)
+{
+    const uint64_t rm = __ballot(reset);
+    const uint64_t below = rm & ((1ull << lane) - 1ull);
+    uint32_t c_in;
+    const int src = below ? 63 - (int)__builtin_clzll(below) : 0;
+    const uint32_t from = (uint32_t)__shfl((int)out, src, 64);
+    if (below) c_in = (lane - src > 1) ? dz_map(from) : from;
+    else c_in = lane == 0 ? row_in : dz_map(row_in);
+    const uint32_t c_out = reset ? out : dz_map(c_in);
+    row_out = (uint32_t)__shfl((int)c_out, 63, 64);
+    return c_in;
+}
+
+/* One dense tile, by the whole workgroup (every thread calls it); `l` still holds the tile's NAL starts, gaps and lengths and
+ * the chunks they lie in.  Not inlined: its registers must not add to the 192 the rows of the ordinary path occupy. */
+__device__ __attribute__((noinline))
+void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned long long* __restrict__ desc,
+                   uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint64_t n,
+                   unsigned long long* __restrict__ total, uint32_t* __restrict__ err)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t wseg = t.tile_lo + (uint64_t)(wv * (int)kTWaveBytes);
+    const uint32_t chunk0 = (uint32_t)(64 * kTRows * wv);
+    const uint64_t tile_bytes = t.arena_len - t.tile_lo < (uint64_t)kTTileBytes ? t.arena_len - t.tile_lo : (uint64_t)kTTileBytes;
+    auto load_row = [&](int r) -> u32x4 {
+        const uint64_t x0 = wseg + 1024ull * (uint32_t)r + 16ull * (uint32_t)lane;
+        if (x0 + 16u <= t.arena_len) return *reinterpret_cast<const u32x4*>(t.arena + x0);
+        if (x0 < t.arena_len) return load_chunk_guarded(t.arena, x0, t.arena_len);
+        return u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    };
+    const uint32_t seg_before = load_dword_guarded(t.arena, (int64_t)wseg - 4, t.arena_len);
+
+    /* ---- first half: bytes that go into my rows, for each count they may be entered with ---- */
+    uint32_t tot[3] = {0u, 0u, 0u}, st[3] = {0u, 1u, 2u};
+    {
+        /* two rows ahead: what the tiles behind this one wait for is this half */
+        u32x4 qa = load_row(0), qb = load_row(1);
+        uint32_t e_prev = seg_before;
+#pragma unroll 1
+        for (int r = 0; r < kTRows; ++r) {
+            DzChunk d;
+            d.q = qa;
+            qa = qb;
+            if (r + 2 < kTRows) qb = load_row(r + 2);
+            const uint32_t xp = from_prev_lane(d.q.w, e_prev);
+            e_prev = (uint32_t)__builtin_amdgcn_readlane((int)d.q.w, 63);
+            const unsigned long long rb = l.rowbits[wv * kTRows + r];
+            const uint64_t row_lo = wseg + 1024ull * (uint32_t)r;
+            if (row_lo >= t.arena_len) break;                       /* behind the arena's end */
+            const bool whole_row = row_lo + 1024u <= t.arena_len;
+            /* a row of nothing but zeros (padding looks like that): closed form */
+            if (whole_row && rb == 0ull && __ballot((d.q.x | d.q.y | d.q.z | d.q.w) != 0u) == 0ull) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) { tot[h] += dz_ins(st[h]) + 63u * 8u; st[h] = dz_map(st[h]); }
+                continue;
+            }
+            dz_classify(d, t, l, chunk0 + 64u * (uint32_t)r + (uint32_t)lane, ((rb >> lane) & 1ull) != 0, xp);
+            /* Behind the row's first chunk that is not all zeros the count a chunk is entered with does not depend on the count
+             * the ROW is entered with: one pass for those, a closed form for the zeros in front, and the first such chunk by itself. */
+            const uint64_t rm = __ballot(d.reset);
+            const int f = rm ? (int)__builtin_ctzll(rm) : 64;       /* the first chunk that resets the count (64: none) */
+            uint32_t ro_any;
+            const uint32_t c_any = dz_count_in(d.reset, d.out, 0u, lane, ro_any);     /* right for lanes behind f, whatever the row's count */
+            const uint32_t common = wave_sum32((d.active && lane > f) ? dz_pick(d.ins, c_any) : 0u);
+            const uint32_t fi0 = f < 64 ? (uint32_t)__shfl((int)d.ins[0], f, 64) : 0u;
+            const uint32_t fi1 = f < 64 ? (uint32_t)__shfl((int)d.ins[1], f, 64) : 0u;
+            const uint32_t fi2 = f < 64 ? (uint32_t)__shfl((int)d.ins[2], f, 64) : 0u;
+            const uint32_t nact = (uint32_t)__builtin_popcountll(__ballot(d.active));
+            const uint32_t nlead = f < 64 ? (uint32_t)f : nact;     /* all-zero chunks in front of it (a cut row ends in a chunk that resets) */
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const uint32_t c_f = nlead == 0u ? st[h] : dz_map(st[h]);
+                const uint32_t lead = nlead ? dz_ins(st[h]) + (nlead - 1u) * 8u : 0u;
+                tot[h] += common + lead + (f < 64 ? (c_f == 0u ? fi0 : c_f == 1u ? fi1 : fi2) : 0u);
+                st[h] = f < 64 ? ro_any : dz_map(st[h]);
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h) { l.dz_tot[wv][h] = tot[h]; l.dz_out[wv][h] = st[h]; }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        /* the count the tile is entered with: the zeros in front of it inside the NAL in progress */
+        const uint32_t c0 = t.tile_lo > t.prev_begin ? wave_lead_count(t.arena, t.prev_begin, t.tile_lo, lane) : 0u;
+        unsigned long long tile_ins = 0;
+        uint32_t c = c0;
+        for (int w = 0; w < kTWaves; ++w) {
+            if (lane == 0) { l.dz_in[w] = c; l.dz_base[w] = (uint32_t)tile_ins; }
+            tile_ins += dz_pick(l.dz_tot[w], c);
+            c = dz_pick(l.dz_out[w], c);
+        }
+        if (lane == 0 && tile != 0) st_desc3(desc + tile, (tile_ins << 2) | 1ull);
+        __builtin_amdgcn_s_setprio(0);
+        const unsigned long long bf = k3_look_back(desc, tile, lane, err);
+        if (lane == 0) {
+            st_desc3(desc + tile, ((bf + tile_ins) << 2) | 2ull);
+            const uint64_t end_pos = t.tile_lo + tile_bytes + bf + tile_ins;
+            l.before = bf;
+            l.ok = end_pos <= out_cap ? 1u : 0u;
+            if (end_pos > out_cap) atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
+            if (last_tile) {
+                *total = end_pos;
+                if (idx_out) idx_out[n - 1].end = end_pos;
+            }
+        }
+    } else {
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+
+    /* ---- second half: the bytes ---- */
+    const bool can_store = l.ok != 0u;
+    if (!can_store && !idx_out) return;
+    uint8_t* const tout = out + t.tile_lo + l.before;
+    const uint64_t abs0 = t.tile_lo + l.before;
+    uint32_t base_ins = l.dz_base[wv], row_in = l.dz_in[wv];
+    u32x4 qa = load_row(0), qb = load_row(1);
+    uint32_t e_prev = seg_before;
+#pragma unroll 1
+    for (int r = 0; r < kTRows; ++r) {
+        DzChunk d;
+        d.q = qa;
+        qa = qb;
+        if (r + 2 < kTRows) qb = load_row(r + 2);
+        const uint32_t xp = from_prev_lane(d.q.w, e_prev);
+        e_prev = (uint32_t)__builtin_amdgcn_readlane((int)d.q.w, 63);
+        const bool hs = ((l.rowbits[wv * kTRows + r] >> lane) & 1ull) != 0;
+        const uint32_t c = chunk0 + 64u * (uint32_t)r + (uint32_t)lane;
+        if (wseg + 1024ull * (uint32_t)r >= t.arena_len) break;
+        dz_classify(d, t, l, c, hs, xp);
+        uint32_t ro;
+        const uint32_t c_in = dz_count_in(d.reset, d.out, row_in, lane, ro);
+        row_in = ro;
+        const uint32_t mine = d.active ? dz_pick(d.ins, c_in) : 0u;
+        uint32_t row_tot;
+        const uint32_t before_me = wave_excl_scan_u32(mine, lane, row_tot);
+        const uint64_t pos = 16ull * c + base_ins + before_me;
+        base_ins += row_tot;
+        if (!d.active) continue;
+        if (d.start) {
+            uint32_t co;
+            (void)dz_start_chunk<true>(t, l, c, d.q, d.nb, c_in, co, tout, abs0, pos, can_store, idx_out);
+        } else if (can_store) {
+            const uint32_t mask = dz_mask_for(d, c_in);
+            if (mask == 0u) arena_store16(tout + pos, d.q);
+            else (void)emit_chunk16(tout + pos, d.q.x, d.q.y, d.q.z, d.q.w, 16u, mask);
+        }
+    }
+}
+
 #ifndef HBS3T_COPY_DEPTH
 #define HBS3T_COPY_DEPTH 3      /* stores of a wavefront in flight during k3_tiles' copy */
 #endif
@@ -1364,6 +1684,9 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     t.arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - t.a0;
     const uint64_t ntiles = t.arena_len / kTTileBytes + 1;
     HBS3_T_DECL
+    uint64_t d_tile = 0;
+    for (;;) {
+    int pending = 0;                   /* 1: a dense tile -- walked below the tile loop, where no row is live (as in hbs_scan4.hip) */
     for (;;) {
         const int lane = launder_lane(tid0) & 63;
         const int tid = launder_lane(tid0);
@@ -1517,13 +1840,10 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const uint32_t wt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[2]), wt3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[3]);
         const uint32_t nflag = wt0 + wt1 + wt2 + wt3;
         const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? wt0 : (wv == 2) ? wt0 + wt1 : wt0 + wt1 + wt2;
-        if (nflag > kTDenseLimit) {                                /* dense in elements: give the call up (see kTDenseLimit) */
-            if (tid == 0) {
-                atomicOr(const_cast<uint32_t*>(&tflag[2]), 1u);
-                st_desc3(desc + tile, 2ull);                       /* "everything up to here: 0 bytes" -- whoever waits goes on, writing what will be overwritten */
-            }
-            __builtin_amdgcn_s_setprio(0);
-            continue;
+        if (nflag > kTDenseLimit) {                                /* dense in elements: this tile is walked by rows (k3_dense_tile) */
+            d_tile = tile;
+            pending = 1;
+            break;
         }
         for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
             const int r = __builtin_ctzll(rm);
@@ -1654,6 +1974,9 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             });
         }
         HBS3_T_MARK(6)
+    }
+    if (pending == 0) break;
+    k3_dense_tile(l, t, d_tile, d_tile == ntiles - 1, desc, out, out_cap, idx_out, n, total, err);
     }
     HBS3_T_FLUSH
 }

@@ -349,6 +349,9 @@ uint64_t hbs_sps_tables_offset(void);
  * 1 the three steps, 2 the arena tiles whenever the index allows them (whatever the arena's size and density).
  * The bytes are the same whichever runs (h264_nal.c:92-132). */
 int hbs_ctx_set_emit_path(hbs_ctx* ctx, int path);
+/* Diagnostic: 1 when the arena-tile kernel did the whole of the last hbs_emit_annexb on this context (the index was eligible
+ * and no tile was handed to another kernel), 0 when another path did (waits for the call to finish). */
+int hbs_ctx_last_emit_by_tiles(hbs_ctx* ctx);
 
 /*
  * Synthetic workload S(seed, n_nals, mode) of SURVEY.md 8(d), generated in HBM:

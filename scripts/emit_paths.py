@@ -13,11 +13,13 @@ ctx = hbs.Context(0)
 ctx.set_emit_path(0)
 g = ctx.synth_stream(0x1234, N, mode)
 rb, sb = g["rbsp_bytes"], g["stream_bytes"]
-mixed = os.environ.get("HBS_EMIT_MIXED") == "1"
+mixed = os.environ.get("HBS_EMIT_MIXED") in ("1", "2")          # 2: the regions are pure zeros (what cabac_zero_words leave in an RBSP)
 if mixed:
     region = 640 << 10
     stride = (rb // 64) & ~15
     pat = torch.tensor([0, 0, 3], dtype=torch.uint8, device="cuda").repeat(region // 3 + 1)[:region]
+    if os.environ.get("HBS_EMIT_MIXED") == "2":
+        pat = torch.zeros(region, dtype=torch.uint8, device="cuda")
     for k in range(max(1, int(rb * 0.01 / region))):
         off = (k % 64) * stride + stride // 2 + (k // 64) * (region + 4096)
         if off + region < rb:
@@ -26,7 +28,7 @@ summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
 ref_out = ref_idx = None
 for path in (0, 1, 2):
     ctx.set_emit_path(path)
-    out = torch.zeros(sb + (sb // 50 if mixed else 0) + 4096, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(sb + (sb // 40 if mixed else 0) + 4096, dtype=torch.uint8, device="cuda")
     idx_out = torch.zeros(N * 32, dtype=torch.uint8, device="cuda")
     ts = []
     for i in range(6):

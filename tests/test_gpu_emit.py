@@ -175,25 +175,51 @@ def test_emit_arena_tiles_with_several_batches_of_elements(ctx, orc, shape):
         assert np.array_equal(got_idx, outs[0][1]), (shape, path, "output index")
 
 
-def test_emit_arena_tiles_give_up_on_dense_tiles(ctx, orc):
-    """an arena that is sparse but for one stretch of 00 00 03 padding (cabac_zero_words): the tile holding it has thousands of
-    elements, the arena-tile kernel gives the call up (hbs_emit.hip: kTDenseLimit) and the kernel by NALs, enqueued behind it,
-    produces the bytes and the output index -- whatever the tile kernel had written by then is overwritten"""
+def test_emit_arena_tiles_walk_dense_tiles_by_rows(ctx, orc):
+    """an arena that is sparse but for stretches the density probe does not see -- 00 00 03 padding, pure zeros (what
+    cabac_zero_words leave in an RBSP), zeros with a NAL beginning inside them, runs that cross wavefront and tile
+    boundaries with odd and even lengths: the tiles that hold them have thousands of elements and are walked by rows
+    (k3_dense_tile; until round 4 the tile kernel gave the whole call up).  Bytes against the oracle's rbsp_to_nal, the
+    output index against the kernel by NALs, and the tile kernel must have done the whole call."""
     T = 192 * 1024
+    W = 48 * 1024
     rng = np.random.RandomState(36)
-    for dense_at, dense_len in ((3 * T + 1000, 150_000), (100, 30_000), (9 * T - 40_000, 80_000)):
-        lens = [int(x) for x in rng.randint(2000, 60000, size=60)]
+    cases = [("pad", 3 * T + 1000, 150_000), ("pad", 100, 30_000), ("pad", 9 * T - 40_000, 80_000),
+             ("zero", 2 * T + 5000, 200_000), ("zero", 4 * T - 7, 50_001), ("zero", 5 * T + W - 3, 40_006), ("zero", 16, T + 16),
+             ("zero", 7 * T + 1, 2 * T + 3), ("mix", 6 * T + 123, 120_000)]
+    for kind, dense_at, dense_len in cases:
+        lens = [int(x) for x in rng.randint(2000, 60000, size=70)]
         arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
-        arena[dense_at: dense_at + dense_len] = np.tile(np.array([0, 0, 3], dtype=np.uint8), dense_len // 3 + 1)[:dense_len]
+        if kind == "pad":
+            arena[dense_at: dense_at + dense_len] = np.tile(np.array([0, 0, 3], dtype=np.uint8), dense_len // 3 + 1)[:dense_len]
+        elif kind == "zero":
+            arena[dense_at: dense_at + dense_len] = 0
+        else:                                            # zeros and small values, runs of every length
+            arena[dense_at: dense_at + dense_len] = ALPHA[rng.randint(0, len(ALPHA), size=dense_len)]
         idx = fake_index(lens, [int(rng.randint(3, 6)) for _ in lens])
         want = orc.emit_annexb(arena, idx)
         ctx.set_emit_path(0)
         _, idx_nals = ctx.emit_annexb(dev(arena), idx)
         ctx.set_emit_path(2)
         by_tiles, idx_tiles = ctx.emit_annexb(dev(arena), idx)
+        stayed = ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h)
         ctx.set_emit_path(-1)
-        assert np.array_equal(by_tiles, want), dense_at
-        assert np.array_equal(idx_tiles, idx_nals), dense_at
+        assert np.array_equal(by_tiles, want), (kind, dense_at, dense_len, int(np.flatnonzero(by_tiles[:len(want)] != want[:len(by_tiles)])[0]) if len(by_tiles) == len(want) else (len(by_tiles), len(want)))
+        assert np.array_equal(idx_tiles, idx_nals), (kind, dense_at)
+        assert stayed == 1, (kind, dense_at)
+    # NALs that begin inside a stretch of zeros, at chunk edges and inside chunks
+    lens = [50_000, 100_000, 17, 16, 1, 40_000, 300_000, 33, 250_000]
+    arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+    arena[30_000: 30_000 + 400_000] = 0
+    idx = fake_index(lens, [3, 4, 3, 5, 3, 4, 3, 3, 4])
+    want = orc.emit_annexb(arena, idx)
+    ctx.set_emit_path(2)
+    got, got_idx = ctx.emit_annexb(dev(arena), idx)
+    stayed = ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h)
+    ctx.set_emit_path(0)
+    _, idx_nals = ctx.emit_annexb(dev(arena), idx)
+    ctx.set_emit_path(-1)
+    assert np.array_equal(got, want) and np.array_equal(got_idx, idx_nals) and stayed == 1
 
 
 def test_emit_arena_tiles_refuse_an_index_outside_the_arena(ctx, orc):
