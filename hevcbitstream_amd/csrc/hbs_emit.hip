@@ -50,8 +50,8 @@ __device__ __forceinline__ bool emit_probe_dense_tiles(const uint32_t* probe) { 
 /* the arena-tile kernel (k3_tiles, below) takes the sparse case when k3t_check found the index eligible: tflag[0] = a
  * violation was seen, tflag[1] = the global conditions hold */
 __device__ __forceinline__ bool tile_path_on(const uint32_t* tflag) { return tflag && tflag[1] == 1u && tflag[0] == 0u && tflag[3] == 0u; }
-/* tflag[2]: the tile kernel met a tile dense in elements and gave up -- the kernel by NALs, enqueued behind it, does the call */
-__device__ __forceinline__ bool tile_path_done(const uint32_t* tflag) { return tile_path_on(tflag) && tflag[2] == 0u; }
+/* (tflag[2] was "the tile kernel gave up on a tile dense in elements": since round 4 it walks such a tile by rows, nothing sets it) */
+__device__ __forceinline__ bool tile_path_done(const uint32_t* tflag) { return tile_path_on(tflag); }
 
 /* the three steps are for what the probe calls dense -- unless the tile kernel, in front of them, has done the call */
 __device__ __forceinline__ bool three_steps_run(const uint32_t* probe, const uint32_t* tflag)
@@ -63,14 +63,21 @@ __device__ __forceinline__ bool three_steps_run(const uint32_t* probe, const uin
  * caller's RBSP buffer.  The call then ends with HBS_E_ARG and nothing is read through the index. */
 __device__ __forceinline__ bool index_bad(const uint32_t* vflag) { return vflag[3] != 0u; }
 
-enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2 };
+enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2, kWhenEither = 3 };
 /* the helper kernels of the two fall-back chains: those of the kernel by NALs (its item list) run when the data is sparse and
  * the tile kernel, in front of them since round 3, has not done the call; those of the three steps when these run */
 __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when, const uint32_t* tflag)
 {
     if (when == kWhenAlways) return false;
     if (when == kWhenSparse) return (probe && emit_probe_dense(probe)) || tile_path_done(tflag);
+    if (when == kWhenEither) return emit_skip(probe, kWhenSparse, tflag) && !three_steps_run(probe, tflag);
     return !three_steps_run(probe, tflag);
+}
+/* kWhenEither (the automatic mode, probe != nullptr: one scan serves whichever chain runs): where the scan's total goes */
+__device__ __forceinline__ unsigned long long* scan_total_of(unsigned long long* total, unsigned long long* total_dense,
+                                                             const uint32_t* probe, int when, const uint32_t* tflag)
+{
+    return (when == kWhenEither && three_steps_run(probe, tflag)) ? total_dense : total;
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
@@ -289,10 +296,11 @@ void k_scan_reduce(const unsigned long long* __restrict__ v, uint64_t n, unsigne
 }
 
 __global__ __launch_bounds__(kScanBlocks)
-void k_scan_parts(unsigned long long* __restrict__ part, unsigned long long* __restrict__ total,
+void k_scan_parts(unsigned long long* __restrict__ part, unsigned long long* __restrict__ total_sparse, unsigned long long* __restrict__ total_dense,
                   const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
 {
     if (emit_skip(probe, when, tflag)) return;
+    unsigned long long* const total = scan_total_of(total_sparse, total_dense, probe, when, tflag);
     __shared__ unsigned long long sh[kScanBlocks];
     const int tid = threadIdx.x;
     const unsigned long long s = part[tid];
@@ -333,9 +341,11 @@ void k_scan_apply(const unsigned long long* __restrict__ v, unsigned long long* 
 constexpr uint64_t kScanOneMax = 1ull << 18;
 __global__ __launch_bounds__(1024)
 void k_scan_one(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
-                unsigned long long* __restrict__ total, const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
+                unsigned long long* __restrict__ total_sparse, unsigned long long* __restrict__ total_dense,
+                const uint32_t* __restrict__ probe, int when, const uint32_t* __restrict__ tflag)
 {
     if (emit_skip(probe, when, tflag)) return;
+    unsigned long long* const total = scan_total_of(total_sparse, total_dense, probe, when, tflag);
     __shared__ unsigned long long sh[1024];
     const int tid = threadIdx.x;
     const uint64_t per = (n + 1023u) / 1024u;
@@ -357,14 +367,15 @@ void k_scan_one(const unsigned long long* __restrict__ v, unsigned long long* __
 
 static void launch_scan_u64(const unsigned long long* v, unsigned long long* out, uint64_t n, unsigned long long* total,
                             unsigned long long* part /* kScanBlocks entries */, hipStream_t st,
-                            const uint32_t* probe = nullptr, int when = kWhenAlways, const uint32_t* tflag = nullptr)
+                            const uint32_t* probe = nullptr, int when = kWhenAlways, const uint32_t* tflag = nullptr,
+                            unsigned long long* total_dense = nullptr /* kWhenEither: the total's place when the three steps run */)
 {
     if (n <= kScanOneMax) {
-        k_scan_one<<<1, 1024, 0, st>>>(v, out, n, total, probe, when, tflag);
+        k_scan_one<<<1, 1024, 0, st>>>(v, out, n, total, total_dense, probe, when, tflag);
         return;
     }
     k_scan_reduce<<<kScanBlocks, 256, 0, st>>>(v, n, part, probe, when, tflag);
-    k_scan_parts<<<1, kScanBlocks, 0, st>>>(part, total, probe, when, tflag);
+    k_scan_parts<<<1, kScanBlocks, 0, st>>>(part, total, total_dense, probe, when, tflag);
     k_scan_apply<<<kScanBlocks, 256, 0, st>>>(v, out, n, part, probe, when, tflag);
 }
 
@@ -813,6 +824,11 @@ __device__ __forceinline__ void emit_batch(const u32x4 (&R)[kEmitRows], const ui
 
 /* bytes of the output in front of group g (wavefront 0, all lanes); 256 groups per step:
  * lane l looks at the groups at distance l, 64 + l, 128 + l, 192 + l */
+/* a look-back word: status in bits 0-1 (0 nothing yet, 1 the tile's own bytes, 2 everything up to and including it), the bytes
+ * above, and -- k3_tiles' dense tiles only -- a tag in bits 60-63 that says what count of zeros the tile leaves behind
+ * (k3_dense_tile): the sums below ignore it */
+constexpr int kDescTagShift = 60;
+constexpr unsigned long long kDescValueMask = (1ull << kDescTagShift) - 1ull;
 __device__ __forceinline__ unsigned long long k3_look_back(const unsigned long long* __restrict__ desc, uint64_t g, int lane, uint32_t* err)
 {
     unsigned long long prefix = 0;
@@ -847,7 +863,7 @@ __device__ __forceinline__ unsigned long long k3_look_back(const unsigned long l
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint64_t dist = (uint64_t)(64 * q + lane);
-            if (dist < pos && (q < stop_q || (q == stop_q && lane <= stop_l))) x += v[q] >> 2;
+            if (dist < pos && (q < stop_q || (q == stop_q && lane <= stop_l))) x += (v[q] & kDescValueMask) >> 2;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
@@ -882,6 +898,33 @@ __global__ void k3_seg_count(const hbs_nal_entry* __restrict__ idx, uint64_t n, 
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t len = idx[k].rbsp_len;
         segs[k] = len <= kEmitSegBytes ? 1ull : (unsigned long long)((len + kEmitSegBytes - 1u) / kEmitSegBytes);
+    }
+}
+
+/* the automatic mode's first step of BOTH fall-back chains in one launch (round 4: every launch that rules itself out on the device
+ * still costs 4.7 us of the call): segments per NAL for the kernel by NALs, or bytes per NAL for the three steps -- whichever
+ * chain the probe and the tile kernel's eligibility leave to run, if any.  Both write nal_total; the chains exclude each other. */
+__global__ __launch_bounds__(256)
+void k3_sizes(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+              unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ probe, const uint32_t* __restrict__ vflag)
+{
+    if (three_steps_run(probe, vflag)) {
+        if (index_bad(vflag)) return;
+        const int lane = threadIdx.x & 63;
+        const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+        const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+        for (uint64_t k = wave; k < n; k += nwaves) {
+            const uint64_t begin = idx[k].rbsp_off;
+            const uint32_t len = idx[k].rbsp_len;
+            const uint32_t ins = count_nal(rbsp, begin, len, lane);
+            if (lane == 0) nal_total[k] = gap_of(idx, k, gap_mode) + len + ins;
+        }
+        return;
+    }
+    if (emit_skip(probe, kWhenSparse, vflag)) return;
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t len = idx[k].rbsp_len;
+        nal_total[k] = len <= kEmitSegBytes ? 1ull : (unsigned long long)((len + kEmitSegBytes - 1u) / kEmitSegBytes);
     }
 }
 
@@ -1196,7 +1239,7 @@ struct LdsT {
     uint32_t dz_in[kTWaves], dz_base[kTWaves];       /* ... the count each wavefront's rows are entered with, and the bytes inserted in front of them in the tile */
     unsigned long long before;                       /* bytes inserted in front of the tile                  */
     uint32_t ok;
-    uint32_t ticket, abort;
+    uint32_t ticket;
 };
 
 struct TileCtx {
@@ -1341,6 +1384,23 @@ __device__ __forceinline__ uint32_t tile_element(const TileCtx& t, const LdsT& l
     return ins;
 }
 
+#ifdef HBS_DZ_TIMING
+/* dev aid (never in the shipped library): cycles (s_memtime, 100 MHz) wavefront 0 spends in each part of k3_dense_tile, summed over tiles */
+__device__ unsigned long long g_dz_cycles[8];
+extern "C" int hbs_debug_dz_cycles(unsigned long long* host_out, int reset)
+{
+    static const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dz_cycles), sizeof(z));
+    if (reset) rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dz_cycles), z, sizeof(z));
+    return rc;
+}
+#define DZ_T_DECL unsigned long long dz_prev = __builtin_amdgcn_s_memtime();
+#define DZ_T_MARK(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long dz_now = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_dz_cycles[i], dz_now - dz_prev); dz_prev = dz_now; }
+#else
+#define DZ_T_DECL
+#define DZ_T_MARK(i)
+#endif
+
 /* ---- dense tiles (round 4) ------------------------------------------------------------------------------
  * A tile with more than kTDenseLimit elements -- a stretch of zeros in the arena: what cabac_zero_words or 00 00 03 padding
  * leave behind -- used to hand the WHOLE call to the kernel by NALs (a 16 GiB arena with 1 % of such bytes: 2.3 x the
@@ -1383,14 +1443,17 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4& q, uint32_t i)
     return (w >> (8u * (i & 3u))) & 0xFFu;
 }
 
-/* the count arena byte `pos` is entered with, inside the NAL that begins at `begin` (<= pos): the run of zeros in front of it,
- * followed back a KiB at a time by the whole wavefront (lane l looks at the 16 bytes that end 16 l in front of the current end) */
-__device__ __forceinline__ uint32_t wave_lead_count(const uint8_t* __restrict__ arena, uint64_t begin, uint64_t pos, int lane)
+/* the run of zeros in front of arena byte `pos`, inside the NAL that begins at `begin` (<= pos), followed back a KiB at a time by
+ * the whole wavefront (lane l looks at the 16 bytes that end 16 l in front of the current end) -- for `max_kib` KiB at most:
+ * open = the bound was reached with nothing but zeros seen (the run goes on) */
+__device__ __forceinline__ uint64_t wave_lead_run(const uint8_t* __restrict__ arena, uint64_t begin, uint64_t pos, int lane, uint32_t max_kib, bool& open)
 {
     struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
     uint64_t end = pos, run = 0;
-    for (;;) {
+    open = false;
+    for (uint32_t it = 0;; ++it) {
         if (end <= begin) break;
+        if (it >= max_kib) { open = true; break; }
         uint32_t tz;                                               /* zeros at the top of my window, counted down to `begin` at most */
         const int64_t lo = (int64_t)end - 16 * (int64_t)(lane + 1);
         if (lo >= (int64_t)begin) {
@@ -1410,7 +1473,57 @@ __device__ __forceinline__ uint32_t wave_lead_count(const uint8_t* __restrict__ 
         run += 16u * (uint64_t)first + (uint64_t)(uint32_t)__shfl((int)tz, first, 64);
         break;
     }
-    return dz_count_of(run);
+    return run;
+}
+/* ... and the count byte `pos` is entered with (the whole run) */
+__device__ __forceinline__ uint32_t wave_lead_count(const uint8_t* __restrict__ arena, uint64_t begin, uint64_t pos, int lane)
+{
+    bool open;
+    return dz_count_of(wave_lead_run(arena, begin, pos, lane, 0xFFFFFFFFu, open));
+}
+
+/* What a dense tile leaves in its look-back word's tag for the tiles behind it (round 4).  The count a dense tile is entered
+ * with used to be found by walking the run of zeros in front of it back to its first byte: every tile of a long stretch of
+ * zeros walked the whole stretch (a 16 GiB arena with 1 % of it in 640 KiB stretches of zeros: 35 ms against 6.1).  Now:
+ *   tag 1 + e   the count behind the tile is e, whatever it was entered with (something in it is not a zero, or a NAL begins)
+ *               -- written with the tile's first word, before anything is waited for;
+ *   tag 4       nothing but zeros and no NAL begins: the count behind it is dz_map(the count in front) -- written at once
+ *               too, and replaced by 1 + e with the status-1 word once the tile knows its own;
+ *   tag 0       with a status: an ordinary tile (at most kTDenseLimit flagged chunks: its zeros end within ~16 KiB).
+ * A dense tile first looks one KiB back; if that is all zeros it reads the words of the tiles in front: the nearest one that is
+ * not tag 4 gives the count (directly, or by a walk from its end that is short by construction), and any tag-4 tiles between
+ * map it once (dz_map is idempotent).  No tile waits for more than its predecessors' FIRST words. */
+constexpr unsigned long long kDzTagPure = 4ull;
+__device__ __forceinline__ uint32_t dz_entry_count(const TileCtx& t, const unsigned long long* __restrict__ desc, uint64_t tile, int lane, uint32_t* err)
+{
+    if (tile == 0 || t.tile_lo <= t.prev_begin) return 0u;
+    bool open;
+    const uint64_t run1 = wave_lead_run(t.arena, t.prev_begin, t.tile_lo, lane, 1u, open);
+    if (!open) return dz_count_of(run1);
+    uint64_t win = 0;                                              /* tiles tile-1-win .. tile-64-win are looked at */
+    uint32_t spins = 0;
+    for (;;) {
+        const uint64_t dist = win + (uint64_t)lane;                /* tile - 1 - dist */
+        const bool valid = dist < tile;
+        const unsigned long long v = valid ? ld_desc3(desc + (tile - 1 - dist)) : 0ull;
+        const unsigned long long tag = v >> kDescTagShift;
+        const bool pure = valid && tag == kDzTagPure;
+        const uint64_t notpure = __ballot(!pure);
+        if (notpure == 0ull) { win += 64; continue; }              /* 64 tiles of nothing but zeros: further back */
+        const int f = (int)__builtin_ctzll(notpure);
+        const unsigned long long vf = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), f) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, f);
+        const uint64_t df = win + (uint64_t)f;
+        uint32_t c;
+        if (df >= tile) c = 0u;                                    /* (in front of the arena: cannot be, tile 0 holds a NAL start) */
+        else if (vf == 0ull) {                                     /* that tile has not said anything yet */
+            if (++spins > kEmitSpinLimit) { if (lane == 0) atomicMax(err, (uint32_t)(-HBS_E_TIMEOUT)); return 0u; }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        } else if ((vf >> kDescTagShift) != 0ull) c = (uint32_t)(vf >> kDescTagShift) - 1u;
+        else c = wave_lead_count(t.arena, t.prev_begin, (tile - df) * (uint64_t)kTTileBytes, lane);   /* an ordinary tile: from its end */
+        return df > 0 ? dz_map(c) : c;
+    }
 }
 
 /* a chunk in which NALs begin (or the arena's partial last chunk): byte by byte, entered with `count`.  Returns the bytes that go
@@ -1538,6 +1651,7 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
         return u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     };
     const uint32_t seg_before = load_dword_guarded(t.arena, (int64_t)wseg - 4, t.arena_len);
+    DZ_T_DECL
 
     /* ---- first half: bytes that go into my rows, for each count they may be entered with ---- */
     uint32_t tot[3] = {0u, 0u, 0u}, st[3] = {0u, 1u, 2u};
@@ -1589,10 +1703,24 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
 #pragma unroll
         for (int h = 0; h < 3; ++h) { l.dz_tot[wv][h] = tot[h]; l.dz_out[wv][h] = st[h]; }
     }
+    DZ_T_MARK(0)
     __syncthreads();
+    DZ_T_MARK(1)
     if (wv == 0) {
+        /* what the tile does for each count it may be entered with; the same count behind it for all three: the tiles behind need
+         * not wait for this one's own (dz_entry_count) */
+        uint32_t f_out[3];
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            uint32_t c = (uint32_t)h;
+            for (int w = 0; w < kTWaves; ++w) c = dz_pick(l.dz_out[w], c);
+            f_out[h] = c;
+        }
+        const bool constant = f_out[0] == f_out[1] && f_out[1] == f_out[2];
+        if (lane == 0) st_desc3(desc + tile, (constant ? 1ull + f_out[0] : kDzTagPure) << kDescTagShift);
         /* the count the tile is entered with: the zeros in front of it inside the NAL in progress */
-        const uint32_t c0 = t.tile_lo > t.prev_begin ? wave_lead_count(t.arena, t.prev_begin, t.tile_lo, lane) : 0u;
+        const uint32_t c0 = dz_entry_count(t, desc, tile, lane, err);
+        DZ_T_MARK(2)
         unsigned long long tile_ins = 0;
         uint32_t c = c0;
         for (int w = 0; w < kTWaves; ++w) {
@@ -1600,11 +1728,13 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
             tile_ins += dz_pick(l.dz_tot[w], c);
             c = dz_pick(l.dz_out[w], c);
         }
-        if (lane == 0 && tile != 0) st_desc3(desc + tile, (tile_ins << 2) | 1ull);
+        const unsigned long long tag = (1ull + c) << kDescTagShift;  /* c: the count behind the tile */
+        if (lane == 0 && tile != 0) st_desc3(desc + tile, tag | (tile_ins << 2) | 1ull);
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long bf = k3_look_back(desc, tile, lane, err);
+        DZ_T_MARK(3)
         if (lane == 0) {
-            st_desc3(desc + tile, ((bf + tile_ins) << 2) | 2ull);
+            st_desc3(desc + tile, tag | ((bf + tile_ins) << 2) | 2ull);
             const uint64_t end_pos = t.tile_lo + tile_bytes + bf + tile_ins;
             l.before = bf;
             l.ok = end_pos <= out_cap ? 1u : 0u;
@@ -1657,6 +1787,10 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
             else (void)emit_chunk16(tout + pos, d.q.x, d.q.y, d.q.z, d.q.w, 16u, mask);
         }
     }
+    DZ_T_MARK(4)
+#ifdef HBS_DZ_TIMING
+    if (threadIdx.x == 0) atomicAdd(&g_dz_cycles[7], 1ull);
+#endif
 }
 
 #ifndef HBS3T_COPY_DEPTH
@@ -1684,6 +1818,9 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     t.arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - t.a0;
     const uint64_t ntiles = t.arena_len / kTTileBytes + 1;
     HBS3_T_DECL
+#ifdef HBS_DZ_TIMING
+    unsigned long long dz_tile_t0 = 0;
+#endif
     uint64_t d_tile = 0;
     for (;;) {
     int pending = 0;                   /* 1: a dense tile -- walked below the tile loop, where no row is live (as in hbs_scan4.hip) */
@@ -1691,20 +1828,15 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const int lane = launder_lane(tid0) & 63;
         const int tid = launder_lane(tid0);
         __syncthreads();                                           /* the previous tile is done with l */
-        if (tid == 0) {
-            l.ticket = atomicAdd(ticket, 1u);
-            l.abort = __hip_atomic_load(&tflag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) l.ticket = atomicAdd(ticket, 1u);
         if (tid < kTWaves * kTRows) l.rowbits[tid] = 0ull;
         __syncthreads();
         const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
         if (tile >= ntiles) break;
-        if (l.abort != 0u) {
-            /* somebody gave up: nothing written from here on matters, but the tiles that wait for this one must not wait for ever */
-            if (tid == 0) st_desc3(desc + tile, 2ull);
-            continue;
-        }
         HBS3_T_MARK(0)
+#ifdef HBS_DZ_TIMING
+        dz_tile_t0 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_setprio(3);
         t.tile_lo = tile * (uint64_t)kTTileBytes;
         const bool last_tile = tile == ntiles - 1;
@@ -1976,21 +2108,15 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         HBS3_T_MARK(6)
     }
     if (pending == 0) break;
+#ifdef HBS_DZ_TIMING
+    if (threadIdx.x == 0) atomicAdd(&g_dz_cycles[5], __builtin_amdgcn_s_memtime() - dz_tile_t0);
+#endif
     k3_dense_tile(l, t, d_tile, d_tile == ntiles - 1, desc, out, out_cap, idx_out, n, total, err);
     }
     HBS3_T_FLUSH
 }
 
 /* between the tile kernel that gave up and the kernel by NALs that takes over: the look-back words and counters they share */
-__global__ __launch_bounds__(256)
-void k3t_reset(unsigned long long* __restrict__ desc, uint64_t words, uint32_t* __restrict__ ticket, unsigned long long* __restrict__ total,
-               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
-{
-    if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag) || tflag[2] == 0u) return;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) desc[i] = 0ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *ticket = 0u; *total = 0ull; }
-}
-
 int emit_tile_grid_blocks(int device)
 {
     hipDeviceProp_t prop;
@@ -2030,21 +2156,29 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
      * arena; its last kProbeBlocks workgroups are the density probe */
     if (a.n) k3t_check<<<kCheckBlocks + (probe ? kProbeBlocks : 0u), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap,
                                              emit_desc_words(a.items_cap), tflag ? 1 : 0, a.tiles == 2 ? 1 : 0, a.tflag, a.err, a.probe);
+    /* (round 4: the chains behind the tile kernel that rule themselves out on the device were tried on side streams, forked behind
+     * k3t_check and joined in front of the summary; the event waits cost more than the empty launches -- 0.461 against 0.440 ms at
+     * 1 GiB.  What helps is fewer launches: k3t_reset is gone with the give-up, and the two chains share k3_sizes and one scan.) */
+    const bool both = a.n && want_sparse && want_dense;              /* the automatic mode: the chains share their first step and their scan */
     if (a.n && want_sparse) {
         if (tflag) {
-            /* arena tiles first; the kernel by NALs behind them runs when they do not apply -- or gave up on a tile dense in elements */
+            /* arena tiles first; the kernel by NALs behind them runs when they do not apply */
             k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.first_k, probe, tflag);
             uint64_t tb = (uint64_t)a.tile_blocks;
             const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
             if (tb > max_tiles) tb = max_tiles;
             k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap,
                                                               a.index_out, a.total, a.err, probe, tflag);
-            k3t_reset<<<256, 256, 0, st>>>(a.desc, emit_desc_words(a.items_cap), a.ticket, a.total, probe, tflag);
         }
         /* items of the kernel by NALs: segments per NAL, their exclusive scan, the item list (skipped on the device when the tile
-         * kernel has done the call, or when the list is the identity) */
-        k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe, a.tflag);
-        launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse, a.tflag);
+         * kernel does the call, or when the list is the identity) */
+        if (both) {
+            k3_sizes<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
+            launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenEither, a.tflag, a.total_dense);
+        } else {
+            k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe, a.tflag);
+            launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenSparse, a.tflag);
+        }
         k3_expand<<<1024, 256, 0, st>>>(a.nal_total, a.out_off, a.n, a.n_items, a.items, a.items_cap, probe, a.tflag);
         const uint64_t ngroups = (a.items_cap + kEmitGroup - 1) / kEmitGroup;       /* upper bound */
         uint64_t blocks = (uint64_t)a.grid_blocks;
@@ -2053,8 +2187,10 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
                                                          a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err, probe, tflag, a.tflag);
     }
     if (a.n && want_dense) {
-        k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
-        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, probe, kWhenDense, a.tflag);
+        if (!both) {
+            k3_count<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
+            launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, probe, kWhenDense, a.tflag);
+        }
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe, a.tflag);
     }
     if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);

@@ -555,7 +555,8 @@ extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] 
  * rejected NALs) for the entries whose successor the tiles already wrote.  The last entry the tiles found, and one the
  * end-of-stream rules append, are thread 0's -- it is the only thread that touches them, and nothing here writes
  * hdr->final_nals / final_kept, which every thread reads. */
-constexpr int kFinishBlocks = 128;
+constexpr int kFinishBlocksMin = 128, kFinishBlocksMax = 2048;   /* sized by the entries there can be (four a thread): 128 workgroups took 40 us over
+                                                                    the 2 M entries of a 2 GiB stream of 1 KiB NALs, 89 us at 512 bytes */
 __global__ __launch_bounds__(256)
 void k_scan_finish(const uint8_t* __restrict__ stream, uint64_t n,
                    hbs_nal_entry* index, uint64_t index_cap,
@@ -563,11 +564,25 @@ void k_scan_finish(const uint8_t* __restrict__ stream, uint64_t n,
 {
     const uint64_t found0 = hdr->final_nals;
     const uint64_t lim = found0 < index_cap ? found0 : index_cap;
-    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k + 1 < lim; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t off = index[k].rbsp_off;
-        const int32_t st = index[k].status;
-        index[k].rbsp_len = (uint32_t)(index[k + 1].rbsp_off - off);
-        if ((st & HBS_ST_ERROR) && (st & HBS_ST_TRAILING03)) index[k].status = st & ~HBS_ST_TRAILING03;
+    /* a wavefront takes 64 consecutive entries: each lane loads the second half of its entry (rbsp_off, rbsp_len, status) in
+     * one piece, the next entry's rbsp_off comes from the lane above (lane 63 loads it) */
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t k0 = wave * 64u; k0 + 1 < lim; k0 += nwaves * 64u) {
+        const uint64_t k = k0 + (uint64_t)lane;
+        const bool in = k + 1 < lim;
+        u32x4 h = u32x4{0u, 0u, 0u, 0u};
+        if (k < lim) h = reinterpret_cast<const u32x4*>(index + k)[1];
+        const uint64_t off = ((uint64_t)h.y << 32) | h.x;
+        uint32_t nlo = (uint32_t)__shfl_down((int)h.x, 1, 64), nhi = (uint32_t)__shfl_down((int)h.y, 1, 64);
+        if (lane == 63 && in) { const uint64_t o = index[k + 1].rbsp_off; nlo = (uint32_t)o; nhi = (uint32_t)(o >> 32); }
+        if (in) {
+            const int32_t st = (int32_t)h.w;
+            uint2 o;
+            o.x = (uint32_t)((((uint64_t)nhi << 32) | nlo) - off);
+            o.y = (uint32_t)(((st & HBS_ST_ERROR) && (st & HBS_ST_TRAILING03)) ? (st & ~HBS_ST_TRAILING03) : st);
+            *reinterpret_cast<uint2*>(&index[k].rbsp_len) = o;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint8_t tail[8];
@@ -680,6 +695,8 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
             /* Both kernels are enqueued; each reads the probe's verdict from the run header and the
              * one it rules out returns at once (no host round trip, the call stays asynchronous).
              * They share the descriptor array and the ticket: whichever runs finds both untouched. */
+            /* (a side stream for the kernel that rules itself out, forked and joined with events, was tried in round 4: the two
+             * event waits cost more than the empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
             if (index_only) launch_scan_index5(a, tiles5, kGateIfSparse, st);
             else launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
@@ -690,7 +707,11 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         }
         if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
     }
-    k_scan_finish<<<kFinishBlocks, 256, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);
+    /* no more entries than start codes fit the stream (3 bytes each) */
+    const uint64_t may = a.index_cap < a.n / 3 + 1 ? a.index_cap : a.n / 3 + 1;
+    uint64_t fb = (may + 1023) / 1024;
+    fb = fb < (uint64_t)kFinishBlocksMin ? (uint64_t)kFinishBlocksMin : fb > (uint64_t)kFinishBlocksMax ? (uint64_t)kFinishBlocksMax : fb;
+    k_scan_finish<<<dim3((unsigned)fb), 256, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);
     return hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ static_assert(k5TileRows % k5SpanRows == 0 && k5TileRows % 64 == 0, "tile = whol
 /* ---- the streaming half: flags of one span of k5SpanRows KiB --------------------------------- */
 
 /* one span in registers: its k5SpanRows rows and the dwords just outside */
-struct Span5 { u32x4 q[k5SpanRows]; uint32_t before, after; };
+struct Span5 { u32x4 q[k5SpanRows]; uint32_t before, before2, after; };
 
 __device__ __forceinline__ void span_load(Span5& s, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int lane)
 {
@@ -47,13 +47,26 @@ __device__ __forceinline__ void span_load(Span5& s, const uint8_t* __restrict__ 
         for (int r = 0; r < k5SpanRows; ++r) s.q[r] = load_chunk_guarded(stream, base + 1024u * r + 16u * lane, n);
     }
     s.before = base >= 4 ? *reinterpret_cast<const uint32_t*>(stream + base - 4) : 0xFFFFFFFFu;
+    s.before2 = base >= 8 ? *reinterpret_cast<const uint32_t*>(stream + base - 8) : 0xFFFFFFFFu;
     s.after = load_dword_guarded(stream, (int64_t)(base + k5SpanBytes), n);
 }
 
-/* lane r of the result: the flag word of row r of the span at `base` (bit l = chunk l of that row) */
-__device__ __forceinline__ unsigned long long span_flags(const Span5& s, uint64_t n, uint64_t base, uint64_t cut, int lane)
+/* what a flagged lane leaves for the batch that walks its chunk as an element (round 4): the chunk's bytes [-8, 20) and its
+ * number in the tile, in a ring of k5Ring entries in LDS.  Until round 4 a batch FETCHED those bytes again from the stream --
+ * by then (a tile is 256 KiB and 3072 wavefronts stream at once) they had left the L2: a dependent round trip to HBM per
+ * batch at loaded latency, and a sector per element on top of the stream's bytes (12 % at one NAL per KiB). */
+constexpr uint32_t k5Ring = 192;
+struct Ring5 { uint32_t head, tail, pending; bool spilled; };     /* head, tail: modulo k5Ring */
+
+/* lane r of the result: the flag word of row r of the span at `base` (bit l = chunk l of that row).
+ * kDeposit: the flagged lanes also leave a Deposit each, in order, at ring slots tail .. (the first `room` of them);
+ * chunk0 = the span's first chunk number in its tile; count = the span's elements. */
+template <bool kDeposit>
+__device__ __forceinline__ unsigned long long span_flags(const Span5& s, uint64_t n, uint64_t base, uint64_t cut, int lane,
+                                                         Deposit* __restrict__ dep, uint32_t chunk0, uint32_t tail, uint32_t room, uint32_t& count)
 {
     unsigned long long mine = 0;
+    uint32_t cnt = 0;
 #pragma unroll
     for (int r = 0; r < k5SpanRows; ++r) {
         const uint32_t e_prev = r == 0 ? s.before : (uint32_t)__builtin_amdgcn_readlane((int)s.q[r ? r - 1 : 0].w, 63);
@@ -70,7 +83,22 @@ __device__ __forceinline__ unsigned long long span_flags(const Span5& s, uint64_
         }
         m |= __ballot(g0 < n && (g0 >> 4) == cut);
         if (lane == r) mine = m;
+        if (kDeposit && m != 0ull) {
+            const uint32_t e_prev_z = r == 0 ? s.before2 : (uint32_t)__builtin_amdgcn_readlane((int)s.q[r ? r - 1 : 0].z, 63);
+            const uint32_t xpp = from_prev_lane(s.q[r].z, e_prev_z);
+            const uint32_t rank = cnt + lanes_below(m);
+            if (((m >> lane) & 1ull) != 0ull && rank < room) {
+                uint32_t slot = tail + rank;
+                if (slot >= k5Ring) slot -= k5Ring;
+                Deposit d;
+                d.xpp = xpp; d.xp = xp; d.x0 = s.q[r].x; d.x1 = s.q[r].y; d.x2 = s.q[r].z; d.x3 = s.q[r].w; d.xn = xn;
+                d.chunk = chunk0 + 64u * (uint32_t)r + (uint32_t)lane;
+                dep[slot] = d;
+            }
+            cnt += (uint32_t)__builtin_popcountll(m);
+        }
     }
+    count = cnt;
     return mine;
 }
 
@@ -127,6 +155,32 @@ __device__ __forceinline__ TileAgg make_batch(Elem& el, const Lds5& l, uint32_t 
     }
     /* the last element of this batch, for the next one */
     const uint32_t cnt = nelem - i0 < 64u ? nelem - i0 : 64u;
+    const uint32_t c_last = (uint32_t)__shfl((int)c, (int)(cnt - 1u), 64);
+    prev_end = base + 16ull * ((uint64_t)c_last + 1u);
+    return ea;
+}
+
+/* the same for `cnt` (<= 64) elements whose bytes wait in the ring, from slot `head` on */
+__device__ __forceinline__ TileAgg ring_batch(Elem& el, const Deposit* __restrict__ dep, uint32_t head, uint32_t cnt, int lane,
+                                              const uint8_t* __restrict__ stream, uint64_t base, uint64_t n, uint64_t& prev_end)
+{
+    const bool have = (uint32_t)lane < cnt;
+    uint32_t slot = head + (have ? (uint32_t)lane : 0u);
+    if (slot >= k5Ring) slot -= k5Ring;
+    const Deposit& d = dep[slot];
+    const uint32_t c = d.chunk;
+    const uint32_t c_prev = (uint32_t)__shfl_up((int)c, 1, 64);
+    const uint64_t my_prev_end = lane == 0 ? prev_end : base + 16ull * ((uint64_t)c_prev + 1u);
+    TileAgg ea = agg_identity();
+    el.gap = 0; el.chunk = 0;
+    if (have) {
+        el.v.xpp = d.xpp; el.v.xp = d.xp; el.v.x0 = d.x0; el.v.x1 = d.x1; el.v.x2 = d.x2; el.v.x3 = d.x3; el.v.xn = d.xn;
+        el.v.stream = stream; el.v.g0 = base + 16ull * c; el.v.n = n;
+        elem_walk(el.v, el.m, el.s, el.cls);
+        el.gap = span_bytes(my_prev_end, el.v.g0, n);
+        el.chunk = c;
+        ea = elem_agg(el.gap, el.s);
+    }
     const uint32_t c_last = (uint32_t)__shfl((int)c, (int)(cnt - 1u), 64);
     prev_end = base + 16ull * ((uint64_t)c_last + 1u);
     return ea;
@@ -220,7 +274,8 @@ __device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32
 struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
 static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
 struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
-constexpr uint32_t k5RecCap = 2u * (uint32_t)k5TileRows;                  /* elements recorded per tile: two a KiB (6 % of the stream's size as workspace) */
+constexpr uint32_t k5RecCap = 3u * (uint32_t)k5TileRows;                  /* elements recorded per tile: three a KiB (9 % of the stream's size as workspace; two until round 4:
+                                                                             NALs of 512 bytes passed it in every other tile, and such a tile is streamed twice) */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
 constexpr int k5ChunkTiles = 64;
 
@@ -262,11 +317,56 @@ __device__ __forceinline__ void tile_words(Lds5& l, const uint8_t* __restrict__ 
         cur = nxt;
         if (sp + 1 < k5TileRows / k5SpanRows && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
         unsigned long long w = 0;
-        if (sbase < n) w = span_flags(cur, n, sbase, cut, launder_lane(lane));
+        uint32_t cnt;
+        if (sbase < n) w = span_flags<false>(cur, n, sbase, cut, launder_lane(lane), nullptr, 0u, 0u, 0u, cnt);
         if (lane < k5SpanRows) l.words[sp * k5SpanRows + lane] = w;
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+/* ... and, for the streaming kernel, the flagged chunks' bytes into the ring; whenever 64 of them wait, on_batch(head, 64) walks
+ * them (the next span's loads are in flight meanwhile).  A span that does not fit the ring's free slots spills the tile:
+ * nothing more is deposited or walked, and the caller does the tile's elements the old way, from its flag words. */
+template <class F>
+__device__ __forceinline__ Ring5 tile_words_ring(Lds5& l, Deposit* __restrict__ dep, const uint8_t* __restrict__ stream, uint64_t n,
+                                                 uint64_t base, uint64_t cut, int lane, F&& on_batch)
+{
+    Span5 cur, nxt;
+    Ring5 rg; rg.head = 0; rg.tail = 0; rg.pending = 0; rg.spilled = false;
+    if (base < n) span_load(nxt, stream, n, base, launder_lane(lane));
+#pragma unroll 1
+    for (int sp = 0; sp < k5TileRows / k5SpanRows; ++sp) {
+        const uint64_t sbase = base + (uint64_t)sp * k5SpanBytes;
+        cur = nxt;
+        if (sp + 1 < k5TileRows / k5SpanRows && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
+        unsigned long long w = 0;
+        uint32_t cnt = 0;
+        if (sbase < n) w = span_flags<true>(cur, n, sbase, cut, launder_lane(lane), dep, (uint32_t)(sp * k5SpanRows * 64), rg.tail,
+                                            rg.spilled ? 0u : k5Ring - rg.pending, cnt);
+        if (lane < k5SpanRows) l.words[sp * k5SpanRows + lane] = w;
+        cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+        if (!rg.spilled) {
+            if (rg.pending + cnt > k5Ring) rg.spilled = true;
+            else {
+                rg.pending += cnt;
+                rg.tail += cnt; if (rg.tail >= k5Ring) rg.tail -= k5Ring;
+                if (rg.pending >= 64u) {
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+                    while (rg.pending >= 64u) {
+                        on_batch(rg.head, 64u);
+                        rg.head += 64u; if (rg.head >= k5Ring) rg.head -= k5Ring;
+                        rg.pending -= 64u;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return rg;
 }
 
 /* elements of the tile and whether it is walked by rows (16 or more elements per flagged row: zero stuffing, padding) */
@@ -310,11 +410,12 @@ __device__ __forceinline__ void rec_load(const Rec5* r, Elem& el, uint64_t base,
     el.v.xpp = el.v.xp = el.v.x0 = el.v.x1 = el.v.x2 = el.v.x3 = el.v.xn = 0;      /* bytes: only a copy would want them */
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
     if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
     __shared__ Lds5 l;
+    __shared__ Deposit ring[k5Ring];
     const Ws5 w5 = ws5_carve(ws, num_tiles);
     const int lane0 = threadIdx.x;
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
@@ -326,13 +427,26 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         if (tile >= num_tiles) break;
         const uint64_t base = tile * k5TileBytes;
         const uint64_t tile_end = base + k5TileBytes;
-        tile_words(l, stream, n, base, cut, lane);
+        TileAgg acc = agg_identity();
+        uint64_t prev_end = base;
+        uint32_t nwalked = 0;
+        auto on_batch = [&](uint32_t head, uint32_t cnt) {
+            Elem el;
+            TileAgg ea = ring_batch(el, ring, head, cnt, lane, stream, base, n, prev_end);
+            if ((uint32_t)lane < cnt && nwalked + (uint32_t)lane < k5RecCap) rec_store(&w5.rec[tile * k5RecCap + nwalked + (uint32_t)lane], el, base);
+            ea = wave_scan_combine(ea, lane);
+            acc = combine(acc, agg_readlane(ea, 63));
+            nwalked += cnt;
+        };
+        const Ring5 rg = tile_words_ring(l, ring, stream, n, base, cut, lane, on_batch);
         bool by_rows;
         const uint32_t nelem = tile_census(l, lane, by_rows);
         const uint32_t npass = (nelem + 63u) >> 6;
-        TileAgg acc = agg_identity();
-        uint64_t prev_end = base;
-        if (by_rows) {
+        if (!by_rows && !rg.spilled) {
+            if (rg.pending) on_batch(rg.head, rg.pending);           /* the rest: fewer than 64 */
+        } else if (by_rows) {
+            acc = agg_identity();                                     /* (what was walked before the tile turned out dense is dropped) */
+            prev_end = base;
             const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
             tile_rows(stream, n, base, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
                 DenseRow d;
@@ -346,7 +460,9 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                     acc = combine(acc, agg_readlane(ea, 63));
                 }
             });
-        } else {
+        } else {                                                      /* spilled: the tile's elements from its flag words, their bytes from the stream */
+            acc = agg_identity();
+            prev_end = base;
             const bool record = nelem <= k5RecCap;
 #pragma unroll 1
             for (uint32_t p = 0; p < npass; ++p) {

@@ -220,6 +220,20 @@ def test_emit_arena_tiles_walk_dense_tiles_by_rows(ctx, orc):
     _, idx_nals = ctx.emit_annexb(dev(arena), idx)
     ctx.set_emit_path(-1)
     assert np.array_equal(got, want) and np.array_equal(got_idx, idx_nals) and stayed == 1
+    # one NAL with 70 tiles of nothing but zeros in it (runs of odd and of even length): a tile learns the count it is entered
+    # with from the words of the tiles in front (dz_entry_count), more than one window of 64 of them back
+    for z0, z1 in ((5_000, 13_900_000), (5_001, 13_900_000), (16 * 1024, 70 * T + 16 * 1024)):
+        lens = [10_000, 14_000_000, 5_000]
+        arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+        arena[10_000 + z0: 10_000 + z1] = 0
+        idx = fake_index(lens, [4, 3, 4])
+        want = orc.emit_annexb(arena, idx)
+        ctx.set_emit_path(2)
+        got, got_idx = ctx.emit_annexb(dev(arena), idx)
+        stayed = ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h)
+        ctx.set_emit_path(-1)
+        assert np.array_equal(got, want), (z0, z1)
+        assert stayed == 1
 
 
 def test_emit_arena_tiles_refuse_an_index_outside_the_arena(ctx, orc):
