@@ -63,7 +63,7 @@ __device__ __forceinline__ bool three_steps_run(const uint32_t* probe, const uin
  * caller's RBSP buffer.  The call then ends with HBS_E_ARG and nothing is read through the index. */
 __device__ __forceinline__ bool index_bad(const uint32_t* vflag) { return vflag[3] != 0u; }
 
-enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2, kWhenEither = 3 };
+enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2, kWhenEither = 3, kWhenNoTiles = 4 };
 /* the helper kernels of the two fall-back chains: those of the kernel by NALs (its item list) run when the data is sparse and
  * the tile kernel, in front of them since round 3, has not done the call; those of the three steps when these run */
 __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when, const uint32_t* tflag)
@@ -71,6 +71,7 @@ __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when, const
     if (when == kWhenAlways) return false;
     if (when == kWhenSparse) return (probe && emit_probe_dense(probe)) || tile_path_done(tflag);
     if (when == kWhenEither) return emit_skip(probe, kWhenSparse, tflag) && !three_steps_run(probe, tflag);
+    if (when == kWhenNoTiles) return tile_path_on(tflag);           /* small NALs: a lane per NAL unless the arena tiles do the call */
     return !three_steps_run(probe, tflag);
 }
 /* kWhenEither (the automatic mode, probe != nullptr: one scan serves whichever chain runs): where the scan's total goes */
@@ -153,6 +154,26 @@ __device__ __forceinline__ u32x4 load_nal_chunk(const uint8_t* __restrict__ rbsp
 
 /* A flagged chunk, exactly: its bytes (one 16-byte load), the count it is entered with (the dword in front; a run of four
  * or more zeros is followed back in memory), the 03s it gets.  off is a multiple of 16 below len. */
+/* lead_count() (hbs_emit.h: the count a byte is entered with = the run of zeros in front of it inside its NAL), sixteen bytes a
+ * step: byte by byte, every element inside a long run of zeros walked the run back through a chain of dependent loads -- a tile
+ * with 16 KiB of zeros in it took milliseconds (round 4: scripts/emit_paths.py with HBS_EMIT_MIXED=2) */
+__device__ __forceinline__ uint32_t lead_count_dev(const uint8_t* __restrict__ rbsp, uint64_t nal_begin, uint64_t p)
+{
+    struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
+    uint64_t z = 0;
+#pragma unroll 1
+    while (p - z >= nal_begin + 16u) {
+        const u32x4 q = reinterpret_cast<const U16*>(rbsp + (p - z - 16u))->v;
+        if ((q.x | q.y | q.z | q.w) == 0u) { z += 16u; continue; }
+        const uint32_t tz = q.w ? (uint32_t)__builtin_clz(q.w) >> 3 : q.z ? 4u + ((uint32_t)__builtin_clz(q.z) >> 3)
+                          : q.y ? 8u + ((uint32_t)__builtin_clz(q.y) >> 3) : 12u + ((uint32_t)__builtin_clz(q.x) >> 3);
+        z += tz;
+        return z == 0 ? 0u : ((z & 1ull) ? 1u : 2u);
+    }
+    while (p - z > nal_begin && rbsp[p - 1 - z] == 0) ++z;
+    return z == 0 ? 0u : ((z & 1ull) ? 1u : 2u);
+}
+
 struct ExactChunk { u32x4 q; uint32_t nb, mask; };
 __device__ __forceinline__ ExactChunk exact_chunk(const uint8_t* __restrict__ rbsp, uint64_t begin, uint32_t len, uint32_t off)
 {
@@ -163,7 +184,7 @@ __device__ __forceinline__ ExactChunk exact_chunk(const uint8_t* __restrict__ rb
     uint32_t count = 0;                                   /* a NAL starts with count = 0 */
     if (off != 0) {
         count = lead_count4(reinterpret_cast<const U4*>(rbsp + begin + off - 4u)->v);
-        if (count == kLeadUnknown) count = lead_count(rbsp, begin, begin + off);
+        if (count == kLeadUnknown) count = lead_count_dev(rbsp, begin, begin + off);
     }
     e.mask = insert_mask16(e.q.x, e.q.y, e.q.z, e.q.w, e.nb, count);
     return e;
@@ -184,7 +205,7 @@ __device__ __forceinline__ ExactChunk exact_from_regs(const u32x4& q, uint32_t x
     uint32_t count = 0;
     if (off != 0) {
         count = lead_count4(xp);
-        if (count == kLeadUnknown) count = lead_count(rbsp, begin, begin + off);
+        if (count == kLeadUnknown) count = lead_count_dev(rbsp, begin, begin + off);
     }
     e.mask = insert_mask16(q.x, q.y, q.z, q.w, e.nb, count);
     return e;
@@ -463,32 +484,63 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
  * as it is written (h264_nal.c:92-132): pass 1 the bytes that go in, an exclusive scan of the NALs' output sizes (the
  * three steps' own), pass 2 the bytes -- read as unaligned dwords, written as unaligned dwords from a small register
  * buffer.  Picked on the HOST (mean NAL size = rbsp_bytes / n below kTinyMeanBytes): no device-side gate, no probe. */
+constexpr uint64_t kTilesMinMeanBytes = 224;     /* ... from this mean up the arena tiles are tried first (878 starts per tile on average; 1024 is their limit) */
 constexpr uint64_t kTinyMeanBytes = 448;         /* (a mean of 384 bytes and more fits the arena tiles in principle -- at most 512 starts per 192 KiB -- but sizes scatter) */
 
 /* a lane's NAL, 16 bytes a load (a dword a load fetched every 128-byte line thirty-two times: 64 lanes x 32 wavefronts of
  * lines do not stay in a 16 KiB L1) */
 template <class F>
-__device__ __forceinline__ void tiny_bytes(const uint8_t* __restrict__ p, uint32_t len, F&& f)
+__device__ __forceinline__ void tiny_bytes(const uint8_t* __restrict__ arena, uint64_t arena_bytes, uint64_t begin, uint32_t len, F&& f)
 {
     struct __attribute__((packed, aligned(1))) U16 { u32x4 v; };
-    uint32_t i = 0;
+    /* 64 bytes a step, the four loads issued together and the next step's in flight (one load in flight per lane: a NAL of 384
+     * bytes was 24 memory round trips, 7.5 ms over 2 GiB; four: 4.4 ms).  A chunk may reach past the NAL's end -- the bytes
+     * behind it are not looked at -- but not past the arena's. */
+    auto load4 = [&](u32x4* q, uint32_t i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t at = begin + i + 16u * (uint32_t)k;
+            q[k] = u32x4{0u, 0u, 0u, 0u};
+            if (i + 16u * (uint32_t)k < len) {
+                if (at + 16u <= arena_bytes) q[k] = reinterpret_cast<const U16*>(arena + at)->v;
+                else q[k] = load_chunk_guarded(arena, at, arena_bytes);
+            }
+        }
+    };
+    u32x4 cur[4], nxt[4];
+    load4(cur, 0u);
 #pragma unroll 1
-    for (; i + 16u <= len; i += 16u) {
-        const u32x4 q = reinterpret_cast<const U16*>(p + i)->v;
-        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    for (uint32_t i = 0; i < len; i += 64u) {
+        if (i + 64u < len) load4(nxt, i + 64u);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 c = k == 0 ? cur[0] : k == 1 ? cur[1] : k == 2 ? cur[2] : cur[3];
+            const uint32_t at = i + 16u * (uint32_t)k;
+            if (at >= len) break;
+            const uint32_t nb = len - at < 16u ? len - at : 16u;
+            uint32_t w[4] = {c.x, c.y, c.z, c.w};
+            if (nb == 16u) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+                for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { f(w[d] & 0xFFu); w[d] >>= 8; }
+                    for (int b = 0; b < 4; ++b) { f(w[d] & 0xFFu); w[d] >>= 8; }
+            } else {
+#pragma unroll 1
+                for (uint32_t b = 0; b < nb; ++b) {
+                    f(w[0] & 0xFFu);
+                    w[0] = (w[0] >> 8) | (w[1] << 24); w[1] = (w[1] >> 8) | (w[2] << 24); w[2] = (w[2] >> 8) | (w[3] << 24); w[3] >>= 8;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
     }
-#pragma unroll 1
-    for (; i < len; ++i) f((uint32_t)p[i]);
 }
 
-__device__ __forceinline__ uint32_t tiny_count(const uint8_t* __restrict__ p, uint32_t len)
+__device__ __forceinline__ uint32_t tiny_count(const uint8_t* __restrict__ arena, uint64_t arena_bytes, uint64_t begin, uint32_t len)
 {
     uint32_t ins = 0, count = 0;
-    tiny_bytes(p, len, [&](uint32_t v) {
+    tiny_bytes(arena, arena_bytes, begin, len, [&](uint32_t v) {
         if (count == 2u && v <= 3u) { ++ins; count = 0u; }
         count = v == 0u ? count + 1u : 0u;
     });
@@ -496,13 +548,13 @@ __device__ __forceinline__ uint32_t tiny_count(const uint8_t* __restrict__ p, ui
 }
 
 __global__ __launch_bounds__(256)
-void k3_count_tiny(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+void k3_count_tiny(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
                    unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ vflag)
 {
-    if (index_bad(vflag)) return;
+    if (index_bad(vflag) || tile_path_on(vflag)) return;           /* (the arena tiles, in front, do the call when the index allows them) */
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t len = idx[k].rbsp_len;
-        nal_total[k] = gap_of(idx, k, gap_mode) + len + tiny_count(rbsp + idx[k].rbsp_off, len);
+        nal_total[k] = gap_of(idx, k, gap_mode) + len + tiny_count(rbsp, rbsp_bytes, idx[k].rbsp_off, len);
     }
 }
 
@@ -527,12 +579,12 @@ struct TinyOut {
 };
 
 __global__ __launch_bounds__(256)
-void k3_emit_tiny(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
+void k3_emit_tiny(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
                   const unsigned long long* __restrict__ nal_total, const unsigned long long* __restrict__ out_off,
                   uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
                   const uint32_t* __restrict__ vflag)
 {
-    if (index_bad(vflag)) return;
+    if (index_bad(vflag) || tile_path_on(vflag)) return;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t begin = idx[k].rbsp_off;
         const uint32_t len = idx[k].rbsp_len;
@@ -549,7 +601,7 @@ void k3_emit_tiny(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restr
         for (uint64_t g = 0; g + 1 < gap; ++g) o.put(0u);                        /* zero_byte / leading zeros, then 01 */
         if (gap) o.put(1u);
         uint32_t count = 0;
-        tiny_bytes(rbsp + begin, len, [&](uint32_t v) {
+        tiny_bytes(rbsp, rbsp_bytes, begin, len, [&](uint32_t v) {
             if (count == 2u && v <= 3u) { o.put(3u); count = 0u; }
             o.put(v);
             count = v == 0u ? count + 1u : 0u;
@@ -902,7 +954,7 @@ __global__ void k3_seg_count(const hbs_nal_entry* __restrict__ idx, uint64_t n, 
 }
 
 /* the automatic mode's first step of BOTH fall-back chains in one launch (round 4: every launch that rules itself out on the device
- * still costs 4.7 us of the call): segments per NAL for the kernel by NALs, or bytes per NAL for the three steps -- whichever
+ * still costs a few us of the call): segments per NAL for the kernel by NALs, or bytes per NAL for the three steps -- whichever
  * chain the probe and the tile kernel's eligibility leave to run, if any.  Both write nal_total; the chains exclude each other. */
 __global__ __launch_bounds__(256)
 void k3_sizes(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
@@ -1106,6 +1158,15 @@ __global__ void k3_summary(const unsigned long long* total, uint64_t n, uint64_t
     sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
 }
 
+__global__ void k3_summary_small(const unsigned long long* total_tiles, const unsigned long long* total_lanes, uint64_t n, uint64_t rbsp_bytes,
+                                 const uint32_t* err, hbs_summary* sum, const uint32_t* tflag)
+{
+    sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes;
+    sum->stream_bytes = tile_path_on(tflag) ? *total_tiles : *total_lanes;
+    sum->stop_reason = n ? -1 : 0; sum->error = -(int32_t)*err;
+    sum->reserved[0] = sum->reserved[1] = sum->reserved[2] = 0;
+}
+
 /* ---- synthetic RBSP ---------------------------------------------------------- */
 
 __global__ void k_synth_len(uint64_t seed, uint64_t n, unsigned long long* __restrict__ lens)
@@ -1155,12 +1216,13 @@ void k_synth_fill(uint64_t seed, uint64_t n, int mode, const unsigned long long*
  * store at (its arena offset + bytes inserted in front of it).  Same bytes as the other paths (h264_nal.c:92-132 per NAL).
  *
  * Eligibility is decided on the device (k3t_check): NALs contiguous and in order, first byte 16-byte aligned, gaps below
- * 1 MiB, no 192 KiB window with more than 512 NAL starts, workspace large enough; otherwise k3_fused runs as before. */
+ * 1 MiB, no 192 KiB window with more than 1024 NAL starts, workspace large enough; otherwise k3_fused runs as before. */
 constexpr int kTRows = 48, kTWaves = 4, kTThreads = 64 * kTWaves;
 constexpr uint32_t kTWaveBytes = (uint32_t)kTRows * 1024u, kTTileBytes = (uint32_t)kTWaves * kTWaveBytes;
 constexpr int kTChunks = (int)(kTTileBytes / 16u);
 constexpr int kTParkRows = 28;
-constexpr uint32_t kTMaxStarts = 512, kTMaxGap = 1u << 20;     /* two NAL starts per thread of the workgroup */
+constexpr uint32_t kTMaxStarts = 1024, kTMaxGap = 1u << 20;    /* NAL starts a tile may hold (512 until round 4: NALs of 256-448 bytes went a lane per NAL instead, at 0.12 of the peak) */
+constexpr uint32_t kTFastStarts = 2u * (uint32_t)kTThreads;    /* ... of which the first two per thread are fetched inside the flag pass, the rest behind it */
 constexpr uint64_t kTMinArena = 192ull << 20;      /* below, the kernel by NALs is as fast or faster (0.12 against 0.115 ms at 128 MiB, 0.173 against 0.186 at 256 MiB) */
 constexpr int kTElemPass = 64;
 constexpr int kTElemWaves = 2;                  /* a tile with several batches of elements: wavefront 1 parks rows too and takes every other batch (as hbs_scan4.hip) */
@@ -1339,7 +1401,7 @@ __device__ __forceinline__ uint32_t tile_element(const TileCtx& t, const LdsT& l
         uint32_t xp = load_dword_guarded(t.arena, (int64_t)x0 - 4, t.arena_len);
         if (d < 4) xp |= 0xFFFFFFFFu >> (8u * (uint32_t)d);           /* bytes of the NAL in front: not zeros of this one */
         count = lead_count4(xp);
-        if (count == kLeadUnknown) count = d == 4 ? 2u : lead_count(t.arena, begin, x0);
+        if (count == kLeadUnknown) count = d == 4 ? 2u : lead_count_dev(t.arena, begin, x0);
     }
     if (j0 == j1) {                                                  /* no NAL begins here: a flagged chunk as in the other paths */
         const uint32_t mask = insert_mask16(q.x, q.y, q.z, q.w, nb, count);
@@ -1632,6 +1694,96 @@ __device__ __forceinline__ uint32_t dz_count_in(bool reset, uint32_t out, uint32
     return c_in;
 }
 
+/* ---- the first half again, without a branch in it (round 4) -----------------------------------------------------
+ * Row by row with the rows' special cases as branches, the first half of a dense tile ran as ONE chain of dependent
+ * instructions per wavefront -- 2.4 us a row, 117 us a tile by the shader clock, and every tile behind waits for the bytes it
+ * adds up (deeper prefetch changed nothing: it is not the memory).  Here a group of eight rows is classified first, every
+ * row by the same straight-line code (what each chunk adds for each of the three counts it may be entered with, the count
+ * behind it, whether it is all zeros), so that the eight rows' instructions interleave; the combination in order behind
+ * it is a ballot, a shuffle and a scan per row.  Chunks in which a NAL begins are redone by dz_start3 (not inlined: a few
+ * rows of a tile).  Whole tiles only; the arena's last tile, cut by its end, takes the loop below as before. */
+struct DzFast { uint32_t i0, i1, i2, out, reset; };
+__device__ __forceinline__ DzFast dz_fast(const u32x4& q)
+{
+    DzFast r;
+    const uint32_t lz = low_zero_bytes(q), tz = top_zero_bytes(q);
+    const bool allz = lz >= 16u;
+    const uint32_t mask0 = insert_mask16(q.x, q.y, q.z, q.w, 16u, 0u);
+    const uint32_t v = byte_of(q, lz & 15u);
+    const uint32_t keep = allz ? 0u : (mask0 & ~((2u << lz) - 1u)); /* behind the first byte that is not zero: the same whatever the count was */
+    const uint32_t below = allz ? 0xFFFFu : ((1u << lz) - 1u);
+    const bool small = !allz && v <= 3u;
+    const uint32_t at = allz ? 0u : (1u << lz);
+    /* entered with h: the leading zeros take 03s by dz_lead_bits(h); the first other byte takes one when it is <= 3 and the
+     * zeros in front of it (h + lz) are two, four, ... */
+    const uint32_t f0 = (small && lz != 0u && (lz & 1u) == 0u) ? at : 0u;
+    const uint32_t f1 = (small && (lz & 1u) != 0u) ? at : 0u;
+    const uint32_t f2 = (small && (lz & 1u) == 0u) ? at : 0u;
+    r.i0 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(0u) & below) | f0);
+    r.i1 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(1u) & below) | f1);
+    r.i2 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(2u) & below) | f2);
+    r.out = dz_count_of(tz);
+    r.reset = allz ? 0u : 1u;
+    return r;
+}
+/* a chunk in which NALs begin, for the three counts: byte by byte (several NALs begin in it: NALs shorter than a chunk) */
+__device__ __attribute__((noinline))
+DzFast dz_start3_serial(const uint32_t* starts, const uint32_t* gaps, uint32_t m, uint32_t p, uint32_t j0, u32x4 q0)
+{
+    DzFast r;
+    r.reset = 1u; r.out = 0u;
+    uint32_t ins[3];
+#pragma unroll 1
+    for (uint32_t h = 0; h < 3u; ++h) {
+        u32x4 q = q0;
+        uint32_t j = j0, n_in = 0, count = h;
+#pragma unroll 1
+        for (uint32_t i = 0; i < 16u; ++i) {
+            while (j < m && starts[j] == p + i) { n_in += gaps[j]; count = 0; ++j; }
+            const uint32_t v = q.x & 0xFFu;
+            if (count == 2u && v <= 3u) { ++n_in; count = 0; }
+            count = (v == 0u) ? count + 1u : 0u;
+            q.x = (q.x >> 8) | (q.y << 24); q.y = (q.y >> 8) | (q.z << 24); q.z = (q.z >> 8) | (q.w << 24); q.w >>= 8;
+        }
+        ins[h] = n_in;
+        r.out = count;
+    }
+    r.i0 = ins[0]; r.i1 = ins[1]; r.i2 = ins[2];
+    return r;
+}
+/* bytes [from, to) of the chunk kept, the others 0xFF (from, to in 0..16) */
+__device__ __forceinline__ u32x4 dz_keep_bytes(const u32x4& q, uint32_t from, uint32_t to)
+{
+    auto word = [&](uint32_t w, uint32_t base) -> uint32_t {       /* bytes base .. base+3 */
+        uint32_t ff = 0u;
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) ff |= ((base + b < from || base + b >= to) ? 0xFFu : 0u) << (8u * b);
+        return w | ff;
+    };
+    u32x4 r; r.x = word(q.x, 0u); r.y = word(q.y, 4u); r.z = word(q.z, 8u); r.w = word(q.w, 12u);
+    return r;
+}
+/* ... the usual case, one NAL begins in the chunk (at byte s, its gap in front): the bytes in front of s belong to the NAL in
+ * progress and are entered with the count in question, the bytes from s on to the new NAL, entered with 0 -- two chunks with
+ * the other's bytes made 0xFF, the straight-line way (byte by byte through LDS this was 10 us a row, half of the first half) */
+__device__ __forceinline__ DzFast dz_start3(const LdsT& l, uint32_t m, uint32_t c, const u32x4& q)
+{
+    const uint32_t p = 16u * c;
+    const uint32_t j0 = lower_bound_lds(l.starts, m, p);
+    const uint32_t s0 = l.starts[j0 < m ? j0 : 0u] - p, gap0 = l.gaps[j0 < m ? j0 : 0u];
+    const bool several = j0 + 1u < m && l.starts[j0 + 1u] < p + 16u;
+    if (several || j0 >= m || s0 >= 16u) return dz_start3_serial(l.starts, l.gaps, m, p, j0, q);
+    DzFast r = dz_fast(dz_keep_bytes(q, 0u, s0));
+    const u32x4 hi = dz_keep_bytes(q, s0, 16u);
+    const uint32_t more = gap0 + (uint32_t)__builtin_popcount(insert_mask16(hi.x, hi.y, hi.z, hi.w, 16u, 0u));
+    r.i0 += more; r.i1 += more; r.i2 += more;
+    r.out = dz_count_of(top_zero_bytes(hi) < 16u - s0 ? top_zero_bytes(hi) : 16u - s0);
+    r.reset = 1u;
+    return r;
+}
+constexpr int kDzGroup = 8;
+static_assert(kTRows % kDzGroup == 0, "whole groups of rows");
+
 /* One dense tile, by the whole workgroup (every thread calls it); `l` still holds the tile's NAL starts, gaps and lengths and
  * the chunks they lie in.  Not inlined: its registers must not add to the 192 the rows of the ordinary path occupy. */
 __device__ __attribute__((noinline))
@@ -1655,7 +1807,57 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
 
     /* ---- first half: bytes that go into my rows, for each count they may be entered with ---- */
     uint32_t tot[3] = {0u, 0u, 0u}, st[3] = {0u, 1u, 2u};
-    {
+    if (tile_bytes == (uint64_t)kTTileBytes) {
+        /* a whole tile: groups of kDzGroup rows (see dz_fast above), the next group's loads in flight */
+        u32x4 cur[kDzGroup], nxt[kDzGroup];
+#pragma unroll
+        for (int i = 0; i < kDzGroup; ++i) cur[i] = *reinterpret_cast<const u32x4*>(t.arena + wseg + 1024ull * (uint32_t)i + 16ull * (uint32_t)lane);
+#pragma unroll 1
+        for (int g = 0; g < kTRows / kDzGroup; ++g) {
+            if (g + 1 < kTRows / kDzGroup) {
+#pragma unroll
+                for (int i = 0; i < kDzGroup; ++i)
+                    nxt[i] = *reinterpret_cast<const u32x4*>(t.arena + wseg + 1024ull * (uint32_t)(kDzGroup * (g + 1) + i) + 16ull * (uint32_t)lane);
+            }
+            DzFast a[kDzGroup];
+#pragma unroll
+            for (int i = 0; i < kDzGroup; ++i) a[i] = dz_fast(cur[i]);
+#pragma unroll
+            for (int i = 0; i < kDzGroup; ++i) {
+                const unsigned long long rb = l.rowbits[wv * kTRows + kDzGroup * g + i];
+                if (rb != 0ull) {                                   /* NALs begin in this row: those chunks byte by byte */
+                    if ((rb >> lane) & 1ull) a[i] = dz_start3(l, t.m, chunk0 + 64u * (uint32_t)(kDzGroup * g + i) + (uint32_t)lane, cur[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kDzGroup; ++i) {
+                const uint64_t rm = __ballot(a[i].reset != 0u);
+                const int f = rm ? (int)__builtin_ctzll(rm) : 64;   /* the row's first chunk that resets the count (64: none) */
+                const uint64_t below = rm & ((1ull << lane) - 1ull);
+                const int src = below ? 63 - (int)__builtin_clzll(below) : 0;
+                const uint32_t from = (uint32_t)__shfl((int)a[i].out, src, 64);
+                const uint32_t c_any = (lane - src > 1) ? dz_map(from) : from;             /* right for the lanes behind f, whatever the row is entered with */
+                const uint32_t c_out = a[i].reset ? a[i].out : dz_map(c_any);
+                const uint32_t ro_any = (uint32_t)__builtin_amdgcn_readlane((int)c_out, 63);
+                const uint32_t mine = c_any == 0u ? a[i].i0 : (c_any == 1u ? a[i].i1 : a[i].i2);
+                const uint32_t common = wave_sum32(lane > f ? mine : 0u);
+                const int fl = f < 64 ? f : 63;
+                const uint32_t fi0 = (uint32_t)__builtin_amdgcn_readlane((int)a[i].i0, fl);
+                const uint32_t fi1 = (uint32_t)__builtin_amdgcn_readlane((int)a[i].i1, fl);
+                const uint32_t fi2 = (uint32_t)__builtin_amdgcn_readlane((int)a[i].i2, fl);
+                const uint32_t nlead = (uint32_t)f;                 /* all-zero chunks in front of it */
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const uint32_t c_f = nlead == 0u ? st[h] : dz_map(st[h]);
+                    const uint32_t lead = nlead ? dz_ins(st[h]) + (nlead - 1u) * 8u : 0u;
+                    tot[h] += common + lead + (f < 64 ? (c_f == 0u ? fi0 : c_f == 1u ? fi1 : fi2) : 0u);
+                    st[h] = f < 64 ? ro_any : dz_map(st[h]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kDzGroup; ++i) cur[i] = nxt[i];
+        }
+    } else {
         /* two rows ahead: what the tiles behind this one wait for is this half */
         u32x4 qa = load_row(0), qb = load_row(1);
         uint32_t e_prev = seg_before;
@@ -1881,7 +2083,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         uint64_t nk_off[2] = {0, 0};                               /* this thread's two NALs of the tile (numbers tid and tid + 256): rbsp_off */
         uint64_t nk_start[2] = {0, 0}, nk_pend[2] = {0, 0};        /* ... start in the caller's stream and the end of the NAL in front (gap_of) */
         uint32_t nk_len[2] = {0, 0};
-        static_assert(kTMaxStarts == 2 * kTThreads, "two per thread");
+        static_assert(kTFastStarts == 2 * kTThreads && kTMaxStarts >= kTFastStarts, "two per thread inside the flag pass");
         t_for_n<kTRows / 4>([&](auto gc) {
             constexpr int g0 = 4 * decltype(gc)::value;
             uint64_t fmask[4];
@@ -1946,6 +2148,18 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
+        if (t.m > kTFastStarts) {
+            /* a tile of small NALs: the starts past the first 512, fetched here (the rows are all in by now) */
+#pragma unroll 1
+            for (uint32_t j = kTFastStarts + (uint32_t)tid; j < t.m; j += (uint32_t)kTThreads) {
+                const uint64_t k = t.k_lo + j;
+                const uint32_t rel = (uint32_t)(idx[k].rbsp_off - t.a0 - t.tile_lo);
+                l.starts[j] = rel;
+                l.gaps[j] = (uint32_t)(gap_mode == 1 ? synth_gap(k) : idx[k].start - (k ? idx[k - 1].end : 0ull));
+                l.lens[j] = idx[k].rbsp_len;
+                atomicOr(&l.rowbits[rel >> 10], 1ull << ((rel >> 4) & 63u));
+            }
+        }
         __syncthreads();                                           /* rowbits, starts, gaps are complete */
         uint32_t sm_lo = 0, sm_hi = 0;                             /* lane r: chunks of row r in which a NAL begins */
         if (lane < kTRows) {
@@ -1966,13 +2180,17 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const uint32_t inc = wave_incl_scan32(cnt, lane);
         const uint32_t local_pre = inc - cnt;
         const uint64_t rowmask = __ballot(cnt != 0u);
-        if (lane == 63) l.wave_tot[wv] = inc;
+        /* a KiB row with every chunk flagged: a run of zeros (or padding) at least that long.  Such a tile is walked by rows too,
+         * however few its elements: as elements, each chunk of the run finds the count it is entered with by walking the run back */
+        const bool full_row = __ballot(lane < kTRows && (fm_lo & fm_hi) == 0xFFFFFFFFu) != 0ull;
+        if (lane == 63) l.wave_tot[wv] = inc | (full_row ? 0x80000000u : 0u);
         __syncthreads();
-        const uint32_t wt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[0]), wt1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[1]);
-        const uint32_t wt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[2]), wt3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[3]);
+        const uint32_t ww0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[0]), ww1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[1]);
+        const uint32_t ww2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[2]), ww3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.wave_tot[3]);
+        const uint32_t wt0 = ww0 & 0x7FFFFFFFu, wt1 = ww1 & 0x7FFFFFFFu, wt2 = ww2 & 0x7FFFFFFFu, wt3 = ww3 & 0x7FFFFFFFu;
         const uint32_t nflag = wt0 + wt1 + wt2 + wt3;
         const uint32_t wave_base = (wv == 0) ? 0u : (wv == 1) ? wt0 : (wv == 2) ? wt0 + wt1 : wt0 + wt1 + wt2;
-        if (nflag > kTDenseLimit) {                                /* dense in elements: this tile is walked by rows (k3_dense_tile) */
+        if (nflag > kTDenseLimit || ((ww0 | ww1 | ww2 | ww3) & 0x80000000u) != 0u) {   /* dense in elements: this tile is walked by rows (k3_dense_tile) */
             d_tile = tile;
             pending = 1;
             break;
@@ -2137,14 +2355,25 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     const unsigned grid = 256 * 16;
     if (emit_takes_tiny_path(a.n, a.rbsp_bytes, a.two_pass, a.tiles)) {
-        /* the index checked against the arena (tflag[3]), then a lane per NAL: sizes, their scan, the bytes */
-        k3t_check<<<kCheckBlocks, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap), 0, 0, a.tflag, a.err, a.probe);
+        /* the index checked against the arena (tflag[3]) and, for means the arena tiles can hold (up to 1024 NAL starts per 192 KiB),
+         * against their conditions: the tile kernel when they hold, a lane per NAL otherwise -- sizes, their scan, the bytes */
+        const bool try_tiles = a.rbsp_bytes >= kTMinArena && a.rbsp_bytes / a.n >= kTilesMinMeanBytes;
+        k3t_check<<<kCheckBlocks, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap),
+                                                try_tiles ? 1 : 0, 0, a.tflag, a.err, a.probe);
+        if (try_tiles) {
+            k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.first_k, nullptr, a.tflag);
+            uint64_t tb = (uint64_t)a.tile_blocks;
+            const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
+            if (tb > max_tiles) tb = max_tiles;
+            k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap,
+                                                              a.index_out, a.total, a.err, nullptr, a.tflag);
+        }
         const uint64_t want = (a.n + 255) / 256;
         const unsigned tgrid = (unsigned)(want < 8192 ? want : 8192);
-        k3_count_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.tflag);
-        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, nullptr, kWhenAlways, a.tflag);
-        k3_emit_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, a.tflag);
-        k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
+        k3_count_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.tflag);
+        launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, nullptr, kWhenNoTiles, a.tflag);
+        k3_emit_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, a.tflag);
+        k3_summary_small<<<1, 1, 0, st>>>(a.total, a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary, a.tflag);
         return hipGetLastError();
     }
     /* forced one way (HBS_EMIT_TWO_PASS=1 / =0), or -- the default -- picked on the device from a density probe */

@@ -345,6 +345,43 @@ def test_emit_arenas_of_tiny_nals(ctx, orc):
         ctx.emit_annexb(dev(arena), idx, out_cap=300 * 44 + 100)      # the inserted 03s do not fit
 
 
+def test_emit_arena_tiles_hold_up_to_1024_nal_starts(ctx, orc):
+    """round 4: a 192 KiB tile takes up to 1024 NAL starts (512 before), the ones past the first 512 fetched behind the flag
+    pass -- arenas of 224-448 byte NALs go to the tile kernel instead of a lane per NAL.  Pinned to the tiles on small arenas:
+    means of 300 and 230 bytes (the second passes 1024 ELEMENTS in places: those tiles are walked by rows, NAL starts in most
+    of their rows), plain and zero-heavy bytes, a few NALs shorter than a chunk (several starts in one chunk); bytes against the
+    oracle, the output index against the kernel by NALs, and the tile kernel did the call."""
+    rng = np.random.RandomState(91)
+    for mean, nn, zeros in ((300, 20000, False), (300, 12000, True), (230, 24000, False), (230, 16000, True)):
+        lens = [int(x) for x in rng.randint(mean // 2, mean + mean // 2 + 1, size=nn)]
+        for k in range(50, nn, 997):
+            lens[k] = int(rng.randint(0, 16))
+        gaps = [int(rng.randint(3, 6)) for _ in lens]
+        total = sum(lens)
+        arena = ALPHA[rng.randint(0, len(ALPHA), size=total)].copy() if zeros else rng.randint(0, 256, size=total).astype(np.uint8)
+        idx = fake_index(lens, gaps)
+        want = orc.emit_annexb(arena, idx)
+        ctx.set_emit_path(0)
+        _, idx_nals = ctx.emit_annexb(dev(arena), idx)
+        ctx.set_emit_path(2)
+        got, got_idx = ctx.emit_annexb(dev(arena), idx)
+        stayed = ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h)
+        ctx.set_emit_path(-1)
+        assert np.array_equal(got, want), (mean, nn, zeros)
+        assert np.array_equal(got_idx, idx_nals), (mean, nn, zeros)
+        assert stayed == 1, (mean, nn, zeros)
+    # the automatic path on an arena past the tile kernel's minimum size (192 MiB), mean 320 bytes: tiles, not a lane per NAL
+    nn = 660_000
+    lens = rng.randint(160, 481, size=nn).astype(np.int64)
+    arena = rng.randint(0, 256, size=int(lens.sum())).astype(np.uint8)
+    arena[rng.randint(0, len(arena), size=len(arena) // 50)] = 0
+    idx = fake_index([int(x) for x in lens], [3 + (k & 1) for k in range(nn)])
+    want = orc.emit_annexb(arena, idx)
+    got, _ = ctx.emit_annexb(dev(arena), idx)
+    assert ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h) == 1
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_device_generator_matches_oracle(ctx, orc, mode):
     n = 3000
