@@ -164,7 +164,7 @@ void release_pair(Pair* p)                          /* the physical memory goes 
  *      until the end (so that the next ones are other memory), and after two of those in a row an unmapped "ballast"
  *      allocation of 4, 8, 16 ... GiB skips ahead in the run;
  *   4. the chosen candidates are mapped at their place in the buffer; everything else is released.
- * Bounded: at most nchunks + kExtraCands candidates and kBallastMax of ballast; when memory runs out or the bound is reached,
+ * Bounded: at most nchunks + kExtraCands candidates and kBallastMax of ballast, 24 GiB of the device left free; when memory runs out or the bound is reached,
  * whatever is at hand is used (the report says how many chunks were placed knowingly).
  */
 static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
@@ -221,8 +221,16 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
     struct Cand { hipMemGenericAllocationHandle_t h; uint8_t* va; int other; bool used; };     /* other: 1 = not R's class, 0 = R's, -1 = unknown */
     std::vector<Cand> cands;
     std::vector<hipMemGenericAllocationHandle_t> ballast;
-    constexpr int kExtraCands = 24;
-    constexpr uint64_t kBallastMax = 96ull << 30;
+    /* (24 candidates past the chunks until round 4's last day: a box whose allocator handed out 35 chunks of the unwanted class in
+     * a row ended with 5 of 16 chunks placed and 0.713 instead of 0.726.  Candidates and ballast go back at the end; both stop
+     * while kKeepFree of the device's memory is still free.) */
+    constexpr int kExtraCands = 88;
+    constexpr uint64_t kBallastMax = 128ull << 30, kKeepFree = 24ull << 30;
+    auto room_for = [&](uint64_t more) -> bool {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return (uint64_t)fr >= more + kKeepFree;
+    };
     const uint64_t half = (kChunk / 2) / kTile * kTile;
     void* scratch = nullptr;
     const uint64_t scratch_slots = nfull + kExtraCands + 1;
@@ -234,7 +242,7 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
         if (pr && !pr->ok) { delete pr; pr = nullptr; }
     }
     auto new_cand = [&]() -> bool {                      /* false: no more memory (or address slots) */
-        if (cands.size() >= scratch_slots) return false;
+        if (cands.size() >= scratch_slots || (cands.size() >= nfull && !room_for(kChunk))) return false;
         Cand c; c.other = -1; c.used = false;
         hipError_t ce = hipMemCreate(&c.h, kChunk, &prop, 0);
         if (ce != hipSuccess) { if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: hipMemCreate: %s\n", hipGetErrorString(ce)); (void)hipGetLastError(); return false; }
@@ -272,7 +280,7 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
         uint64_t ballast_bytes = 0, next_ballast = 4ull << 30;
         int unwanted_in_a_row = 0;
         while ((have[0] < need[0] || have[1] < need[1]) && cands.size() < nfull + (uint64_t)kExtraCands) {
-            if (unwanted_in_a_row >= 2 && ballast_bytes + next_ballast <= kBallastMax) {
+            if (unwanted_in_a_row >= 2 && ballast_bytes + next_ballast <= kBallastMax && room_for(next_ballast + kChunk)) {
                 hipMemGenericAllocationHandle_t b;
                 if (hipMemCreate(&b, next_ballast, &prop, 0) == hipSuccess) {
                     ballast.push_back(b); ballast_bytes += next_ballast; next_ballast *= 2; unwanted_in_a_row = 0;

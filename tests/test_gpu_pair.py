@@ -54,7 +54,7 @@ def test_probed_arena_gives_the_same_bytes_and_the_report_adds_up():
         rep = c.last_pair_report
         # two whole GiB (measured) and a remainder
         assert rep["chunks"] == 3 and rep["probed"] >= 2 and rep["accepted_fast"] + rep["unprobed_after_budget"] == 3
-        assert rep["rejected"] <= 26 and rep["accepted_fast"] <= 3
+        assert rep["rejected"] <= 90 and rep["accepted_fast"] <= 3
         c.index_extract_async(stream, index, cap, rbsp, summary)
         s = c.read_summary(summary)
         assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["rbsp_bytes"]) == rb

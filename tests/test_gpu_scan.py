@@ -154,6 +154,51 @@ def test_index_only_streams(ctx, orc):
             assert np.array_equal(got_idx[f], want_idx[f]), (rep, size, f)
 
 
+def test_index_only_ring_of_flagged_chunks(ctx, orc):
+    """round 4: the index-only scan leaves the flagged chunks' bytes in a ring of 192 entries in LDS and walks them 64 at a time
+    inside its streaming loop.  Streams that fill, wrap and overflow the ring: NALs of 512 bytes and of 1 KiB (several batches
+    per 256 KiB tile, more elements than a tile used to record), and tiles that are sparse but for ONE 16 KiB span with
+    ~150 start codes in it while 40-70 elements still wait (the span does not fit: the tile's elements are redone from its
+    flag words) -- at several offsets of that span in the tile.  Without an arena (kernel 5 and the automatic mode take the
+    index-only kernels; the others their own) and with one."""
+    rng = np.random.RandomState(58)
+    T = 256 * 1024
+
+    def put_nals(s, lo, hi, step_lo, step_hi):
+        at = lo
+        while at + 8 < hi:
+            sc = (0, 0, 1) if rng.randint(3) else (0, 0, 0, 1)
+            s[at:at + len(sc)] = sc
+            s[at + len(sc)] = 0x40
+            at += int(rng.randint(step_lo, step_hi))
+
+    def both(s):
+        want_idx, _, why = orc.index_extract(s)
+        got_idx, got_arena, sm = run(ctx, s, want_rbsp=False)
+        assert got_arena is None and int(sm["error"]) == 0 and int(sm["stop_reason"]) == why
+        assert len(got_idx) == len(want_idx), (len(got_idx), len(want_idx))
+        for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+            assert np.array_equal(got_idx[f], want_idx[f]), f
+        check(ctx, orc, s)
+
+    for mean in (512, 1024):
+        n = 5 * T + 12345
+        s = rng.randint(1, 256, size=n).astype(np.uint8)
+        put_nals(s, 0, n, mean * 3 // 4, mean * 5 // 4)
+        both(s)
+    for waiting in (40, 50, 57, 63, 70):
+        for span in (1, 7, 15):
+            n = 3 * T + 999
+            s = rng.randint(1, 256, size=n).astype(np.uint8)
+            s[0:4] = (0, 0, 1, 0x40)
+            base = T                                              # the second tile
+            step = max(64, (span * 16384) // waiting)
+            put_nals(s, base + 100, base + span * 16384 - 64, step, step + 1)       # ~`waiting` elements in front of the span
+            put_nals(s, base + span * 16384, base + (span + 1) * 16384, 100, 120)   # ~150 in the span
+            put_nals(s, base + (span + 1) * 16384 + 3000, n, 20000, 40000)
+            both(s)
+
+
 def test_repeatable(ctx, orc):
     """same context, back-to-back calls (descriptor workspace is reused)."""
     stream, idx, arena = orc.gen_stream(99, 500, 0)
