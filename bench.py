@@ -457,7 +457,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     if sweep:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import nal_sweep
-        res["nal_size_sweep"] = nal_sweep.sweep(torch, hbs, ctx, [512, 1024, 2048, 4096, 10240, 65536, 524288], 2.0)
+        res["nal_size_sweep"] = nal_sweep.sweep(torch, hbs, ctx, [64, 256, 384, 512, 1024, 2048, 4096, 10240, 65536, 524288], 2.0)
     return res
 
 

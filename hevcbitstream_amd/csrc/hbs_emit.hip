@@ -478,14 +478,14 @@ void k3_emit(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__
 }
 
 /* ---- arenas of tiny NALs: a LANE per NAL (round 4) ---------------------------------------------------
- * NALs below 384 bytes -- one slice per CTU row at a low bitrate -- have more than 512 starts per 192 KiB, so the arena
+ * NALs below ~200 bytes -- one slice per CTU row at a low bitrate -- have more than 1024 starts per 192 KiB, so the arena
  * tiles do not apply, and the kernels by NALs give every NAL a wavefront (or a 12 KiB slot): a 64-byte NAL used one lane in
  * sixteen (0.008 of the HBM peak at 64 bytes, 0.04 at 384).  Here every lane walks its own NAL byte by byte, rbsp_to_nal
  * as it is written (h264_nal.c:92-132): pass 1 the bytes that go in, an exclusive scan of the NALs' output sizes (the
  * three steps' own), pass 2 the bytes -- read as unaligned dwords, written as unaligned dwords from a small register
  * buffer.  Picked on the HOST (mean NAL size = rbsp_bytes / n below kTinyMeanBytes): no device-side gate, no probe. */
 constexpr uint64_t kTilesMinMeanBytes = 224;     /* ... from this mean up the arena tiles are tried first (878 starts per tile on average; 1024 is their limit) */
-constexpr uint64_t kTinyMeanBytes = 448;         /* (a mean of 384 bytes and more fits the arena tiles in principle -- at most 512 starts per 192 KiB -- but sizes scatter) */
+constexpr uint64_t kTinyMeanBytes = 448;         /* below this mean the host takes this route (arena tiles first from kTilesMinMeanBytes up, see launch_emit_annexb) */
 
 /* a lane's NAL, 16 bytes a load (a dword a load fetched every 128-byte line thirty-two times: 64 lanes x 32 wavefronts of
  * lines do not stay in a 16 KiB L1) */
@@ -1227,8 +1227,7 @@ constexpr uint64_t kTMinArena = 192ull << 20;      /* below, the kernel by NALs 
 constexpr int kTElemPass = 64;
 constexpr int kTElemWaves = 2;                  /* a tile with several batches of elements: wavefront 1 parks rows too and takes every other batch (as hbs_scan4.hip) */
 constexpr uint32_t kTDenseLimit = 1024;       /* a tile with more elements than this: wavefront 0 would walk them 64 at a time while every tile
-                                                 behind waits (~5 us a batch) -- the call is handed to the kernel by NALs instead, whose cost
-                                                 grows gently with the density of zero pairs */
+                                                 behind waits (~5 us a batch) -- such a tile is walked by rows instead (k3_dense_tile) */
 /* an entry of the tile's element list: chunk number | why it is one */
 constexpr uint32_t kTListFlag = 0x8000u;      /* chunk_flag(): a 03 may have to go in                     */
 constexpr uint32_t kTListStart = 0x4000u;     /* a NAL begins in it (or it is the arena's partial last chunk) */
@@ -2305,6 +2304,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             const uint32_t cc0 = (uint32_t)(64 * kTRows * wv + lane);
             const uint32_t segv = l.seg[lane];
             const uint32_t seg64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.seg[kTElemPass]);
+            /* (asking for a row's seg word one row ahead was tried in round 4: slower, 1.10 -> 1.14 ms on 2 GiB of 1 KiB NALs) */
             t_for_n<kTRows>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const uint32_t cc = cc0 + 64u * r;
@@ -2334,7 +2334,6 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     HBS3_T_FLUSH
 }
 
-/* between the tile kernel that gave up and the kernel by NALs that takes over: the look-back words and counters they share */
 int emit_tile_grid_blocks(int device)
 {
     hipDeviceProp_t prop;

@@ -611,7 +611,7 @@ void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStre
 {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    static const int per_cu = [] {                             /* what is resident: 165 VGPRs per lane -> 3 wavefronts per SIMD (8 or 16 per CU measured slower) */
+    static const int per_cu = [] {                             /* what is resident: 168 VGPRs per lane (held there by amdgpu_waves_per_eu: 7 per-tile values live in scratch) -> 3 wavefronts per SIMD (8 or 16 per CU measured slower) */
         const char* e = getenv("HBS5_WAVES_PER_CU");            /* debugging aid */
         return e && atoi(e) > 0 && atoi(e) <= 32 ? atoi(e) : 12;
     }();

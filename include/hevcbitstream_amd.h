@@ -344,8 +344,9 @@ uint64_t hbs_sps_tables_offset(void);
  * NALs (<= 256 NALs, <= 32 KiB of RBSP: the legacy rbsp_to_nal); otherwise a single pass: by ARENA TILES when the
  * index's NALs lie back to back in the arena in index order (what hbs_index_extract and hbs_write_headers produce;
  * checked on the device together with a few size limits, hbs_emit.hip: k3t_check; a tile that turns out dense in zero
- * pairs hands the call to the next one), else by NALs (items of <= 12 KiB);
- * or, on zero-heavy payload (density probe on the device), count / scan / emit.  0 pins the single pass by NALs,
+ * pairs -- padding, cabac_zero_words -- is walked by rows by its own workgroup), else by NALs (items of <= 12 KiB);
+ * or, on zero-heavy payload (density probe on the device), count / scan / emit; arenas whose mean NAL is below 448
+ * bytes: the arena tiles when they apply (up to 1024 NAL starts per 192 KiB), else a lane per NAL.  0 pins the single pass by NALs,
  * 1 the three steps, 2 the arena tiles whenever the index allows them (whatever the arena's size and density).
  * The bytes are the same whichever runs (h264_nal.c:92-132). */
 int hbs_ctx_set_emit_path(hbs_ctx* ctx, int path);
