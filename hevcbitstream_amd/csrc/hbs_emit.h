@@ -147,6 +147,84 @@ HBS_D void emit_segment(const uint8_t* rbsp, uint64_t nal_begin, uint64_t seg_be
 
 /* ---- synthetic stream S(seed, n_nals, mode): SURVEY.md 8(d) ---------------- */
 
+/* ---- chunk algebra of k3_tiles' dense tiles (hbs_emit.hip: k3_dense_tile), host + device so that the CPU tests walk it too ----
+ * What a 16-byte chunk does to rbsp_to_nal's state (h264_nal.c:110-116) depends on the count it is entered with -- 0, 1 or 2
+ * zeros seen -- only through its leading zeros: an all-zero chunk maps the count 0 -> 2, 1 -> 1, 2 -> 2 and takes 7 / 8 / 8 bytes
+ * in; any other chunk leaves a count of its own. */
+HBS_HD uint32_t dz_map(uint32_t c) { return c == 1u ? 1u : 2u; }          /* an all-zero chunk: the count behind it */
+HBS_HD uint32_t dz_ins(uint32_t c) { return c == 0u ? 7u : 8u; }          /* ... and the 03s that go into it */
+HBS_HD uint32_t dz_count_of(uint64_t run) { return run == 0 ? 0u : ((run & 1ull) ? 1u : 2u); }
+HBS_HD uint32_t dz_lead_bits(uint32_t c) { return c == 0u ? 0x5554u : (c == 1u ? 0xAAAAu : 0x5555u); }   /* 03s in leading zeros */
+/* zero bytes at the top (highest address) end of the chunk w0..w3 (little-endian words), 0..16 */
+HBS_HD uint32_t top_zero_bytes4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    if (w3) return (uint32_t)__builtin_clz(w3) >> 3;
+    if (w2) return 4u + ((uint32_t)__builtin_clz(w2) >> 3);
+    if (w1) return 8u + ((uint32_t)__builtin_clz(w1) >> 3);
+    if (w0) return 12u + ((uint32_t)__builtin_clz(w0) >> 3);
+    return 16u;
+}
+/* ... at the low end */
+HBS_HD uint32_t low_zero_bytes4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    if (w0) return (uint32_t)__builtin_ctz(w0) >> 3;
+    if (w1) return 4u + ((uint32_t)__builtin_ctz(w1) >> 3);
+    if (w2) return 8u + ((uint32_t)__builtin_ctz(w2) >> 3);
+    if (w3) return 12u + ((uint32_t)__builtin_ctz(w3) >> 3);
+    return 16u;
+}
+HBS_HD uint32_t byte_of4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i)
+{
+    const uint32_t w = i < 4u ? w0 : i < 8u ? w1 : i < 12u ? w2 : w3;
+    return (w >> (8u * (i & 3u))) & 0xFFu;
+}
+/* what a chunk does, for the three counts: the bytes that go in (i0, i1, i2), the count behind it (out; when reset) and whether
+ * it sets the count at all (reset = 0: all zeros) */
+struct DzFast { uint32_t i0, i1, i2, out, reset; };
+HBS_HD DzFast dz_fast4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    DzFast r;
+    const uint32_t lz = low_zero_bytes4(w0, w1, w2, w3), tz = top_zero_bytes4(w0, w1, w2, w3);
+    const bool allz = lz >= 16u;
+    const uint32_t mask0 = insert_mask16(w0, w1, w2, w3, 16u, 0u);
+    const uint32_t v = byte_of4(w0, w1, w2, w3, lz & 15u);
+    const uint32_t keep = allz ? 0u : (mask0 & ~((2u << lz) - 1u)); /* behind the first byte that is not zero: the same whatever the count was */
+    const uint32_t below = allz ? 0xFFFFu : ((1u << lz) - 1u);
+    const bool small = !allz && v <= 3u;
+    const uint32_t at = allz ? 0u : (1u << lz);
+    /* entered with h: the leading zeros take 03s by dz_lead_bits(h); the first other byte takes one when it is <= 3 and the
+     * zeros in front of it (h + lz) are two, four, ... */
+    const uint32_t f0 = (small && lz != 0u && (lz & 1u) == 0u) ? at : 0u;
+    const uint32_t f1 = (small && (lz & 1u) != 0u) ? at : 0u;
+    const uint32_t f2 = (small && (lz & 1u) == 0u) ? at : 0u;
+    r.i0 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(0u) & below) | f0);
+    r.i1 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(1u) & below) | f1);
+    r.i2 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(2u) & below) | f2);
+    r.out = dz_count_of(tz);
+    r.reset = allz ? 0u : 1u;
+    return r;
+}
+/* word `base / 4` of the chunk with its bytes outside [from, to) made 0xFF (from, to in 0..16) */
+HBS_HD uint32_t dz_keep_word(uint32_t w, uint32_t base, uint32_t from, uint32_t to)
+{
+    uint32_t ff = 0u;
+    for (uint32_t b = 0; b < 4u; ++b) ff |= ((base + b < from || base + b >= to) ? 0xFFu : 0u) << (8u * b);
+    return w | ff;
+}
+/* a chunk in which ONE NAL begins, at byte s (its start code of `gap` bytes in front): the bytes in front of s belong to the NAL
+ * in progress and are entered with the count in question, the bytes from s on to the new NAL, entered with 0 */
+HBS_HD DzFast dz_one_start4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t s, uint32_t gap)
+{
+    DzFast r = dz_fast4(dz_keep_word(w0, 0u, 0u, s), dz_keep_word(w1, 4u, 0u, s), dz_keep_word(w2, 8u, 0u, s), dz_keep_word(w3, 12u, 0u, s));
+    const uint32_t h0 = dz_keep_word(w0, 0u, s, 16u), h1 = dz_keep_word(w1, 4u, s, 16u), h2 = dz_keep_word(w2, 8u, s, 16u), h3 = dz_keep_word(w3, 12u, s, 16u);
+    const uint32_t more = gap + (uint32_t)__builtin_popcount(insert_mask16(h0, h1, h2, h3, 16u, 0u));
+    r.i0 += more; r.i1 += more; r.i2 += more;
+    const uint32_t tz = top_zero_bytes4(h0, h1, h2, h3);
+    r.out = dz_count_of(tz < 16u - s ? tz : 16u - s);
+    r.reset = 1u;
+    return r;
+}
+
 HBS_HD uint32_t synth_rbsp_len(uint64_t seed, uint64_t k)
 {
     return 8192u + (uint32_t)(mix64(seed ^ ((k + 1) * kGolden)) % 4097u);

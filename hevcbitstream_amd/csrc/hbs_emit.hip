@@ -1475,34 +1475,10 @@ extern "C" int hbs_debug_dz_cycles(unsigned long long* host_out, int reset)
  *   - the count the TILE is entered with is found by wavefront 0 walking back a KiB at a time (parity of the run of zeros);
  *   - chunks in which a NAL begins (and the arena's partial last chunk) are walked byte by byte.
  * The tile then publishes its bytes like any other, resolves its look-back, and writes. */
-__device__ __forceinline__ uint32_t dz_map(uint32_t c) { return c == 1u ? 1u : 2u; }          /* an all-zero chunk: the count behind it */
-__device__ __forceinline__ uint32_t dz_ins(uint32_t c) { return c == 0u ? 7u : 8u; }          /* ... and the 03s that go into it */
-__device__ __forceinline__ uint32_t dz_count_of(uint64_t run) { return run == 0 ? 0u : ((run & 1ull) ? 1u : 2u); }
-__device__ __forceinline__ uint32_t dz_lead_bits(uint32_t c) { return c == 0u ? 0x5554u : (c == 1u ? 0xAAAAu : 0x5555u); }   /* 03s in leading zeros */
-
-/* zero bytes at the top (highest address) end of the chunk, 0..16 */
-__device__ __forceinline__ uint32_t top_zero_bytes(const u32x4& q)
-{
-    if (q.w) return (uint32_t)__builtin_clz(q.w) >> 3;
-    if (q.z) return 4u + ((uint32_t)__builtin_clz(q.z) >> 3);
-    if (q.y) return 8u + ((uint32_t)__builtin_clz(q.y) >> 3);
-    if (q.x) return 12u + ((uint32_t)__builtin_clz(q.x) >> 3);
-    return 16u;
-}
-/* ... at the low end */
-__device__ __forceinline__ uint32_t low_zero_bytes(const u32x4& q)
-{
-    if (q.x) return (uint32_t)__builtin_ctz(q.x) >> 3;
-    if (q.y) return 4u + ((uint32_t)__builtin_ctz(q.y) >> 3);
-    if (q.z) return 8u + ((uint32_t)__builtin_ctz(q.z) >> 3);
-    if (q.w) return 12u + ((uint32_t)__builtin_ctz(q.w) >> 3);
-    return 16u;
-}
-__device__ __forceinline__ uint32_t byte_of(const u32x4& q, uint32_t i)
-{
-    const uint32_t w = i < 4u ? q.x : i < 8u ? q.y : i < 12u ? q.z : q.w;
-    return (w >> (8u * (i & 3u))) & 0xFFu;
-}
+/* (dz_map, dz_ins, dz_count_of, dz_lead_bits, dz_fast4, dz_one_start4: hbs_emit.h, shared with the CPU tests) */
+__device__ __forceinline__ uint32_t top_zero_bytes(const u32x4& q) { return top_zero_bytes4(q.x, q.y, q.z, q.w); }
+__device__ __forceinline__ uint32_t low_zero_bytes(const u32x4& q) { return low_zero_bytes4(q.x, q.y, q.z, q.w); }
+__device__ __forceinline__ uint32_t byte_of(const u32x4& q, uint32_t i) { return byte_of4(q.x, q.y, q.z, q.w, i); }
 
 /* the run of zeros in front of arena byte `pos`, inside the NAL that begins at `begin` (<= pos), followed back a KiB at a time by
  * the whole wavefront (lane l looks at the 16 bytes that end 16 l in front of the current end) -- for `max_kib` KiB at most:
@@ -1701,30 +1677,7 @@ __device__ __forceinline__ uint32_t dz_count_in(bool reset, uint32_t out, uint32
  * behind it, whether it is all zeros), so that the eight rows' instructions interleave; the combination in order behind
  * it is a ballot, a shuffle and a scan per row.  Chunks in which a NAL begins are redone by dz_start3 (not inlined: a few
  * rows of a tile).  Whole tiles only; the arena's last tile, cut by its end, takes the loop below as before. */
-struct DzFast { uint32_t i0, i1, i2, out, reset; };
-__device__ __forceinline__ DzFast dz_fast(const u32x4& q)
-{
-    DzFast r;
-    const uint32_t lz = low_zero_bytes(q), tz = top_zero_bytes(q);
-    const bool allz = lz >= 16u;
-    const uint32_t mask0 = insert_mask16(q.x, q.y, q.z, q.w, 16u, 0u);
-    const uint32_t v = byte_of(q, lz & 15u);
-    const uint32_t keep = allz ? 0u : (mask0 & ~((2u << lz) - 1u)); /* behind the first byte that is not zero: the same whatever the count was */
-    const uint32_t below = allz ? 0xFFFFu : ((1u << lz) - 1u);
-    const bool small = !allz && v <= 3u;
-    const uint32_t at = allz ? 0u : (1u << lz);
-    /* entered with h: the leading zeros take 03s by dz_lead_bits(h); the first other byte takes one when it is <= 3 and the
-     * zeros in front of it (h + lz) are two, four, ... */
-    const uint32_t f0 = (small && lz != 0u && (lz & 1u) == 0u) ? at : 0u;
-    const uint32_t f1 = (small && (lz & 1u) != 0u) ? at : 0u;
-    const uint32_t f2 = (small && (lz & 1u) == 0u) ? at : 0u;
-    r.i0 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(0u) & below) | f0);
-    r.i1 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(1u) & below) | f1);
-    r.i2 = (uint32_t)__builtin_popcount(keep | (dz_lead_bits(2u) & below) | f2);
-    r.out = dz_count_of(tz);
-    r.reset = allz ? 0u : 1u;
-    return r;
-}
+__device__ __forceinline__ DzFast dz_fast(const u32x4& q) { return dz_fast4(q.x, q.y, q.z, q.w); }
 /* a chunk in which NALs begin, for the three counts: byte by byte (several NALs begin in it: NALs shorter than a chunk) */
 __device__ __attribute__((noinline))
 DzFast dz_start3_serial(const uint32_t* starts, const uint32_t* gaps, uint32_t m, uint32_t p, uint32_t j0, u32x4 q0)
@@ -1750,21 +1703,8 @@ DzFast dz_start3_serial(const uint32_t* starts, const uint32_t* gaps, uint32_t m
     r.i0 = ins[0]; r.i1 = ins[1]; r.i2 = ins[2];
     return r;
 }
-/* bytes [from, to) of the chunk kept, the others 0xFF (from, to in 0..16) */
-__device__ __forceinline__ u32x4 dz_keep_bytes(const u32x4& q, uint32_t from, uint32_t to)
-{
-    auto word = [&](uint32_t w, uint32_t base) -> uint32_t {       /* bytes base .. base+3 */
-        uint32_t ff = 0u;
-#pragma unroll
-        for (uint32_t b = 0; b < 4u; ++b) ff |= ((base + b < from || base + b >= to) ? 0xFFu : 0u) << (8u * b);
-        return w | ff;
-    };
-    u32x4 r; r.x = word(q.x, 0u); r.y = word(q.y, 4u); r.z = word(q.z, 8u); r.w = word(q.w, 12u);
-    return r;
-}
-/* ... the usual case, one NAL begins in the chunk (at byte s, its gap in front): the bytes in front of s belong to the NAL in
- * progress and are entered with the count in question, the bytes from s on to the new NAL, entered with 0 -- two chunks with
- * the other's bytes made 0xFF, the straight-line way (byte by byte through LDS this was 10 us a row, half of the first half) */
+/* ... the usual case, one NAL begins in the chunk (dz_one_start4: two half chunks in closed form; byte by byte through LDS this
+ * was 10 us a row, half of the first half) */
 __device__ __forceinline__ DzFast dz_start3(const LdsT& l, uint32_t m, uint32_t c, const u32x4& q)
 {
     const uint32_t p = 16u * c;
@@ -1772,13 +1712,7 @@ __device__ __forceinline__ DzFast dz_start3(const LdsT& l, uint32_t m, uint32_t 
     const uint32_t s0 = l.starts[j0 < m ? j0 : 0u] - p, gap0 = l.gaps[j0 < m ? j0 : 0u];
     const bool several = j0 + 1u < m && l.starts[j0 + 1u] < p + 16u;
     if (several || j0 >= m || s0 >= 16u) return dz_start3_serial(l.starts, l.gaps, m, p, j0, q);
-    DzFast r = dz_fast(dz_keep_bytes(q, 0u, s0));
-    const u32x4 hi = dz_keep_bytes(q, s0, 16u);
-    const uint32_t more = gap0 + (uint32_t)__builtin_popcount(insert_mask16(hi.x, hi.y, hi.z, hi.w, 16u, 0u));
-    r.i0 += more; r.i1 += more; r.i2 += more;
-    r.out = dz_count_of(top_zero_bytes(hi) < 16u - s0 ? top_zero_bytes(hi) : 16u - s0);
-    r.reset = 1u;
-    return r;
+    return dz_one_start4(q.x, q.y, q.z, q.w, s0, gap0);
 }
 constexpr int kDzGroup = 8;
 static_assert(kTRows % kDzGroup == 0, "whole groups of rows");

@@ -36,7 +36,21 @@ def lib():
         _lib.sim_emit_annexb.restype = C.c_int64
         _lib.sim_synth_rbsp.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         _lib.sim_synth_rbsp.restype = C.c_int64
+        _lib.sim_dz_walk.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.sim_dz_walk.restype = None
     return _lib
+
+
+def dz_walk(chunks, start_at, gaps):
+    """k3_dense_tile's chunk algebra over len(chunks) / 16 chunks: (bytes that go in, count behind) for the entering counts 0, 1, 2"""
+    chunks = np.ascontiguousarray(chunks, dtype=np.uint8)
+    start_at = np.ascontiguousarray(start_at, dtype=np.int8)
+    gaps = np.ascontiguousarray(gaps, dtype=np.uint32)
+    assert len(chunks) % 16 == 0 and len(start_at) == len(chunks) // 16 == len(gaps)
+    tot = np.zeros(3, dtype=np.uint32)
+    st = np.zeros(3, dtype=np.uint32)
+    lib().sim_dz_walk(chunks.ctypes.data, len(chunks) // 16, start_at.ctypes.data, gaps.ctypes.data, tot.ctypes.data, st.ctypes.data)
+    return [int(x) for x in tot], [int(x) for x in st]
 
 
 VARIANT = 2          # 2: LDS-image kernel logic (hbs_tile.h), 3: register-resident kernel logic (hbs_chunk.h)

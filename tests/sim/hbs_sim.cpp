@@ -124,6 +124,28 @@ extern "C" int sim_index_extract(const uint8_t* stream, uint64_t n,
     return 0;
 }
 
+/* k3_tiles' dense tiles: the chunk algebra of hbs_emit.h (dz_fast4, dz_one_start4, dz_map) stepped chunk by chunk over `nchunks`
+ * chunks of 16 bytes -- what k3_dense_tile's first half adds up, with its wavefronts' ballots and shuffles replaced by a loop.
+ * start_at[c]: the byte of chunk c at which a NAL begins (-1: none; at most one a chunk, as the closed form asks), gaps[c] its
+ * start code's bytes.  tot[h] = bytes that go in when the first chunk is entered with count h, st[h] = the count behind the last. */
+extern "C" void sim_dz_walk(const uint8_t* bytes, uint64_t nchunks, const int8_t* start_at, const uint32_t* gaps, uint32_t* tot, uint32_t* st)
+{
+    using namespace hbs;
+    for (uint32_t h = 0; h < 3; ++h) { tot[h] = 0; st[h] = h; }
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        uint32_t w[4];
+        for (int d = 0; d < 4; ++d)
+            w[d] = (uint32_t)bytes[16 * c + 4 * d] | ((uint32_t)bytes[16 * c + 4 * d + 1] << 8) | ((uint32_t)bytes[16 * c + 4 * d + 2] << 16) |
+                   ((uint32_t)bytes[16 * c + 4 * d + 3] << 24);
+        const DzFast f = start_at[c] >= 0 ? dz_one_start4(w[0], w[1], w[2], w[3], (uint32_t)start_at[c], gaps[c]) : dz_fast4(w[0], w[1], w[2], w[3]);
+        for (uint32_t h = 0; h < 3; ++h) {
+            const uint32_t ci = st[h];
+            tot[h] += ci == 0 ? f.i0 : ci == 1 ? f.i1 : f.i2;
+            st[h] = f.reset ? f.out : dz_map(ci);
+        }
+    }
+}
+
 /* K3 per-segment logic stepped in NAL order (see hbs_emit.hip for the wave-level driver) */
 extern "C" int64_t sim_emit_annexb(const uint8_t* rbsp, const hbs_nal_entry* idx, uint64_t n, int gap_mode,
                                    uint8_t* out, uint64_t out_cap, hbs_nal_entry* idx_out)
