@@ -303,7 +303,7 @@ int hbs_ctx_last_kernel(hbs_ctx* c)
     if (e != hipSuccess) return fail(c, e, "read-back of the density probe");
     uint64_t chunks = 0, flagged = 0;
     for (int i = 0; i < 64; ++i) { chunks += h.probe_slot[i][0]; flagged += h.probe_slot[i][1]; }
-    c->last_variant = hbs::probe_says_dense((uint32_t)chunks, (uint32_t)flagged) ? 2 : (c->last_index_only ? 5 : 4);
+    c->last_variant = hbs::probe_says_dense((uint32_t)chunks, (uint32_t)flagged, c->last_index_only ? hbs::kDenseOneInIndexOnly : hbs::kDenseOneIn) ? 2 : (c->last_index_only ? 5 : 4);
     c->probe_pending = 0;
     return c->last_variant;
 }

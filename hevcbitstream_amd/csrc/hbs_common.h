@@ -97,17 +97,30 @@ constexpr uint32_t kDenseOneIn = HBS_DENSE_ONE_IN;    /* Round 3: the probe coun
                                            tile's count below the limit.  (Round 2: 1 in 40 of the chunks with a zero PAIR, i.e. ~6 x fewer elements.) */
 constexpr int kExactFlagMin = 2;        /* rows of 1 KiB with more flagged chunks than this are asked again, exactly (chunk_pattern_any_dev): one or two
                                            are a start code, most likely, and the second test would buy nothing */
-HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged) { return (uint64_t)flagged * kDenseOneIn > (uint64_t)chunks; }
-enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2 };
+/* Without an arena (round 4): the streaming index-only kernel keeps its pace to about twice that density -- a 2 GiB stream of
+ * 448-byte NALs (one chunk in 24 an element) 0.66 ms against the LDS-image kernel's 1.48, of 384-byte NALs 1.13 against 1.50, of
+ * 256-byte NALs (1 in 14) 1.47 against 1.57, of 128-byte NALs 2.5 against 1.8 (scripts/r4/pin_time.py) -- so its calls ask the
+ * probe with a threshold of their own. */
+constexpr uint32_t kDenseOneInIndexOnly = 15;
+HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged, uint32_t one_in = kDenseOneIn) { return (uint64_t)flagged * one_in > (uint64_t)chunks; }
+enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2, kGateIfSparseIdx = 3, kGateIfDenseIdx = 4 };   /* ...Idx: an index-only call's threshold */
 #ifdef __HIPCC__
 /* the density probe's verdict (hbs_common.h), by a whole wavefront: lane l reads slot l */
-__device__ __forceinline__ bool probe_dense_dev(const RunHeader* __restrict__ hdr)
+__device__ __forceinline__ bool probe_dense_dev(const RunHeader* __restrict__ hdr, uint32_t one_in = kDenseOneIn)
 {
     const int lane = threadIdx.x & 63;
     uint32_t c = hdr->probe_slot[lane][0], f = hdr->probe_slot[lane][1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); f += __shfl_xor(f, d, 64); }
-    return probe_says_dense(c, f);
+    return probe_says_dense(c, f, one_in);
+}
+/* a kernel of the automatic mode launched with `gate`: true = the probe rules it out, it returns at once */
+__device__ __forceinline__ bool gate_closed(int gate, const RunHeader* __restrict__ hdr)
+{
+    if (gate == kGateNone) return false;
+    const bool idx = gate == kGateIfSparseIdx || gate == kGateIfDenseIdx;
+    const bool dense = probe_dense_dev(hdr, idx ? kDenseOneInIndexOnly : kDenseOneIn);
+    return (gate == kGateIfSparse || gate == kGateIfSparseIdx) ? dense : !dense;
 }
 #endif
 

@@ -532,7 +532,7 @@ void k_scan_extract(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num
                     uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
                     unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, int sched, int gate)
 {
-    if (gate == kGateIfDense && !probe_dense_dev(hdr)) return;
+    if (gate_closed(gate, hdr)) return;
     __shared__ TileLds l;
     scan_tiles(l, stream, n, num_tiles, index, index_cap, rbsp, rbsp_cap, desc, hdr, sched);
 }
@@ -697,10 +697,10 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
              * They share the descriptor array and the ticket: whichever runs finds both untouched. */
             /* (a side stream for the kernel that rules itself out, forked and joined with events, was tried in round 4: the two
              * event waits cost more than the empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
-            if (index_only) launch_scan_index5(a, tiles5, kGateIfSparse, st);
+            if (index_only) launch_scan_index5(a, tiles5, kGateIfSparseIdx, st);
             else launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
-                a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateIfDense);
+                a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, index_only ? kGateIfDenseIdx : kGateIfDense);
         } else {
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateNone);

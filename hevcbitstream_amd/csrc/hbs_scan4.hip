@@ -366,7 +366,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                      unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, const uint8_t* __restrict__ tail,
                      int gate)
 {
-    if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
+    if (gate_closed(gate, hdr)) return;
     __shared__ Lds4 l;
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);

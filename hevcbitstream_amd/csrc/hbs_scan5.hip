@@ -274,8 +274,8 @@ __device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32
 struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
 static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
 struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
-constexpr uint32_t k5RecCap = 3u * (uint32_t)k5TileRows;                  /* elements recorded per tile: three a KiB (9 % of the stream's size as workspace; two until round 4:
-                                                                             NALs of 512 bytes passed it in every other tile, and such a tile is streamed twice) */
+constexpr uint32_t k5RecCap = 4u * (uint32_t)k5TileRows;                  /* elements recorded per tile: four a KiB (12.5 % of the stream's size as workspace; two until round 4:
+                                                                             NALs of 512 bytes passed it in every other tile, and such a tile is streamed twice; three: NALs of 384) */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
 constexpr int k5ChunkTiles = 64;
 
@@ -413,7 +413,7 @@ __device__ __forceinline__ void rec_load(const Rec5* r, Elem& el, uint64_t base,
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
-    if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
+    if (gate_closed(gate, hdr)) return;
     __shared__ Lds5 l;
     __shared__ Deposit ring[k5Ring];
     const Ws5 w5 = ws5_carve(ws, num_tiles);
@@ -492,7 +492,7 @@ __device__ __forceinline__ TileAgg agg_load_or_identity(const TileAgg* a, uint64
 __global__ __launch_bounds__(64)
 void k_index5_chunks(uint64_t num_tiles, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
 {
-    if (gate == kGateIfSparse && probe_dense_dev(const_cast<RunHeader*>(hdr))) return;
+    if (gate_closed(gate, hdr)) return;
     const Ws5 w5 = ws5_carve(ws, num_tiles);
     const int lane = threadIdx.x;
     const uint64_t c = blockIdx.x;
@@ -503,7 +503,7 @@ void k_index5_chunks(uint64_t num_tiles, void* __restrict__ ws, const RunHeader*
 __global__ __launch_bounds__(64)
 void k_index5_prefix(uint64_t num_tiles, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
 {
-    if (gate == kGateIfSparse && probe_dense_dev(const_cast<RunHeader*>(hdr))) return;
+    if (gate_closed(gate, hdr)) return;
     const Ws5 w5 = ws5_carve(ws, num_tiles);
     const int lane = threadIdx.x;
     const uint64_t chunks = ws5_chunks(num_tiles);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64)
 void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
                    hbs_nal_entry* __restrict__ index, uint64_t index_cap, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
-    if (gate == kGateIfSparse && probe_dense_dev(hdr)) return;
+    if (gate_closed(gate, hdr)) return;
     __shared__ Lds5 l;
     const Ws5 w5 = ws5_carve(ws, num_tiles);
     const int lane = threadIdx.x;
