@@ -365,6 +365,58 @@ def mixed_index_only(torch, ctx, stream, sb, n_cap, uniform_ms):
     return {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4), "over_uniform": round(ms / uniform_ms, 3)}
 
 
+def emit_mixed_lines(torch, ctx, g, n, rb, sb, uniform_ms):
+    """hbs_emit_annexb on a copy of the bench arena with 1 % of it overwritten in 640 KiB stretches placed between the density
+    probe's 64 windows (scripts/emit_paths.py): `00 00 03` padding, then zeros.  The default path (arena tiles) timed; its bytes and
+    output index compared with the kernel by NALs (path 0) on the padding arena."""
+    region = 640 << 10
+    stride = (rb // 64) & ~15
+    out_cap = sb + sb // 40 + 4096
+    res = {}
+    for name, byte3 in (("padding_00_00_03", 3), ("zeros", 0)):
+        arena = g["rbsp"][:rb].clone()
+        pat = torch.tensor([0, 0, byte3], dtype=torch.uint8, device="cuda").repeat(region // 3 + 1)[:region]
+        dense = 0
+        for k in range(max(1, int(rb * 0.01 / region))):
+            off = (k % 64) * stride + stride // 2 + (k // 64) * (region + 4096)
+            if off + region < rb:
+                arena[off: off + region] = pat
+                dense += region
+        out = torch.zeros(out_cap, dtype=torch.uint8, device="cuda")
+        idx_out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+        summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ctx.emit_annexb_async(arena, rb, g["index"], n, 1, out, idx_out, summary)
+        for i in range(4):
+            ev[i].record()
+            if i < 3:
+                ctx.emit_annexb_async(arena, rb, g["index"], n, 1, out, idx_out, summary)
+        torch.cuda.synchronize()
+        ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(3))
+        s = ctx.read_summary(summary)
+        assert int(s["error"]) == 0, s
+        by_tiles = int(ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h))
+        total = int(s["stream_bytes"])
+        line = {"ms": round(ms, 3), "over_uniform": round(ms / uniform_ms, 3), "dense_bytes": dense, "emitted_bytes": total,
+                "arena_tiles_did_the_call": by_tiles}
+        if byte3 == 3:                                               # (the kernel by NALs takes 0.19 s on the zeros)
+            out2 = torch.zeros(out_cap, dtype=torch.uint8, device="cuda")
+            idx2 = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+            ctx.set_emit_path(0)
+            try:
+                ctx.emit_annexb_async(arena, rb, g["index"], n, 1, out2, idx2, summary)
+                s2 = ctx.read_summary(summary)
+            finally:
+                ctx.set_emit_path(-1)
+            assert int(s2["error"]) == 0 and int(s2["stream_bytes"]) == total
+            assert torch.equal(out[:total], out2[:total]) and torch.equal(idx_out, idx2), "arena tiles != kernel by NALs on the mixed arena"
+            line["check"] = "bytes and output index equal to the kernel by NALs'"
+            del out2, idx2
+        res[name] = line
+        del arena, out, idx_out
+    return res
+
+
 def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
@@ -408,7 +460,16 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     res["emit_annexb"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s emitted", "ms": round(ms, 3),
                           "hbm_traffic_GBs": round((rb + sb) / ms / 1e6, 1), "workload": "the bench arena: %d NALs, %.2f GiB" % (n, rb / 2**30),
                           "output_placement": "hbs_pair_alloc against the arena: %s" % json.dumps(emit_placement)}
+    uniform_emit_ms = ms
     del out, idx_out
+    # K3 on an arena with stretches the density probe does not see (1 % of it in 640 KiB stretches of 00 00 03 padding, then of
+    # zeros): the tile kernel walks those tiles by rows; bytes and output index compared with the kernel by NALs.  Reported, never
+    # allowed to take the line down: a failure here is recorded as text.
+    try:
+        res["emit_annexb"]["mixed_arena"] = emit_mixed_lines(torch, ctx, g, n, rb, sb, uniform_emit_ms)
+    except Exception as e:                                            # noqa: BLE001
+        res["emit_annexb"]["mixed_arena"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
     stream, _ = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
     d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
     index, rbsp, summ, cap = ctx.alloc_outputs(d.numel())
