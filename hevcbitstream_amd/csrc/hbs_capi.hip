@@ -43,6 +43,7 @@ struct hbs_ctx {
     int emit_tile_blocks, emit_tiles; /* ... of the arena-tile kernel; 0 never / 1 when eligible / 2 pinned */
     int emit_path_set;                /* hbs_ctx_set_emit_path was called: the environment no longer decides */
     const uint32_t* last_emit_tflag;  /* the last hbs_emit_annexb's verdict words (device): hbs_ctx_last_emit_by_tiles */
+    uint32_t emit_calls;              /* hbs_emit_annexb calls so far: stamps the dense tiles counted ahead (never 0) */
     int sched;
     unsigned long long* desc;
     uint64_t desc_tiles;
@@ -392,7 +393,8 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     const uint64_t b_items = round256(items_cap * 8), b_desc = round256(hbs::emit_desc_words(items_cap) * 8);
     const uint64_t first_cap = rbsp_bytes / (192u * 1024u) + 4;          /* arena tiles of the tile kernel (hbs_emit.hip: kTTileBytes) */
     const uint64_t b_first = round256(first_cap * 8);
-    int rc = ensure_ws(c, b_seg + 2 * b_n + b_items + b_desc + 1024 + b_first);
+    const uint64_t b_cand = round256(first_cap * 4), b_dz = round256(first_cap * hbs::emit_dz_table_words() * 4);   /* dense tiles counted ahead */
+    int rc = ensure_ws(c, b_seg + 2 * b_n + b_items + b_desc + 1024 + b_first + b_cand + b_dz);
     if (rc) return rc;
     if (c->emit_blocks <= 0) {
         c->emit_blocks = hbs::emit_grid_blocks(c->device);
@@ -424,6 +426,11 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.probe = reinterpret_cast<uint32_t*>(tail + 768 + 128);
     a.tflag = reinterpret_cast<uint32_t*>(tail + 768 + 192);
     a.first_k = reinterpret_cast<unsigned long long*>(tail + 1024); a.first_cap = first_cap;
+    a.cand_count = reinterpret_cast<uint32_t*>(tail + 640); a.cand_ticket = reinterpret_cast<uint32_t*>(tail + 704);   /* cleared with the counters */
+    a.cand_list = reinterpret_cast<uint32_t*>(tail + 1024 + b_first); a.cand_cap = first_cap;
+    a.dz_table = reinterpret_cast<uint32_t*>(tail + 1024 + b_first + b_cand);
+    c->emit_calls += 1; if (c->emit_calls == 0) c->emit_calls = 1;
+    a.call_no = c->emit_calls;
     a.tiles = c->emit_tiles; a.tile_blocks = c->emit_tile_blocks;
     c->last_emit_tflag = a.tflag;
     a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */

@@ -359,7 +359,7 @@ void k_scan_apply(const unsigned long long* __restrict__ v, unsigned long long* 
 /* the same scan by ONE workgroup, for up to kScanOneMax values: a thread sums its slice, the 1024 sums are scanned in LDS, the
  * thread writes its slice's prefixes.  One launch instead of three -- and an emit call enqueues two scans of which at most one
  * does anything (round 3: a 1 GiB call was 17 launches around one that matters). */
-constexpr uint64_t kScanOneMax = 1ull << 18;
+constexpr uint64_t kScanOneMax = 1ull << 18;      /* (2^21 was tried in round 4 to save two empty launches on the bench arena: one workgroup over 1.7 M values takes 4 ms when it runs) */
 __global__ __launch_bounds__(1024)
 void k_scan_one(const unsigned long long* __restrict__ v, unsigned long long* __restrict__ out, uint64_t n,
                 unsigned long long* __restrict__ total_sparse, unsigned long long* __restrict__ total_dense,
@@ -1139,6 +1139,7 @@ void k3_fused(const uint8_t* __restrict__ rbsp, uint64_t arena, const hbs_nal_en
 /* items never outnumber this: one per NAL plus one per started 12 KiB of payload */
 uint64_t emit_items_bound(uint64_t n, uint64_t payload_bytes) { return n + payload_bytes / kEmitSegBytes + 1; }
 uint64_t emit_desc_words(uint64_t items_cap) { return (items_cap + kEmitGroup - 1) / kEmitGroup + 1; }
+uint64_t emit_dz_table_words() { return 32; }
 
 int emit_grid_blocks(int device)
 {
@@ -1531,6 +1532,8 @@ __device__ __forceinline__ uint32_t wave_lead_count(const uint8_t* __restrict__ 
  * not tag 4 gives the count (directly, or by a walk from its end that is short by construction), and any tag-4 tiles between
  * map it once (dz_map is idempotent).  No tile waits for more than its predecessors' FIRST words. */
 constexpr unsigned long long kDzTagPure = 4ull;
+constexpr uint32_t kDzTableWords = 32;            /* (= emit_dz_table_words()) per tile: 4 wavefronts x (bytes for the three counts, count behind for the three), [24] = the call's number
+                                                     when the tile was counted ahead (k3t_sample, below) */
 __device__ __forceinline__ uint32_t dz_entry_count(const TileCtx& t, const unsigned long long* __restrict__ desc, uint64_t tile, int lane, uint32_t* err)
 {
     if (tile == 0 || t.tile_lo <= t.prev_begin) return 0u;
@@ -1722,7 +1725,8 @@ static_assert(kTRows % kDzGroup == 0, "whole groups of rows");
 __device__ __attribute__((noinline))
 void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned long long* __restrict__ desc,
                    uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint64_t n,
-                   unsigned long long* __restrict__ total, uint32_t* __restrict__ err)
+                   unsigned long long* __restrict__ total, uint32_t* __restrict__ err,
+                   int ahead, uint32_t* __restrict__ dz_table, uint32_t call_no)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1740,7 +1744,13 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
 
     /* ---- first half: bytes that go into my rows, for each count they may be entered with ---- */
     uint32_t tot[3] = {0u, 0u, 0u}, st[3] = {0u, 1u, 2u};
-    if (tile_bytes == (uint64_t)kTTileBytes) {
+    uint32_t* const entry = dz_table ? dz_table + tile * (uint64_t)kDzTableWords : nullptr;
+    /* counted ahead in this call (k3t_sample): the table has what the loops below would find */
+    const bool counted = !ahead && entry && __hip_atomic_load(entry + 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == call_no;
+    if (counted) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h) { tot[h] = entry[6 * wv + h]; st[h] = entry[6 * wv + 3 + h]; }
+    } else if (tile_bytes == (uint64_t)kTTileBytes) {
         /* a whole tile: groups of kDzGroup rows (see dz_fast above), the next group's loads in flight */
         u32x4 cur[kDzGroup], nxt[kDzGroup];
 #pragma unroll
@@ -1839,6 +1849,15 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
         for (int h = 0; h < 3; ++h) { l.dz_tot[wv][h] = tot[h]; l.dz_out[wv][h] = st[h]; }
     }
     DZ_T_MARK(0)
+    if (ahead) {                                                   /* count ahead: the results to the table, nothing else */
+        if (entry && lane == 0) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) { entry[6 * wv + h] = tot[h]; entry[6 * wv + 3 + h] = st[h]; }
+        }
+        __syncthreads();
+        if (entry && tid == 0) { __threadfence(); __hip_atomic_store(entry + 24, call_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+    }
     __syncthreads();
     DZ_T_MARK(1)
     if (wv == 0) {
@@ -1936,12 +1955,75 @@ __device__ __forceinline__ void t_rows_apply(F&& f, std::integer_sequence<int, I
 template <int N, class F>
 __device__ __forceinline__ void t_for_n(F&& f) { t_rows_apply(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
+/* ---- dense tiles counted ahead of the tile kernel (round 4) ---------------------------------------------------------------
+ * A dense tile's first half -- the bytes it adds, for the three counts it may be entered with -- takes ~60 us, and in k3_tiles every
+ * tile behind it waits for that sum: a 16 GiB arena with 1 % of it in stretches of padding ran 1.65 x the uniform time.  But the
+ * sum does not depend on anything in front of the tile.  So: k3t_sample looks at 64 bytes in every 64 KiB of every tile, at 64 bytes
+ * in every 16 KiB of the tiles that show something, and lists the tiles in which a sixth of those chunks end a pattern 00 00 {<= 3}; k3_tiles runs ONCE OVER THAT LIST in "count ahead" mode --
+ * rows, flags, NAL starts as always, then k3_dense_tile's first half, whose per-wavefront results go to a table -- and then as
+ * before, where a dense tile whose table entry carries this call's number skips its first half.  A tile the sample misses (a
+ * stretch shorter than ~16 KiB) is counted in place as before; a listed tile that is not dense costs its rows once more. */
+constexpr int kSampleMin = 8;       /* 8 of 48 sampled chunks (two of twelve sectors): a sixth of the tile; a zero-heavy arena (2-3 % of its chunks) shows 1-2 */
+__global__ __launch_bounds__(256)
+void k3t_sample(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
+                uint32_t* __restrict__ cand_list, uint32_t* __restrict__ cand_count, uint64_t cand_cap, uint32_t* __restrict__ dz_table,
+                const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
+{
+    if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
+    const uint64_t a0 = idx[0].rbsp_off;
+    const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
+    const uint64_t ntiles = arena_len / kTTileBytes + 1;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    /* Two looks.  First 64 bytes in every 64 KiB (three sectors a tile, lanes 0-11): on coded video no chunk of them ends a pattern
+     * 00 00 {<= 3} and the tile is done -- a quarter of the sectors of the full look, which took 50 us over a 16 GiB arena, all of
+     * it DRAM row misses.  A tile with a hit gets the full look: 64 bytes in every 16 KiB (twelve sectors, 48 chunks); listed when
+     * kSampleMin of them hit. */
+    auto sample_at = [&](uint64_t tile, int sec, int sub) -> uint64_t {       /* sector `sec` of 12, chunk `sub` of 4 */
+        return tile * (uint64_t)kTTileBytes + 16384ull * (uint64_t)sec + 1024ull * (uint64_t)((5 * sec + (int)tile) & 15) +
+               64ull * (uint64_t)((7 * sec + (int)(tile >> 2)) & 15) + 16ull * (uint64_t)sub;
+    };
+    auto hit = [&](const u32x4& q) -> bool {                         /* the question the tile kernel's flag pass asks */
+        return chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) && chunk_pattern_any_dev(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+    };
+    constexpr int kAtOnce = 4;                                      /* tiles a wavefront samples together: their loads in flight at the same time */
+    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint64_t tile0 = wave * kAtOnce; tile0 < ntiles; tile0 += nwaves * kAtOnce) {
+        u32x4 q[kAtOnce];
+#pragma unroll
+        for (int i = 0; i < kAtOnce; ++i) {
+            const uint64_t tile = tile0 + (uint64_t)i;
+            const uint64_t x = sample_at(tile, 4 * (lane >> 2) + 1, lane & 3);          /* sectors 1, 5, 9 */
+            q[i] = none;
+            if (lane < 12 && tile < ntiles && x + 16u <= arena_len) q[i] = *reinterpret_cast<const u32x4*>(rbsp + a0 + x);
+        }
+#pragma unroll
+        for (int i = 0; i < kAtOnce; ++i) {
+            const uint64_t tile = tile0 + (uint64_t)i;
+            if (tile >= ntiles) break;
+            if (lane == 0) dz_table[tile * (uint64_t)kDzTableWords + 24u] = 0u;     /* (the workspace is not cleared: no stale entry may carry this call's number) */
+            if (__ballot(hit(q[i])) == 0ull) continue;
+            const uint64_t x = sample_at(tile, lane >> 2, lane & 3);
+            u32x4 qq = none;
+            if (lane < 48 && x + 16u <= arena_len) qq = *reinterpret_cast<const u32x4*>(rbsp + a0 + x);
+            const uint32_t hits = (uint32_t)__builtin_popcountll(__ballot(hit(qq)));
+            if (hits >= (uint32_t)kSampleMin && lane == 0) {
+                const uint32_t slot = atomicAdd(cand_count, 1u);
+                if (slot < cand_cap) cand_list[slot] = (uint32_t)tile;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kTThreads, 2)
 void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
               const unsigned long long* __restrict__ first_k, unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
               uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err,
-              const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
+              const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag,
+              int ahead /* 1: the listed tiles only, up to their dense first half (see k3t_sample) */,
+              const uint32_t* __restrict__ cand_list, const uint32_t* __restrict__ cand_count, uint64_t cand_cap, uint32_t* __restrict__ cand_ticket,
+              uint32_t* __restrict__ dz_table, uint32_t call_no)
 {
     if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
     __shared__ LdsT l;
@@ -1963,7 +2045,15 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         const int lane = launder_lane(tid0) & 63;
         const int tid = launder_lane(tid0);
         __syncthreads();                                           /* the previous tile is done with l */
-        if (tid == 0) l.ticket = atomicAdd(ticket, 1u);
+        if (tid == 0) {
+            if (ahead) {
+                const uint32_t tk = atomicAdd(cand_ticket, 1u);
+                const uint64_t have = *cand_count < cand_cap ? *cand_count : cand_cap;
+                l.ticket = tk < have ? cand_list[tk] : 0xFFFFFFFFu;
+            } else {
+                l.ticket = atomicAdd(ticket, 1u);
+            }
+        }
         if (tid < kTWaves * kTRows) l.rowbits[tid] = 0ull;
         __syncthreads();
         const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
@@ -2128,6 +2218,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             pending = 1;
             break;
         }
+        if (ahead) continue;                                       /* listed, not dense: nothing to count ahead */
         for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
             const int r = __builtin_ctzll(rm);
             const uint32_t rp = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
@@ -2263,7 +2354,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
 #ifdef HBS_DZ_TIMING
     if (threadIdx.x == 0) atomicAdd(&g_dz_cycles[5], __builtin_amdgcn_s_memtime() - dz_tile_t0);
 #endif
-    k3_dense_tile(l, t, d_tile, d_tile == ntiles - 1, desc, out, out_cap, idx_out, n, total, err);
+    k3_dense_tile(l, t, d_tile, d_tile == ntiles - 1, desc, out, out_cap, idx_out, n, total, err, ahead, dz_table, call_no);
     }
     HBS3_T_FLUSH
 }
@@ -2275,6 +2366,23 @@ int emit_tile_grid_blocks(int device)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_tiles, kTThreads, 0) != hipSuccess || per_cu < 1) return -1;
     return prop.multiProcessorCount * per_cu;
+}
+
+/* the tile kernel with its dense tiles counted ahead: the sample, the listed tiles up to their first half, then all tiles */
+static void launch_tiles(const EmitArgs& a, unsigned tb, const uint32_t* probe, const uint32_t* tflag, hipStream_t st)
+{
+    const bool ahead = a.dz_table && a.cand_list && a.cand_cap;
+    if (ahead) {
+        k3t_sample<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.cand_list, a.cand_count, a.cand_cap, a.dz_table, probe, tflag);
+        /* (a workgroup per 64 tiles of the arena, at least 64, at most all: the list is short or empty, and a launch of workgroups
+         * with 77 KiB of LDS each is not free -- 10 us for 512 of them, under the profiler) */
+        const uint64_t want = a.rbsp_bytes / kTTileBytes / 64u + 1u;
+        const unsigned tb_ahead = (unsigned)(want < 64u ? (tb < 64u ? tb : 64u) : (want > tb ? tb : want));
+        k3_tiles<<<dim3(tb_ahead), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
+                                                 probe, tflag, 1, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, a.dz_table, a.call_no);
+    }
+    k3_tiles<<<dim3(tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
+                                             probe, tflag, 0, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, ahead ? a.dz_table : nullptr, a.call_no);
 }
 
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
@@ -2298,8 +2406,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
             uint64_t tb = (uint64_t)a.tile_blocks;
             const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
             if (tb > max_tiles) tb = max_tiles;
-            k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap,
-                                                              a.index_out, a.total, a.err, nullptr, a.tflag);
+            launch_tiles(a, (unsigned)tb, nullptr, a.tflag, st);
         }
         const uint64_t want = (a.n + 255) / 256;
         const unsigned tgrid = (unsigned)(want < 8192 ? want : 8192);
@@ -2329,13 +2436,12 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
             uint64_t tb = (uint64_t)a.tile_blocks;
             const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
             if (tb > max_tiles) tb = max_tiles;
-            k3_tiles<<<dim3((unsigned)tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap,
-                                                              a.index_out, a.total, a.err, probe, tflag);
+            launch_tiles(a, (unsigned)tb, probe, tflag, st);
         }
         /* items of the kernel by NALs: segments per NAL, their exclusive scan, the item list (skipped on the device when the tile
          * kernel does the call, or when the list is the identity) */
         if (both) {
-            k3_sizes<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
+            k3_sizes<<<2048, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, probe, a.tflag);
             launch_scan_u64(a.nal_total, a.out_off, a.n, a.n_items, a.scan_tmp, st, probe, kWhenEither, a.tflag, a.total_dense);
         } else {
             k3_seg_count<<<1024, 256, 0, st>>>(a.index_in, a.n, a.nal_total, probe, a.tflag);

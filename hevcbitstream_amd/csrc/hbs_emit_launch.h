@@ -37,6 +37,13 @@ struct EmitArgs {
     uint64_t first_cap;
     int tiles;                        /* 0: never the arena-tile kernel; 1: when the index is eligible; 2: ... whatever the arena's size */
     int tile_blocks;                  /* resident workgroups of the arena-tile kernel (emit_tile_grid_blocks)          */
+    /* dense tiles counted ahead of the tile kernel (hbs_emit.hip: k3t_sample) */
+    uint32_t* cand_list;              /* cand_cap entries: tiles the sample lists                                       */
+    uint32_t* cand_count;             /* 1, inside the cleared stretch                                                  */
+    uint32_t* cand_ticket;            /* 1, inside the cleared stretch                                                  */
+    uint64_t cand_cap;
+    uint32_t* dz_table;               /* emit_dz_table_words() words per arena tile; an entry is valid when it carries call_no */
+    uint32_t call_no;                 /* this call's number on its context (never 0)                                    */
 };
 
 struct SynthArgs {
@@ -55,6 +62,7 @@ int emit_grid_blocks(int device);
 int emit_tile_grid_blocks(int device);
 uint64_t emit_items_bound(uint64_t n, uint64_t payload_bytes);
 uint64_t emit_desc_words(uint64_t items_cap);
+uint64_t emit_dz_table_words();
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st);
 hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st);
 
