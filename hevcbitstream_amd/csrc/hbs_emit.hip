@@ -1717,6 +1717,7 @@ __device__ __forceinline__ DzFast dz_start3(const LdsT& l, uint32_t m, uint32_t 
     if (several || j0 >= m || s0 >= 16u) return dz_start3_serial(l.starts, l.gaps, m, p, j0, q);
     return dz_one_start4(q.x, q.y, q.z, q.w, s0, gap0);
 }
+constexpr uint32_t kDzRowBuf = 2048;            /* bytes of a row with what goes into it that are put together in LDS (1024 + 512 of 03s + start codes) */
 constexpr int kDzGroup = 8;
 static_assert(kTRows % kDzGroup == 0, "whole groups of rows");
 
@@ -1909,6 +1910,8 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
     uint8_t* const tout = out + t.tile_lo + l.before;
     const uint64_t abs0 = t.tile_lo + l.before;
     uint32_t base_ins = l.dz_base[wv], row_in = l.dz_in[wv];
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    uint8_t* const rowbuf = reinterpret_cast<uint8_t*>(&l.park[0][0][0]) + (size_t)(kDzRowBuf + 64u) * (uint32_t)wv;   /* (the parked rows' place: nothing is parked in a dense tile) */
     u32x4 qa = load_row(0), qb = load_row(1);
     uint32_t e_prev = seg_before;
 #pragma unroll 1
@@ -1930,16 +1933,60 @@ void k3_dense_tile(LdsT& l, TileCtx t, uint64_t tile, bool last_tile, unsigned l
         uint32_t row_tot;
         const uint32_t before_me = wave_excl_scan_u32(mine, lane, row_tot);
         const uint64_t pos = 16ull * c + base_ins + before_me;
+        const uint32_t row_base = base_ins;
         base_ins += row_tot;
-        if (!d.active) continue;
-        if (d.start) {
-            uint32_t co;
-            (void)dz_start_chunk<true>(t, l, c, d.q, d.nb, c_in, co, tout, abs0, pos, can_store, idx_out);
-        } else if (can_store) {
-            const uint32_t mask = dz_mask_for(d, c_in);
-            if (mask == 0u) arena_store16(tout + pos, d.q);
-            else (void)emit_chunk16(tout + pos, d.q.x, d.q.y, d.q.z, d.q.w, 16u, mask);
+        /* a row into which nothing goes and in which no NAL begins: the chunks as they are */
+        const bool special = __ballot(d.active && (d.start || mine != 0u)) != 0ull;
+        if (!special) {
+            if (d.active && can_store) arena_store16(tout + pos, d.q);
+            continue;
         }
+        /* Otherwise the row's bytes are put together in LDS -- every lane writes its chunk with its 03s (a NAL start: with its
+         * start code) at its place in the row -- and go out as whole 16-byte pieces: written straight to the stream, a chunk with
+         * 03s was up to 24 single-byte stores per lane (~300 us a tile of padding).  A row longer than the buffer (a start code of
+         * hundreds of bytes) takes the old way. */
+        const uint32_t row_out0 = 16u * (chunk0 + 64u * (uint32_t)r) + row_base;       /* where the row's first byte goes, from tout */
+        const uint32_t row_len = wave_sum32(d.active ? d.nb + mine : 0u);
+        if (row_len > kDzRowBuf || !can_store) {
+            if (!d.active) continue;
+            if (d.start) {
+                uint32_t co;
+                (void)dz_start_chunk<true>(t, l, c, d.q, d.nb, c_in, co, tout, abs0, pos, can_store, idx_out);
+            } else if (can_store) {
+                const uint32_t mask = dz_mask_for(d, c_in);
+                if (mask == 0u) arena_store16(tout + pos, d.q);
+                else (void)emit_chunk16(tout + pos, d.q.x, d.q.y, d.q.z, d.q.w, 16u, mask);
+            }
+            continue;
+        }
+        const uint32_t off = (uint32_t)(pos - (uint64_t)row_out0);
+        if (d.active) {
+            if (d.start) {
+                uint32_t co;                                       /* (its index entries carry stream offsets: abs0 + pos, as before) */
+                (void)dz_start_chunk<true>(t, l, c, d.q, d.nb, c_in, co, rowbuf - row_out0, abs0, pos, true, idx_out);
+            } else {
+                const uint32_t mask = dz_mask_for(d, c_in);
+                lds_u8* const lb = (lds_u8*)(rowbuf) + off;
+                uint32_t o = 0, w0 = d.q.x, w1 = d.q.y, w2 = d.q.z, w3 = d.q.w;
+#pragma unroll
+                for (uint32_t i = 0; i < 16u; ++i) {
+                    if ((mask >> i) & 1u) lb[o++] = (uint8_t)3;
+                    lb[o++] = (uint8_t)w0;
+                    w0 = (w0 >> 8) | (w1 << 24); w1 = (w1 >> 8) | (w2 << 24); w2 = (w2 >> 8) | (w3 << 24); w3 >>= 8;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          /* (the start chunk's bytes went through flat stores) */
+        {
+            const lds_u8* const lb = (const lds_u8*)(rowbuf);
+            uint8_t* const dst = tout + row_out0;
+#pragma unroll 1
+            for (uint32_t j = (uint32_t)lane; 16u * j + 16u <= row_len; j += 64u) arena_store16(dst + 16u * j, *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lb + 16u * j));
+            const uint32_t t0 = row_len & ~15u;
+            if ((uint32_t)lane < row_len - t0) dst[t0 + (uint32_t)lane] = lb[t0 + (uint32_t)lane];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     DZ_T_MARK(4)
 #ifdef HBS_DZ_TIMING
