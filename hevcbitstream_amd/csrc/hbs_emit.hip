@@ -1239,24 +1239,41 @@ static_assert(kTChunks <= (int)kTListChunk + 1, "a chunk number fits the list en
 __global__ __launch_bounds__(256)
 void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
                uint64_t first_cap, uint64_t desc_words, int want_tiles, int pinned, uint32_t* __restrict__ tflag, uint32_t* __restrict__ err,
-               uint32_t* __restrict__ probe)
+               uint32_t* __restrict__ probe, unsigned long long* __restrict__ first_k)
 {
     if (blockIdx.x >= kCheckBlocks) {                /* launched only when a probe is wanted */
         probe_window(rbsp, rbsp_bytes, probe, blockIdx.x - kCheckBlocks);
         return;
     }
     bool bad = false, outside = false;
+    /* first_k[t] = the first NAL that begins at or behind arena tile t (k3t_first's table, filled on the way since round 4: one
+     * launch and one pass over the index less).  The index is not trusted yet: tile numbers are clamped to the table, so a
+     * corrupt index costs time, not memory -- and then nobody reads the table. */
+    const uint64_t a0 = idx[0].rbsp_off;
+    const bool fill = want_tiles && first_k != nullptr && first_cap != 0;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)kCheckBlocks * blockDim.x) {
         const uint64_t off = idx[k].rbsp_off;
         if (off > rbsp_bytes || idx[k].rbsp_len > rbsp_bytes - off) outside = true;      /* every kernel behind this one trusts the index */
-        if (k > 0 && off != idx[k - 1].rbsp_off + idx[k - 1].rbsp_len) bad = true;
+        const uint64_t prev_off = k > 0 ? idx[k - 1].rbsp_off : 0ull;
+        if (k > 0 && off != prev_off + idx[k - 1].rbsp_len) bad = true;
         if (gap_of(idx, k, gap_mode) >= (uint64_t)kTMaxGap) bad = true;
         if (k + kTMaxStarts < n && idx[k + kTMaxStarts].rbsp_off - off < (uint64_t)kTTileBytes) bad = true;
+        if (fill) {
+            const uint64_t lo = k == 0 ? 0ull : (prev_off - a0) / kTTileBytes + 1ull;
+            uint64_t hi = (off - a0) / kTTileBytes;
+            if (hi > first_cap - 1) hi = first_cap - 1;
+            for (uint64_t t = lo; t <= hi; ++t) first_k[t] = k;
+        }
+    }
+    if (fill && blockIdx.x == 0 && threadIdx.x == 0) {             /* the tiles behind the last NAL's first byte */
+        const uint64_t lo = (idx[n - 1].rbsp_off - a0) / kTTileBytes + 1ull;
+        uint64_t hi = (idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0) / kTTileBytes + 1ull;
+        if (hi > first_cap - 1) hi = first_cap - 1;
+        for (uint64_t t = lo; t <= hi; ++t) first_k[t] = n;
     }
     if (bad) atomicOr(&tflag[0], 1u);
     if (outside) { atomicOr(&tflag[3], 1u); atomicMax(err, (uint32_t)(-HBS_E_ARG)); }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint64_t a0 = idx[0].rbsp_off;
         const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
         const uint64_t ntiles = arena_len / kTTileBytes + 1;
         /* The tile kernel's row loads are unpredicated 16-byte loads anywhere in [a0, a0 + arena_len), clamped to the arena's
@@ -1269,21 +1286,6 @@ void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
                         ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
                         ntiles + 1 <= first_cap && ntiles + 1 <= desc_words;
         tflag[1] = ok ? 1u : 0u;
-    }
-}
-
-/* first_k[t] = the first NAL that begins at or behind tile t's first byte (t = 0 .. ntiles, the last one = n) */
-__global__ __launch_bounds__(256)
-void k3t_first(const hbs_nal_entry* __restrict__ idx, uint64_t n, unsigned long long* __restrict__ first_k,
-               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
-{
-    if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
-    const uint64_t a0 = idx[0].rbsp_off;
-    const uint64_t ntiles = (idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0) / kTTileBytes + 1;
-    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k <= n; k += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t lo = k == 0 ? 0 : (idx[k - 1].rbsp_off - a0) / kTTileBytes + 1;
-        const uint64_t hi = k < n ? (idx[k].rbsp_off - a0) / kTTileBytes : ntiles;
-        for (uint64_t t = lo; t <= hi; ++t) first_k[t] = k;
     }
 }
 
@@ -2447,9 +2449,8 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
          * against their conditions: the tile kernel when they hold, a lane per NAL otherwise -- sizes, their scan, the bytes */
         const bool try_tiles = a.rbsp_bytes >= kTMinArena && a.rbsp_bytes / a.n >= kTilesMinMeanBytes;
         k3t_check<<<kCheckBlocks, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap),
-                                                try_tiles ? 1 : 0, 0, a.tflag, a.err, a.probe);
+                                                try_tiles ? 1 : 0, 0, a.tflag, a.err, a.probe, a.first_k);
         if (try_tiles) {
-            k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.first_k, nullptr, a.tflag);
             uint64_t tb = (uint64_t)a.tile_blocks;
             const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
             if (tb > max_tiles) tb = max_tiles;
@@ -2471,7 +2472,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     /* always: it is also what checks every entry of the index against rbsp_bytes (tflag[3]) before anything follows one into the
      * arena; its last kProbeBlocks workgroups are the density probe */
     if (a.n) k3t_check<<<kCheckBlocks + (probe ? kProbeBlocks : 0u), 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap,
-                                             emit_desc_words(a.items_cap), tflag ? 1 : 0, a.tiles == 2 ? 1 : 0, a.tflag, a.err, a.probe);
+                                             emit_desc_words(a.items_cap), tflag ? 1 : 0, a.tiles == 2 ? 1 : 0, a.tflag, a.err, a.probe, a.first_k);
     /* (round 4: the chains behind the tile kernel that rule themselves out on the device were tried on side streams, forked behind
      * k3t_check and joined in front of the summary; the event waits cost more than the empty launches -- 0.461 against 0.440 ms at
      * 1 GiB.  What helps is fewer launches: k3t_reset is gone with the give-up, and the two chains share k3_sizes and one scan.) */
@@ -2479,7 +2480,6 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
     if (a.n && want_sparse) {
         if (tflag) {
             /* arena tiles first; the kernel by NALs behind them runs when they do not apply */
-            k3t_first<<<1024, 256, 0, st>>>(a.index_in, a.n, a.first_k, probe, tflag);
             uint64_t tb = (uint64_t)a.tile_blocks;
             const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
             if (tb > max_tiles) tb = max_tiles;
