@@ -2064,17 +2064,18 @@ void k3t_sample(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restric
     }
 }
 
+template <int kAheadMode>       /* 1: the listed tiles only, up to their dense first half (see k3t_sample) -- an instance of its own, so that the main pass carries none of it */
 __global__ __launch_bounds__(kTThreads, 2)
 void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
               const unsigned long long* __restrict__ first_k, unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket,
               uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err,
               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag,
-              int ahead /* 1: the listed tiles only, up to their dense first half (see k3t_sample) */,
               const uint32_t* __restrict__ cand_list, const uint32_t* __restrict__ cand_count, uint64_t cand_cap, uint32_t* __restrict__ cand_ticket,
               uint32_t* __restrict__ dz_table, uint32_t call_no)
 {
     if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
+    constexpr int ahead = kAheadMode;
     __shared__ LdsT l;
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -2413,7 +2414,7 @@ int emit_tile_grid_blocks(int device)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_tiles, kTThreads, 0) != hipSuccess || per_cu < 1) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_tiles<0>, kTThreads, 0) != hipSuccess || per_cu < 1) return -1;
     return prop.multiProcessorCount * per_cu;
 }
 
@@ -2427,11 +2428,11 @@ static void launch_tiles(const EmitArgs& a, unsigned tb, const uint32_t* probe, 
          * with 77 KiB of LDS each is not free -- 10 us for 512 of them, under the profiler) */
         const uint64_t want = a.rbsp_bytes / kTTileBytes / 64u + 1u;
         const unsigned tb_ahead = (unsigned)(want < 64u ? (tb < 64u ? tb : 64u) : (want > tb ? tb : want));
-        k3_tiles<<<dim3(tb_ahead), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
-                                                 probe, tflag, 1, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, a.dz_table, a.call_no);
+        k3_tiles<1><<<dim3(tb_ahead), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
+                                                 probe, tflag, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, a.dz_table, a.call_no);
     }
-    k3_tiles<<<dim3(tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
-                                             probe, tflag, 0, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, ahead ? a.dz_table : nullptr, a.call_no);
+    k3_tiles<0><<<dim3(tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
+                                             probe, tflag, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, ahead ? a.dz_table : nullptr, a.call_no);
 }
 
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
