@@ -382,7 +382,8 @@ def emit_mixed_lines(torch, ctx, g, n, rb, sb, uniform_ms):
             if off + region < rb:
                 arena[off: off + region] = pat
                 dense += region
-        out = torch.zeros(out_cap, dtype=torch.uint8, device="cuda")
+        torch.cuda.empty_cache()
+        out, placement = ctx.pair_alloc(arena, out_cap)              # placed against this arena, as the uniform run's output is against its own
         idx_out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
         summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -398,7 +399,7 @@ def emit_mixed_lines(torch, ctx, g, n, rb, sb, uniform_ms):
         by_tiles = int(ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h))
         total = int(s["stream_bytes"])
         line = {"ms": round(ms, 3), "over_uniform": round(ms / uniform_ms, 3), "dense_bytes": dense, "emitted_bytes": total,
-                "arena_tiles_did_the_call": by_tiles}
+                "arena_tiles_did_the_call": by_tiles, "output_placement": placement}
         if byte3 == 3:                                               # (the kernel by NALs takes 0.19 s on the zeros)
             out2 = torch.zeros(out_cap, dtype=torch.uint8, device="cuda")
             idx2 = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
@@ -445,6 +446,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     del index
     res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
     res["mixed_stream"]["index_only"] = mixed_index_only(torch, ctx, g["stream"][:sb], sb, n + 64, ms)
+    torch.cuda.empty_cache()                                          # (what torch keeps cached is not free memory to hbs_pair_alloc's candidates)
     out, emit_placement = ctx.pair_alloc(g["rbsp"], sb + 4096)       # the emitted stream placed against the arena it is read from
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
