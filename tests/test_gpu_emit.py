@@ -236,6 +236,49 @@ def test_emit_arena_tiles_walk_dense_tiles_by_rows(ctx, orc):
         assert stayed == 1
 
 
+def test_emit_arena_tiles_count_dense_tiles_ahead(ctx, orc):
+    """round 4: k3t_sample looks at 64 bytes in every 64 KiB of a tile (sectors 1, 5, 9 of twelve), then at 64 in every 16 KiB of
+    a tile that shows something, and lists the tile when 8 of those 48 chunks end a pattern 00 00 {<= 3}; the listed tiles' first
+    halves are counted ahead of the main pass.  Tiles that are listed AND dense (a stretch of padding), listed and NOT dense
+    (patterns exactly where the sample looks, nowhere else: the count-ahead pass drops them), dense and NOT listed (a stretch of
+    20 KiB between the sampled sectors' rows is still counted in place) -- bytes against the oracle, the tile kernel did the call."""
+    T = 192 * 1024
+    rng = np.random.RandomState(97)
+
+    def sample_at(tile, sec, sub):                       # hbs_emit.hip: k3t_sample
+        return tile * T + 16384 * sec + 1024 * ((5 * sec + tile) & 15) + 64 * ((7 * sec + (tile >> 2)) & 15) + 16 * sub
+
+    lens = [int(x) for x in rng.randint(20000, 90000, size=40)]
+    arena = rng.randint(1, 256, size=sum(lens)).astype(np.uint8)
+    ntiles = len(arena) // T
+    assert ntiles >= 9
+    for tile in (2, 5):                                  # listed, not dense: 48 chunks with a pattern, the rest of the tile clean
+        for sec in range(12):
+            for sub in range(4):
+                x = sample_at(tile, sec, sub)
+                arena[x + 5: x + 8] = (0, 0, 1)
+    arena[3 * T + 1000: 3 * T + 1000 + 150_000] = np.tile(np.array([0, 0, 3], dtype=np.uint8), 50_000)      # listed and dense
+    arena[7 * T + 70_000: 7 * T + 90_000] = 0                                                               # dense (a full row of zeros), seen or not
+    idx = fake_index(lens, [3 + (k & 1) for k in range(len(lens))])
+    want = orc.emit_annexb(arena, idx)
+    ctx.set_emit_path(2)
+    got, got_idx = ctx.emit_annexb(dev(arena), idx)
+    stayed = ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h)
+    ctx.set_emit_path(0)
+    _, idx_nals = ctx.emit_annexb(dev(arena), idx)
+    ctx.set_emit_path(-1)
+    assert np.array_equal(got, want) and np.array_equal(got_idx, idx_nals) and stayed == 1
+    # the same arena twice more on the same context: the table's stamps are this call's only
+    ctx.set_emit_path(2)
+    arena2 = arena.copy()
+    arena2[3 * T + 1000: 3 * T + 1000 + 150_000] = rng.randint(1, 256, size=150_000)     # the stretch is gone: a stale entry would be wrong
+    want2 = orc.emit_annexb(arena2, idx)
+    got2, _ = ctx.emit_annexb(dev(arena2), idx)
+    got3, _ = ctx.emit_annexb(dev(arena), idx)
+    ctx.set_emit_path(-1)
+    assert np.array_equal(got2, want2) and np.array_equal(got3, want)
+
+
 def test_emit_arena_tiles_refuse_an_index_outside_the_arena(ctx, orc):
     """round 2's advice: the arena-tile kernel reads its rows unpredicated, so an index that points past the caller's RBSP
     buffer (built by hand, or corrupt) must not reach it even when the path is pinned: k3t_check compares the index with
