@@ -2269,14 +2269,21 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             break;
         }
         if (ahead) continue;                                       /* listed, not dense: nothing to count ahead */
-        for (uint64_t rm = rowmask; rm != 0ull; rm &= rm - 1ull) {
-            const int r = __builtin_ctzll(rm);
-            const uint32_t rp = wave_base + (uint32_t)__builtin_amdgcn_readlane((int)local_pre, r);
-            const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)fm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)fm_lo, r);
-            const uint64_t so = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sm_hi, r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)sm_lo, r);
-            const uint32_t chunk = (uint32_t)(64 * (kTRows * wv + r) + lane);
-            if ((f >> lane) & 1ull)          /* (the arena's partial last chunk was not seen by chunk_flag(): the general way) */
-                l.list[rp + lanes_below(f)] = (uint16_t)(chunk | ((((so >> lane) & 1ull) && chunk != cut_chunk) ? kTListStart : kTListFlag));
+        /* the tile's list: lane r writes the elements of ITS row (it holds the row's flag word), one per step -- as many steps as
+         * the fullest row has elements.  (Until round 4 a step per row with elements, all lanes on one row: with NALs of 1 KiB
+         * that was 48 steps a wavefront, ~8 k cycles of every tile.) */
+        if (lane < kTRows) {
+            uint64_t f = ((uint64_t)fm_hi << 32) | fm_lo;
+            const uint64_t so = ((uint64_t)sm_hi << 32) | sm_lo;
+            uint32_t j = wave_base + local_pre;
+            const uint32_t row0 = (uint32_t)(64 * (kTRows * wv + lane));
+#pragma unroll 1
+            while (f != 0ull) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(f);
+                const uint32_t chunk = row0 + b;     /* (the arena's partial last chunk was not seen by chunk_flag(): the general way) */
+                l.list[j++] = (uint16_t)(chunk | ((((so >> b) & 1ull) && chunk != cut_chunk) ? kTListStart : kTListFlag));
+                f &= f - 1ull;
+            }
         }
         __syncthreads();
         HBS3_T_MARK(2)
