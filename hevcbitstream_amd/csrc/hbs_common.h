@@ -99,7 +99,7 @@ constexpr int kExactFlagMin = 2;        /* rows of 1 KiB with more flagged chunk
                                            are a start code, most likely, and the second test would buy nothing */
 /* Without an arena (round 4): the streaming index-only kernel keeps its pace to about twice that density -- a 2 GiB stream of
  * 448-byte NALs (one chunk in 24 an element) 0.66 ms against the LDS-image kernel's 1.48, of 384-byte NALs 1.13 against 1.50, of
- * 256-byte NALs (1 in 14) 1.47 against 1.57, of 128-byte NALs 2.5 against 1.8 (scripts/r4/pin_time.py) -- so its calls ask the
+ * 256-byte NALs (1 in 14) 1.47 against 1.57, of 128-byte NALs 2.5 against 1.8 (scripts/pin_time.py) -- so its calls ask the
  * probe with a threshold of their own. */
 constexpr uint32_t kDenseOneInIndexOnly = 15;
 HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged, uint32_t one_in = kDenseOneIn) { return (uint64_t)flagged * one_in > (uint64_t)chunks; }

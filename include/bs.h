@@ -4,9 +4,10 @@
  * The reference's header is an all-inline bit reader/writer; applications of
  * the library only meet `bs_t*` in the prototypes of h264_stream.h.  Here the
  * type is kept layout-identical (32 bytes on LP64) and the bit I/O itself is
- * internal to the library: on the GPU it is a 64-bit window reader
- * (hevcbitstream_amd/csrc/hbs_bits.h), in the test oracle a bit-serial
- * restatement (oracle/hbs_oracle_bits.c).
+ * internal to the library: on the GPU it is the whole-field reader / writer
+ * `BitIOT` of hevcbitstream_amd/csrc/hbs_parse.h over the 64-bit windows of
+ * hevcbitstream_amd/csrc/hbs_bitfast.h, in the test oracle a bit-serial
+ * restatement (oracle/hbs_oracle_bits.h).
  */
 #ifndef _H264_BS_H
 #define _H264_BS_H        1

@@ -1,5 +1,5 @@
 """dev aid: k3_tiles' phases (diag build, shader clock per tile) on a 2 GiB arena of NALs of a given mean size
-usage: make diag; python3 scripts/r4/emit_phase_mean.py 1024"""
+usage: make diag; python3 scripts/emit_phase_mean.py 1024"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -15,9 +15,9 @@ for s in 512 1024 10240; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$s -- python3 scripts/nal_sweep.py --gib 2 --sizes $s > $O/st_$s.txt 2>&1
   f=$(find $O/st_$s -name "*kernel_stats.csv" | head -1); grep -v "at::native" $f > $O/idx5_stats_$s.csv; find $O/st_$s -type f -delete; rm -f $O/st_$s.txt
 done
-rm -f $O/pair_time.txt; for i in 1 2 3 4 5 6; do timeout 300 python scripts/r4/pair_time.py >> $O/pair_time.txt 2>> $O/pair_time.err; done
+rm -f $O/pair_time.txt; for i in 1 2 3 4 5 6; do timeout 300 python scripts/pair_time.py >> $O/pair_time.txt 2>> $O/pair_time.err; done
 timeout 300 python tests/tools/cli_time.py > $O/cli_time.txt 2>&1
-timeout 600 python scripts/r4/fix_time.py > $O/fix_time.txt 2>&1
+timeout 600 python scripts/fix_time.py > $O/fix_time.txt 2>&1
 timeout 500 python tests/tools/soak_gpu.py 300 11 > $O/soak_r04.txt 2>&1
 timeout 400 python tests/tools/soak_emit_small.py > $O/soak_emit_small.txt 2>&1
 timeout 900 python tests/tools/fuzz_gpu_parse.py 1000 300 > $O/fuzz_gpu_parse.txt 2>&1

@@ -1,6 +1,6 @@
 """hbs_pair_alloc / hbs_pair_free: output buffers placed against their input (include/hevcbitstream_amd.h).  What is tested
 here is function -- the memory is ordinary device memory, results through it are the oracle's, the report adds up, freeing
-works; the speed it buys is measured by scripts/r4/pair_time.py and bench.py."""
+works; the speed it buys is measured by scripts/pair_time.py and bench.py."""
 import numpy as np
 import pytest
 
