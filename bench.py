@@ -637,9 +637,6 @@ def main():
 
     ctx = hbs.Context(local_rank)
     ctx.enable_timing(True)
-    if multi:
-        # the scan's persistent workgroups fill the GPU; RCCL's kernels need somewhere to run beside it
-        ctx.reserve_workgroups(int(os.environ.get("HBS_BENCH_SPARE_WGS", "32")))
     n = args.nals
     from hevcbitstream_amd.shard import shard_seed
     g = ctx.synth_stream(shard_seed(SEED, rank), n, args.mode)   # independent shard per rank, generated in HBM
@@ -661,6 +658,12 @@ def main():
     gatherer = shard.PipelinedLibraryGather(torch, hbs, local_rank, dist, rank, world, cap, depth=2) if multi else None
     if gatherer is not None and gatherer.comm.world_seen() != world:
         raise SystemExit("bench.py: the communicator reports %d ranks, %d were launched" % (gatherer.comm.world_seen(), world))
+    spare_wgs = 0
+    if gatherer is not None:
+        # the scan's persistent workgroups fill the GPU; RCCL's kernels need somewhere to run beside it: 8 slots per peer,
+        # 32 ... 64 of the 512 (hbs_comm_reserve_hint; HBS_BENCH_SPARE_WGS overrides for experiments)
+        spare_wgs = int(os.environ.get("HBS_BENCH_SPARE_WGS", gatherer.comm.reserve_hint()))
+        ctx.reserve_workgroups(spare_wgs)
     counter = [0]
     pending = [None]
 
@@ -734,9 +737,14 @@ def main():
         per_rank_t = torch.empty(world * 3, dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(per_rank_t, mine_t)
         per_rank_t = per_rank_t.view(world, 3).cpu().tolist()
+        # every rank's arena placement (chunks wanted / placed in the class its piece of the stream is not in): a slow rank can
+        # then be told from a misplaced one
+        per_rank_place = [None] * world
+        dist.all_gather_object(per_rank_place, placement)
     else:
         total_bytes, total_nals = float(sb), float(n)
         per_rank_t = None
+        per_rank_place = None
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -790,7 +798,9 @@ def main():
                              "api": "hbs_gather_index (include/hevcbitstream_amd.h), root = -1", "rccl_world": gatherer.comm.world_seen(),
                              "kernel_ms": round(k_ms, 4)}
             out["per_rank"] = [{"rank": r, "kernel_ms": round(t[0], 4), "gather_ms": round(t[1], 4),
-                                "roofline_frac": round(t[2] / (t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for r, t in enumerate(per_rank_t)]
+                                "roofline_frac": round(t[2] / (t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "arena_placement": per_rank_place[r]} for r, t in enumerate(per_rank_t)]
+            out["gather"]["reserved_workgroups"] = spare_wgs
         # HBM bytes per launch by PMC (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes): counters cannot be read from
         # inside this process, so the figure of the committed profile of this very workload and kernel is quoted
         tr = pmc_traffic(kernel_name, algo_bytes)

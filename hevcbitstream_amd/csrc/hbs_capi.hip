@@ -42,7 +42,9 @@ struct hbs_ctx {
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
     int emit_tile_blocks, emit_tiles; /* ... of the arena-tile kernel; 0 never / 1 when eligible / 2 pinned */
     int emit_path_set;                /* hbs_ctx_set_emit_path was called: the environment no longer decides */
-    const uint32_t* last_emit_tflag;  /* the last hbs_emit_annexb's verdict words (device): hbs_ctx_last_emit_by_tiles */
+    const uint32_t* last_emit_tflag;  /* the last hbs_emit_annexb's verdict words: a COPY in emit_verdict (the words themselves live in the shared
+                                         workspace, which the next call of any kind overwrites or reallocates); null: no verdict (small path) */
+    uint32_t* emit_verdict;           /* 16 bytes of device memory owned by the context */
     uint32_t emit_calls;              /* hbs_emit_annexb calls so far: stamps the dense tiles counted ahead (never 0) */
     int sched;
     unsigned long long* desc;
@@ -155,6 +157,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->tail) (void)hipFree(c->tail);
     if (c->ws) (void)hipFree(c->ws);
     if (c->zeros) (void)hipFree(c->zeros);
+    if (c->emit_verdict) (void)hipFree(c->emit_verdict);
     if (c->ws2) (void)hipFree(c->ws2);
     if (c->ring0[0]) for (int i = 0; i < kTimingRing; ++i) { (void)hipEventDestroy(c->ring0[i]); (void)hipEventDestroy(c->ring1[i]); }
     (void)hipStreamDestroy(c->own_stream);
@@ -432,9 +435,16 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     c->emit_calls += 1; if (c->emit_calls == 0) c->emit_calls = 1;
     a.call_no = c->emit_calls;
     a.tiles = c->emit_tiles; a.tile_blocks = c->emit_tile_blocks;
-    c->last_emit_tflag = a.tflag;
     a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;
+    if (!c->emit_verdict) {
+        const hipError_t ea = hipMalloc(reinterpret_cast<void**>(&c->emit_verdict), 16);
+        if (ea != hipSuccess) return fail(c, ea, "hipMalloc(emit verdict)");
+    }
+    /* the verdict words leave the shared workspace with the call's last kernel (round 4's advice: hbs_ctx_last_emit_by_tiles after
+     * any other call read bytes that call had overwritten, or a freed workspace); the one-launch small path writes none */
+    a.verdict_out = c->emit_verdict;
+    c->last_emit_tflag = hbs::emit_takes_small_path(a.n, a.rbsp_bytes, a.two_pass) ? nullptr : c->emit_verdict;
     hipError_t e = hbs::launch_emit_annexb(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_emit_annexb");
 }

@@ -1150,9 +1150,12 @@ int emit_grid_blocks(int device)
     return prop.multiProcessorCount * per_cu;
 }
 
+/* (verdict_out: the context's own copy of the four verdict words -- the words themselves live in the shared workspace) */
 __global__ void k3_summary(const unsigned long long* total, uint64_t n, uint64_t rbsp_bytes, const uint32_t* err, hbs_summary* sum,
-                           const unsigned long long* total_dense = nullptr, const uint32_t* probe = nullptr, const uint32_t* tflag = nullptr)
+                           const unsigned long long* total_dense = nullptr, const uint32_t* probe = nullptr, const uint32_t* tflag = nullptr,
+                           const uint32_t* verdict_in = nullptr, uint32_t* verdict_out = nullptr)
 {
+    if (verdict_out) for (int i = 0; i < 4; ++i) verdict_out[i] = verdict_in[i];
     sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes;
     sum->stream_bytes = (probe && three_steps_run(probe, tflag)) ? *total_dense : *total;
     sum->stop_reason = n ? -1 : 0; sum->error = -(int32_t)*err;
@@ -1160,8 +1163,9 @@ __global__ void k3_summary(const unsigned long long* total, uint64_t n, uint64_t
 }
 
 __global__ void k3_summary_small(const unsigned long long* total_tiles, const unsigned long long* total_lanes, uint64_t n, uint64_t rbsp_bytes,
-                                 const uint32_t* err, hbs_summary* sum, const uint32_t* tflag)
+                                 const uint32_t* err, hbs_summary* sum, const uint32_t* tflag, uint32_t* verdict_out)
 {
+    if (verdict_out) for (int i = 0; i < 4; ++i) verdict_out[i] = tflag[i];
     sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = rbsp_bytes;
     sum->stream_bytes = tile_path_on(tflag) ? *total_tiles : *total_lanes;
     sum->stop_reason = n ? -1 : 0; sum->error = -(int32_t)*err;
@@ -2469,7 +2473,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         k3_count_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.tflag);
         launch_scan_u64(a.nal_total, a.out_off, a.n, a.total_dense, a.scan_tmp, st, nullptr, kWhenNoTiles, a.tflag);
         k3_emit_tiny<<<tgrid, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, a.tflag);
-        k3_summary_small<<<1, 1, 0, st>>>(a.total, a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary, a.tflag);
+        k3_summary_small<<<1, 1, 0, st>>>(a.total, a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary, a.tflag, a.verdict_out);
         return hipGetLastError();
     }
     /* forced one way (HBS_EMIT_TWO_PASS=1 / =0), or -- the default -- picked on the device from a density probe */
@@ -2516,8 +2520,8 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         }
         k3_emit<<<grid, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.nal_total, a.out_off, a.out, a.out_cap, a.index_out, a.err, probe, a.tflag);
     }
-    if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary);
-    else k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary, a.total_dense, probe, a.tflag);
+    if (a.n && a.two_pass > 0) k3_summary<<<1, 1, 0, st>>>(a.total_dense, a.n, a.rbsp_bytes, a.err, a.summary, nullptr, nullptr, nullptr, a.tflag, a.verdict_out);
+    else k3_summary<<<1, 1, 0, st>>>(a.total, a.n, a.rbsp_bytes, a.err, a.summary, a.total_dense, probe, a.tflag, a.tflag, a.verdict_out);
     return hipGetLastError();
 }
 

@@ -32,6 +32,7 @@ struct EmitArgs {
     unsigned long long* total_dense;  /* 1: the three-step path's total                                   */
     uint32_t* probe;                  /* 2: chunks sampled, chunks flagged                                */
     uint64_t clear_bytes;             /* desc .. probe are one stretch of the workspace this long: one clear per call */
+    uint32_t* verdict_out;            /* 4 words owned by the context: the summary kernel leaves a copy of tflag[0..3] there (nullable) */
     uint32_t* tflag;                  /* 3, inside that stretch: the arena-tile kernel's eligibility (k3t_check) and its "gave up" */
     unsigned long long* first_k;      /* first_cap entries: per arena tile, the first NAL that begins in it               */
     uint64_t first_cap;
@@ -64,6 +65,8 @@ uint64_t emit_items_bound(uint64_t n, uint64_t payload_bytes);
 uint64_t emit_desc_words(uint64_t items_cap);
 uint64_t emit_dz_table_words();
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st);
+/* the whole call in one launch of one workgroup (a few small NALs): no verdict words are written */
+bool emit_takes_small_path(uint64_t n, uint64_t rbsp_bytes, int two_pass);
 hipError_t launch_synth_rbsp(const SynthArgs& a, hipStream_t st);
 
 } // namespace hbs

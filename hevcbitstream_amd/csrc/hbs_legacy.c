@@ -266,10 +266,15 @@ static void fetch_results(uint64_t bytes, hbs_summary* sum, hbs_nal_entry* ent)
 #define WIN_MIN (128u << 10)
 #define WIN_MAX (64u << 20)
 #define WIN_TRACE_CAP_MAX 1024u
-static uint32_t g_win_trace_cap = WIN_TRACE_CAP_MAX;     /* trace records the batch keeps per NAL (HBS_LEGACY_TRACE_CAP lowers it: a testing aid) */
-#define WIN_TRACE_CAP g_win_trace_cap
+#define WIN_TRACE_CAP_MIN 128u
+#define WIN_TRACE_BYTES_MAX (256ull << 20)   /* trace records one batch may hold, on the device and on the host (round 4's advice: 1024 records
+                                                 for every NAL of a 64 MiB window of 300-byte NALs were 2.7 GB; the worst case 17 GB) */
+static uint32_t g_win_trace_cap = WIN_TRACE_CAP_MAX;     /* trace records a batch keeps per NAL at most (HBS_LEGACY_TRACE_CAP lowers it: a testing aid) */
+#define WIN_TRACE_CAP W.trace_cap
 typedef struct {
     int valid, trace;
+    int parsed_ok;                   /* 0: indexed and extracted only -- the parse waits for the first read, which knows the mode (and the caller's sets) */
+    uint32_t trace_cap;              /* trace records kept per NAL in THIS batch: g_win_trace_cap, less when n x cap x 12 B would pass WIN_TRACE_BYTES_MAX */
     const uint8_t* base;             /* the caller's buffer the batch was made from, and a copy of those bytes */
     uint64_t len;
     uint8_t* copy; uint64_t copy_cap;
@@ -291,7 +296,27 @@ typedef struct {
     uint8_t* d_misc;                             /* summary (64), end-state SPS slot, end-state PPS */
 } window_t;
 static window_t W;
-static int g_read_mode = 1;          /* 1: the last read was read_debug_hevc_nal_unit -- the mode the next batch is parsed in */
+/* Back-off (round 4's advice).  A batch costs an upload of up to 64 MiB, index, extraction, a parse and the way back; a caller
+ * whose reads are not the batch's NALs in order (it parses from a scratch copy, flips between the two readers, edits h->sps)
+ * gets nothing for it, and without a brake the next find_nal_unit of a large buffer built the next batch: once per NAL,
+ * quadratic in the buffer.  So a batch that is dropped before it paid for itself suppresses the next g_backoff batch builds -- 1,
+ * 2, 4 ... 65536, doubling while batches keep failing -- and one that pays resets the count.  "Paid": the calls answered from it
+ * (reads, or the find_nal_unit calls of a caller that only walks) at ~150 us apiece, what each costs by itself, against ~300 us
+ * + the window's bytes at ~4 GB/s up and down: 3 calls for a 128 KiB buffer, ~115 for a full 64 MiB window. */
+static uint32_t g_backoff = 0, g_skip_builds = 0;
+static uint64_t g_stat[4];           /* batches built, reads answered from a batch, reads answered one call at a time, builds suppressed */
+static int g_no_batch = -1;          /* HBS_LEGACY_NO_BATCH, read once */
+
+static void window_drop(void)
+{
+    if (!W.valid) return;
+    W.valid = 0;
+    if ((W.served > W.find_next ? W.served : W.find_next) * 600000ull >= 1200000ull + W.len) g_backoff = 0;
+    else {
+        g_backoff = g_backoff ? (g_backoff < 65536u ? g_backoff * 2 : g_backoff) : 1;
+        g_skip_builds = g_backoff;
+    }
+}
 
 static void grow_dev(uint8_t** p, uint64_t* cap, uint64_t want)
 {
@@ -301,17 +326,49 @@ static void grow_dev(uint8_t** p, uint64_t* cap, uint64_t want)
     *cap = want + want / 4 + 4096;
     if ((rc = hbs_dev_alloc(g_ctx, *cap, (void**)p))) die("hbs_dev_alloc", rc);
 }
-static void grow_host(void** p, uint64_t* cap, uint64_t want)
+/* host buffers of a batch; 0: no memory -- a batch that does not fit the host is not kept, the calls go one at a time */
+static int grow_host_try(void** p, uint64_t* cap, uint64_t want)
 {
-    if (want <= *cap) return;
+    void* q;
+    if (want <= *cap) return 1;
+    q = malloc((size_t)(want + want / 4 + 4096));
+    if (!q) return 0;
     free(*p);
-    *cap = want + want / 4 + 4096;
-    *p = malloc((size_t)*cap);
-    if (!*p) { fprintf(stderr, "libhevcbitstream: out of host memory\n"); abort(); }
+    *p = q; *cap = want + want / 4 + 4096;
+    return 1;
 }
 #define W_SUM ((hbs_summary*)W.d_misc)
 #define W_END_SPS (W.d_misc + 256)
 #define W_END_PPS (W.d_misc + 256 + ((hbs_sps_slot_bytes() + 255) & ~(uint64_t)255))
+
+/* NALs [a, b) of the batch once more, ONE at a time through the sequential parser (what read_nal runs for a single call), only
+ * for what they leave behind in the device-side state: the way out when the state behind a partial range cannot be derived in
+ * one pass (round 4's advice: this used to abort()) */
+static void window_replay(uint64_t a, uint64_t b)
+{
+    uint64_t k;
+    int rc;
+    need_block(0);
+    for (k = a; k < b; ++k) {
+        const int t = W.parsed_ok ? W.parsed[k].nal_unit_type : -1;
+        if ((W.ent[k].status & HBS_ST_ERROR)) continue;                      /* read_nal returns before it parses: nothing changes */
+        if (W.parsed_ok && !(t == HEVC_NAL_UNIT_TYPE_SPS_NUT || t == HEVC_NAL_UNIT_TYPE_PPS_NUT || (t >= 0 && t <= 9) || (t >= 16 && t <= 21))) continue;
+        if ((rc = hbs_parse_headers_ctx(g_ctx, W.d_rbsp, (const hbs_nal_entry*)W.d_index + k, 1, g_dparsed, g_dstruct, sizeof(hevc_vps_t) + 64,
+                                        g_dsps_slot, g_dpps, (hbs_summary*)(g_dblock + RES_SUMMARY2)))) die("hbs_parse_headers_ctx", rc);
+        if (!W.parsed_ok) {
+            hbs_parsed_nal p;
+            if ((rc = hbs_copy_to_host(g_ctx, &p, g_dparsed, sizeof(p)))) die("hbs_copy_to_host", rc);
+            if (p.struct_off == ~0ull) continue;
+            if (p.nal_unit_type == HEVC_NAL_UNIT_TYPE_SPS_NUT && (rc = hbs_copy_device(g_ctx, g_dsps_slot, g_dstruct, sizeof(hevc_sps_t)))) die("hbs_copy_device", rc);
+            if (p.nal_unit_type == HEVC_NAL_UNIT_TYPE_PPS_NUT && (rc = hbs_copy_device(g_ctx, g_dpps, g_dstruct, sizeof(hevc_pps_t)))) die("hbs_copy_device", rc);
+            continue;
+        }
+        if (W.parsed[k].struct_off == ~0ull) continue;
+        /* an SPS's derived tables went straight into the slot's tables; the struct follows (as in read_nal) */
+        if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT && (rc = hbs_copy_device(g_ctx, g_dsps_slot, g_dstruct, sizeof(hevc_sps_t)))) die("hbs_copy_device", rc);
+        if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT && (rc = hbs_copy_device(g_ctx, g_dpps, g_dstruct, sizeof(hevc_pps_t)))) die("hbs_copy_device", rc);
+    }
+}
 
 /* the device-side parser state (g_dsps_slot, g_dpps) up to the NALs answered from the batch so far */
 static void window_settle(void)
@@ -319,31 +376,44 @@ static void window_settle(void)
     int rc;
     hbs_summary s;
     if (!W.valid || W.synced >= W.served) return;
-    if (W.synced == 0 && W.served == W.n) {                    /* everything: the state the batch itself computed */
+    if (W.parsed_ok && W.synced == 0 && W.served == W.n) {     /* everything: the state the batch itself computed */
         if ((rc = hbs_copy_device(g_ctx, g_dsps_slot, W_END_SPS, hbs_sps_slot_bytes()))) die("hbs_copy_device", rc);
         if ((rc = hbs_copy_device(g_ctx, g_dpps, W_END_PPS, sizeof(hevc_pps_t)))) die("hbs_copy_device", rc);
     } else {
         const uint64_t a = W.synced, m = W.served - W.synced;
-        if ((rc = hbs_parse_headers_state(g_ctx, W.d_rbsp, (const hbs_nal_entry*)W.d_index + a, m,
+        /* (the records of this pass go behind the batch's own, which the host has already: the device copy is scratch by now) */
+        rc = W.d_structs ? hbs_parse_headers_state(g_ctx, W.d_rbsp, (const hbs_nal_entry*)W.d_index + a, m,
                                           (hbs_parsed_nal*)(W.d_index + W.ent_cap * sizeof(hbs_nal_entry)) + a, W.d_structs, W.d_structs_cap,
-                                          g_dsps_slot, g_dpps, NULL, 0, NULL, W_SUM, g_dsps_slot, g_dpps))) die("hbs_parse_headers_state", rc);
-        if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
-        if (s.reserved[1] || s.error) {
-            fprintf(stderr, "libhevcbitstream: the parser state behind %llu NALs of a batch could not be derived (error %d)\n", (unsigned long long)W.served, s.error);
-            abort();
-        }
+                                          g_dsps_slot, g_dpps, NULL, 0, NULL, W_SUM, g_dsps_slot, g_dpps) : HBS_E_ARG;
+        if (rc == 0 && (rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
+        /* reserved[1]: a chain of own RPS sets deeper than the exact re-walk follows, somewhere in this range (the batch as a whole
+         * had none at its END, or it would not have been kept; an intermediate point can); error: the struct arena of the batch
+         * was cut for all of it, a range cannot need more -- either way the single-NAL sequential path gives the same state */
+        if (rc || s.reserved[1] || s.error) window_replay(a, W.served);
     }
     W.synced = W.served;
 }
 
-/* parse (again) the NALs [from, W.n) of the window in the given mode, from the device-side state, and fetch the answers */
+/* parse the NALs of the window in the given mode, from the device-side state, and fetch the answers; W.valid = 0 when the batch
+ * cannot be kept (a chain of own sets deeper than the re-walk follows, no memory for it): one call at a time then */
 static void window_parse(int trace)
 {
     int rc;
     hbs_summary s;
-    const uint64_t n = W.n;
+    uint64_t n = W.n;
     hbs_nal_entry* d_ent = (hbs_nal_entry*)W.d_index;
     hbs_parsed_nal* d_par = (hbs_parsed_nal*)(W.d_index + W.ent_cap * sizeof(hbs_nal_entry));
+    W.trace_cap = g_win_trace_cap;
+    if (trace) {
+        /* bounded trace memory: fewer records per NAL first (a NAL with more goes one call at a time, the batch continues behind
+         * it), then fewer NALs (the next find_nal_unit behind the batch's last NAL builds the next batch from there) */
+        while ((uint64_t)W.trace_cap > WIN_TRACE_CAP_MIN && n * (uint64_t)W.trace_cap * sizeof(hbs_trace_rec) > WIN_TRACE_BYTES_MAX) W.trace_cap /= 2;
+        if (n * (uint64_t)W.trace_cap * sizeof(hbs_trace_rec) > WIN_TRACE_BYTES_MAX) {
+            n = WIN_TRACE_BYTES_MAX / ((uint64_t)W.trace_cap * sizeof(hbs_trace_rec));
+            W.n = n;
+            W.rbsp_bytes = W.ent[n - 1].rbsp_off + W.ent[n - 1].rbsp_len;
+        }
+    }
     /* how large is the struct arena? (a plan-only pass: sizes and offsets, nothing parsed) */
     if ((rc = hbs_parse_headers_ctx(g_ctx, W.d_rbsp, d_ent, n, d_par, NULL, 0, g_dsps_slot, g_dpps, W_SUM))) die("hbs_parse_headers_ctx", rc);
     if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
@@ -358,17 +428,20 @@ static void window_parse(int trace)
     }
     if ((rc = hbs_read_summary(g_ctx, W_SUM, &s))) die("hbs_read_summary", rc);
     if (s.error || s.reserved[1]) { W.valid = 0; return; }      /* (a chain of own sets deeper than the re-walk follows: one call at a time) */
-    grow_host((void**)&W.structs, &W.structs_cap, W.struct_bytes + 64);
+    if (!grow_host_try((void**)&W.structs, &W.structs_cap, W.struct_bytes + 64)) { W.valid = 0; return; }
     if ((rc = hbs_copy_to_host(g_ctx, W.parsed, d_par, n * sizeof(hbs_parsed_nal)))) die("hbs_copy_to_host", rc);
     if (W.struct_bytes && (rc = hbs_copy_to_host(g_ctx, W.structs, W.d_structs, W.struct_bytes))) die("hbs_copy_to_host", rc);
     if (trace) {
-        free(W.trn); W.trn = (uint32_t*)malloc((size_t)(n * 4 + 64));
+        free(W.trn); free(W.tr);
+        W.trn = (uint32_t*)malloc((size_t)(n * 4 + 64));
+        W.tr = (hbs_trace_rec*)malloc((size_t)(n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec) + 64));
+        if (!W.trn || !W.tr) { free(W.trn); free(W.tr); W.trn = NULL; W.tr = NULL; W.valid = 0; return; }
         if ((rc = hbs_copy_to_host(g_ctx, W.trn, W.d_tr + n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec), n * 4))) die("hbs_copy_to_host", rc);
-        free(W.tr); W.tr = (hbs_trace_rec*)malloc((size_t)(n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec) + 64));
         /* (the records of a NAL sit WIN_TRACE_CAP apart: one copy of the block) */
         if ((rc = hbs_copy_to_host(g_ctx, W.tr, W.d_tr, n * (uint64_t)WIN_TRACE_CAP * sizeof(hbs_trace_rec)))) die("hbs_copy_to_host", rc);
     }
     W.trace = trace;
+    W.parsed_ok = 1;
 }
 
 /* index + extract + parse the first min(size, WIN_MAX) bytes of buf as one batch; 0: no batch (too many NALs, nothing terminated) */
@@ -377,12 +450,15 @@ static int window_build(uint8_t* buf, int size)
     int rc;
     hbs_summary s;
     uint64_t len = (uint64_t)size < WIN_MAX ? (uint64_t)size : WIN_MAX, cap, n;
-    {
+    static int env_read = 0;
+    if (!env_read) {
         const char* tc = getenv("HBS_LEGACY_TRACE_CAP");
         if (tc && atoi(tc) > 0 && (uint32_t)atoi(tc) < WIN_TRACE_CAP_MAX) g_win_trace_cap = (uint32_t)atoi(tc);
+        env_read = 1;
     }
     window_settle();
-    W.valid = 0;
+    window_drop();
+    g_stat[0] += 1;
     cap = len / 48 + 64;                                        /* NALs of 48 bytes and less: not what this is for */
     grow_dev(&W.d_stream, &W.d_stream_cap, len + 64);
     grow_dev(&W.d_rbsp, &W.d_rbsp_cap, len + 64);
@@ -392,6 +468,7 @@ static int window_build(uint8_t* buf, int size)
         free(W.ent); free(W.parsed);
         W.ent = (hbs_nal_entry*)malloc((size_t)(W.ent_cap * sizeof(hbs_nal_entry)));
         W.parsed = (hbs_parsed_nal*)malloc((size_t)(W.ent_cap * sizeof(hbs_parsed_nal)));
+        if (!W.ent || !W.parsed) { free(W.ent); free(W.parsed); W.ent = NULL; W.parsed = NULL; W.ent_cap = 0; return 0; }   /* no batch: one call at a time */
     }
     if (!W.d_misc && (rc = hbs_dev_alloc(g_ctx, 256 + 2 * ((hbs_sps_slot_bytes() + 255) & ~(uint64_t)255) + sizeof(hevc_pps_t), (void**)&W.d_misc))) die("hbs_dev_alloc", rc);
     /* straight from the caller's buffer (a pageable copy that waits: page-locking a staging buffer of this size costs more than it saves) */
@@ -406,13 +483,14 @@ static int window_build(uint8_t* buf, int size)
     if (n < 2) return 0;
     W.n = n; W.len = len; W.base = buf;
     W.rbsp_bytes = W.ent[n - 1].rbsp_off + W.ent[n - 1].rbsp_len;
-    grow_host((void**)&W.copy, &W.copy_cap, len);
+    if (!grow_host_try((void**)&W.copy, &W.copy_cap, len)) return 0;
     memcpy(W.copy, buf, (size_t)len);
-    grow_host((void**)&W.rbsp, &W.rbsp_cap, W.rbsp_bytes + 64);
+    if (!grow_host_try((void**)&W.rbsp, &W.rbsp_cap, W.rbsp_bytes + 64)) return 0;
     if (W.rbsp_bytes && (rc = hbs_copy_to_host(g_ctx, W.rbsp, W.d_rbsp, W.rbsp_bytes))) die("hbs_copy_to_host", rc);
-    W.valid = 1; W.find_next = 0; W.served = 0; W.synced = 0;
-    window_parse(g_read_mode);
-    return W.valid;
+    /* The parse waits for the first read: only that call knows the mode (plain or trace -- round 4 parsed every first batch in
+     * trace mode and a plain reader paid for a second pass) and the parameter sets the caller's object holds. */
+    W.valid = 1; W.parsed_ok = 0; W.find_next = 0; W.served = 0; W.synced = 0;
+    return 1;
 }
 
 /* ---- byte layer ------------------------------------------------------------------------- */
@@ -436,11 +514,15 @@ static int find_nal_unit_unlocked(uint8_t* buf, int size, int* nal_start, int* n
             return *nal_end - *nal_start;
         }
     }
-    if ((uint64_t)size >= WIN_MIN && !getenv("HBS_LEGACY_NO_BATCH")) {
+    if (g_no_batch < 0) g_no_batch = getenv("HBS_LEGACY_NO_BATCH") ? 1 : 0;
+    if ((uint64_t)size >= WIN_MIN && !g_no_batch) {
         /* a buffer worth a batch (not one this call was already answered from: that is the case above) */
         const int rest_of_old = W.valid && W.find_next >= W.n && buf == W.base + W.ent[W.n - 1].end &&
                                 (uint64_t)size <= W.len - W.ent[W.n - 1].end;     /* what the batch left: its unterminated last NAL */
-        if (!rest_of_old && window_build(buf, size)) {
+        if (!rest_of_old && g_skip_builds > 0) {                                   /* the last batches did not pay: not this time */
+            g_skip_builds -= 1;
+            g_stat[3] += 1;
+        } else if (!rest_of_old && window_build(buf, size)) {
             const hbs_nal_entry* cur = &W.ent[0];
             *nal_start = (int)cur->start;
             *nal_end = (int)cur->end;
@@ -723,11 +805,13 @@ static int serve_from_window(hevc_stream_t* h, uint8_t* buf, int size, int* stri
     } else if (t == HEVC_NAL_UNIT_TYPE_SPS_NUT) {
         memcpy(h->sps, src, sizeof(hevc_sps_t));
         memcpy(g_sps_shadow, src, sizeof(hevc_sps_t));                   /* what the device-side state will hold once it is brought up to here */
+        g_sps_shadow_ok = 1;
         if (h->sps->sps_seq_parameter_set_id >= 0 && h->sps->sps_seq_parameter_set_id < 32)
             memcpy(h->sps_table[h->sps->sps_seq_parameter_set_id], h->sps, sizeof(hevc_sps_t));
     } else if (t == HEVC_NAL_UNIT_TYPE_PPS_NUT) {
         memcpy(h->pps, src, sizeof(hevc_pps_t));
         memcpy(g_pps_shadow, src, sizeof(hevc_pps_t));
+        g_pps_shadow_ok = 1;
         if (h->pps->pic_parameter_set_id >= 0 && h->pps->pic_parameter_set_id < 256)
             memcpy(h->pps_table[h->pps->pic_parameter_set_id], h->pps, sizeof(hevc_pps_t));
     } else if (is_slice(t)) {
@@ -761,28 +845,50 @@ static int read_nal(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int
     *stripped = 0;
     if (size < 0) return -1;
     if (need_ctx()) return -1;
-    g_read_mode = trace ? 1 : 0;
     if (W.valid && W.served < W.n) {
-        const uint64_t k = W.served;
+        uint64_t k = W.served;
         const hbs_nal_entry* we = &W.ent[k];
-        const int mine = buf == W.base + we->start && (uint64_t)size == we->end - we->start && memcmp(buf, W.copy + we->start, (size_t)size) == 0 &&
-                         g_sps_shadow_ok && g_pps_shadow_ok && memcmp(g_sps_shadow, h->sps, sizeof(hevc_sps_t)) == 0 &&
-                         memcmp(g_pps_shadow, h->pps, sizeof(hevc_pps_t)) == 0;
+        int mine;
+        if (!W.parsed_ok && buf >= W.base + we->start && buf < W.base + W.len) {
+            /* the batch's parse, now that the mode and the caller's parameter sets are known */
+            sync_context(h);
+            window_parse(trace);
+            if (!W.valid) { W.valid = 1; window_drop(); }
+        }
+        mine = W.valid && W.parsed_ok && buf == W.base + we->start && (uint64_t)size == we->end - we->start;
+        if (!mine && W.valid && W.parsed_ok && buf > W.base + we->start && buf < W.base + W.len) {
+            /* A LATER NAL of the batch: the caller skipped some (an AUD, SEI or VPS it has no use for).  Skipped NALs that the
+             * parser would not have taken anything from or left anything behind -- everything but SPS, PPS and slices -- change
+             * nothing for the NALs behind them: the batch goes on at this one, and the state pass over the skipped range
+             * (window_settle) passes over them just as well.  A skipped parameter set or slice ends the batch. */
+            uint64_t j = k;
+            const uint64_t off = (uint64_t)(buf - W.base);
+            while (j < W.n && W.ent[j].start < off) {
+                const int tj = W.parsed[j].nal_unit_type;
+                if ((W.ent[j].status & HBS_ST_ERROR) == 0 && (tj == HEVC_NAL_UNIT_TYPE_SPS_NUT || tj == HEVC_NAL_UNIT_TYPE_PPS_NUT || is_slice(tj))) break;
+                ++j;
+            }
+            if (j < W.n && W.ent[j].start == off && (uint64_t)size == W.ent[j].end - off) { k = j; we = &W.ent[k]; W.served = k; mine = 1; }
+        }
+        mine = mine && memcmp(buf, W.copy + we->start, (size_t)size) == 0;
+        mine = mine && W.valid && g_sps_shadow_ok && g_pps_shadow_ok && memcmp(g_sps_shadow, h->sps, sizeof(hevc_sps_t)) == 0 &&
+               memcmp(g_pps_shadow, h->pps, sizeof(hevc_pps_t)) == 0;
         if (mine && trace != W.trace && k == W.synced) {
             /* the batch was parsed for the other reader: parse what is left of it again, in this one */
             window_settle();
             if (k) {                                            /* (from NAL k on: the window shrinks to its rest) */
-                W.valid = 0;
+                window_drop();
             } else window_parse(trace);
         }
-        if (mine && W.valid && trace == W.trace && (!trace || W.trn[k] <= WIN_TRACE_CAP)) return serve_from_window(h, buf, size, stripped, trace);
+        if (mine && W.valid && trace == W.trace && (!trace || W.trn[k] <= WIN_TRACE_CAP)) { g_stat[1] += 1; return serve_from_window(h, buf, size, stripped, trace); }
         /* not the call the batch expected, or one it cannot answer: the old way, from the state behind the NALs answered so far */
         window_settle();
         if (mine && W.valid) { /* this very NAL, one call at a time; the batch goes on behind it */ }
-        else W.valid = 0;
+        else window_drop();
     } else if (W.valid) {
         window_settle();                                        /* everything answered: the old way continues from the state behind the batch */
     }
+    g_stat[2] += 1;
     need_bufs((uint64_t)size + 16, 0);
     need_block((uint64_t)size + 16);
     upload_input(sc, 3, buf, (uint64_t)size);
@@ -851,9 +957,22 @@ void hbs_legacy_reset_tables(void)
     legacy_lock();
     if (need_ctx() == 0) {
         W.valid = 0;
+        g_backoff = g_skip_builds = 0;
         if ((rc = hbs_fill_device(g_ctx, g_dsps_slot, 0, hbs_sps_slot_bytes()))) die("hbs_fill_device", rc);
-        g_sps_shadow_ok = 0;
+        /* the slot's SPS is all zero now and the shadow says so: batches stay possible (round 4's advice: with the shadow marked
+         * unknown every batch was built and then turned down until a one-call SPS read came by) */
+        memset(g_sps_shadow, 0, sizeof(hevc_sps_t));
+        g_sps_shadow_ok = 1;
     }
+    legacy_unlock();
+}
+
+/* Test hook: out[0] batches built, [1] reads answered from a batch, [2] reads answered one call at a time, [3] batch builds
+ * suppressed by the back-off. */
+void hbs_legacy_batch_stats(uint64_t out[4])
+{
+    legacy_lock();
+    memcpy(out, g_stat, sizeof(g_stat));
     legacy_unlock();
 }
 
@@ -862,9 +981,9 @@ void hbs_legacy_reset_tables(void)
 static int read_nal_w(hevc_stream_t* h, uint8_t* buf, int size, int* stripped, int trace)
 {
     const int was_valid = W.valid;
-    const uint64_t k = W.served;
     const int r = read_nal(h, buf, size, stripped, trace);
-    if (was_valid && W.valid && W.served == k && k < W.n && buf == W.base + W.ent[k].start && (uint64_t)size == W.ent[k].end - W.ent[k].start) {
+    const uint64_t k = W.served;         /* (answered from the batch: already one further, and buf is not that NAL) */
+    if (was_valid && W.valid && k < W.n && buf == W.base + W.ent[k].start && (uint64_t)size == W.ent[k].end - W.ent[k].start) {
         W.served = k + 1;
         W.synced = k + 1;
     }
@@ -915,7 +1034,7 @@ static int write_hevc_nal_unit_unlocked(hevc_stream_t* h, uint8_t* buf, int size
     if (size < 0) return -1;
     if (need_ctx()) return -1;
     window_settle();                                                     /* the writers read (and an SPS rewrites) the tables in force */
-    W.valid = 0;
+    window_drop();
     cap = (uint32_t)((long)size * 3 / 4);
     need_bufs(16, (uint64_t)cap + 16);
     need_block(0);

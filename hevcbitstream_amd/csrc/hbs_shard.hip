@@ -49,8 +49,10 @@ Rccl g_rccl;
 bool load_rccl()
 {
     if (g_rccl.so) return true;
-    /* HBS_RCCL_LIB: another library with RCCL's entry points (tests/sim/fake_rccl.c: a transport between processes that
-     * share ONE GPU, which RCCL itself refuses; the product never sets it) */
+    /* HBS_RCCL_LIB (a supported override, include/hevcbitstream_amd.h): the path of the library to take RCCL's ten entry points
+     * from instead of the librccl.so.1 the loader finds -- a site's own RCCL build, or, in this project's tests, a shared-memory
+     * transport between processes that share ONE GPU (tests/sim/fake_rccl.cpp), which RCCL itself refuses.  Read once, at the
+     * first communicator; a library named here that does not load is an error, never a silent fall-back. */
     const char* alt = getenv("HBS_RCCL_LIB");
     void* so = alt && *alt ? dlopen(alt, RTLD_NOW | RTLD_GLOBAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!so && !(alt && *alt)) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -149,6 +151,18 @@ void hbs_comm_destroy(hbs_comm* h)
 
 int hbs_comm_rank(const hbs_comm* h) { return h ? h->rank : HBS_E_ARG; }
 int hbs_comm_world(const hbs_comm* h) { return h ? h->world : HBS_E_ARG; }
+
+/* Workgroup slots to leave beside the persistent scan (hbs_ctx_reserve_workgroups) so that the gather's kernels find a CU while
+ * the next scan runs.  A function of the world: the all-to-all form of the exchange (root = -1) is one grouped broadcast per
+ * rank, and RCCL runs a group's transfers on one channel -- one workgroup -- per peer at least; measured at world 1 (round 3:
+ * with 8 or 16 free slots RCCL still waited for the scan, with 32 a 54 MB copy ran beside it), so: 8 per peer, at least 32 (a
+ * lone rank's local copy), at most 64 of the 512 (one eighth of the GPU: beyond it the scan loses more than the gather wins). */
+int hbs_comm_reserve_hint(const hbs_comm* h)
+{
+    if (!h) return HBS_E_ARG;
+    const int want = 8 * (h->world - 1);
+    return want < 32 ? 32 : want > 64 ? 64 : want;
+}
 
 static int gather_impl(hbs_ctx* ctx, hbs_comm* h, const hbs_nal_entry* d_index, uint64_t n_local, int stopped,
                        uint64_t stream_base, uint64_t rbsp_base, int root,

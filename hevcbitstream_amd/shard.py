@@ -77,6 +77,11 @@ class LibraryComm:
         """the communicator's own idea of its size"""
         return int(self.lib.hbs_comm_world(self.h))
 
+    def reserve_hint(self):
+        """workgroup slots to leave free beside the scan for this communicator's exchange (hbs_comm_reserve_hint)"""
+        self.lib.hbs_comm_reserve_hint.argtypes = [C.c_void_p]
+        return int(self.lib.hbs_comm_reserve_hint(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.hbs_comm_destroy(self.h)

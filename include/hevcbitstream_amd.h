@@ -386,7 +386,9 @@ int hbs_write_headers(hbs_ctx* ctx, const hbs_parsed_nal* d_parsed, uint64_t n_n
  * Every rank indexes its own bytes; the one exchange of the path is the gather of the NAL index: the counts (8 bytes per
  * rank) to everybody, then exactly count x 32 bytes per rank, to `root` or (root = -1) to every rank, over RCCL (xGMI inside
  * a node).  Stream bytes and RBSP arenas never travel.  RCCL is looked up at run time (librccl.so.1; the copy the process
- * already carries, if any), so the library has no link-time dependency on it.
+ * already carries, if any), so the library has no link-time dependency on it.  Environment HBS_RCCL_LIB=<path> (read once, when
+ * the first communicator is made) names the library to take RCCL's entry points from instead -- a site's own RCCL build; this
+ * project's tests point it at a shared-memory stand-in to run world > 1 on one GPU.  A path that does not load is an error.
  *
  *   hbs_comm_unique_id   rank 0 makes the 128-byte id; the caller hands it to every rank by its own means (MPI, a file, a socket,
  *                        torch.distributed ...)
@@ -415,6 +417,9 @@ int  hbs_comm_adopt(hbs_ctx* ctx, void* nccl_comm, int rank, int world, hbs_comm
 void hbs_comm_destroy(hbs_comm* comm);
 int  hbs_comm_rank(const hbs_comm* comm);
 int  hbs_comm_world(const hbs_comm* comm);
+/* how many workgroup slots hbs_ctx_reserve_workgroups should leave free for this communicator's exchange to run beside the
+ * next scan: 8 per peer, between 32 and 64 (of 512) */
+int  hbs_comm_reserve_hint(const hbs_comm* comm);
 int  hbs_gather_index(hbs_ctx* ctx, hbs_comm* comm, const hbs_nal_entry* d_index, uint64_t n_local,
                       uint64_t stream_base, uint64_t rbsp_base, int root,
                       hbs_nal_entry* d_all, uint64_t cap_all, uint64_t* counts_out);
@@ -495,6 +500,11 @@ uint64_t hbs_ctx_device_bytes(hbs_ctx* ctx);
  * the reference (file-static, zero at program start, hevc_stream.c:26-32) and device state here; this puts them back to
  * "program start", which the reference can only do by starting a new process.  Not part of the reference's API. */
 void hbs_legacy_reset_tables(void);
+/* Legacy symbols only, a measuring / testing aid: how the loop of a caller was answered so far -- out[0] batches built (one
+ * upload + index + extraction + parse of up to 64 MiB each), [1] reads answered from a batch, [2] reads answered one call at a
+ * time, [3] batch builds suppressed by the back-off (a batch that is dropped before the calls answered from it were worth its
+ * cost makes the next 1, 2, 4, ... find_nal_unit calls of large buffers go without one; hbs_legacy.c). */
+void hbs_legacy_batch_stats(uint64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ walked again (hbs_parse_fix.h).  Every NAL is compared with the oracle's sequent
 import os
 import sys
 import time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import hevcbitstream_amd as hbs

@@ -3,7 +3,7 @@ the placement effect and what the measuring allocator makes of it.  usage: pair_
 import os
 import sys
 import time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hevcbitstream_amd as hbs
 

@@ -414,3 +414,106 @@ def test_batch_api_two_contexts_two_threads(orc):
     for t in th:
         t.join()
     assert not errors, errors[:5]
+
+
+def _picture_stream(seed, n_pictures, with_aud=True, forbidden_every=0):
+    """NALs of a 4K30-like sequence with an AUD in front of every picture and an SEI behind its first slice (neither is
+    dispatched by the reference's reader: callers skip them or get -1), padded to batch size"""
+    from tests.hevc_synth import Synth
+    g = Synth(seed, rich=False)
+    rng = np.random.RandomState(seed + 1)
+    nals, count = [], 0
+    for pic in range(n_pictures):
+        idr = pic % 20 == 0
+        if with_aud:
+            nals.append(bytes([35 << 1, 1, 0x50]))
+        if idr:
+            nals += [g.vps(), g.sps_nal(3840, 2160, ctb_log2=6), g.pps_nal(force={"tiles": 0, "lists_mod": 1} if forbidden_every else {"tiles": 0})]
+        for sl in range(4):
+            payload = rng.randint(0, 256, size=int(rng.randint(300, 1500))).astype(np.uint8).tobytes()
+            count += 1
+            if forbidden_every and not idr and count % forbidden_every == 0:
+                nals.append(g.slice_nal(19, first=(sl == 0), payload=payload, slice_type=1, address=sl * 510))
+            else:
+                nals.append(g.slice_nal(19 if idr else 1, first=(sl == 0), payload=payload, address=sl * 510))
+            if sl == 0 and with_aud:
+                nals.append(bytes([39 << 1, 1, 1, 2, 3, 0x80]))
+    return nals
+
+
+@pytest.mark.parametrize("caller", ["in-order", "skips-aud-sei", "scratch-copy", "skips-a-slice", "flips-reader"])
+def test_batch_loop_with_deviating_callers(caller):
+    """One batch per buffer (hbs_legacy.c) under callers that are NOT hevc_analyze's loop (round 4's advice): a caller that skips
+    the AUD / SEI NALs (the batch goes on at the NAL it asks for), one that parses every NAL from a scratch copy (the batch never
+    fits: after the first, the back-off keeps them from being built once per NAL), one that skips a slice (ends the batch: the
+    state behind the skipped range must not include it), one that reads some NALs with the other reader.  Every answer against
+    the oracle's sequential parser fed the same calls."""
+    import hevcbitstream_amd as hbs
+    from tests.hevc_synth import annexb
+    lib = hbs.load_library()
+    u8p = C.POINTER(C.c_uint8)
+    lib.find_nal_unit.argtypes = [u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.read_hevc_nal_unit.argtypes = [C.c_void_p, u8p, C.c_int]
+    lib.read_debug_hevc_nal_unit.argtypes = [C.c_void_p, u8p, C.c_int]
+    lib.hbs_legacy_batch_stats.argtypes = [C.POINTER(C.c_uint64)]
+    nals = _picture_stream(31, 120, forbidden_every=9 if caller == "skips-a-slice" else 0)
+    buf = np.frombuffer(annexb(nals) + b"\x00\x00\x01", dtype=np.uint8).copy()
+    assert len(buf) > (128 << 10)
+    base = buf.ctypes.data
+    lib.hbs_legacy_reset_tables()
+    ours, orc_p = LegacyHevc(lib), _orc.OracleHevc()
+    st0 = (C.c_uint64 * 4)()
+    lib.hbs_legacy_batch_stats(st0)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    p, k, reads = 0, 0, 0
+    while True:
+        s, e = C.c_int(0), C.c_int(0)
+        r = lib.find_nal_unit(C.cast(base + p, u8p), len(buf) - p, C.byref(s), C.byref(e))
+        if r <= 0:
+            break
+        nal = bytes(buf[p + s.value: p + e.value])
+        assert nal == nals[k], k
+        t = (nal[0] >> 1) & 0x3F
+        skip = (caller == "skips-aud-sei" and t in (35, 39)) or (caller == "skips-a-slice" and k % 37 == 20 and t < 32)
+        if not skip:
+            if caller == "scratch-copy":
+                tmp = np.frombuffer(nal + b"\xff" * 8, dtype=np.uint8).copy()
+                ra = lib.read_hevc_nal_unit(ours.h, tmp.ctypes.data_as(u8p), len(nal))
+            elif caller == "flips-reader" and k % 50 == 25:
+                # the debug reader prints to stdout: send the C library's stdout to /dev/null for this call
+                C.CDLL(None).fflush(None)
+                keep = os.dup(1)
+                os.dup2(devnull, 1)
+                try:
+                    ra = lib.read_debug_hevc_nal_unit(ours.h, C.cast(base + p + s.value, u8p), len(nal))
+                    C.CDLL(None).fflush(None)
+                finally:
+                    os.dup2(keep, 1)
+                    os.close(keep)
+            else:
+                ra = lib.read_hevc_nal_unit(ours.h, C.cast(base + p + s.value, u8p), len(nal))
+            rb = orc_p.read(nal)
+            assert ra == rb, (caller, k, t, ra, rb)
+            a, b = ours.snapshot(), orc_p.snapshot()
+            kind = "sh" if (t <= 9 or 16 <= t <= 21) else {32: "vps", 33: "sps", 34: "pps"}.get(t)
+            for name in (["nal"] + ([kind] if kind else [])):
+                assert np.array_equal(a[name], b[name]), (caller, k, name)
+            if kind == "sh" and ra >= 0:
+                assert ours.slice_data() == orc_p.slice_data(), (caller, k)
+            reads += 1
+        p += e.value
+        k += 1
+    os.close(devnull)
+    assert k == len(nals)
+    st = (C.c_uint64 * 4)()
+    lib.hbs_legacy_batch_stats(st)
+    built, from_batch, one_by_one, suppressed = [int(st[i]) - int(st0[i]) for i in range(4)]
+    assert from_batch + one_by_one == reads
+    if caller in ("in-order", "skips-aud-sei"):
+        assert built == 1 and from_batch == reads, (built, from_batch, one_by_one, reads)
+    if caller == "scratch-copy":
+        # batches of 128 KiB+ are tried at find calls 1, 3, 6, 11, 20, ...: a dozen for ~1000 NALs, not one per NAL
+        assert from_batch == 0 and built <= 12 and suppressed > 500, (built, suppressed, reads)
+    if caller in ("skips-a-slice", "flips-reader"):
+        assert from_batch > reads // 2, (built, from_batch, one_by_one, reads)
+    orc_p.close()

@@ -105,7 +105,7 @@ def test_library_gather_and_parts_of_one_stream(orc):
 
 
 def test_two_ranks_share_one_gpu(orc, tmp_path):
-    """hbs_gather_index / hbs_gather_parts with world = 2 and 3 on ONE GPU (tests/tools/shard_worker.py, one process per rank):
+    """hbs_gather_index / hbs_gather_parts with world = 2, 3 and 8 on ONE GPU (tests/tools/shard_worker.py, one process per rank):
     to all and to every root with ranks of different (and zero) counts; a receiver whose buffer is too small -- EVERY rank gets
     HBS_E_CAPACITY and the communicator stays usable (round 2's advice: the receiver used to return alone, the others hung);
     one stream in parts with an empty NAL in the first or the last part (the whole-stream walk ends there).  RCCL refuses two
@@ -135,7 +135,7 @@ def test_two_ranks_share_one_gpu(orc, tmp_path):
     lib.fake_rccl_segment_bytes.restype = C.c_uint64
     lib.fake_rccl_segment_bytes.argtypes = [C.c_int, C.c_uint64]
     slot = 4 << 20
-    for world in (2, 3):
+    for world in (2, 3, 8):       # 8: a full node -- grouped broadcasts / send-receive with seven peers, ranks with no entries
         shm = shared_memory.SharedMemory(create=True, size=int(lib.fake_rccl_segment_bytes(world, slot)))
         try:
             env = dict(os.environ, HBS_RCCL_LIB=fake, HBS_FAKE_RCCL_SHM="/" + shm.name.lstrip("/"), HBS_FAKE_RCCL_SLOT=str(slot))

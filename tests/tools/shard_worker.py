@@ -19,6 +19,7 @@ orc = _orc.oracle()
 ctx = hbs.Context(0)
 comm = shard.LibraryComm(ctx, None, rank, world, ident=b"\x5a" * 128)
 assert comm.world_seen() == world
+assert comm.reserve_hint() == min(64, max(32, 8 * (world - 1))), comm.reserve_hint()      # slots for the exchange beside the scan: a function of the world
 E = shard.ENTRY_BYTES
 
 
@@ -36,7 +37,7 @@ def dev(e):
 
 
 # 1. independent shards of different sizes (one of them empty), to everybody and to each root
-sizes = [1000, 0, 37, 5][:world] if world <= 4 else [100 + r for r in range(world)]
+sizes = [1000, 0, 37, 5, 0, 211, 64, 3][:world] if world <= 8 else [100 + r for r in range(world)]      # (world 8: two empty ranks, seven peers per group)
 mine = entries(sizes[rank], 1000 * rank)
 want_all = np.concatenate([entries(sizes[r], 1000 * r) for r in range(world)])
 for root in [-1] + list(range(world)):
