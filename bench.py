@@ -181,6 +181,136 @@ def cpu_baseline_parse(stream_dev, index_dev, rbsp_dev, m, parsed, structs_dev):
             "parity_checked_nals": m}
 
 
+def cpu_baseline_1gib(stream_dev, sb, n, index_dev, rbsp_dev, rb, index_only_dev, emitted_dev, emitted_index_dev):
+    """BASELINE configs 2 and 4 pinned on the reference at the size they name: the WHOLE 1 GiB stream through the reference's own
+    loop on one host core (find_nal_unit + nal_to_rbsp per NAL, hevc_analyze.c:135-177 / h264_nal.c:38-200; timed), every entry
+    of the GPU's index (with and without an arena) and every byte of its RBSP arena compared with what that walk produced; then
+    the reference's rbsp_to_nal (h264_nal.c:92-132; timed) over the reference's arena, every byte and every output entry of the
+    stream the GPU re-emitted compared with it -- and with the input bytes (the round trip config 4 asks for)."""
+    import numpy as np
+    from tests._refwalk import device_equals_host, reference_emit, reference_walk
+    from tests import _orc
+    host = stream_dev[:sb].cpu().numpy()
+    t0 = time.perf_counter()
+    ent, ref_arena, ref_rb, kind = reference_walk(host, n + 16)
+    t_walk = time.perf_counter() - t0
+    assert len(ent) == n and ref_rb == rb, (len(ent), n, ref_rb, rb)
+    got = index_dev[: n * 32].cpu().numpy().view(_orc.NAL_ENTRY)
+    got5 = index_only_dev[: n * 32].cpu().numpy().view(_orc.NAL_ENTRY)
+    for f in ("start", "end", "rbsp_off"):
+        assert np.array_equal(got[f], ent[f]), "config 2: index field %s differs from the %s's" % (f, kind)
+    for f in ("start", "end"):
+        assert np.array_equal(got5[f], ent[f]), "config 2, index only: field %s differs from the %s's" % (f, kind)
+    assert np.array_equal(got["rbsp_len"].astype(np.int64), ent["rbsp_len"].astype(np.int64)), "config 2: rbsp_len"
+    assert int((ent["rc_rbsp"] < 0).sum()) == 0
+    device_equals_host(rbsp_dev, ref_arena, ref_rb, "config 2: RBSP arena")
+    t0 = time.perf_counter()
+    ref_stream, ref_sb = reference_emit(ref_arena, ent, sb + (1 << 16))
+    t_emit = time.perf_counter() - t0
+    assert ref_sb == sb and np.array_equal(ref_stream[:sb], host), "the reference's own round trip"
+    device_equals_host(emitted_dev, ref_stream, sb, "config 4: re-emitted stream")
+    eo = emitted_index_dev[: n * 32].cpu().numpy().view(_orc.NAL_ENTRY)
+    for f in ("start", "end"):
+        assert np.array_equal(eo[f], ent[f]), "config 4: output index field %s" % f
+    what = {"reference": "oracle/_ref/libhevcref.so (the reference compiled here, gcc -O2) driven by oracle/ref_driver.c",
+            "port": "oracle/hbs_oracle_nal.c (the restatement pinned to it), gcc -O2"}[kind]
+    return {"config2": {"value": round(sb / t_walk / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+                        "sample": "the whole stream, %d NALs / %.3f GiB: find_nal_unit + nal_to_rbsp per NAL, %s, 1 thread, %.2f s; every entry of the GPU's index "
+                                  "(start, end, rbsp_off, rbsp_len; start / end of the index-only call too) and all %d bytes of its RBSP arena compared with this walk's: equal"
+                                  % (n, sb / 2**30, what, t_walk, ref_rb)},
+            "config4": {"value": round(sb / t_emit / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+                        "sample": "rbsp_to_nal per NAL over the whole arena, %s, 1 thread, %.2f s; all %d bytes the GPU emitted and its output index compared with this: equal, "
+                                  "and equal to the input stream (bit-exact round trip)" % (what, t_emit, sb)}}
+
+
+def configs_1gib(torch, hbs, ctx, check=True, reps=12):
+    """BASELINE.json configs[1] and configs[3] at the size they name: S(0x1234, 104 858 NALs) = 1.0003 GiB of ~10 KiB NALs,
+    resident in HBM.  Config 2: start-code scan + NAL index + RBSP extraction (hbs_index_extract), and the scan alone (no arena);
+    config 4: the arena re-emitted as Annex-B (hbs_emit_annexb).  Per call: kernel_ms = the library's HIP events around the
+    dominant kernel(s) on their own stream (what the 16 GiB headline's roofline uses), call_ms = the whole call, every launch of
+    it, from events around calls issued back to back; fractions of the 8 TB/s peak from the algorithmic bytes.  With `check`
+    (the default bench run) the WHOLE stream goes through the reference on the host and everything is compared (cpu_baseline_1gib)."""
+    n = 104_858
+    g = ctx.synth_stream(SEED, n, 0)
+    sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    stream = g["stream"][:sb]
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=stream)
+    place_arena = dict(ctx.last_pair_report)
+
+    def timed(fn, with_kernel_ms):
+        ks = []
+        fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        for i in range(reps + 1):
+            ev[i].record()
+            if i < reps:
+                fn()
+                if with_kernel_ms:
+                    ks.append(ctx.kernel_ms())           # (waits for that call: the next one is issued behind an idle stream -- the call_ms
+        torch.cuda.synchronize()                          #  loop below runs without it)
+        if with_kernel_ms:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            for i in range(reps + 1):
+                ev[i].record()
+                if i < reps:
+                    fn()
+            torch.cuda.synchronize()
+        calls = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+        ks.sort()
+        return (ks[len(ks) // 2] if ks else None), calls[len(calls) // 2], calls[0]
+
+    res = {"workload": "S(seed=0x1234, n_nals=%d, uniform): %.4f GiB Annex-B, ~10 KiB NALs, resident in HBM (BASELINE.json configs[1] and configs[3])" % (n, sb / 2**30),
+           "stream_bytes": sb, "nals": n, "rbsp_bytes": rb}
+    # config 2, with the arena
+    k_ms, c_med, c_min = timed(lambda: ctx.index_extract_async(stream, index, cap, rbsp, summary), True)
+    s = ctx.read_summary(summary)
+    assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["rbsp_bytes"]) == rb, s
+    algo = sb + rb + 32 * n
+    kern = {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4"}.get(ctx.last_kernel(), "?")
+    res["config2_extract"] = {"value": round(sb / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": kern, "kernel_ms": round(k_ms, 4), "call_ms": round(c_med, 4),
+                              "call_ms_min": round(c_min, 4), "algorithmic_bytes": algo,
+                              "roofline": {"bound": "hbm", "achieved": round(algo / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 4), "frac_of_call": round(algo / c_med / 1e6 / HBM_PEAK_GBS, 4)},
+                              "arena_placement": place_arena}
+    # config 2, the scan alone
+    index5 = torch.empty_like(index)
+    summary5 = torch.zeros_like(summary)
+    k_ms, c_med, c_min = timed(lambda: ctx.index_extract_async(stream, index5, cap, None, summary5), True)
+    s5 = ctx.read_summary(summary5)
+    assert int(s5["error"]) == 0 and int(s5["nal_count"]) == n
+    algo5 = sb + 32 * n
+    kern5 = {4: "hbs::k_scan_extract4", 5: "hbs::k_index5_stream (+ its aggregate / prefix / entry passes)", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?")
+    res["config2_index_only"] = {"value": round(sb / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": kern5, "kernel_ms": round(k_ms, 4), "call_ms": round(c_med, 4),
+                                 "call_ms_min": round(c_min, 4), "algorithmic_bytes": algo5,
+                                 "roofline": {"bound": "hbm", "achieved": round(algo5 / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": round(algo5 / k_ms / 1e6 / HBM_PEAK_GBS, 4), "frac_of_call": round(algo5 / c_med / 1e6 / HBM_PEAK_GBS, 4)}}
+    # config 4: the arena the scan extracted, re-emitted (default path)
+    torch.cuda.empty_cache()
+    out, place_out = ctx.pair_alloc(rbsp, sb + 4096)
+    idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+    esum = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    _, c_med, c_min = timed(lambda: ctx.emit_annexb_async(rbsp, rb, index, n, 1, out, idx_out, esum), False)
+    se = ctx.read_summary(esum)
+    assert int(se["error"]) == 0 and int(se["stream_bytes"]) == sb, se
+    by_tiles = int(ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h))
+    assert torch.equal(out[:sb], stream), "config 4: re-emitted stream != input bytes"
+    algo4 = rb + sb + 64 * n                                  # arena read, stream written, an index entry read and one written per NAL
+    res["config4_emit"] = {"value": round(sb / c_med / 1e6, 1), "unit": "GB/s emitted", "kernel": "hbs::k3_tiles<0>" if by_tiles else "hbs::k3_fused / k3_emit",
+                           "call_ms": round(c_med, 4), "call_ms_min": round(c_min, 4), "algorithmic_bytes": algo4,
+                           "roofline": {"bound": "hbm", "achieved": round(algo4 / c_med / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(algo4 / c_med / 1e6 / HBM_PEAK_GBS, 4),
+                                        "note": "of the WHOLE call (every launch of it): the library records no events inside hbs_emit_annexb"},
+                           "output_placement": place_out, "round_trip": "emitted bytes == input stream (compared on the device)"}
+    if check:
+        cb = cpu_baseline_1gib(stream, sb, n, index, rbsp, rb, index5, out, idx_out)
+        res["config2_extract"]["cpu_baseline"] = cb["config2"]
+        res["config2_index_only"]["parity"] = "start / end of every entry equal to the same walk's"
+        res["config4_emit"]["cpu_baseline"] = cb["config4"]
+    del out, idx_out, index5, index, rbsp
+    torch.cuda.empty_cache()
+    return res
+
+
 def pmc_traffic(kernel_name, algo_bytes):
     """profiles/r*/traffic_<kernel>.json of the newest round -- if it is about this kernel, this workload AND this
     source: the file records the digest of hevcbitstream_amd/csrc at profiling time; after any change to the kernels
@@ -426,6 +556,9 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     from tests.hevc_synth import stream_4k30
     res = {}
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    # BASELINE's own 1 GiB configs (2: scan + nal_to_rbsp, 4: the rbsp_to_nal write path), each with a roofline of its own and the
+    # whole stream compared with the reference's walk
+    res["configs_1GiB"] = configs_1gib(torch, hbs, ctx, check=cpu_parse)
     # find_nal_unit alone: the same stream, no RBSP arena asked for (the streaming kernel of hbs_scan5.hip)
     index, _, summ0, cap = ctx.alloc_outputs(sb, index_cap=n + 8, want_rbsp=False)
     kms = []
@@ -807,6 +940,35 @@ def main():
         if tr is not None:
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
+        if world == 1 and not args.plain_alloc:
+            # what placement buys, in THIS process: the same steps into an arena from torch's allocator (placement left to chance;
+            # outside the timed region), and what a second placed allocation costs now that the pool knows its chunks
+            index_p, rbsp_p, summary_p, cap_p = ctx.alloc_outputs(sb, index_cap=n + 8)
+            kp = []
+            for i in range(6):
+                ctx.index_extract_async(stream, index_p, cap_p, rbsp_p, summary_p)
+                if i:
+                    kp.append(ctx.kernel_ms())
+            assert int(ctx.read_summary(summary_p)["rbsp_bytes"]) == rb
+            kp.sort()
+            del rbsp_p, index_p
+            torch.cuda.empty_cache()
+            t_a = time.perf_counter()
+            again, rep2 = ctx.pair_alloc(stream, sb + 16)
+            torch.cuda.synchronize()
+            t_again = time.perf_counter() - t_a
+            ka = []
+            for i in range(4):
+                ctx.index_extract_async(stream, index, cap, again, summary)
+                if i:
+                    ka.append(ctx.kernel_ms())
+            ka.sort()
+            del again
+            out["roofline"]["placement"] = {"kernel_ms_placed_arena": round(k_ms, 4), "kernel_ms_plain_arena": round(kp[len(kp) // 2], 4),
+                                            "plain_over_placed": round(kp[len(kp) // 2] / k_ms, 4),
+                                            "second_placed_allocation": dict(rep2, seconds=round(t_again, 4), kernel_ms=round(ka[len(ka) // 2], 4)),
+                                            "note": "same process, same stream: the timed steps' arena (hbs_pair_alloc) against an arena from torch's allocator, "
+                                                    "then a SECOND hbs_pair_alloc of the same size while the first is alive (the pool's chunks are classed once)"}
         if world == 1 and args.cpu_sample_nals > 0:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(stream, index, rbsp, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:

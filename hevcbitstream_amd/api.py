@@ -18,6 +18,13 @@ WRITTEN = np.dtype([("rc", "<i4"), ("rbsp_size", "<u4"), ("slice_data_size", "<i
 PARSED = np.dtype([("rc", "<i4"), ("nal_unit_type", "<i4"), ("nal_layer_id", "<i4"), ("nal_temporal_id_plus1", "<i4"),
                    ("struct_off", "<u8"), ("slice_data_size", "<i4"), ("slice_data_off", "<u4")])
 
+# layout of hbs_slice_compact: sixteen members of hevc_slice_header_t, by name
+COMPACT_FIELDS = ("first_slice_segment_in_pic_flag", "no_output_of_prior_pics_flag", "pic_parameter_set_id", "dependent_slice_segment_flag",
+                  "slice_segment_address", "slice_type", "pic_output_flag", "slice_pic_order_cnt_lsb",
+                  "short_term_ref_pic_set_sps_flag", "short_term_ref_pic_set_idx", "num_long_term_pics", "slice_temporal_mvp_enabled_flag",
+                  "num_ref_idx_l0_active_minus1", "num_ref_idx_l1_active_minus1", "slice_qp_delta", "num_entry_point_offsets")
+COMPACT = np.dtype([(f, "<i4") for f in COMPACT_FIELDS])
+
 SEI_MAX_MESSAGES = 6
 EXT_NAL = np.dtype([("num_sei_messages", "<i4"), ("primary_pic_type", "<i4"), ("filler_bytes", "<u4"), ("reserved", "<u4"),
                     ("sei", [("payloadType", "<i4"), ("payloadSize", "<i4"), ("payload_off", "<u4"), ("reserved", "<u4")], (SEI_MAX_MESSAGES,))])
@@ -30,12 +37,12 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
-           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_comm_reserve_hint", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
-           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes", "hbs_pair_alloc", "hbs_pair_free", "hbs_parse_headers_state", "hbs_ctx_last_emit_by_tiles"]
+           "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_comm_reserve_hint", "hbs_parse_headers_compact", "hbs_parse_materialize", "hbs_index_parse_compact", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
+           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes", "hbs_pair_alloc", "hbs_pair_free", "hbs_pair_pool_trim", "hbs_pair_pool_stats", "hbs_parse_headers_state", "hbs_ctx_last_emit_by_tiles"]
 
 
 PAIR_REPORT = np.dtype([("chunks", "<u4"), ("probed", "<u4"), ("rejected", "<u4"), ("accepted_fast", "<u4"),
-                        ("unprobed_after_budget", "<u4"), ("reserved", "<f4")])
+                        ("unprobed_after_budget", "<u4"), ("from_pool", "<u4"), ("from_table", "<u4"), ("reserved", "<u4")])
 
 
 class _PairedMemory:
@@ -446,6 +453,60 @@ class Context:
                                       C.c_void_p(payload_off.data_ptr()) if payload_off is not None else None,
                                       C.c_void_p(scan_summary.data_ptr()), C.c_void_p(parse_summary.data_ptr()), C.byref(n))
         self._check(rc, "hbs_index_parse")
+        return int(n.value)
+
+    def parse_compact_async(self, rbsp, index, n_nals, parsed, compact, structs, summary, want=None, initial_sps_slot=None, initial_pps=None):
+        """hbs_parse_headers_compact (want is None) / hbs_parse_materialize (want: int64 / uint64 device tensor of NAL numbers).
+        structs None: plan only."""
+        self._bind_stream()
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None          # noqa: E731
+        common = [self.h, p(rbsp), p(index), n_nals, p(parsed), p(compact), p(structs), structs.numel() if structs is not None else 0,
+                  p(initial_sps_slot), p(initial_pps)]
+        if want is None:
+            self.lib.hbs_parse_headers_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p]
+            self._check(self.lib.hbs_parse_headers_compact(*common, p(summary)), "hbs_parse_headers_compact")
+        else:
+            self.lib.hbs_parse_materialize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+            self._check(self.lib.hbs_parse_materialize(*common, p(want), want.numel(), p(summary)), "hbs_parse_materialize")
+
+    def parse_headers_compact(self, rbsp, index, n_nals, want=None, poison=None):
+        """Plan, allocate, parse: (parsed ndarray[PARSED], compact ndarray[COMPACT], structs device tensor holding the parameter
+        sets and -- want: a list of NAL numbers -- the full slice headers of those NALs)."""
+        t = self.torch
+        dev = t.device("cuda", self.device)
+        parsed = t.empty(max(n_nals, 1) * PARSED.itemsize, dtype=t.uint8, device=dev)
+        compact = t.empty(max(n_nals, 1) * COMPACT.itemsize, dtype=t.uint8, device=dev)
+        summary = t.zeros(SUMMARY.itemsize, dtype=t.uint8, device=dev)
+        want_dev = None if want is None else t.as_tensor(np.asarray(want, dtype=np.int64), device=dev)
+        self.parse_compact_async(rbsp, index, n_nals, parsed, compact, None, summary, want_dev)
+        need = int(self.read_summary(summary)["reserved"][0])
+        structs = t.empty(need + 16, dtype=t.uint8, device=dev)
+        if poison is not None:
+            structs.fill_(poison)
+        self.parse_compact_async(rbsp, index, n_nals, parsed, compact, structs, summary, want_dev)
+        s = self.read_summary(summary)
+        if int(s["error"]) != 0:
+            e = HbsError("hbs_parse_headers_compact: error %d" % int(s["error"]))
+            e.code = int(s["error"])
+            raise e
+        return (parsed[: n_nals * PARSED.itemsize].cpu().numpy().view(PARSED).copy(),
+                compact[: n_nals * COMPACT.itemsize].cpu().numpy().view(COMPACT).copy(), structs)
+
+    def index_parse_compact_async(self, stream, index, index_cap, parsed, compact, structs, scan_summary, parse_summary, window=0, payload_off=None):
+        """hbs_index_parse_compact: as index_parse_async with the compact parse behind the scan"""
+        self._bind_stream()
+        self.lib.hbs_index_parse_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        n = C.c_uint64(0)
+        rc = self.lib.hbs_index_parse_compact(self.h, C.c_void_p(stream.data_ptr() if stream.numel() else None), stream.numel(),
+                                              C.c_void_p(index.data_ptr()), index_cap, window, C.c_void_p(parsed.data_ptr()), C.c_void_p(compact.data_ptr()),
+                                              C.c_void_p(structs.data_ptr()) if structs is not None else None,
+                                              structs.numel() if structs is not None else 0,
+                                              C.c_void_p(payload_off.data_ptr()) if payload_off is not None else None,
+                                              C.c_void_p(scan_summary.data_ptr()), C.c_void_p(parse_summary.data_ptr()), C.byref(n))
+        self._check(rc, "hbs_index_parse_compact")
         return int(n.value)
 
     def parse_extended(self, rbsp, index, n_nals, parsed_dev):

@@ -15,6 +15,7 @@
 #include "hbs_parse_launch.h"
 #include "hbs_hdrwin.h"
 #include "hbs_parse.h"
+#include "hbs_parse_compact.h"
 
 #ifndef HBS_DEFAULT_KERNEL
 #define HBS_DEFAULT_KERNEL 0
@@ -510,12 +511,50 @@ int hbs_parse_headers_trace(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
                                    d_trace, trace_cap, d_trace_count, d_summary, nullptr, nullptr);
 }
 
+static int parse_impl(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                      hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                      const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                      hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary,
+                      uint8_t* d_state_sps_slot, uint8_t* d_state_pps,
+                      hbs_slice_compact* d_compact, const uint64_t* d_want, uint64_t n_want);
+
 int hbs_parse_headers_state(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                             hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
                             const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
                             hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary,
                             uint8_t* d_state_sps_slot, uint8_t* d_state_pps)
 {
+    return parse_impl(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, d_initial_sps_slot, d_initial_pps,
+                      d_trace, trace_cap, d_trace_count, d_summary, d_state_sps_slot, d_state_pps, nullptr, nullptr, 0);
+}
+
+int hbs_parse_headers_compact(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                              hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap,
+                              const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary)
+{
+    if (!d_compact && n_nals) return HBS_E_ARG;
+    return parse_impl(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, d_initial_sps_slot, d_initial_pps,
+                      nullptr, 0, nullptr, d_summary, nullptr, nullptr, d_compact, nullptr, 0);
+}
+
+int hbs_parse_materialize(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                          hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap,
+                          const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                          const uint64_t* d_nal_list, uint64_t n_list, hbs_summary* d_summary)
+{
+    if ((!d_compact && n_nals) || (n_list && !d_nal_list)) return HBS_E_ARG;
+    return parse_impl(c, d_rbsp, d_index, n_nals, d_parsed, d_structs, structs_cap, d_initial_sps_slot, d_initial_pps,
+                      nullptr, 0, nullptr, d_summary, nullptr, nullptr, d_compact, d_nal_list, n_list);
+}
+
+static int parse_impl(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                      hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap,
+                      const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                      hbs_trace_rec* d_trace, uint32_t trace_cap, uint32_t* d_trace_count, hbs_summary* d_summary,
+                      uint8_t* d_state_sps_slot, uint8_t* d_state_pps,
+                      hbs_slice_compact* d_compact, const uint64_t* d_want, uint64_t n_want)
+{
+    static_assert(sizeof(hbs_slice_compact) == sizeof(hbs::SliceCompact), "public record == kernel record");
     if ((d_state_sps_slot == nullptr) != (d_state_pps == nullptr)) return HBS_E_ARG;
     if (d_state_sps_slot && (!d_structs || !n_nals)) return HBS_E_ARG;
     static_assert(sizeof(hbs_trace_rec) == sizeof(hbs::TraceRec), "public record == kernel record");
@@ -534,8 +573,9 @@ int hbs_parse_headers_state(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     const uint64_t b_rows = round256(hbs::parse_own_rows_bytes(n_nals));
     /* the exact re-walk's records: three words per NAL, a summary word per 256, the temporaries of its lanes */
     const uint64_t b_n4 = round256((n_nals + 1) * 4), b_bsum = round256((n_nals / 256 + 2) * 4), b_fix = round256(hbs::parse_fix_temps_bytes());
+    const uint64_t b_fixs = d_compact ? round256(hbs::parse_fix_structs_bytes()) : 0;     /* a compact parse's re-walk has no slots to walk into */
     const uint64_t fix_off = 3 * b_n + 512 + round256(1024 * 24) + b_rows;
-    int rc = ensure_ws(c, fix_off + 3 * b_n4 + b_bsum + 256 + b_fix);
+    int rc = ensure_ws(c, fix_off + 3 * b_n4 + b_bsum + 256 + b_fix + b_fixs);
     if (rc) return rc;
     uint8_t* w = static_cast<uint8_t*>(c->ws);
     hbs::ParseArgs a;
@@ -561,15 +601,41 @@ int hbs_parse_headers_state(hbs_ctx* c, const uint8_t* d_rbsp, const hbs_nal_ent
     a.fix_temps = reinterpret_cast<hbs::RpsRow*>(w + fix_off + 3 * b_n4 + b_bsum + 256);
     a.trace = reinterpret_cast<hbs::TraceRec*>(d_trace); a.trace_cap = trace_cap; a.trace_count = d_trace_count;
     a.state_sps_slot_out = d_state_sps_slot; a.state_pps_out = d_state_pps;
-    a.sequential = d_state_sps_slot ? 0 : c->parse_sequential;
+    a.compact = reinterpret_cast<hbs::SliceCompact*>(d_compact); a.want_list = d_want; a.want_n = d_compact ? n_want : 0;
+    a.fix_structs = d_compact ? w + fix_off + 3 * b_n4 + b_bsum + 256 + b_fix : nullptr;
+    a.sequential = (d_state_sps_slot || d_compact) ? 0 : c->parse_sequential;
     hipError_t e = hbs::launch_parse_headers(a, c->stream);
     return e == hipSuccess ? 0 : fail(c, e, "launch_parse_headers");
 }
+
+static int index_parse_impl(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
+                            hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
+                            hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
+                            hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out);
 
 int hbs_index_parse(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
                     hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
                     hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
                     hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out)
+{
+    return index_parse_impl(c, d_stream, stream_bytes, d_index, index_cap, header_window, d_parsed, nullptr, d_structs, structs_cap, d_payload_off,
+                            d_scan_summary, d_parse_summary, nal_count_out);
+}
+
+int hbs_index_parse_compact(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
+                            hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
+                            hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
+                            hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out)
+{
+    if (!d_compact) return HBS_E_ARG;
+    return index_parse_impl(c, d_stream, stream_bytes, d_index, index_cap, header_window, d_parsed, d_compact, d_structs, structs_cap, d_payload_off,
+                            d_scan_summary, d_parse_summary, nal_count_out);
+}
+
+static int index_parse_impl(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
+                            hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
+                            hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
+                            hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out)
 {
     if (!c || !d_scan_summary || !d_parse_summary || !d_index || !index_cap || !d_parsed) return HBS_E_ARG;
     if (header_window == 0) header_window = 512;
@@ -605,9 +671,10 @@ int hbs_index_parse(hbs_ctx* c, const uint8_t* d_stream, uint64_t stream_bytes,
     hipError_t e = hbs::launch_hdr_strip(a, c->stream);
     if (e != hipSuccess) return fail(c, e, "launch_hdr_strip");
     /* 3. K4 on the windows, 4. slice_data_size against the real lengths, windows that were too small reported */
-    rc = hbs_parse_headers(c, a.arena, a.idx2, nals, d_parsed, d_structs, structs_cap, d_parse_summary);
+    rc = d_compact ? hbs_parse_headers_compact(c, a.arena, a.idx2, nals, d_parsed, d_compact, d_structs, structs_cap, nullptr, nullptr, d_parse_summary)
+                   : hbs_parse_headers(c, a.arena, a.idx2, nals, d_parsed, d_structs, structs_cap, d_parse_summary);
     if (rc) return rc;
-    e = hbs::launch_hdr_fix(a, d_parsed, d_parse_summary, reinterpret_cast<unsigned long long*>(d_payload_off), c->stream);
+    e = hbs::launch_hdr_fix(a, d_parsed, d_parse_summary, reinterpret_cast<unsigned long long*>(d_payload_off), c->stream, d_compact ? 1 : 0);
     return e == hipSuccess ? 0 : fail(c, e, "launch_hdr_fix");
 }
 

@@ -2093,6 +2093,10 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     unsigned long long dz_tile_t0 = 0;
 #endif
     uint64_t d_tile = 0;
+#ifndef HBS3_FIRST_BY_TICKET
+#define HBS3_FIRST_BY_TICKET 0         /* 1: a workgroup's first tile by ticket too (round 4's way; A/B timing) */
+#endif
+    bool first_tile = true;
     for (;;) {
     int pending = 0;                   /* 1: a dense tile -- walked below the tile loop, where no row is live (as in hbs_scan4.hip) */
     for (;;) {
@@ -2105,9 +2109,11 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 const uint64_t have = *cand_count < cand_cap ? *cand_count : cand_cap;
                 l.ticket = tk < have ? cand_list[tk] : 0xFFFFFFFFu;
             } else {
-                l.ticket = atomicAdd(ticket, 1u);
+                /* the first tile is the workgroup's number, the others come by ticket (as hbs_scan4.hip) */
+                l.ticket = (!HBS3_FIRST_BY_TICKET && first_tile) ? blockIdx.x : (HBS3_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(ticket, 1u);
             }
         }
+        first_tile = false;
         if (tid < kTWaves * kTRows) l.rowbits[tid] = 0ull;
         __syncthreads();
         const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);

@@ -25,7 +25,7 @@ struct HdrWinArgs {
 
 uint64_t hdrwin_arena_bytes(uint64_t index_cap, uint32_t window, uint64_t stream_bytes);
 hipError_t launch_hdr_strip(const HdrWinArgs& a, hipStream_t st);
-hipError_t launch_hdr_fix(const HdrWinArgs& a, void* parsed, hbs_summary* summary, unsigned long long* payload_off, hipStream_t st);
+hipError_t launch_hdr_fix(const HdrWinArgs& a, void* parsed, hbs_summary* summary, unsigned long long* payload_off, hipStream_t st, int compact = 0);
 
 } // namespace hbs
 #endif

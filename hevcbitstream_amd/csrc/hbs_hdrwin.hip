@@ -151,13 +151,13 @@ void k_hdr_strip(const uint8_t* __restrict__ stream, const hbs_nal_entry* __rest
 __global__ __launch_bounds__(256)
 void k_hdr_fix(const hbs_nal_entry* __restrict__ index, const hbs_nal_entry* __restrict__ idx2, uint64_t nals,
                ParsedWin* __restrict__ parsed, const uint32_t* __restrict__ flags, hbs_summary* __restrict__ summary,
-               const uint8_t* __restrict__ stream, const EpbNote* __restrict__ notes, unsigned long long* __restrict__ payload_off)
+               const uint8_t* __restrict__ stream, const EpbNote* __restrict__ notes, unsigned long long* __restrict__ payload_off, int compact)
 {
     bool overflow = false;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nals; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t full = index[k].rbsp_len, have = idx2[k].rbsp_len;
         ParsedWin p = parsed[k];
-        const bool slice = p.nal_unit_type >= 0 && p.nal_unit_type < 32 && p.struct_off != ~0ull;
+        const bool slice = p.nal_unit_type >= 0 && p.nal_unit_type < 32 && (p.struct_off != ~0ull || compact);    /* (a compact parse gives slices no struct) */
         const bool pset = p.nal_unit_type >= 32 && p.nal_unit_type <= 34;
         if (payload_off) payload_off[k] = ~0ull;
         if (have < full) {
@@ -222,13 +222,13 @@ hipError_t launch_hdr_strip(const HdrWinArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_hdr_fix(const HdrWinArgs& a, void* parsed, hbs_summary* summary, unsigned long long* payload_off, hipStream_t st)
+hipError_t launch_hdr_fix(const HdrWinArgs& a, void* parsed, hbs_summary* summary, unsigned long long* payload_off, hipStream_t st, int compact)
 {
     if (a.nals) {
         uint64_t blocks = (a.nals + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         k_hdr_fix<<<dim3((unsigned)blocks), 256, 0, st>>>(a.index, a.idx2, a.nals, static_cast<ParsedWin*>(parsed),
-                                                           reinterpret_cast<const uint32_t*>(a.bump + 1), summary, a.stream, static_cast<const EpbNote*>(a.notes), payload_off);
+                                                           reinterpret_cast<const uint32_t*>(a.bump + 1), summary, a.stream, static_cast<const EpbNote*>(a.notes), payload_off, compact);
     }
     return hipGetLastError();
 }

@@ -307,10 +307,14 @@ static uint32_t g_backoff = 0, g_skip_builds = 0;
 static uint64_t g_stat[4];           /* batches built, reads answered from a batch, reads answered one call at a time, builds suppressed */
 static int g_no_batch = -1;          /* HBS_LEGACY_NO_BATCH, read once */
 
+static int g_debug = -1;              /* HBS_LEGACY_DEBUG: the batch's life on stderr (a debugging aid) */
+#define DBG(...) do { if (g_debug < 0) g_debug = getenv("HBS_LEGACY_DEBUG") ? 1 : 0; if (g_debug) fprintf(stderr, "hbs_legacy: " __VA_ARGS__); } while (0)
+
 static void window_drop(void)
 {
     if (!W.valid) return;
     W.valid = 0;
+    DBG("drop: served %llu, found %llu of %llu NALs, synced %llu\n", (unsigned long long)W.served, (unsigned long long)W.find_next, (unsigned long long)W.n, (unsigned long long)W.synced);
     if ((W.served > W.find_next ? W.served : W.find_next) * 600000ull >= 1200000ull + W.len) g_backoff = 0;
     else {
         g_backoff = g_backoff ? (g_backoff < 65536u ? g_backoff * 2 : g_backoff) : 1;
@@ -389,6 +393,7 @@ static void window_settle(void)
         /* reserved[1]: a chain of own RPS sets deeper than the exact re-walk follows, somewhere in this range (the batch as a whole
          * had none at its END, or it would not have been kept; an intermediate point can); error: the struct arena of the batch
          * was cut for all of it, a range cannot need more -- either way the single-NAL sequential path gives the same state */
+        DBG("settle [%llu, %llu): rc %d deep %llu error %d\n", (unsigned long long)a, (unsigned long long)W.served, rc, rc ? 0ull : (unsigned long long)s.reserved[1], rc ? 0 : s.error);
         if (rc || s.reserved[1] || s.error) window_replay(a, W.served);
     }
     W.synced = W.served;
@@ -490,6 +495,7 @@ static int window_build(uint8_t* buf, int size)
     /* The parse waits for the first read: only that call knows the mode (plain or trace -- round 4 parsed every first batch in
      * trace mode and a plain reader paid for a second pass) and the parameter sets the caller's object holds. */
     W.valid = 1; W.parsed_ok = 0; W.find_next = 0; W.served = 0; W.synced = 0;
+    DBG("build: %llu NALs in %llu bytes\n", (unsigned long long)n, (unsigned long long)len);
     return 1;
 }
 

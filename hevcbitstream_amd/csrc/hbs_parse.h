@@ -78,12 +78,12 @@ HBS_HD RowView view_of_zeros(const int* zeros32)        /* a row nobody has writ
 
 /* What a slice's walk did with the derived tables, recorded by every parse (hbs_parse_fix.h decides from it whose answer
  * depends on NALs in front of its SPS): bits 0-5 own row written + 1, bits 6-11 row its own set was predicted from + 1,
- * bits 12-17 row num_pic_total_curr read + 1 (0 = none each).  Which rows a slice touches does not depend on what the rows
- * hold -- the indices are read from the bits in front of any table-dependent length -- so the record of a slice that read
- * the wrong content is still right. */
-HBS_HD uint32_t deps_pack(int own_written_idx, int ref_row, int read_row)
+ * bits 12-17 row num_pic_total_curr read + 1 (0 = none each), bit 18: it read the row of ITS OWN set's index without having coded a set (round 5: the batch walk gave it a
+ * private, empty row there).  Which rows a slice touches does not depend on what the rows hold -- the indices are read from the bits in front of any table-dependent length --
+ * so the record of a slice that read the wrong content is still right. */
+HBS_HD uint32_t deps_pack(int own_written_idx, int ref_row, int read_row, int own_idx = -2)
 {
-    return (uint32_t)(own_written_idx + 1) | ((uint32_t)(ref_row + 1) << 6) | ((uint32_t)(read_row + 1) << 12);
+    return (uint32_t)(own_written_idx + 1) | ((uint32_t)(ref_row + 1) << 6) | ((uint32_t)(read_row + 1) << 12) | ((read_row >= 0 && read_row == own_idx && own_written_idx != read_row) ? (1u << 18) : 0u);
 }
 HBS_HD int deps_own(uint32_t d) { return (int)(d & 63u) - 1; }
 HBS_HD int deps_ref(uint32_t d) { return (int)((d >> 6) & 63u) - 1; }
@@ -443,7 +443,7 @@ struct ParserT {
     }
 
     /* ---- 7.3.7 + derivation (hevc_stream.c:1032-1085, :61-113) ------------------------------ */
-    HBS_M void st_ref_pic_set(hevc_st_ref_pic_set_t* rps, int stRpsIdx, int num_sets)
+    template <class RPS> HBS_M void st_ref_pic_set(RPS* rps, int stRpsIdx, int num_sets)
     {
         if (stRpsIdx == num_sets && can_write(stRpsIdx)) rec_own = stRpsIdx;
         int inter = 0;
@@ -832,7 +832,7 @@ struct ParserT {
     }
 
     /* hevc_stream.c:35-59 */
-    HBS_M int num_pic_total_curr(const hevc_slice_header_t* sh, int sps_flag, int rps_idx, int nlt_sps, int nlt) const
+    template <class SH> HBS_M int num_pic_total_curr(const SH* sh, int sps_flag, int rps_idx, int nlt_sps, int nlt) const
     {
         int n = 0;
         const int cur = sps_flag ? rps_idx : sps->num_short_term_ref_pic_sets;
@@ -852,7 +852,7 @@ struct ParserT {
     }
 
     /* ---- 7.3.6.3 (hevc_stream.c:969-1029) -------------------------------------------------------------- */
-    HBS_M void pred_weight_table(hevc_pred_weight_table_t* pwt, int slice_type, int l0, int l1)
+    template <class PWT> HBS_M void pred_weight_table(PWT* pwt, int slice_type, int l0, int l1)
     {
         pwt->luma_log2_weight_denom = b.ue(HBS_SITE(0), pwt->luma_log2_weight_denom);
         const int cat = (sps->separate_colour_plane_flag == 0) ? sps->chroma_format_idc : 0;
@@ -878,7 +878,7 @@ struct ParserT {
     }
 
     /* ---- 7.3.6 (hevc_stream.c:782-966); *sh is zero except collocated_from_l0_flag = 1 (:19-24) ----------- */
-    HBS_M void slice_segment_header(hevc_slice_header_t* sh, int nal_unit_type, const hevc_pps_t* last_pps,
+    template <class SH> HBS_M void slice_segment_header(SH* sh, int nal_unit_type, const hevc_pps_t* last_pps,
                                     const hevc_sps_t* last_sps, const hevc_pps_t* zero_pps, const hevc_sps_t* zero_sps)
     {
         const uint32_t first = b.u1(HBS_SITE(0), sh->first_slice_segment_in_pic_flag);

@@ -14,6 +14,7 @@
  */
 #include <hip/hip_runtime.h>
 #include "hbs_parse.h"
+#include "hbs_parse_compact.h"
 #include "hbs_parse_fix.h"
 #include "hbs_parse_ext.h"
 #include "hbs_parse_launch.h"
@@ -21,9 +22,13 @@
 namespace hbs {
 
 
+/* compact: slices get no slot in the struct arena (k4_want gives the listed ones theirs back) and every NAL a zero record */
 __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
-                        ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size, uint32_t* __restrict__ deps)
+                        ParsedNal* __restrict__ parsed, unsigned long long* __restrict__ slot_size, uint32_t* __restrict__ deps,
+                        SliceCompact* __restrict__ compact = nullptr, unsigned long long* __restrict__ total = nullptr, uint32_t* __restrict__ err = nullptr,
+                        uint32_t* __restrict__ div_flag = nullptr, uint32_t* __restrict__ fix_count = nullptr)
 {
+    if (compact && blockIdx.x == 0 && threadIdx.x == 0) { *total = 0ull; *err = 0u; *div_flag = 0u; fix_count[0] = 0u; fix_count[1] = 0u; }
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const hbs_nal_entry e = idx[k];
         ParsedNal p;
@@ -33,10 +38,22 @@ __global__ void k4_plan(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* _
         if (!(e.status & HBS_ST_ERROR)) {            /* nal_to_rbsp failed: read_hevc_nal_unit returns before the header (:167) */
             nal_header_of(rbsp + e.rbsp_off, e.rbsp_len, p);
             sz = slot_bytes_of(p.nal_unit_type);
+            if (compact && is_slice_type_nal(p.nal_unit_type)) sz = 0;
         }
         parsed[k] = p;
         slot_size[k] = sz;
         deps[k] = 0u;
+        if (compact) compact[k] = compact_zero();
+    }
+}
+
+/* hbs_parse_materialize: the listed NALs, where they are slices, get a slot after all */
+__global__ void k4_want(const ParsedNal* __restrict__ parsed, uint64_t n, const uint64_t* __restrict__ list, uint64_t m,
+                        unsigned long long* __restrict__ slot_size)
+{
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = list[j];
+        if (k < n && is_slice_type_nal(parsed[k].nal_unit_type)) slot_size[k] = slot_bytes_of(parsed[k].nal_unit_type);
     }
 }
 
@@ -281,8 +298,33 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
     const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
     parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
     if (diverged) *diverged = ps.diverged;
-    if (deps_out && slice) *deps_out = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read);
+    if (deps_out && slice) *deps_out = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read, ps.own_idx);
     return ps.b.tr_n;
+}
+
+/* the same for a slice that has no struct: the walk into a sink (hbs_parse_compact.h), its compact record into *compact */
+__device__ __forceinline__ void parse_lane_sink(int type, const hbs_nal_entry& e, const uint8_t* my_win, uint32_t wb, const uint8_t* src,
+                                                const uint8_t* sps_slot, const uint8_t* pps_struct, const uint8_t* zeros,
+                                                ParsedNal& out, SliceCompact* compact, RpsRow* own_row, int* diverged, uint32_t* deps_out)
+{
+    ParserT<kModeRead> ps;
+    ps.b.win = my_win; ps.b.full = src; ps.b.win_bytes = wb; ps.b.size = e.rbsp_len; ps.b.pos = 16;
+    ps.b.tr = nullptr; ps.b.tr_cap = 0; ps.b.tr_n = 0; ps.b.wbuf = nullptr;
+    ps.sps = nullptr; ps.pps = nullptr; ps.init_rows();
+    const hevc_sps_t* zero_sps = reinterpret_cast<const hevc_sps_t*>(zeros);
+    const hevc_pps_t* zero_pps = reinterpret_cast<const hevc_pps_t*>(zeros);
+    const hevc_sps_t* last_sps = zero_sps;
+    const hevc_pps_t* last_pps = zero_pps;
+    if (sps_slot) {
+        last_sps = reinterpret_cast<const hevc_sps_t*>(sps_slot);
+        ps.sps_rps = reinterpret_cast<const RpsTables*>(sps_slot + round16(sizeof(hevc_sps_t)));
+    }
+    if (pps_struct) last_pps = reinterpret_cast<const hevc_pps_t*>(pps_struct);
+    ps.own = own_row;
+    const int consumed = (int)(e.end - e.start) - ((e.status & HBS_ST_TRAILING03) ? 1 : 0);
+    parse_slice_into_sink(ps, type, consumed, &out, compact, last_pps, last_sps, zero_pps, zero_sps);
+    *diverged = ps.diverged;
+    *deps_out = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read, ps.own_idx);
 }
 
 /* One NAL per LANE: a wavefront walks 64 consecutive NALs at once.  The walk is a long chain of
@@ -299,7 +341,9 @@ __device__ __forceinline__ uint32_t parse_lane(int type, bool slice, const hbs_n
 #endif
 constexpr int kParseLanes = HBS_PARSE_LANES;          /* NALs a wavefront walks at once (lanes 0 .. kParseLanes-1) */
 constexpr unsigned kZeroBlocks = 1024;                /* spare workgroups of the parameter-set launch that clear slice slots */
-template <int kMode>
+/* kSink (pass 1 of a compact parse): the slices WITHOUT a slot, into sinks; otherwise: the NALs with one, as always -- and, in a
+ * compact parse, the record of a slice that has a slot (hbs_parse_materialize) taken from its struct */
+template <int kMode, bool kSink = false>
 __global__ __launch_bounds__(256)
 void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n, int pass,
               ParsedNal* __restrict__ parsed, uint8_t* __restrict__ structs, uint64_t structs_cap,
@@ -308,7 +352,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
               RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks, uint32_t* __restrict__ div_flag,
-              uint32_t* __restrict__ deps)
+              uint32_t* __restrict__ deps, SliceCompact* __restrict__ compact = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -336,12 +380,17 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         if (active) {
             e = idx[k];
             off = parsed[k].struct_off;
-            if (off + slot_bytes_of(type) > structs_cap) {
+            if (compact && slice && (off == ~0ull) != kSink) {      /* the other slice pass's */
+                active = false;
+            } else if (kSink) {
+                /* no slot: nothing to check */
+            } else if (off + slot_bytes_of(type) > structs_cap) {
                 atomicMax(err, (uint32_t)(-HBS_E_CAPACITY));
                 parsed[k].struct_off = ~0ull;
                 active = false;
             }
         }
+        if (compact && __ballot(active) == 0ull) continue;     /* (a compact parse runs two slice passes: most wavefronts of one have nothing to do) */
         if (pass == 1) {                                       /* fresh rows for the slices' own short-term RPS, by the whole wave */
             uint4* q = reinterpret_cast<uint4*>(my_rows);
             const uint4 z = make_uint4(0, 0, 0, 0);
@@ -376,8 +425,16 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             ParsedNal out = parsed[k];
             int dv = 0;
             uint32_t dp = 0u;
-            const uint32_t tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, out,
-                                                    trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane], nullptr, &dv, &dp);
+            uint32_t tr_n = 0;
+            if (kSink) {
+                SliceCompact rec;
+                parse_lane_sink(type, e, my_win, wb, src, sps_slot, pps_struct, zeros, out, &rec, &my_rows[lane], &dv, &dp);
+                compact[k] = rec;
+            } else {
+                tr_n = parse_lane<kMode>(type, slice, e, structs + off, my_win, wb, src, sps_slot, pps_struct, zeros, out,
+                                         trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &my_rows[lane], nullptr, &dv, &dp);
+                if (compact && slice) compact[k] = compact_of(*reinterpret_cast<const hevc_slice_header_t*>(structs + off));
+            }
             if (slice) deps[k] = dp;
             if (dv) atomicOr(div_flag, 1u);        /* some slices are walked again, exactly (k4_fix) */
             parsed[k] = out;
@@ -667,17 +724,23 @@ constexpr unsigned kFixBlocks = 128;             /* x 64 lanes: slices walked ag
 template <int kMode>
 __global__ __launch_bounds__(64)
 void k4_fix(FixCtx c, const uint32_t* __restrict__ list, uint32_t* __restrict__ fix_count, RpsRow* __restrict__ temps,
-            TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count, const uint32_t* __restrict__ gate)
+            TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count, const uint32_t* __restrict__ gate,
+            SliceCompact* __restrict__ compact = nullptr, uint8_t* __restrict__ tmp_structs = nullptr)
 {
     if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const uint32_t count = fix_count[0];
     const uint32_t me = blockIdx.x * 64u + threadIdx.x;
     RpsRow* const my = temps + (uint64_t)me * kFixTemps;
+    uint8_t* const my_struct = tmp_structs ? tmp_structs + (uint64_t)me * slot_bytes_of(HEVC_NAL_UNIT_TYPE_TRAIL_R) : nullptr;
     for (uint32_t q = me; q < count; q += gridDim.x * 64u) {
         const uint64_t k = list[q];
         uint32_t tr_n = 0;
 #if HBS_FIX_ENABLED
-        const bool ok = fix_slice<kMode>(c, k, my, trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &tr_n);
+        const bool ok = fix_slice<kMode>(c, k, my, trace ? trace + k * (uint64_t)trace_cap : nullptr, trace_cap, &tr_n, my_struct);
+        if (ok && compact) {                                     /* the record again, from the struct the exact walk filled (its slot, or this lane's own) */
+            const uint64_t so = c.parsed[k].struct_off;
+            compact[k] = compact_of(*reinterpret_cast<const hevc_slice_header_t*>(so != ~0ull ? c.structs + so : my_struct));
+        }
 #else
         const bool ok = false; (void)my;
 #endif
@@ -825,6 +888,13 @@ __global__ void k4_summary(uint64_t n, const unsigned long long* total, const ui
     sum->reserved[1] = sum->reserved[2] = 0;
 }
 
+/* a compact parse has no sequential pass to fall back on: a chain of own sets deeper than the exact re-walk follows (never seen in
+ * 12 000 fuzzed streams) is reported -- error HBS_E_DEPTH, reserved[1] = 1 -- and the caller takes hbs_parse_headers */
+__global__ void k4_compact_verdict(const uint32_t* __restrict__ fix_count, hbs_summary* __restrict__ sum)
+{
+    if (fix_count[1]) { sum->reserved[1] = 1; if (sum->error == 0) sum->error = HBS_E_DEPTH; }
+}
+
 /* workgroups of the parse kernel: a wavefront per 64 NALs, at most kParseMaxBlocks workgroups */
 unsigned parse_grid_blocks(uint64_t n)
 {
@@ -833,9 +903,51 @@ unsigned parse_grid_blocks(uint64_t n)
 }
 uint64_t parse_own_rows_bytes(uint64_t n) { return (uint64_t)parse_grid_blocks(n) * 4u * 64u * sizeof(RpsRow); }
 uint64_t parse_fix_temps_bytes() { return (uint64_t)kFixBlocks * 64u * (uint64_t)kFixTemps * sizeof(RpsRow); }
+uint64_t parse_fix_structs_bytes() { return (uint64_t)kFixBlocks * 64u * slot_bytes_of(HEVC_NAL_UNIT_TYPE_TRAIL_R); }
 
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
 {
+    if (a.compact) {
+        /* ---- compact parse (hbs_parse_headers_compact / hbs_parse_materialize): parameter sets into the struct arena as always,
+         * slices walked into sinks (k4_parse<.., true>), except the listed ones; out-of-spec slices exactly, each by itself,
+         * into a slot of the lane that walks it.  the counters (a.err, a.total, a.div_flag, a.fix_count) are cleared by the plan kernel: no memsets. */
+        if (a.n == 0) {
+            hipError_t e0 = hipMemsetAsync(a.total, 0, 512, st);           /* total, err, div_flag share 512 bytes of the workspace */
+            if (e0 != hipSuccess) return e0;
+            k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);
+            return hipGetLastError();
+        }
+        k4_plan<<<1024, 256, 0, st>>>(a.rbsp, a.index, a.n, a.parsed, a.slot_size, a.deps, a.compact, a.total, a.err, a.div_flag, a.fix_count);
+        if (a.want_n) {
+            const uint64_t wb = (a.want_n + 255) / 256;
+            k4_want<<<dim3((unsigned)(wb < 1024 ? wb : 1024)), 256, 0, st>>>(a.parsed, a.n, a.want_list, a.want_n, a.slot_size);
+        }
+        Scan3* part = reinterpret_cast<Scan3*>(a.scan_tmp);
+        k4_scan_reduce<<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part);
+        k4_scan_parts<<<1, kScan4Blocks, 0, st>>>(part, a.total);
+        k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
+        if (!a.structs) { k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary); return hipGetLastError(); }     /* plan only */
+        const unsigned pblocks = parse_grid_blocks(a.n);
+        /* parameter sets (and, when slices are wanted in full, the clearing of their slots by the spare workgroups) */
+        k4_parse<kModeRead, false><<<pblocks + (a.want_n ? kZeroBlocks : 0u), 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps,
+            a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, a.compact);
+        k4_parse<kModeRead, true><<<pblocks, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps,
+            a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, a.compact);
+        if (a.want_n)
+            k4_parse<kModeRead, false><<<pblocks, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps,
+                a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, a.compact);
+        k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary);
+        FixCtx c;
+        c.rbsp = a.rbsp; c.idx = a.index; c.n = a.n; c.parsed = a.parsed; c.structs = a.structs; c.structs_cap = a.structs_cap;
+        c.ctx_sps = a.ctx_sps; c.ctx_pps = a.ctx_pps; c.zeros = a.zeros; c.init_sps_slot = a.initial_sps_slot; c.init_pps = a.initial_pps;
+        c.deps = a.deps; c.wmask = a.wmask; c.bsum = a.bsum;
+        const unsigned mblocks = (unsigned)((a.n + kFixBlock - 1) / kFixBlock);
+        k4_fix_masks<<<mblocks, kFixBlock, 0, st>>>(a.parsed, a.structs, a.deps, a.n, a.wmask, a.bsum, a.fix_count, a.div_flag);
+        k4_fix_list<<<mblocks < 1024u ? mblocks : 1024u, 256, 0, st>>>(c, a.fix_list, a.fix_count, a.div_flag);
+        k4_fix<kModeRead><<<kFixBlocks, 64, 0, st>>>(c, a.fix_list, a.fix_count, a.fix_temps, nullptr, 0, nullptr, a.div_flag, a.compact, a.fix_structs);
+        k4_compact_verdict<<<1, 1, 0, st>>>(a.fix_count, a.summary);
+        return hipGetLastError();
+    }
     if (a.sequential && a.structs && a.n > 1) {                           /* a whole batch, one NAL after the other */
         RpsTables* tables = reinterpret_cast<RpsTables*>(a.own_rows);
         static_assert(sizeof(RpsTables) <= 64 * sizeof(RpsRow), "the own-rows workspace of one wavefront holds the tables");

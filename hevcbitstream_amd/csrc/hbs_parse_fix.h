@@ -60,7 +60,7 @@ HBS_HD uint32_t fix_wmask_of(const ParsedNal* parsed, const uint8_t* structs, co
         const int num = reinterpret_cast<const hevc_sps_t*>(structs + parsed[j].struct_off)->num_short_term_ref_pic_sets;
         return num <= 0 ? 0u : (num >= 32 ? ~0u : ((1u << num) - 1u));
     }
-    if (is_slice_type_nal(t) && parsed[j].struct_off != ~0ull) {
+    if (is_slice_type_nal(t)) {                                       /* (a slice that was not parsed has no record: deps 0, no row) */
         const int o = deps_own(deps[j]);
         return in32(o) ? (1u << o) : 0u;
     }
@@ -85,8 +85,12 @@ HBS_HD long long fix_last_writer(const FixCtx& c, int r, uint64_t i)
 /* did the batch parse hand slice i a row whose last writer is somebody else than the SPS in force? */
 HBS_HD bool fix_is_affected(const FixCtx& c, uint64_t i)
 {
-    if (!is_slice_type_nal(c.parsed[i].nal_unit_type) || c.parsed[i].struct_off == ~0ull) return false;
-    const uint32_t d = c.deps[i];
+    if (!is_slice_type_nal(c.parsed[i].nal_unit_type)) return false;
+    const uint32_t d = c.deps[i];                                      /* 0 for a slice that was not parsed: reads no row */
+    /* It counted the pictures of "its own set" without having coded one (an IDR with a P / B slice type): the batch walk read a
+     * private, empty row where the reference reads what the last slice that DID code a set left -- in front of the batch too,
+     * which no last-writer test in here can see (round 5: a batch that continues a stream, hbs_legacy.c, got zeros there). */
+    if ((d >> 18) & 1u) return true;
     const int own = deps_own(d), rows[2] = {deps_ref(d), deps_read(d)};
     for (int q = 0; q < 2; ++q) {
         const int r = rows[q];
@@ -174,13 +178,15 @@ HBS_FIX_FN bool fix_resolve_row(const FixCtx& c, int r, uint64_t i, RpsRow* temp
 #else
 #define HBS_FIX_T static inline
 #endif
+/* tmp_struct: where a slice WITHOUT a slot in the struct arena (hbs_parse_headers_compact) is walked into: one slice slot owned
+ * by the calling lane */
 template <int kMode>
-HBS_FIX_T bool fix_slice(const FixCtx& c, uint64_t i, RpsRow* temps, TraceRec* trace, uint32_t trace_cap, uint32_t* trace_n)
+HBS_FIX_T bool fix_slice(const FixCtx& c, uint64_t i, RpsRow* temps, TraceRec* trace, uint32_t trace_cap, uint32_t* trace_n, uint8_t* tmp_struct = nullptr)
 {
     const uint32_t d = c.deps[i];
     const int own = deps_own(d), ref = deps_ref(d), rd = deps_read(d);
     const int type = c.parsed[i].nal_unit_type;
-    uint8_t* const dst = c.structs + c.parsed[i].struct_off;
+    uint8_t* const dst = c.parsed[i].struct_off != ~0ull ? c.structs + c.parsed[i].struct_off : tmp_struct;
     hevc_slice_header_t* const sh = reinterpret_cast<hevc_slice_header_t*>(dst);
     const bool rd_foreign = rd >= 0 && rd != own;
     RowView vv[2];

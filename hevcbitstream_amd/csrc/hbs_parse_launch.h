@@ -10,6 +10,7 @@ namespace hbs {
 struct ParsedNal;
 struct TraceRec;
 struct RpsRow;
+struct SliceCompact;
 constexpr unsigned kParseMaxBlocks = 2048;
 
 struct ParseArgs {
@@ -46,6 +47,13 @@ struct ParseArgs {
      * hold them there (hbs_parse_headers_state): an SPS slot (struct + tables) and a hevc_pps_t */
     uint8_t* state_sps_slot_out;
     uint8_t* state_pps_out;
+    /* hbs_parse_headers_compact / hbs_parse_materialize: when `compact` is set, slices are walked WITHOUT a struct (a 64-byte
+     * record each in compact[k]) -- except the want_n slices listed in want_list, which get their slot in the struct arena as
+     * in the full parse.  No trace, no state output, not sequential. */
+    SliceCompact* compact;           /* n records (device) or nullptr */
+    const uint64_t* want_list;       /* want_n NAL numbers (device) or nullptr */
+    uint64_t want_n;
+    uint8_t* fix_structs;            /* parse_fix_structs_bytes(): a slice slot per lane of the exact re-walk, for slices without one */
     int sequential;                  /* n == 1 only: the RPS tables behind initial_sps_slot are read AND written, as the
                                         reference's file-static tables are (what the legacy single-NAL symbols need) */
 };
@@ -53,6 +61,7 @@ struct ParseArgs {
 unsigned parse_grid_blocks(uint64_t n);
 uint64_t parse_own_rows_bytes(uint64_t n);
 uint64_t parse_fix_temps_bytes();
+uint64_t parse_fix_structs_bytes();
 hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st);
 hipError_t launch_parse_extended(const uint8_t* rbsp, const hbs_nal_entry* index, uint64_t n, ParsedNal* parsed, hbs_ext_nal* ext, hipStream_t st);
 

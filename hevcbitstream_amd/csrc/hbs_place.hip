@@ -12,7 +12,7 @@
  * turnaround, on two ranks they do not.  HIP does not tell physical addresses, so where a buffer lies relative to an input
  * is MEASURED: a content-free copy with K12's geometry from a piece of the input into the piece of the candidate that will
  * be written from it, against the same copy inside the candidate (one allocation = one class = the slow case by
- * construction).  A candidate that pairs slowly is kept aside while another one is allocated, then freed.
+ * construction).  Since round 5 what is learned is kept: a per-device pool of 1 GiB chunks, each classed once (below).
  *
  * No reference counterpart (the reference allocates with malloc, h264_nal.c / hevc_nal.c); buffers from hipMalloc or
  * torch work with every call exactly as before -- they just land in the slow mode about every other time.
@@ -136,36 +136,92 @@ void* va_take(uint64_t bytes)
     return r;
 }
 
+/* ---- the pool (round 5) -----------------------------------------------------------------------------------------
+ * Round 4 measured on EVERY allocation: 31-77 probe copies of half a GiB, 0.04-5.7 s, up to 128 GiB of ballast held meanwhile,
+ * and everything it had learned about the physical memory it touched was thrown away with the candidates it released.  What a
+ * chunk's class is does not change while the chunk exists, so the knowledge is kept with the chunk:
+ *   - per device ONE reference chunk R, created with the pool and kept mapped: the class of anything is "R's" (0) or "the
+ *     other" (1), from one probe copy against R and one against itself;
+ *   - every 1 GiB chunk the pool ever created is classed ONCE; a buffer is put together from chunks of the class its peer
+ *     piece is not in; hbs_pair_free unmaps a buffer's chunks and puts them back on the pool's free list, class attached;
+ *   - candidates of the class nobody wants right now are not released either: they are the next call's supply (they used to
+ *     be "kept aside, then freed" -- and handed out again by the driver to be measured again);
+ *   - a peer that is itself a buffer of this pool is classed by table lookup, no probe at all.
+ * A second allocation of 16 GiB therefore costs the probes of its peer's 16 pieces (~1 ms each; none for a pool buffer) and
+ * the mapping calls.  The free list is bounded (kPoolKeepDefault, HBS_PAIR_POOL_KEEP_GIB, hbs_pair_pool_trim): what is above
+ * the bound when a call ends goes back to the driver, the majority class first.  Addresses are still used once (va_take). */
+struct Chunk { hipMemGenericAllocationHandle_t h; int cls; };       /* cls: 0 = the reference chunk's class, 1 = the other */
 struct Pair {
     void* va = nullptr;
     uint64_t va_bytes = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::vector<uint64_t> offs, sizes;
+    std::vector<Chunk> chunks;                                       /* chunk k is mapped at va + k GiB */
     int device = 0;
 };
-std::map<void*, Pair*> g_chunked;                  /* under g_mu */
+struct Pool {
+    int device = 0;
+    bool ready = false, failed = false;
+    hipMemGenericAllocationHandle_t ref_h;
+    uint8_t* ref_va = nullptr;                                       /* the reference chunk, mapped for as long as the process lives */
+    double ref_self_ms = 0;                                          /* R against itself: the slow case */
+    std::vector<Chunk> free_chunks;
+    uint64_t created = 0, classified = 0;
+};
+constexpr uint64_t kPoolKeepDefault = 48ull << 30;
+std::map<int, Pool*> g_pools;                       /* under g_mu */
+std::map<void*, Pair*> g_chunked;                   /* under g_mu */
 
-void release_pair(Pair* p)                          /* the physical memory goes back; the addresses are spent */
+void release_pair_to_pool(Pair* p, Pool* pool)      /* the chunks go back to the free list (no pool: to the driver); the addresses are spent */
 {
-    for (size_t i = 0; i < p->handles.size(); ++i) {
-        (void)hipMemUnmap(static_cast<uint8_t*>(p->va) + p->offs[i], p->sizes[i]);
-        (void)hipMemRelease(p->handles[i]);
+    for (size_t i = 0; i < p->chunks.size(); ++i) {
+        (void)hipMemUnmap(static_cast<uint8_t*>(p->va) + i * kChunk, kChunk);
+        if (pool) pool->free_chunks.push_back(p->chunks[i]);
+        else (void)hipMemRelease(p->chunks[i].h);
     }
     delete p;
+}
+
+uint64_t pool_keep_bytes()
+{
+    static const uint64_t keep = [] {
+        const char* e = getenv("HBS_PAIR_POOL_KEEP_GIB");
+        return e && atoi(e) >= 0 ? (uint64_t)atoi(e) << 30 : kPoolKeepDefault;
+    }();
+    return keep;
+}
+
+/* free chunks above `keep` bytes back to the driver, the class there is more of first; returns the bytes released */
+uint64_t pool_trim(Pool* pool, uint64_t keep)
+{
+    uint64_t released = 0;
+    while ((uint64_t)pool->free_chunks.size() * kChunk > keep) {
+        size_t n[2] = {0, 0};
+        for (auto& c : pool->free_chunks) n[c.cls & 1] += 1;
+        const int victim = n[0] >= n[1] ? 0 : 1;
+        for (size_t i = pool->free_chunks.size(); i-- > 0;)
+            if (pool->free_chunks[i].cls == victim) {
+                (void)hipMemRelease(pool->free_chunks[i].h);
+                pool->free_chunks.erase(pool->free_chunks.begin() + (long)i);
+                released += kChunk;
+                break;
+            }
+    }
+    return released;
 }
 
 } // namespace
 
 /*
- * The chunked way.  Physical memory comes in runs of one class in the order hipMemCreate hands it out (runs of 2-10 GiB seen):
- *   1. a reference chunk R; every piece of the peer is classed against it (same class as R / the other class);
- *   2. candidate chunks are created, each mapped into an address slot of its own, and classed against R the same way;
- *   3. a chunk of the buffer wants a candidate of the class its peer piece is NOT in; candidates nobody wants stay allocated
- *      until the end (so that the next ones are other memory), and after two of those in a row an unmapped "ballast"
- *      allocation of 4, 8, 16 ... GiB skips ahead in the run;
- *   4. the chosen candidates are mapped at their place in the buffer; everything else is released.
- * Bounded: at most nchunks + kExtraCands candidates and kBallastMax of ballast, 24 GiB of the device left free; when memory runs out or the bound is reached,
- * whatever is at hand is used (the report says how many chunks were placed knowingly).
+ * The chunked way, from the pool.  Physical memory comes in runs of one class in the order hipMemCreate hands it out (runs of
+ * 2-10 GiB seen, 35 once):
+ *   1. every piece of the peer is classed against R (a pool buffer: by lookup);
+ *   2. chunk k of the buffer wants the class its peer piece is NOT in: taken from the free list when there is one, else new
+ *      chunks are created, each mapped into an address slot of its own and classed against R; those of the class nobody wants
+ *      go to the free list (which also makes the driver hand out OTHER memory next), and after two of those in a row an unmapped
+ *      "ballast" allocation of 4, 8, 16 ... GiB skips ahead in the run (released when the call ends);
+ *   3. the chosen chunks are mapped at their place in the buffer.
+ * Bounded: at most nchunks + kExtraCands new chunks and kBallastMax of ballast per call, kKeepFree of the device left free;
+ * when memory runs out or the bound is reached, whatever is at hand is used (the report says how many chunks were placed
+ * knowingly).
  */
 static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* rep)
 {
@@ -185,7 +241,8 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
     hipMemAccessDesc acc;
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    hipError_t e;
+    hipError_t e = hipSuccess;
+    const bool dbg = getenv("HBS_PAIR_DEBUG") != nullptr;
 #define PAIR_FAIL(what) { hbs_ctx_set_error(ctx, "hbs_pair_alloc: " what, (int)e); rc = HBS_E_HIP; }
 
     /* layout: whole chunks of 1 GiB, the size rounded up (a remainder mapped as a chunk of its own size made hipMemSetAccess
@@ -193,37 +250,73 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
     const uint64_t total = up(bytes, kGran);
     const bool want_probe = d_peer != nullptr && peer_bytes >= kChunk / 2 && total >= kChunk && !getenv("HBS_PAIR_NO_PROBE");
     if (!want_probe) return HBS_E_CAPACITY;                           /* nothing to place: the plain way */
+    if ((reinterpret_cast<uintptr_t>(d_peer) & 15u) != 0) return HBS_E_ARG;     /* the probe loads 16 bytes a lane */
     const uint64_t nfull = (total + kChunk - 1) / kChunk;
-    const uint64_t rest = 0;
-    Pair* p = new (std::nothrow) Pair();
-    if (!p) return HBS_E_HIP;
-    p->device = device;
-    p->va_bytes = nfull * kChunk + rest;
-    int rc = 0;
-    p->va = va_take(p->va_bytes);
-    if (!p->va) { delete p; return HBS_E_CAPACITY; }                  /* the address pool is used up: the caller takes the plain way */
-    uint8_t* const base = static_cast<uint8_t*>(p->va);
-    auto map_at = [&](uint64_t off, uint64_t size, hipMemGenericAllocationHandle_t h) -> bool {
-        e = hipMemMap(base + off, size, 0, h, 0);
-        if (e != hipSuccess) { PAIR_FAIL("hipMemMap") return false; }
-        e = hipMemSetAccess(base + off, size, &acc, 1);
-        if (e != hipSuccess) { PAIR_FAIL("hipMemSetAccess") (void)hipMemUnmap(base + off, size); return false; }
-        p->handles.push_back(h); p->offs.push_back(off); p->sizes.push_back(size);
+    const uint64_t half = (kChunk / 2) / kTile * kTile;
+
+    std::lock_guard<std::mutex> pool_guard(g_mu);                     /* one allocation at a time per process: the pool, the address pool, the probes */
+    Pool*& slot = g_pools[device];
+    if (!slot) { slot = new (std::nothrow) Pool(); if (slot) slot->device = device; }
+    Pool* const pool = slot;
+    if (!pool || pool->failed) return HBS_E_CAPACITY;
+    Prober pr(st, device);
+    if (!pr.ok) return HBS_E_CAPACITY;
+    auto map_new = [&](uint8_t* at, hipMemGenericAllocationHandle_t h) -> bool {
+        hipError_t me = hipMemMap(at, kChunk, 0, h, 0);
+        if (me == hipSuccess) { me = hipMemSetAccess(at, kChunk, &acc, 1); if (me != hipSuccess) (void)hipMemUnmap(at, kChunk); }
+        if (me != hipSuccess) { if (dbg) fprintf(stderr, "hbs_pair_alloc: mapping at %p: %s\n", (void*)at, hipGetErrorString(me)); e = me; (void)hipGetLastError(); return false; }
         return true;
     };
-    if (rest) {
-        hipMemGenericAllocationHandle_t h;
-        e = hipMemCreate(&h, rest, &prop, 0);
-        if (e != hipSuccess) { PAIR_FAIL("hipMemCreate") }
-        else if (!map_at(nfull * kChunk, rest, h)) (void)hipMemRelease(h);
+    if (!pool->ready) {                                               /* the reference chunk: once per device */
+        uint8_t* va = static_cast<uint8_t*>(va_take(kChunk));
+        if (!va || hipMemCreate(&pool->ref_h, kChunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); pool->failed = true; return HBS_E_CAPACITY; }
+        if (!map_new(va, pool->ref_h)) { (void)hipMemRelease(pool->ref_h); pool->failed = true; return HBS_E_CAPACITY; }
+        pool->ref_va = va;
+        pool->ref_self_ms = pr.copy_ms(va, va + half, half);
+        if (pool->ref_self_ms <= 0) { pool->failed = true; return HBS_E_CAPACITY; }
+        pool->ready = true; pool->created = 1;
+        if (dbg) fprintf(stderr, "hbs_pair_alloc: pool of device %d: reference chunk against itself %.4f ms\n", device, pool->ref_self_ms);
     }
 
-    struct Cand { hipMemGenericAllocationHandle_t h; uint8_t* va; int other; bool used; };     /* other: 1 = not R's class, 0 = R's, -1 = unknown */
-    std::vector<Cand> cands;
-    std::vector<hipMemGenericAllocationHandle_t> ballast;
-    /* (24 candidates past the chunks until round 4's last day: a box whose allocator handed out 35 chunks of the unwanted class in
-     * a row ended with 5 of 16 chunks placed and 0.713 instead of 0.726.  Candidates and ballast go back at the end; both stop
-     * while kKeepFree of the device's memory is still free.) */
+    /* 1. what every chunk of the buffer wants: the class its peer piece is not in */
+    std::vector<int> want(nfull, -1);
+    uint64_t need[2] = {0, 0};
+    {
+        /* a peer that is a buffer of this pool: its chunks' classes are on record */
+        const Pair* peer_pair = nullptr;
+        uint64_t peer_pair_off = 0;
+        for (auto& kv : g_chunked) {
+            const uint8_t* lo = static_cast<const uint8_t*>(kv.first);
+            if (static_cast<const uint8_t*>(d_peer) >= lo && static_cast<const uint8_t*>(d_peer) < lo + kv.second->va_bytes && kv.second->device == device) {
+                peer_pair = kv.second; peer_pair_off = (uint64_t)(static_cast<const uint8_t*>(d_peer) - lo); break;
+            }
+        }
+        const uint64_t peer_last = peer_bytes > half ? (uint64_t)((peer_bytes - half) & ~(uint64_t)15) : (uint64_t)0;
+        for (uint64_t k = 0; k < nfull; ++k) {
+            const uint64_t peer_off = std::min(k * kChunk, peer_last);
+            int peer_cls = -1;
+            if (peer_pair && (peer_pair_off & (kChunk - 1)) == 0) {
+                const uint64_t pk = (peer_pair_off + peer_off) / kChunk;
+                if (pk < peer_pair->chunks.size()) { peer_cls = peer_pair->chunks[pk].cls; r.from_table += 1; }
+            }
+            if (peer_cls < 0) {
+                const double t = pr.copy_ms(static_cast<const uint8_t*>(d_peer) + peer_off, pool->ref_va + half, half);
+                if (t <= 0) break;
+                peer_cls = t < kFastRatio * pool->ref_self_ms ? 1 : 0;          /* fast against R: the other class */
+                r.probed += 1;
+                if (dbg) fprintf(stderr, "hbs_pair_alloc: peer piece %llu against the reference chunk: %.4f / %.4f = %.4f -> class %d\n",
+                                 (unsigned long long)k, t, pool->ref_self_ms, t / pool->ref_self_ms, peer_cls);
+            }
+            want[k] = 1 - peer_cls;
+            need[want[k]] += 1;
+        }
+    }
+
+    /* 2. supply: the free list first, new chunks for the rest */
+    uint64_t have[2] = {0, 0};
+    for (auto& c : pool->free_chunks) have[c.cls & 1] += 1;
+    const uint64_t from_pool0 = std::min(have[0], need[0]), from_pool1 = std::min(have[1], need[1]);
+    r.from_pool = (uint32_t)(from_pool0 + from_pool1);
     constexpr int kExtraCands = 88;
     constexpr uint64_t kBallastMax = 128ull << 30, kKeepFree = 24ull << 30;
     auto room_for = [&](uint64_t more) -> bool {
@@ -231,132 +324,99 @@ static int alloc_chunked(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, 
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
         return (uint64_t)fr >= more + kKeepFree;
     };
-    const uint64_t half = (kChunk / 2) / kTile * kTile;
-    void* scratch = nullptr;
-    const uint64_t scratch_slots = nfull + kExtraCands + 1;
-    Prober* pr = nullptr;
-    if (rc == 0 && nfull) {
-        scratch = va_take(scratch_slots * kChunk);
-        if (!scratch) { release_pair(p); return HBS_E_CAPACITY; }
-        pr = new (std::nothrow) Prober(st, device);
-        if (pr && !pr->ok) { delete pr; pr = nullptr; }
-    }
-    auto new_cand = [&]() -> bool {                      /* false: no more memory (or address slots) */
-        if (cands.size() >= scratch_slots || (cands.size() >= nfull && !room_for(kChunk))) return false;
-        Cand c; c.other = -1; c.used = false;
-        hipError_t ce = hipMemCreate(&c.h, kChunk, &prop, 0);
-        if (ce != hipSuccess) { if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: hipMemCreate: %s\n", hipGetErrorString(ce)); (void)hipGetLastError(); return false; }
-        c.va = static_cast<uint8_t*>(scratch) + cands.size() * kChunk;
-        ce = hipMemMap(c.va, kChunk, 0, c.h, 0);
-        if (ce == hipSuccess) ce = hipMemSetAccess(c.va, kChunk, &acc, 1);
-        if (ce != hipSuccess) {
-            if (getenv("HBS_PAIR_DEBUG")) fprintf(stderr, "hbs_pair_alloc: mapping a candidate at %p: %s\n", (void*)c.va, hipGetErrorString(ce));
-            (void)hipGetLastError(); (void)hipMemRelease(c.h); return false;
-        }
-        cands.push_back(c);
-        return true;
-    };
-    std::vector<int> want(nfull, -1);                    /* class wanted for chunk k: 1 = not R's, 0 = R's, -1 = no preference */
-    if (getenv("HBS_PAIR_DEBUG") && nfull) fprintf(stderr, "hbs_pair_alloc: %llu chunks + %llu bytes, prober %s\n", (unsigned long long)nfull, (unsigned long long)rest, pr ? "ready" : "NOT available");
-    if (rc == 0 && nfull && pr && new_cand()) {
-        Cand& R = cands[0];
-        const double self_r = pr->copy_ms(R.va, R.va + half, half);
-        R.other = 0;
-        const bool dbg = getenv("HBS_PAIR_DEBUG") != nullptr;
-        uint64_t need[2] = {0, 0};
-        for (uint64_t k = 0; k < nfull && self_r > 0; ++k) {
-            const uint64_t peer_last = peer_bytes > half ? (uint64_t)((peer_bytes - half) & ~(uint64_t)15) : (uint64_t)0;
-            const uint64_t peer_off = std::min(k * kChunk, peer_last);
-            const double t = pr->copy_ms(static_cast<const uint8_t*>(d_peer) + peer_off, R.va + half, half);
-            if (t <= 0) break;
-            const int peer_other = t < kFastRatio * self_r ? 1 : 0;          /* the peer piece is in the class R is not in */
-            want[k] = 1 - peer_other;
-            need[want[k]] += 1;
-            r.probed += 1;
-            if (dbg) fprintf(stderr, "hbs_pair_alloc: peer piece %llu against the reference chunk: %.4f / %.4f = %.4f -> chunk wants class %d\n",
-                             (unsigned long long)k, t, self_r, t / self_r, want[k]);
-        }
-        uint64_t have[2] = {1, 0};
-        uint64_t ballast_bytes = 0, next_ballast = 4ull << 30;
-        int unwanted_in_a_row = 0;
-        while ((have[0] < need[0] || have[1] < need[1]) && cands.size() < nfull + (uint64_t)kExtraCands) {
-            if (unwanted_in_a_row >= 2 && ballast_bytes + next_ballast <= kBallastMax && room_for(next_ballast + kChunk)) {
-                hipMemGenericAllocationHandle_t b;
-                if (hipMemCreate(&b, next_ballast, &prop, 0) == hipSuccess) {
-                    ballast.push_back(b); ballast_bytes += next_ballast; next_ballast *= 2; unwanted_in_a_row = 0;
-                    if (dbg) fprintf(stderr, "hbs_pair_alloc: ballast %llu GiB\n", (unsigned long long)(ballast_bytes >> 30));
-                } else {
-                    (void)hipGetLastError();
-                    next_ballast /= 2;
-                    if (next_ballast < (1ull << 30)) break;
-                    continue;
-                }
-            }
-            if (!new_cand()) break;
-            Cand& X = cands.back();
-            const double self_x = pr->copy_ms(X.va, X.va + half, half);
-            const double t = pr->copy_ms(cands[0].va, X.va + half, half);
-            if (self_x <= 0 || t <= 0) break;
-            X.other = t < kFastRatio * self_x ? 1 : 0;
-            r.probed += 1;
-            const bool wanted = have[X.other] < need[X.other];
-            have[X.other] += 1;
-            unwanted_in_a_row = wanted ? 0 : unwanted_in_a_row + 1;
-            if (!wanted) r.rejected += 1;
-            if (dbg) fprintf(stderr, "hbs_pair_alloc: candidate %zu against the reference chunk: %.4f / %.4f = %.4f -> class %d%s\n",
-                             cands.size() - 1, t, self_x, t / self_x, X.other, wanted ? "" : " (not needed)");
-        }
-    }
-    /* hand the candidates out: first to the chunks that want their class, then whatever is left to whoever is left */
-    std::vector<int> pick(nfull, -1);
-    for (int pass = 0; pass < 2 && rc == 0; ++pass)
-        for (uint64_t k = 0; k < nfull; ++k) {
-            if (pick[k] >= 0) continue;
-            for (size_t c = 0; c < cands.size(); ++c) {
-                if (cands[c].used) continue;
-                if (pass == 0 && (want[k] < 0 || cands[c].other != want[k])) continue;
-                pick[k] = (int)c; cands[c].used = true;
-                if (pass == 0) r.accepted_fast += 1; else r.unprobed_after_budget += 1;
-                break;
+    std::vector<hipMemGenericAllocationHandle_t> ballast;
+    uint64_t ballast_bytes = 0, next_ballast = 4ull << 30, made = 0;
+    int unwanted_in_a_row = 0;
+    while ((have[0] < need[0] || have[1] < need[1]) && made < nfull + (uint64_t)kExtraCands) {
+        if (unwanted_in_a_row >= 2 && ballast_bytes + next_ballast <= kBallastMax && room_for(next_ballast + kChunk)) {
+            hipMemGenericAllocationHandle_t b;
+            if (hipMemCreate(&b, next_ballast, &prop, 0) == hipSuccess) {
+                ballast.push_back(b); ballast_bytes += next_ballast; next_ballast *= 2; unwanted_in_a_row = 0;
+                if (dbg) fprintf(stderr, "hbs_pair_alloc: ballast %llu GiB\n", (unsigned long long)(ballast_bytes >> 30));
+            } else {
+                (void)hipGetLastError();
+                next_ballast /= 2;
+                if (next_ballast < (1ull << 30)) break;
+                continue;
             }
         }
-    for (uint64_t k = 0; k < nfull && rc == 0; ++k) {
-        hipMemGenericAllocationHandle_t h;
-        if (pick[k] >= 0) {
-            Cand& c = cands[(size_t)pick[k]];
-            e = hipMemUnmap(c.va, kChunk);
-            if (e != hipSuccess) { PAIR_FAIL("hipMemUnmap") break; }
-            h = c.h;
-        } else {
-            e = hipMemCreate(&h, kChunk, &prop, 0);
-            if (e != hipSuccess) { PAIR_FAIL("hipMemCreate") break; }
-            r.unprobed_after_budget += 1;
-        }
-        if (!map_at(k * kChunk, kChunk, h)) {
-            if (pick[k] >= 0) { cands[(size_t)pick[k]].used = false; cands[(size_t)pick[k]].va = nullptr; }    /* released with the rest below */
-            else (void)hipMemRelease(h);
-            break;
-        }
-    }
-    /* everything that was not chosen goes back */
-    (void)hipStreamSynchronize(st);
-    for (auto& c : cands) {
-        if (c.used) continue;
-        if (c.va) (void)hipMemUnmap(c.va, kChunk);
-        (void)hipMemRelease(c.h);
+        if (!room_for(kChunk)) break;
+        Chunk x; x.cls = -1;
+        if (hipMemCreate(&x.h, kChunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        uint8_t* xva = static_cast<uint8_t*>(va_take(kChunk));         /* a slot of its own, used once */
+        if (!xva || !map_new(xva, x.h)) { (void)hipMemRelease(x.h); break; }
+        const double self_x = pr.copy_ms(xva, xva + half, half);
+        const double t = pr.copy_ms(pool->ref_va, xva + half, half);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemUnmap(xva, kChunk);
+        if (self_x <= 0 || t <= 0) { (void)hipMemRelease(x.h); break; }
+        x.cls = t < kFastRatio * self_x ? 1 : 0;
+        made += 1; pool->created += 1; pool->classified += 1;
+        r.probed += 1;
+        const bool wanted = have[x.cls] < need[x.cls];
+        have[x.cls] += 1;
+        unwanted_in_a_row = wanted ? 0 : unwanted_in_a_row + 1;
+        if (!wanted) r.rejected += 1;
+        pool->free_chunks.push_back(x);
+        if (dbg) fprintf(stderr, "hbs_pair_alloc: new chunk %llu against the reference chunk: %.4f / %.4f = %.4f -> class %d%s\n",
+                         (unsigned long long)pool->created, t, self_x, t / self_x, x.cls, wanted ? "" : " (to the free list)");
     }
     for (auto b : ballast) (void)hipMemRelease(b);
-    delete pr;
-#undef PAIR_FAIL
-    if (rc) { release_pair(p); return rc; }
-    r.chunks = (uint32_t)p->handles.size();
-    r.unprobed_after_budget += (uint32_t)(rest ? 1 : 0);
-    {
-        std::lock_guard<std::mutex> g(g_mu);
-        g_chunked[p->va] = p;
+
+    /* 3. the buffer: chunk k from the free list, of its class when there is one, any other when not (a new one when the list is empty) */
+    Pair* p = new (std::nothrow) Pair();
+    if (!p) return HBS_E_HIP;
+    p->device = device;
+    p->va_bytes = nfull * kChunk;
+    p->va = va_take(p->va_bytes);
+    if (!p->va) { delete p; return HBS_E_CAPACITY; }                  /* the address pool is used up: the caller takes the plain way */
+    uint8_t* const base = static_cast<uint8_t*>(p->va);
+    int rc = 0;
+    std::vector<int> chosen(nfull, 0);
+    auto take = [&](int cls) -> long {
+        for (size_t i = 0; i < pool->free_chunks.size(); ++i) if (cls < 0 || pool->free_chunks[i].cls == cls) return (long)i;
+        return -1;
+    };
+    for (int pass = 0; pass < 2 && rc == 0; ++pass)
+        for (uint64_t k = 0; k < nfull && rc == 0; ++k) {
+            if (chosen[k]) continue;
+            long i = pass == 0 ? (want[k] >= 0 ? take(want[k]) : -1) : take(-1);
+            Chunk c;
+            if (i >= 0) { c = pool->free_chunks[(size_t)i]; pool->free_chunks.erase(pool->free_chunks.begin() + i); }
+            else if (pass == 0) continue;
+            else {
+                if (hipMemCreate(&c.h, kChunk, &prop, 0) != hipSuccess) { e = hipErrorOutOfMemory; (void)hipGetLastError(); PAIR_FAIL("hipMemCreate") break; }
+                c.cls = -1; pool->created += 1;
+            }
+            (void)pass;
+            chosen[k] = 1;
+            if (c.cls >= 0 && c.cls == want[k]) r.accepted_fast += 1; else r.unprobed_after_budget += 1;
+            p->chunks.resize(std::max<size_t>(p->chunks.size(), (size_t)k + 1));
+            p->chunks[(size_t)k] = c;
+        }
+    /* (chunks were assigned in two passes: map them in order now) */
+    size_t mapped = 0;
+    for (uint64_t k = 0; k < nfull && rc == 0; ++k) {
+        if (!map_new(base + k * kChunk, p->chunks[(size_t)k].h)) { PAIR_FAIL("hipMemMap") break; }
+        mapped += 1;
     }
+#undef PAIR_FAIL
+    if (rc) {
+        for (size_t k = 0; k < p->chunks.size(); ++k) {
+            if (k < mapped) (void)hipMemUnmap(base + k * kChunk, kChunk);
+            if (chosen[k]) { if (p->chunks[k].cls >= 0) pool->free_chunks.push_back(p->chunks[k]); else (void)hipMemRelease(p->chunks[k].h); }
+        }
+        delete p;
+        (void)pool_trim(pool, pool_keep_bytes());
+        return rc;
+    }
+    (void)pool_trim(pool, pool_keep_bytes());
+    r.chunks = (uint32_t)p->chunks.size();
+    g_chunked[p->va] = p;
     *out = p->va;
     if (rep) *rep = r;
+    if (dbg) fprintf(stderr, "hbs_pair_alloc: %u chunks (%u placed knowingly, %u from the free list), %u probes, %llu chunks left on the free list\n",
+                     r.chunks, r.accepted_fast, r.from_pool, r.probed, (unsigned long long)pool->free_chunks.size());
     return 0;
 }
 
@@ -456,8 +516,8 @@ static int alloc_plain(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, ui
 
 extern "C" {
 
-/* Two ways.  (1) Chunked: the buffer is put together from 1 GiB physical chunks, each classed by measurement, at addresses
- * that are used once (see va_take) -- every piece can be placed, whatever the allocator hands out.  (2) Plain: whole
+/* Two ways.  (1) Chunked: the buffer is put together from 1 GiB physical chunks of the device's pool, each classed by measurement
+ * ONCE, at addresses that are used once (see va_take) -- every piece can be placed, whatever the allocator hands out.  (2) Plain: whole
  * hipMalloc allocations as candidates, the best one kept -- ordinary memory, but an allocation usually spans both classes
  * somewhere.  (1) is used for buffers that get probed at all; (2) for small buffers (one plain allocation, no probing),
  * when HBS_PAIR_PLAIN is set, and when the address pool or the virtual-memory calls give out. */
@@ -494,11 +554,52 @@ int hbs_pair_free(hbs_ctx* ctx, void* ptr)
         }
     }
     if (p) device = p->device;
-    (void)hipSetDevice(device);
+    /* This runs wherever the last reference to a buffer dies (a destructor, a garbage collector, any thread): the caller's current
+     * device is put back afterwards, and only what can still touch the buffer is waited for -- the context's stream when there is
+     * a context, the device otherwise (round 4 switched the device under the caller and always stalled every stream). */
+    int prev = -1;
+    const bool switched = hipGetDevice(&prev) == hipSuccess && prev != device;
+    if (switched) (void)hipSetDevice(device);
     if (ctx) (void)hbs_ctx_synchronize(ctx);
-    (void)hipDeviceSynchronize();
-    if (p) { release_pair(p); return 0; }
-    return hipFree(ptr) == hipSuccess ? 0 : HBS_E_HIP;
+    else (void)hipDeviceSynchronize();
+    int rc = 0;
+    if (p) {
+        std::lock_guard<std::mutex> g(g_mu);
+        auto ip = g_pools.find(device);
+        Pool* pool = ip != g_pools.end() ? ip->second : nullptr;
+        release_pair_to_pool(p, pool);
+        if (pool) (void)pool_trim(pool, pool_keep_bytes());
+    } else {
+        rc = hipFree(ptr) == hipSuccess ? 0 : HBS_E_HIP;
+    }
+    if (switched) (void)hipSetDevice(prev);
+    return rc;
+}
+
+/* free chunks of the context's device above `keep_bytes` go back to the driver (0: all of them); returns the bytes released */
+uint64_t hbs_pair_pool_trim(hbs_ctx* ctx, uint64_t keep_bytes)
+{
+    if (!ctx) return 0;
+    const int device = hbs_ctx_device(ctx);
+    std::lock_guard<std::mutex> g(g_mu);
+    auto ip = g_pools.find(device);
+    if (ip == g_pools.end() || !ip->second) return 0;
+    return pool_trim(ip->second, keep_bytes);
+}
+
+/* out[0] chunks the pool created so far (the reference chunk included), [1] chunks classed by measurement, [2] free chunks of the
+ * reference's class, [3] free chunks of the other class */
+int hbs_pair_pool_stats(hbs_ctx* ctx, uint64_t out[4])
+{
+    if (!ctx || !out) return HBS_E_ARG;
+    const int device = hbs_ctx_device(ctx);
+    out[0] = out[1] = out[2] = out[3] = 0;
+    std::lock_guard<std::mutex> g(g_mu);
+    auto ip = g_pools.find(device);
+    if (ip == g_pools.end() || !ip->second) return 0;
+    out[0] = ip->second->created; out[1] = ip->second->classified;
+    for (auto& c : ip->second->free_chunks) out[2 + (c.cls & 1)] += 1;
+    return 0;
 }
 
 } // extern "C"

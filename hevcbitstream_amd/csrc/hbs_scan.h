@@ -52,9 +52,11 @@ void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, in
 void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 /* index-only streaming kernel (hbs_scan5.hip) */
-uint64_t scan5_tile_bytes();
-uint64_t scan5_workspace_bytes(uint64_t stream_bytes);
-void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
+uint64_t scan5_workspace_bytes(uint64_t stream_bytes);     /* for any tile height the launcher may pick */
+struct Geo5 { int rows; int strided; uint64_t tiles, grid; };   /* KiB per tile; tiles dealt in whole rounds (no ticket); tiles; one-wavefront workgroups */
+Geo5 scan5_geometry(uint64_t n, uint64_t waves);            /* for a stream of n bytes on at most `waves` resident wavefronts */
+int scan5_tile_rows(uint64_t n, uint64_t waves);
+void launch_scan_index5(const ScanArgs& a, int gate, hipStream_t st);
 
 } // namespace hbs
 #endif

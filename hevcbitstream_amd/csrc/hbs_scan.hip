@@ -676,7 +676,6 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     const int sparse_variant = ((a.variant == 5 && !index_only) || automatic) ? 4 : a.variant;
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
     const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;
-    const uint64_t tiles5 = (a.n + scan5_tile_bytes() - 1) / scan5_tile_bytes();
     /* the finest tiling any kernel of this call may use sizes the look-back words to clear */
     const uint64_t num_tiles = (sparse_variant == 4 && !automatic) ? tiles4 : tiles2;
     /* one launch: run header, density probe (automatic mode), padded copy of the last tile (event-sparse kernels),
@@ -688,7 +687,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         if (grid > tiles2) grid = tiles2;
         if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
         if (index_only && !automatic) {
-            launch_scan_index5(a, tiles5, kGateNone, st);
+            launch_scan_index5(a, kGateNone, st);
         } else if (!automatic && sparse_variant == 4) {
             launch_scan_extract4_kernel(a, tiles4, kGateNone, st);
         } else if (automatic) {
@@ -697,7 +696,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
              * They share the descriptor array and the ticket: whichever runs finds both untouched. */
             /* (a side stream for the kernel that rules itself out, forked and joined with events, was tried in round 4: the two
              * event waits cost more than the empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
-            if (index_only) launch_scan_index5(a, tiles5, kGateIfSparseIdx, st);
+            if (index_only) launch_scan_index5(a, kGateIfSparseIdx, st);
             else launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, index_only ? kGateIfDenseIdx : kGateIfDense);

@@ -84,6 +84,9 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #ifndef HBS4_COPY_DEPTH
 #define HBS4_COPY_DEPTH 3      /* stores of a wavefront in flight during the copy (-1: no limit) */
 #endif
+#ifndef HBS4_FIRST_BY_TICKET
+#define HBS4_FIRST_BY_TICKET 0 /* 1: a workgroup's first tile by ticket too (round 4's way; A/B timing) */
+#endif
 #ifdef HBS4_NO_PRIO
 #define HBS4_PRIO(p)
 #else
@@ -354,7 +357,7 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     }
     dense_emit(src, wseg, n, before, before2, after, chunk0, lane, before_me, excl, rbsp != nullptr && l.ex_ok == 1u, rbsp + excl.kept, tgt,
                &l.dep[wv][lane & (kDepCap - 1)].xpp);
-    if (tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+    if (tid == 0) l.ticket = (HBS4_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(&hdr->ticket, 1u);
     __syncthreads();
     return true;
 }
@@ -372,7 +375,11 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
-    if (tid0 == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+    /* The first tile is the workgroup's number, the others come by ticket (tile = gridDim.x + ticket).  512 workgroups asking ONE
+     * address for a ticket in the kernel's first microsecond are served one after the other -- microseconds that a 1 GiB call
+     * notices.  The grid is at most what the GPU holds (scan4_grid_blocks), so every first tile is being worked on when the
+     * tickets start: a look-back still only ever waits for tiles in progress. */
+    if (tid0 == 0) l.ticket = HBS4_FIRST_BY_TICKET ? atomicAdd(&hdr->ticket, 1u) : blockIdx.x;
     __syncthreads();
     HBS4_T_DECL
 
@@ -695,7 +702,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
          * out in stripes instead (tile = workgroup + k x grid, no atomic, no drain of this wavefront's stores
          * in front of it) ran 8.6 ms against 7.06 on the 16 GiB bench stream: workgroups do not progress
          * evenly, and with stripes the fast ones wait in their look-backs for the slow ones. */
-        if (tid == 0) l.ticket = atomicAdd(&hdr->ticket, 1u);
+        if (tid == 0) l.ticket = (HBS4_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(&hdr->ticket, 1u);
         __syncthreads();
         HBS4_T_MARK(5)
 #undef HBS_ROW_PRE

@@ -27,10 +27,15 @@ namespace hbs {
 #endif
 constexpr int k5SpanRows = HBS5_SPAN_ROWS;                    /* rows of 1 KiB a wavefront flags per step */
 constexpr uint64_t k5SpanBytes = (uint64_t)k5SpanRows * 1024u;
-constexpr int k5TileRows = HBS5_TILE_ROWS;                    /* KiB of stream (= flag words) per tile */
-constexpr uint64_t k5TileBytes = (uint64_t)k5TileRows * 1024u;
-constexpr int k5WordsPerLane = k5TileRows / 64;               /* lane l owns words [16 l, 16 l + 16) of its tile when elements are numbered */
-static_assert(k5TileRows % k5SpanRows == 0 && k5TileRows % 64 == 0, "tile = whole spans, whole words per lane");
+/* KiB of stream (= flag words) per tile: a launch parameter since round 5 (`rows`, a whole number of spans, 64 ... 512).  From 4 GiB
+ * up it is k5TileRowsLarge, as always; below, the tiles are cut so that every resident wavefront gets the SAME whole number of
+ * them (scan5_tile_rows): a 1 GiB stream in 256 KiB tiles is 4096 tiles for 3072 wavefronts -- a third of them took a second
+ * tile while the others sat idle, 220 us where the 16 GiB rate says 180. */
+constexpr int k5TileRowsLarge = HBS5_TILE_ROWS;
+constexpr int k5MaxTileRows = 512, k5MinTileRows = 64;
+constexpr int k5MaxWordsPerLane = k5MaxTileRows / 64;         /* lane l owns words [wpl l, wpl l + wpl) of its tile when elements are numbered; wpl = ceil(rows / 64) */
+static_assert(k5TileRowsLarge % k5SpanRows == 0 && k5TileRowsLarge <= k5MaxTileRows && k5MinTileRows % k5SpanRows == 0, "tile = whole spans");
+__host__ __device__ inline uint32_t words_per_lane5(int rows) { return (uint32_t)((rows + 63) / 64); }
 
 /* ---- the streaming half: flags of one span of k5SpanRows KiB --------------------------------- */
 
@@ -105,13 +110,13 @@ __device__ __forceinline__ unsigned long long span_flags(const Span5& s, uint64_
 /* ---- the element half ------------------------------------------------------------------------ */
 
 struct Lds5 {
-    unsigned long long words[k5TileRows];      /* the tile's mask                                   */
+    unsigned long long words[k5MaxTileRows];   /* the tile's mask: [0, rows); zero up to 64 x words_per_lane5(rows)  */
     uint32_t lane_pre[64];                     /* elements in front of lane l's words               */
     uint32_t seg_dummy[64];                    /* elem_emit leaves a segment word per element: nobody copies here */
 };
 
 /* chunk number (in the tile) of element i: the (i - lane_pre[o])-th set bit of owner lane o's words */
-__device__ __forceinline__ uint32_t elem_chunk(const Lds5& l, uint32_t i)
+__device__ __forceinline__ uint32_t elem_chunk(const Lds5& l, uint32_t i, uint32_t wpl)
 {
     /* owner: the last lane whose prefix is <= i */
     uint32_t lo = 0, hi = 63;
@@ -120,7 +125,7 @@ __device__ __forceinline__ uint32_t elem_chunk(const Lds5& l, uint32_t i)
         if (l.lane_pre[mid] <= i) lo = mid; else hi = mid - 1;
     }
     uint32_t k = i - l.lane_pre[lo];
-    uint32_t w = lo * (uint32_t)k5WordsPerLane;
+    uint32_t w = lo * wpl;
     unsigned long long x = l.words[w];
     for (;;) {
         const uint32_t c = (uint32_t)__builtin_popcountll(x);
@@ -135,12 +140,12 @@ __device__ __forceinline__ uint32_t elem_chunk(const Lds5& l, uint32_t i)
 /* elements [i0, i0 + 64) of the tile, one per lane: the exact rules on each, then their combination in order.
  * prev_chunk_end = end of the element in front of element i0 (stream offset), carried from batch to batch. */
 __device__ __forceinline__ TileAgg make_batch(Elem& el, const Lds5& l, uint32_t i0, uint32_t nelem, int lane,
-                                              const uint8_t* __restrict__ stream, uint64_t base, uint64_t n, uint64_t& prev_end)
+                                              const uint8_t* __restrict__ stream, uint64_t base, uint64_t n, uint64_t& prev_end, uint32_t wpl)
 {
     const uint32_t i = i0 + (uint32_t)lane;
     const bool have = i < nelem;
     uint32_t c = 0;
-    if (have) c = elem_chunk(l, i);
+    if (have) c = elem_chunk(l, i, wpl);
     /* the element in front of mine: the lane below, or what the previous batch left */
     const uint32_t c_prev = (uint32_t)__shfl_up((int)c, 1, 64);
     const uint64_t my_prev_end = lane == 0 ? prev_end : base + 16ull * ((uint64_t)c_prev + 1u);
@@ -196,7 +201,7 @@ __device__ __forceinline__ TileAgg ring_batch(Elem& el, const Deposit* __restric
 /* The rows of a tile again, in order, kRowsAhead at a time (the next batch's loads in flight while this one is walked: with
  * one row in flight every row cost a memory round trip): f(r, previous row, row, next row) for the rows that hold a flag. */
 constexpr int kRowsAhead = 8;
-static_assert(k5TileRows % kRowsAhead == 0, "whole batches of rows");
+static_assert(k5SpanRows % kRowsAhead == 0, "whole batches of rows in any tile");
 struct RowEdges5 { uint32_t before, before2, after; };
 __device__ __forceinline__ RowEdges5 rows_edges(const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t tile_end)
 {
@@ -207,11 +212,11 @@ __device__ __forceinline__ RowEdges5 rows_edges(const uint8_t* __restrict__ stre
     return e;
 }
 template <class F>
-__device__ __forceinline__ void tile_rows(const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int lane, const Lds5& l, F&& f)
+__device__ __forceinline__ void tile_rows(const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int rows, int lane, const Lds5& l, F&& f)
 {
-    const bool whole = base + k5TileBytes <= n;                  /* every row of the tile is there: plain loads */
+    const bool whole = base + 1024ull * (uint64_t)rows <= n;     /* every row of the tile is there: plain loads */
     auto fetch = [&](int r) -> u32x4 {
-        const uint64_t g = base + 1024ull * (uint64_t)(r < k5TileRows ? r : k5TileRows - 1) + 16ull * (uint64_t)lane;
+        const uint64_t g = base + 1024ull * (uint64_t)(r < rows ? r : rows - 1) + 16ull * (uint64_t)lane;
         return whole ? *reinterpret_cast<const u32x4*>(stream + g) : load_chunk_guarded(stream, g, n);
     };
     u32x4 cur[kRowsAhead + 2];                                    /* rows b - 1 .. b + kRowsAhead */
@@ -219,7 +224,7 @@ __device__ __forceinline__ void tile_rows(const uint8_t* __restrict__ stream, ui
     for (int i = 0; i <= kRowsAhead; ++i) cur[i + 1] = fetch(i);
     cur[0] = cur[1];
 #pragma unroll 1
-    for (int b = 0; b < k5TileRows; b += kRowsAhead) {
+    for (int b = 0; b < rows; b += kRowsAhead) {
         u32x4 nxt[kRowsAhead];
 #pragma unroll
         for (int i = 0; i < kRowsAhead; ++i) nxt[i] = fetch(b + kRowsAhead + 1 + i);
@@ -236,18 +241,18 @@ __device__ __forceinline__ void tile_rows(const uint8_t* __restrict__ stream, ui
  * state-dependent bytes (the gap in front of it + its kept bytes), found with dense_row_quick's ~100 instructions instead of
  * the walk's ~300 -- rows of 00 00 03 padding; 2: d holds the row's 64 elements */
 template <bool kErrToo>
-__device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32x4& qc, const u32x4& qn, int r, const RowEdges5& e,
+__device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32x4& qc, const u32x4& qn, int r, int rows, const RowEdges5& e,
                                          const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int lane, uint64_t& prev_end, uint32_t& quick_bytes)
 {
     const uint64_t row_lo = base + 1024ull * (uint64_t)r;
     const uint32_t gap0 = span_bytes(prev_end, row_lo, n);
     prev_end = row_lo + 1024ull;
     uint32_t kept;
-    if (row_lo + 1024ull + 64ull <= n && !dense_row_quick<kErrToo>(qp, qc, qn, r, k5TileRows, e.before, e.after, kept)) {
+    if (row_lo + 1024ull + 64ull <= n && !dense_row_quick<kErrToo>(qp, qc, qn, r, rows, e.before, e.after, kept)) {
         quick_bytes = gap0 + wave_sum32(kept);
         return 1;
     }
-    dense_row(d, qp, qc, qn, r, k5TileRows, e.before, e.before2, e.after, stream, base, n, 0u, lane);
+    dense_row(d, qp, qc, qn, r, rows, e.before, e.before2, e.after, stream, base, n, 0u, lane);
     d.el.gap = lane == 0 ? gap0 : 0u;
     return 2;
 }
@@ -274,7 +279,7 @@ __device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32
 struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
 static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
 struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
-constexpr uint32_t k5RecCap = 4u * (uint32_t)k5TileRows;                  /* elements recorded per tile: four a KiB (12.5 % of the stream's size as workspace; two until round 4:
+__host__ __device__ inline uint32_t rec_cap5(int rows) { return 4u * (uint32_t)rows; }   /* elements recorded per tile: four a KiB (12.5 % of the stream's size as workspace; two until round 4:
                                                                              NALs of 512 bytes passed it in every other tile, and such a tile is streamed twice; three: NALs of 384) */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
 constexpr int k5ChunkTiles = 64;
@@ -284,15 +289,15 @@ struct Ws5 {
     uint32_t* nrec;      /* [tiles]                  */
     TileAgg* cagg;       /* [chunks]                 */
     Pre5* cpre;          /* [chunks]                 */
-    Rec5* rec;           /* [tiles][k5RecCap]        */
+    Rec5* rec;           /* [tiles][rec_cap5(rows)]  */
 };
 __host__ __device__ inline uint64_t ws5_chunks(uint64_t tiles) { return (tiles + k5ChunkTiles - 1) / k5ChunkTiles; }
-__host__ __device__ inline Ws5 ws5_carve(void* base, uint64_t tiles)
+__host__ __device__ inline Ws5 ws5_carve(void* base, uint64_t tiles, int rows)
 {
     uint8_t* p = static_cast<uint8_t*>(base);
     Ws5 w;
     const uint64_t ch = ws5_chunks(tiles);
-    w.rec = reinterpret_cast<Rec5*>(p); p += tiles * k5RecCap * sizeof(Rec5);
+    w.rec = reinterpret_cast<Rec5*>(p); p += tiles * rec_cap5(rows) * sizeof(Rec5);
     w.tagg = reinterpret_cast<TileAgg*>(p); p += ((tiles * sizeof(TileAgg) + 255) & ~255ull);
     w.cagg = reinterpret_cast<TileAgg*>(p); p += ((ch * sizeof(TileAgg) + 255) & ~255ull);
     w.cpre = reinterpret_cast<Pre5*>(p); p += ((ch * sizeof(Pre5) + 255) & ~255ull);
@@ -301,21 +306,25 @@ __host__ __device__ inline Ws5 ws5_carve(void* base, uint64_t tiles)
 }
 uint64_t scan5_workspace_bytes(uint64_t stream_bytes)
 {
-    const uint64_t tiles = (stream_bytes + k5TileBytes - 1) / k5TileBytes + 1, ch = ws5_chunks(tiles);
-    return tiles * k5RecCap * sizeof(Rec5) + ((tiles * sizeof(TileAgg) + 255) & ~255ull) + ((ch * sizeof(TileAgg) + 255) & ~255ull) +
+    /* whatever the tile height of the call will be: the records are four a KiB (plus one tile's worth of rounding at the largest
+     * height), the per-tile and per-chunk arrays are counted at the smallest */
+    const uint64_t rec = (stream_bytes / 1024u + 2u * (uint64_t)k5MaxTileRows) * 4u * sizeof(Rec5);
+    const uint64_t tiles = stream_bytes / (1024u * (uint64_t)k5MinTileRows) + 2, ch = ws5_chunks(tiles);
+    return rec + ((tiles * sizeof(TileAgg) + 255) & ~255ull) + ((ch * sizeof(TileAgg) + 255) & ~255ull) +
            ((ch * sizeof(Pre5) + 255) & ~255ull) + tiles * sizeof(uint32_t) + 256;
 }
 
 /* the streaming half of a tile: its flag words into l.words, one span at a time, the next span's loads in flight meanwhile */
-__device__ __forceinline__ void tile_words(Lds5& l, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, uint64_t cut, int lane)
+__device__ __forceinline__ void tile_words(Lds5& l, const uint8_t* __restrict__ stream, uint64_t n, uint64_t base, int rows, uint64_t cut, int lane)
 {
     Span5 cur, nxt;
+    const int nsp = rows / k5SpanRows;
     if (base < n) span_load(nxt, stream, n, base, launder_lane(lane));
 #pragma unroll 1
-    for (int sp = 0; sp < k5TileRows / k5SpanRows; ++sp) {
+    for (int sp = 0; sp < nsp; ++sp) {
         const uint64_t sbase = base + (uint64_t)sp * k5SpanBytes;
         cur = nxt;
-        if (sp + 1 < k5TileRows / k5SpanRows && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
+        if (sp + 1 < nsp && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
         unsigned long long w = 0;
         uint32_t cnt;
         if (sbase < n) w = span_flags<false>(cur, n, sbase, cut, launder_lane(lane), nullptr, 0u, 0u, 0u, cnt);
@@ -330,16 +339,17 @@ __device__ __forceinline__ void tile_words(Lds5& l, const uint8_t* __restrict__ 
  * nothing more is deposited or walked, and the caller does the tile's elements the old way, from its flag words. */
 template <class F>
 __device__ __forceinline__ Ring5 tile_words_ring(Lds5& l, Deposit* __restrict__ dep, const uint8_t* __restrict__ stream, uint64_t n,
-                                                 uint64_t base, uint64_t cut, int lane, F&& on_batch)
+                                                 uint64_t base, int rows, uint64_t cut, int lane, F&& on_batch)
 {
     Span5 cur, nxt;
     Ring5 rg; rg.head = 0; rg.tail = 0; rg.pending = 0; rg.spilled = false;
+    const int nsp = rows / k5SpanRows;
     if (base < n) span_load(nxt, stream, n, base, launder_lane(lane));
 #pragma unroll 1
-    for (int sp = 0; sp < k5TileRows / k5SpanRows; ++sp) {
+    for (int sp = 0; sp < nsp; ++sp) {
         const uint64_t sbase = base + (uint64_t)sp * k5SpanBytes;
         cur = nxt;
-        if (sp + 1 < k5TileRows / k5SpanRows && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
+        if (sp + 1 < nsp && sbase + k5SpanBytes < n) span_load(nxt, stream, n, sbase + k5SpanBytes, launder_lane(lane));
         unsigned long long w = 0;
         uint32_t cnt = 0;
         if (sbase < n) w = span_flags<true>(cur, n, sbase, cut, launder_lane(lane), dep, (uint32_t)(sp * k5SpanRows * 64), rg.tail,
@@ -370,14 +380,16 @@ __device__ __forceinline__ Ring5 tile_words_ring(Lds5& l, Deposit* __restrict__ 
 }
 
 /* elements of the tile and whether it is walked by rows (16 or more elements per flagged row: zero stuffing, padding) */
-__device__ __forceinline__ uint32_t tile_census(Lds5& l, int lane, bool& by_rows)
+__device__ __forceinline__ uint32_t tile_census(Lds5& l, int lane, uint32_t wpl, bool& by_rows)
 {
     uint32_t mycnt = 0, myrows = 0;
 #pragma unroll
-    for (int j = 0; j < k5WordsPerLane; ++j) {
-        const unsigned long long w = l.words[lane * k5WordsPerLane + j];
-        mycnt += (uint32_t)__builtin_popcountll(w);
-        myrows += w != 0ull ? 1u : 0u;
+    for (int j = 0; j < k5MaxWordsPerLane; ++j) {
+        if ((uint32_t)j < wpl) {
+            const unsigned long long w = l.words[(uint32_t)lane * wpl + (uint32_t)j];      /* (words past the tile's rows are zero) */
+            mycnt += (uint32_t)__builtin_popcountll(w);
+            myrows += w != 0ull ? 1u : 0u;
+        }
     }
     const uint32_t inc = wave_incl_scan32(mycnt, lane);
     l.lane_pre[lane] = inc - mycnt;
@@ -411,19 +423,27 @@ __device__ __forceinline__ void rec_load(const Rec5* r, Elem& el, uint64_t base,
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, int rows, int strided, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
     if (gate_closed(gate, hdr)) return;
     __shared__ Lds5 l;
     __shared__ Deposit ring[k5Ring];
-    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane0 = threadIdx.x;
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
+    const uint64_t k5TileBytes = 1024ull * (uint64_t)rows;
+    const uint32_t k5RecCap = rec_cap5(rows), wpl = words_per_lane5(rows);
+    for (int i = rows + lane0; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;     /* the census reads whole words-per-lane groups */
+    /* Tiles.  Large streams (from 4 GiB): by ticket, as always -- twenty and more tiles per wavefront, dynamic balance.  Smaller
+     * ones (`strided`): tile = workgroup number, + gridDim.x per round, no ticket at all.  Until round 5 every tile came by ticket:
+     * 3072 wavefronts asked ONE address for their first ticket in the kernel's first microsecond and for a last, failing one in
+     * its last; read-modify-writes on one address are served one after the other -- tens of microseconds of a 1 GiB call.
+     * Nothing here waits for another tile, so the order tiles are started in is free, and the launcher cuts the stream so that
+     * every wavefront gets the same number of tiles (scan5_geometry). */
+    uint64_t tile = blockIdx.x;
+    if (!strided) { uint32_t t0 = 0; if (lane0 == 0) t0 = atomicAdd(&hdr->ticket, 1u); tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t0); }
     for (;;) {
         const int lane = launder_lane(lane0);
-        uint32_t tk = 0;
-        if (lane == 0) tk = atomicAdd(&hdr->ticket, 1u);
-        const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
         if (tile >= num_tiles) break;
         const uint64_t base = tile * k5TileBytes;
         const uint64_t tile_end = base + k5TileBytes;
@@ -438,9 +458,9 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             acc = combine(acc, agg_readlane(ea, 63));
             nwalked += cnt;
         };
-        const Ring5 rg = tile_words_ring(l, ring, stream, n, base, cut, lane, on_batch);
+        const Ring5 rg = tile_words_ring(l, ring, stream, n, base, rows, cut, lane, on_batch);
         bool by_rows;
-        const uint32_t nelem = tile_census(l, lane, by_rows);
+        const uint32_t nelem = tile_census(l, lane, wpl, by_rows);
         const uint32_t npass = (nelem + 63u) >> 6;
         if (!by_rows && !rg.spilled) {
             if (rg.pending) on_batch(rg.head, rg.pending);           /* the rest: fewer than 64 */
@@ -448,10 +468,10 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             acc = agg_identity();                                     /* (what was walked before the tile turned out dense is dropped) */
             prev_end = base;
             const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
-            tile_rows(stream, n, base, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
+            tile_rows(stream, n, base, rows, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
                 DenseRow d;
                 uint32_t quick = 0;
-                if (row_visit<false>(d, qp, qc, qn, r, edges, stream, n, base, lane, prev_end, quick) == 1) { acc = combine(acc, gap_agg(quick)); return; }
+                if (row_visit<false>(d, qp, qc, qn, r, rows, edges, stream, n, base, lane, prev_end, quick) == 1) { acc = combine(acc, gap_agg(quick)); return; }
                 const uint32_t gap0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.el.gap);
                 if (!d.row_has_event) {
                     acc = combine(acc, gap_agg(gap0 + wave_sum32(d.el.s.carry)));      /* nothing but state-dependent bytes */
@@ -467,7 +487,7 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 #pragma unroll 1
             for (uint32_t p = 0; p < npass; ++p) {
                 Elem el;
-                TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+                TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end, wpl);
                 if (record && 64u * p + (uint32_t)lane < nelem) rec_store(&w5.rec[tile * k5RecCap + 64u * p + (uint32_t)lane], el, base);
                 ea = wave_scan_combine(ea, lane);
                 acc = combine(acc, agg_readlane(ea, 63));
@@ -479,6 +499,12 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             w5.nrec[tile] = (by_rows || nelem > k5RecCap) ? k5Rewalk : nelem;
         }
         __builtin_amdgcn_wave_barrier();                       /* l is reused by the next tile */
+        if (strided) tile += gridDim.x;
+        else {
+            uint32_t tk = 0;
+            if (lane == 0) tk = atomicAdd(&hdr->ticket, 1u);
+            tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        }
     }
 }
 
@@ -490,10 +516,10 @@ __device__ __forceinline__ TileAgg agg_load_or_identity(const TileAgg* a, uint64
 }
 
 __global__ __launch_bounds__(64)
-void k_index5_chunks(uint64_t num_tiles, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
+void k_index5_chunks(uint64_t num_tiles, int rows, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
 {
     if (gate_closed(gate, hdr)) return;
-    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane = threadIdx.x;
     const uint64_t c = blockIdx.x;
     const TileAgg a = wave_scan_combine(agg_load_or_identity(w5.tagg, c * k5ChunkTiles + (uint64_t)lane, num_tiles), lane);
@@ -501,10 +527,10 @@ void k_index5_chunks(uint64_t num_tiles, void* __restrict__ ws, const RunHeader*
 }
 
 __global__ __launch_bounds__(64)
-void k_index5_prefix(uint64_t num_tiles, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
+void k_index5_prefix(uint64_t num_tiles, int rows, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
 {
     if (gate_closed(gate, hdr)) return;
-    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane = threadIdx.x;
     const uint64_t chunks = ws5_chunks(num_tiles);
     Prefix carry; carry.kept = 0; carry.nals = 0; carry.inside = 0;
@@ -525,15 +551,48 @@ void k_index5_prefix(uint64_t num_tiles, void* __restrict__ ws, const RunHeader*
     }
 }
 
+/* k_index5_chunks and k_index5_prefix in ONE launch of one workgroup, for streams of at most k5FusedChunks chunks (4096 tiles: every
+ * call below ~1.5 GiB, where a launch is 2 % of the call): wavefront w forms the aggregates of chunks w, w + 16, ..., then wavefront
+ * 0 their exclusive prefixes. */
+constexpr int k5FusedWaves = 16, k5FusedChunks = 64;
+__global__ __launch_bounds__(64 * k5FusedWaves)
+void k_index5_chunks_prefix(uint64_t num_tiles, int rows, void* __restrict__ ws, const RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate_closed(gate, hdr)) return;
+    __shared__ TileAgg cagg[k5FusedChunks];
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t chunks = ws5_chunks(num_tiles);
+    for (uint64_t c = (uint64_t)wv; c < chunks; c += k5FusedWaves) {
+        const TileAgg a = wave_scan_combine(agg_load_or_identity(w5.tagg, c * k5ChunkTiles + (uint64_t)lane, num_tiles), lane);
+        if (lane == 63) cagg[c] = a;
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    TileAgg mine = agg_identity();
+    if ((uint64_t)lane < chunks) mine = cagg[lane];
+    const TileAgg inc = wave_scan_combine(mine, lane);
+    TileAgg ex = agg_shfl_up(inc, 1);
+    if (lane == 0) ex = agg_identity();
+    Prefix zero; zero.kept = 0; zero.nals = 0; zero.inside = 0;
+    const Prefix p = fold(zero, ex);
+    if ((uint64_t)lane < chunks) {
+        Pre5 o; o.kept = p.kept; o.nals = p.nals; o.inside = p.inside; o.pad = 0;
+        w5.cpre[lane] = o;
+    }
+}
+
 __global__ __launch_bounds__(64)
 void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
-                   hbs_nal_entry* __restrict__ index, uint64_t index_cap, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+                   hbs_nal_entry* __restrict__ index, uint64_t index_cap, int rows, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
     if (gate_closed(gate, hdr)) return;
     __shared__ Lds5 l;
-    const Ws5 w5 = ws5_carve(ws, num_tiles);
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane = threadIdx.x;
     const uint64_t tile = blockIdx.x;
+    const uint64_t k5TileBytes = 1024ull * (uint64_t)rows;
+    const uint32_t k5RecCap = rec_cap5(rows), wpl = words_per_lane5(rows);
     const uint64_t base = tile * k5TileBytes, tile_end = base + k5TileBytes;
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
@@ -569,17 +628,18 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
     }
     /* the tile again, the prefix known: by rows, or its elements 64 at a time */
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
-    tile_words(l, stream, n, base, cut, lane);
+    for (int i = rows + lane; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;
+    tile_words(l, stream, n, base, rows, cut, lane);
     bool by_rows;
-    const uint32_t nelem = tile_census(l, lane, by_rows);
+    const uint32_t nelem = tile_census(l, lane, wpl, by_rows);
     TileAgg accb = agg_identity();
     uint64_t prev_end = base;
     if (by_rows) {
         const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
-        tile_rows(stream, n, base, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
+        tile_rows(stream, n, base, rows, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
             DenseRow d;
             uint32_t quick = 0;
-            if (row_visit<true>(d, qp, qc, qn, r, edges, stream, n, base, lane, prev_end, quick) == 1) { accb = combine(accb, gap_agg(quick)); return; }   /* nothing to write for such a row */
+            if (row_visit<true>(d, qp, qc, qn, r, rows, edges, stream, n, base, lane, prev_end, quick) == 1) { accb = combine(accb, gap_agg(quick)); return; }   /* nothing to write for such a row */
             const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
             TileAgg up = agg_prev_lane(ea);
             if (lane == 0) up = agg_identity();
@@ -592,7 +652,7 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
 #pragma unroll 1
         for (uint32_t p = 0; p < npass; ++p) {
             Elem el;
-            TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end);
+            TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end, wpl);
             ea = wave_scan_combine(ea, lane);
             TileAgg up = agg_prev_lane(ea);
             if (lane == 0) up = agg_identity();
@@ -605,9 +665,30 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
 
 /* ---- host side ---------------------------------------------------------------------------- */
 
-uint64_t scan5_tile_bytes() { return k5TileBytes; }
+/* Tile height (KiB), grid and schedule for a stream of n bytes on at most `waves` resident wavefronts.  From 4 GiB up: tiles of
+ * k5TileRowsLarge by ticket on every wavefront.  Below: the largest tiles the LDS mask holds (fewer, larger tiles measured
+ * faster in a single round: 2048 wavefronts x 512 KiB beat 2980 x 352 KiB on 1 GiB), no fewer than ~2048 of them, dealt in
+ * whole rounds: grid = tiles / rounds, wavefront w takes tiles w, w + grid, ... */
+Geo5 scan5_geometry(uint64_t n, uint64_t waves)
+{
+    Geo5 g;
+    g.rows = k5TileRowsLarge; g.strided = 0; g.grid = waves;
+    if (n >= (4ull << 30) || waves == 0) { g.tiles = (n + 1024ull * (uint64_t)g.rows - 1) / (1024ull * (uint64_t)g.rows); if (g.grid > g.tiles) g.grid = g.tiles; return g; }
+    uint64_t rows = k5MaxTileRows;
+    if (n < 2048ull * 1024ull * (uint64_t)k5MaxTileRows) {
+        rows = (n / 2048u + k5SpanBytes - 1) / k5SpanBytes * (uint64_t)k5SpanRows;
+        if (rows < (uint64_t)k5MinTileRows) rows = k5MinTileRows;
+    }
+    g.rows = (int)rows;
+    g.tiles = (n + 1024ull * rows - 1) / (1024ull * rows);
+    const uint64_t rounds = g.tiles ? (g.tiles + waves - 1) / waves : 1;
+    g.grid = g.tiles ? (g.tiles + rounds - 1) / rounds : 0;
+    g.strided = 1;
+    return g;
+}
+int scan5_tile_rows(uint64_t n, uint64_t waves) { return scan5_geometry(n, waves).rows; }
 
-void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st)
+void launch_scan_index5(const ScanArgs& a, int gate, hipStream_t st)
 {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -615,16 +696,32 @@ void launch_scan_index5(const ScanArgs& a, uint64_t num_tiles, int gate, hipStre
         const char* e = getenv("HBS5_WAVES_PER_CU");            /* debugging aid */
         return e && atoi(e) > 0 && atoi(e) <= 32 ? atoi(e) : 12;
     }();
+    static const int env_rows = [] {                           /* debugging aid: a tile height for every call */
+        const char* e = getenv("HBS5_TILE_ROWS");
+        const int v = e ? atoi(e) : 0;
+        return (v >= k5MinTileRows && v <= k5MaxTileRows && v % k5SpanRows == 0) ? v : 0;
+    }();
     uint64_t waves = (uint64_t)cus * (uint64_t)per_cu;
     /* hbs_ctx_reserve_workgroups: a reserved slot is four wavefronts' worth of registers (one 256-thread workgroup of the
      * event-sparse kernel); these one-wavefront workgroups fill every SIMD otherwise */
     if (a.spare_wgs > 0) waves = waves > 4ull * (uint64_t)a.spare_wgs + 64 ? waves - 4ull * (uint64_t)a.spare_wgs : 64;
-    if (waves > num_tiles) waves = num_tiles;
-    if (waves < 1) waves = 1;
-    k_index5_stream<<<dim3((unsigned)waves), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.ws5, a.hdr, gate);
-    k_index5_chunks<<<dim3((unsigned)ws5_chunks(num_tiles)), dim3(64), 0, st>>>(num_tiles, a.ws5, a.hdr, gate);
-    k_index5_prefix<<<dim3(1), dim3(64), 0, st>>>(num_tiles, a.ws5, a.hdr, gate);
-    k_index5_emit<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, a.ws5, a.hdr, gate);
+    Geo5 g = scan5_geometry(a.n, waves);
+    if (env_rows) {                                            /* (the debugging aid: that height, by ticket) */
+        g.rows = env_rows; g.strided = 0;
+        g.tiles = (a.n + 1024ull * (uint64_t)env_rows - 1) / (1024ull * (uint64_t)env_rows);
+        g.grid = waves < g.tiles ? waves : g.tiles;
+    }
+    const int rows = g.rows;
+    const uint64_t num_tiles = g.tiles;
+    if (num_tiles == 0) return;
+    k_index5_stream<<<dim3((unsigned)(g.grid < 1 ? 1 : g.grid)), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, rows, g.strided, a.ws5, a.hdr, gate);
+    if (ws5_chunks(num_tiles) <= (uint64_t)k5FusedChunks) {
+        k_index5_chunks_prefix<<<dim3(1), dim3(64 * k5FusedWaves), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
+    } else {
+        k_index5_chunks<<<dim3((unsigned)ws5_chunks(num_tiles)), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
+        k_index5_prefix<<<dim3(1), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
+    }
+    k_index5_emit<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
 }
 
 } // namespace hbs

@@ -50,6 +50,8 @@ extern "C" {
 #define HBS_E_ARG         (-3)   /* bad argument (alignment, null, capacity 0)   */
 #define HBS_E_CAPACITY    (-4)   /* index / arena / output capacity too small    */
 #define HBS_E_TIMEOUT     (-5)   /* in-kernel look-back wait gave up (bug guard) */
+#define HBS_E_DEPTH       (-6)   /* hbs_parse_headers_compact / _materialize on an out-of-spec stream whose answer needs the
+                                    sequential parse (a chain of slice-own RPS sets deeper than 3): take hbs_parse_headers */
 
 /* per-NAL status flags */
 #define HBS_ST_ERROR        1    /* nal_to_rbsp() would return -1 (h264_nal.c:156-167) */
@@ -256,6 +258,41 @@ typedef struct hbs_parsed_nal {
 int hbs_parse_headers(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
                       hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, hbs_summary* d_summary);
 /*
+ * ---- compact header parse (round 5) -------------------------------------------------------------------------------
+ * hbs_parse_headers writes one hevc_slice_header_t per slice: 4 024 bytes, cleared and then filled (reference struct
+ * hevc_stream.h:465-515, reader hevc_stream.c:782-941) -- 405 MB for the 100 k NALs of a 4K30 stream, of which a caller that
+ * indexes a stream reads a handful of members.  hbs_parse_headers_compact walks every slice header exactly as
+ * hbs_parse_headers does (same bits, same order, same derived tables, out-of-spec slices walked again exactly) but WITHOUT a
+ * struct: per slice a 64-byte hbs_slice_compact -- sixteen members of hevc_slice_header_t, each equal to the member of the
+ * same name in the struct hbs_parse_headers fills -- next to the same hbs_parsed_nal (rc, NAL header, slice_data_off /
+ * slice_data_size; struct_off = ~0 for slices).  Parameter sets are parsed into d_structs as always (the slices need them;
+ * a VPS + SPS + PPS group is ~0.5 MB).  d_structs = NULL: plan only (d_summary->reserved[0] = arena bytes needed).
+ *
+ * hbs_parse_materialize is the same call with a list of NAL numbers (device memory, any order): the listed NALs that are
+ * slices are walked into full hevc_slice_header_t slots in d_structs behind the parameter sets (d_parsed[k].struct_off says
+ * where), every other slice into its compact record as before.  "The full struct on demand": call it with the NALs a caller
+ * wants to look at closely; the structs are those of hbs_parse_headers, member for member.
+ *
+ * No trace and no parser-state output in these calls.  Errors in d_summary->error: HBS_E_CAPACITY (structs_cap), HBS_E_DEPTH
+ * (an out-of-spec stream whose exact answer needs the sequential parse: a chain of slice-own RPS sets deeper than three,
+ * never seen in 12 000 fuzzed streams; hbs_parse_headers handles it).
+ */
+typedef struct hbs_slice_compact {
+    int32_t first_slice_segment_in_pic_flag, no_output_of_prior_pics_flag, pic_parameter_set_id, dependent_slice_segment_flag;
+    int32_t slice_segment_address, slice_type, pic_output_flag, slice_pic_order_cnt_lsb;
+    int32_t short_term_ref_pic_set_sps_flag, short_term_ref_pic_set_idx, num_long_term_pics, slice_temporal_mvp_enabled_flag;
+    int32_t num_ref_idx_l0_active_minus1, num_ref_idx_l1_active_minus1, slice_qp_delta, num_entry_point_offsets;
+} hbs_slice_compact;
+
+int hbs_parse_headers_compact(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                              hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap,
+                              const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps, hbs_summary* d_summary);
+int hbs_parse_materialize(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry* d_index, uint64_t n_nals,
+                          hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap,
+                          const uint8_t* d_initial_sps_slot, const uint8_t* d_initial_pps,
+                          const uint64_t* d_nal_list, uint64_t n_list, hbs_summary* d_summary);
+
+/*
  * Opt-in extension: the NAL types read_hevc_nal_unit() returns -1 for without reading them
  * (hevc_stream.c:221-222) -- access unit delimiter 35, end of sequence 36, end of bitstream 37, filler data 38,
  * prefix / suffix SEI 39 / 40 -- read the way the reference's own, never dispatched readers would
@@ -299,6 +336,11 @@ int hbs_parse_extended(hbs_ctx* ctx, const uint8_t* d_rbsp, const hbs_nal_entry*
 int hbs_index_parse(hbs_ctx* ctx, const uint8_t* d_stream, uint64_t stream_bytes,
                     hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
                     hbs_parsed_nal* d_parsed, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
+                    hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out);
+/* the same with the compact parse behind the scan (hbs_parse_headers_compact): d_compact[k] for every NAL, no slice structs */
+int hbs_index_parse_compact(hbs_ctx* ctx, const uint8_t* d_stream, uint64_t stream_bytes,
+                    hbs_nal_entry* d_index, uint64_t index_cap, uint32_t header_window,
+                    hbs_parsed_nal* d_parsed, hbs_slice_compact* d_compact, uint8_t* d_structs, uint64_t structs_cap, uint64_t* d_payload_off,
                     hbs_summary* d_scan_summary, hbs_summary* d_parse_summary, uint64_t* nal_count_out);
 
 /* Same, for a batch that continues an earlier one: d_initial_sps_slot (an SPS
@@ -461,28 +503,48 @@ int hbs_copy_device(hbs_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes
  *
  * On MI355X a kernel that reads one large buffer and writes another in long bursts (hbs_index_extract: stream -> RBSP arena;
  * hbs_emit_annexb: arena -> stream) runs ~4-5 % slower when both buffers lie in the same one of two classes of physical
- * memory (16 GiB: 6.20 against 5.90 ms; DESIGN.md section 4, profiles/r04/placement_*.txt) -- decided when the buffers are
- * allocated, the same for every offset inside them, and invisible to HIP.  hbs_pair_alloc returns `bytes` of ordinary
- * hipMalloc memory whose placement against `d_peer` has been MEASURED: every whole GiB of a candidate allocation is timed
- * against the piece of the peer at the same offset (a content-free copy with the kernels' access pattern, half a GiB at a
- * time, on the context's stream; `d_peer` must have its final size and location, its contents do not matter and are not
- * changed) and against itself, which is the slow case by construction.  A candidate that pairs slowly is kept aside while
- * the next one is allocated (up to six, as long as the GPU has room), and freed before the call returns; when none pairs
- * fast in every piece, the one with the most fast pieces is returned.  Cost: 1.6 ms per GiB and candidate.
- * Buffers below 1 GiB, peers below 512 MiB or d_peer == NULL: one plain allocation, no measurement.
- * Free with hbs_pair_free.  Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every
- * other time.  No reference counterpart (the reference's buffers are malloc'ed host memory, hevc_analyze.c:100-103).
+ * memory (16 GiB: 6.20 against 5.90 ms; DESIGN.md section 3, profiles/r04/placement_*.txt) -- decided when the buffers are
+ * allocated, the same for every offset inside them, and invisible to HIP.  hbs_pair_alloc returns `bytes` of device memory
+ * whose placement against `d_peer` (16-byte aligned, its final size and location; contents do not matter and are not changed)
+ * has been MEASURED.  Buffers of 1 GiB and more against peers of 512 MiB and more are put together from 1 GiB physical
+ * chunks (hipMemCreate / hipMemMap) of a per-device POOL:
+ *   - every chunk the pool creates is classed once, by two content-free copies with the kernels' access pattern (half a GiB
+ *     each, ~1 ms, on the context's stream) against the pool's reference chunk and against itself;
+ *   - each GiB piece of the peer is classed the same way (one copy; by table lookup when the peer is itself such a buffer),
+ *     and chunk k of the buffer is one of the class its peer piece is NOT in;
+ *   - hbs_pair_free unmaps the buffer and puts its chunks back on the pool's free list, class attached; chunks of the class
+ *     nobody wanted stay there too.  A later hbs_pair_alloc takes them: no probes but the peer's, typically 16-20 ms for
+ *     16 GiB where the first call of a process takes 0.05-5 s (it has to find memory of both classes: up to `chunks + 88` new
+ *     chunks and 128 GiB of unmapped ballast to skip runs of one class, released when the call ends, 24 GiB of the device
+ *     left free throughout).
+ *   - the free list is bounded: what exceeds HBS_PAIR_POOL_KEEP_GIB (default 48) GiB when a call ends goes back to the driver,
+ *     hbs_pair_pool_trim(ctx, keep_bytes) releases on demand, hbs_pair_pool_stats reports.
+ * What a caller should know about such a buffer: the size is rounded up to whole GiB; it is virtual-memory-API memory -- no
+ * hipFree (hbs_pair_free only), no HIP IPC handle; its addresses come from one 32 TiB reservation per process that is used
+ * front to back and never again (a range that had been unmapped and mapped again served stale physical memory on this stack):
+ * ~17 GiB of addresses per 16 GiB buffer, about 1 900 such allocations per process, after which hbs_pair_alloc silently takes
+ * the plain way below.  One hbs_pair_alloc at a time per process (they share the pool, the address reservation and the probes).
+ * Smaller buffers, smaller peers, d_peer == NULL, HBS_PAIR_PLAIN=1, or when the virtual-memory calls fail: ordinary hipMalloc
+ * memory -- with a peer to measure against, up to six whole allocations are tried and the one with the most fast pieces kept.
+ * hbs_pair_free may be called from any thread (a destructor, a garbage collector): it leaves the caller's current device as it
+ * found it and waits only for the context's stream (the whole device when ctx is NULL).
+ * Plain hipMalloc / torch buffers keep working everywhere; they land in the slow mode about every other time.  No reference
+ * counterpart (the reference's buffers are malloc'ed host memory, hevc_analyze.c:100-103).
  */
 typedef struct hbs_pair_report {
     uint32_t chunks;                 /* GiB pieces of the buffer (the last one may be partial)                         */
-    uint32_t probed;                 /* pieces measured, over all candidates                                           */
-    uint32_t rejected;               /* candidate allocations set aside and freed                                      */
-    uint32_t accepted_fast;          /* pieces of the returned buffer that pair fast with their peer piece             */
+    uint32_t probed;                 /* probe measurements of this call: peer pieces and NEW chunks                    */
+    uint32_t rejected;               /* new chunks of a class nobody wanted (they stay on the pool's free list)        */
+    uint32_t accepted_fast;          /* pieces of the returned buffer known to pair fast with their peer piece         */
     uint32_t unprobed_after_budget;  /* pieces of the returned buffer that do not (or were not measured)               */
-    float    reserved;
+    uint32_t from_pool;              /* pieces that came off the pool's free list (classed by an earlier call)         */
+    uint32_t from_table;             /* peer pieces classed by lookup (the peer is itself a buffer of the pool)        */
+    uint32_t reserved;
 } hbs_pair_report;
 int hbs_pair_alloc(hbs_ctx* ctx, const void* d_peer, uint64_t peer_bytes, uint64_t bytes, void** out, hbs_pair_report* report /* may be NULL */);
 int hbs_pair_free(hbs_ctx* ctx, void* ptr);
+uint64_t hbs_pair_pool_trim(hbs_ctx* ctx, uint64_t keep_bytes);
+int hbs_pair_pool_stats(hbs_ctx* ctx, uint64_t out[4] /* chunks created, chunks classed, free chunks of class 0, of class 1 */);
 
 /* Synchronising copy of a device hbs_summary to the host. */
 int hbs_read_summary(hbs_ctx* ctx, const hbs_summary* d_summary, hbs_summary* h_summary);

@@ -297,7 +297,7 @@ static int64_t sim_parse_impl(const uint8_t* rbsp, const hbs_nal_entry* idx, uin
             ParsedNal out = parsed[k];
             parse_one_nal(ps, type, dst, consumed, &out, last_pps, last_sps, zero_pps, zero_sps);
             parsed[k] = out;
-            if (slice) { deps[k] = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read); any_diverged |= ps.diverged; }
+            if (slice) { deps[k] = deps_pack(ps.rec_own, ps.rec_ref, ps.rec_read, ps.own_idx); any_diverged |= ps.diverged; }
             if (g_sim_trace_count) g_sim_trace_count[k] = ps.b.tr_n;
         }
     if (g_sim_state_out) {

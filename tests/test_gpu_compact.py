@@ -1,0 +1,130 @@
+"""hbs_parse_headers_compact / hbs_parse_materialize / hbs_index_parse_compact (round 5) against hbs_parse_headers, which the
+other tests pin on the oracle and on the compiled reference: the walk of a slice header into a sink instead of a
+hevc_slice_header_t (reader hevc_stream.c:782-941, struct hevc_stream.h:465-515) must leave the same record per NAL (rc, NAL
+header, slice_data_off / slice_data_size), sixteen members per slice equal to the same-named members of the full struct, and --
+on demand -- the full struct, member for member.  Streams: rich random sequences (long-term pictures, weighted prediction,
+entry points, own RPS sets), damaged ones, a 4K30-like stream, and one with out-of-spec slices (the exact re-walk)."""
+import numpy as np
+import pytest
+
+from tests import _orc
+from tests.hevc_synth import annexb, stream_4k30
+from tests.test_sim_parse_logic import broken, sequence
+
+pytestmark = pytest.mark.gpu
+SLICE = 4024
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hevcbitstream_amd as hbs
+    c = hbs.Context(0)
+    yield c
+    c.close()
+
+
+def both(ctx, stream_bytes, want=None):
+    import torch
+    import hevcbitstream_amd as hbs
+    d = torch.from_numpy(np.frombuffer(stream_bytes, dtype=np.uint8).copy()).cuda()
+    index, rbsp, summary, cap = ctx.alloc_outputs(d.numel())
+    ctx.index_extract_async(d, index, cap, rbsp, summary)
+    n = int(ctx.read_summary(summary)["nal_count"])
+    full_p, full_s = ctx.parse_headers(rbsp, index, n, poison=0xA5)
+    if want is not None:
+        want = want(full_p)
+    cp, cc, cs = ctx.parse_headers_compact(rbsp, index, n, want=want, poison=0x5A)
+    return d, index, rbsp, n, full_p, full_s.cpu().numpy(), cp, cc, cs.cpu().numpy(), want, hbs
+
+
+def check(full_p, full_s, cp, cc, cs, want=None):
+    from hevcbitstream_amd.api import COMPACT_FIELDS
+    n = len(full_p)
+    t = full_p["nal_unit_type"]
+    is_slice = ((t >= 0) & (t <= 9)) | ((t >= 16) & (t <= 21))
+    for f in ("rc", "nal_unit_type", "nal_layer_id", "nal_temporal_id_plus1", "slice_data_size", "slice_data_off"):
+        assert np.array_equal(full_p[f], cp[f]), (f, int(np.flatnonzero(full_p[f] != cp[f])[0]))
+    wanted = np.zeros(n, dtype=bool)
+    if want is not None and len(want):
+        wanted[np.asarray(want, dtype=np.int64)] = True
+    has_full = full_p["struct_off"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+    # slices: no struct unless wanted; parameter sets: their struct, equal to the full parse's
+    assert np.all(cp["struct_off"][is_slice & ~wanted] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert np.array_equal(cp["struct_off"] != np.uint64(0xFFFFFFFFFFFFFFFF), has_full & (~is_slice | wanted))
+    idx = {name: i for name, i, cnt in _orc.flat_fields("hevc_slice_header_t")}
+    sizes = {32: _orc.layout()["hevc_vps_t"]["size"], 33: _orc.layout()["hevc_sps_t"]["size"], 34: _orc.layout()["hevc_pps_t"]["size"]}
+    for k in range(n):
+        if is_slice[k] and has_full[k]:
+            fo = int(full_p["struct_off"][k])
+            sh = full_s[fo: fo + SLICE].view(np.int32)
+            for f in COMPACT_FIELDS:
+                assert int(cc[f][k]) == int(sh[idx[f]]), (k, f, int(cc[f][k]), int(sh[idx[f]]))
+            if wanted[k]:
+                co = int(cp["struct_off"][k])
+                assert np.array_equal(cs[co: co + SLICE], full_s[fo: fo + SLICE]), (k, "materialised struct")
+        elif int(t[k]) in sizes and has_full[k]:
+            fo, co, sz = int(full_p["struct_off"][k]), int(cp["struct_off"][k]), sizes[int(t[k])]
+            assert np.array_equal(cs[co: co + sz], full_s[fo: fo + sz]), (k, int(t[k]))
+            assert all(int(cc[f][k]) == 0 for f in COMPACT_FIELDS)
+        else:
+            assert all(int(cc[f][k]) == 0 for f in COMPACT_FIELDS), k
+
+
+def test_rich_and_damaged_sequences(ctx):
+    nals = []
+    for seed in range(300, 340):
+        nals += sequence(seed)
+    for seed in range(40):
+        nals += broken(sequence(seed), np.random.RandomState(1000 + seed), lambda t: t not in (33, 34))
+    _, _, _, n, fp, fs, cp, cc, cs, _, _ = both(ctx, annexb(nals))
+    assert n == len(nals)
+    check(fp, fs, cp, cc, cs)
+
+
+def test_stream_with_out_of_spec_slices(ctx):
+    """one slice in 50 reads an RPS row an earlier slice left (the exact re-walk runs, into a lane's own slot)"""
+    stream, n = stream_4k30(21, n_pictures=600, slices_per_picture=8, idr_every=60, payload_bytes=(60, 200), forbidden_every=50)
+    _, _, _, m, fp, fs, cp, cc, cs, _, _ = both(ctx, stream)
+    assert m == n
+    check(fp, fs, cp, cc, cs)
+
+
+def test_materialize_some(ctx):
+    """hbs_parse_materialize: every 7th slice, every forbidden one among them, and a few non-slices in the list (ignored)"""
+    stream, n = stream_4k30(23, n_pictures=300, slices_per_picture=8, idr_every=30, payload_bytes=(60, 200), forbidden_every=25)
+
+    def want(fp):
+        t = fp["nal_unit_type"]
+        sl = np.flatnonzero(((t >= 0) & (t <= 9)) | ((t >= 16) & (t <= 21)))
+        return sorted(set(sl[::7].tolist() + sl[24::25].tolist() + [0, 1, 2]))[::-1]       # (any order)
+
+    _, _, _, m, fp, fs, cp, cc, cs, w, _ = both(ctx, stream, want=want)
+    assert m == n and len(w) > 300
+    check(fp, fs, cp, cc, cs, want=w)
+
+
+def test_index_parse_compact_equals_index_parse(ctx):
+    """hbs_index_parse_compact (scan, header windows, compact parse) against hbs_index_parse on a stream with real payloads"""
+    import torch
+    from hevcbitstream_amd.api import COMPACT, PARSED, SUMMARY
+    stream, n = stream_4k30(5, n_pictures=400, slices_per_picture=8, idr_every=40, payload_bytes=(3000, 9000))
+    d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+    cap = n + 8
+    outs = []
+    for compact in (False, True):
+        index = torch.zeros(cap * 32, dtype=torch.uint8, device="cuda")
+        parsed = torch.zeros(cap * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+        cc = torch.zeros(cap * COMPACT.itemsize, dtype=torch.uint8, device="cuda")
+        structs = torch.zeros(n * 4200 + (8 << 20), dtype=torch.uint8, device="cuda")
+        ss, ps = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda"), torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+        pay = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        if compact:
+            got = ctx.index_parse_compact_async(d, index, cap, parsed, cc, structs, ss, ps, payload_off=pay)
+        else:
+            got = ctx.index_parse_async(d, index, cap, parsed, structs, ss, ps, payload_off=pay)
+        assert got == n and int(ctx.read_summary(ps)["error"]) == 0
+        outs.append((index[: n * 32].cpu().numpy(), parsed[: n * PARSED.itemsize].cpu().numpy().view(PARSED), cc[: n * COMPACT.itemsize].cpu().numpy().view(COMPACT),
+                     structs.cpu().numpy(), pay[:n].cpu().numpy()))
+    (i0, p0, _, s0, y0), (i1, p1, c1, s1, y1) = outs
+    assert np.array_equal(i0, i1) and np.array_equal(y0, y1)
+    check(p0, s0, p1, c1, s1)
