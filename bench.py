@@ -311,6 +311,28 @@ def configs_1gib(torch, hbs, ctx, check=True, reps=12):
     return res
 
 
+def cpu_baseline_compact(parsed, structs_dev, compact_parsed_dev, compact_dev):
+    """checking leg of parse_headers_compact: every per-NAL record and the sixteen members of every slice's compact record against
+    the structs of the full parse (which cpu_baseline_parse compares with the reference); member offsets from the layout the
+    ABI test pins (tests/golden/field_layout.json through tests/_orc.py).  Returns the number of slices compared."""
+    import numpy as np
+    from tests import _orc
+    from hevcbitstream_amd.api import COMPACT, COMPACT_FIELDS, PARSED
+    cp_h = compact_parsed_dev.cpu().numpy().view(PARSED)
+    cc_h = compact_dev.cpu().numpy().view(COMPACT)
+    st_h = structs_dev.cpu().numpy()
+    for f in ("rc", "nal_unit_type", "nal_layer_id", "nal_temporal_id_plus1", "slice_data_size", "slice_data_off"):
+        assert np.array_equal(cp_h[f], parsed[f]), "compact parse: record field %s differs from the full parse's" % f
+    t = parsed["nal_unit_type"]
+    sl = np.flatnonzero((((t >= 0) & (t <= 9)) | ((t >= 16) & (t <= 21))) & (parsed["struct_off"] != np.uint64(0xFFFFFFFFFFFFFFFF)))
+    offs = parsed["struct_off"][sl].astype(np.int64)
+    words = st_h[: (len(st_h) // 4) * 4].view(np.int32)
+    where = {name: i for name, i, cnt in _orc.flat_fields("hevc_slice_header_t")}
+    for f in COMPACT_FIELDS:
+        assert np.array_equal(cc_h[f][sl], words[offs // 4 + where[f]]), "compact parse: member %s differs from the full struct's" % f
+    return int(len(sl))
+
+
 def pmc_traffic(kernel_name, algo_bytes):
     """profiles/r*/traffic_<kernel>.json of the newest round -- if it is about this kernel, this workload AND this
     source: the file records the digest of hevcbitstream_amd/csrc at profiling time; after any change to the kernels
@@ -391,7 +413,8 @@ def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, s
     p2 = parsed2.cpu().numpy().view(PARSED)
     # rc = bytes of the NAL consumed (grows with the payload) or -1
     assert np.array_equal(p2["rc"] < 0, parsed_s["rc"] < 0) and np.array_equal(p2["nal_unit_type"], parsed_s["nal_unit_type"])
-    assert torch.equal(structs2, structs_s), "header structs differ from those of the same headers in the small stream"
+    used = structs_s.numel() - 16                             # (the arena is allocated 16 bytes longer than the parse fills)
+    assert torch.equal(structs2[:used], structs_s[:used]), "header structs differ from those of the same headers in the small stream"
     res = {"value": round(sb2 / ms / 1e6, 1), "unit": "GB/s of stream, scan + index + extraction + header parse", "ms": round(ms, 3),
            "nal_per_s": round(m / ms * 1e3, 1), "stream_bytes": sb2, "nals": m,
            "workload": "synthetic 4K30 sequence, %d NALs, slice payloads 16-28 KiB (%.2f GiB): hbs_index_extract then hbs_parse_headers, "
@@ -413,12 +436,33 @@ def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, s
     ms3 = min(ts[1:])
     assert got == m and int(ctx.read_summary(psum3)["error"]) == 0
     assert torch.equal(index3[: m * 32], index2[: m * 32]) and torch.equal(parsed3, parsed2), "hbs_index_parse: index / records differ from the arena path"
-    assert torch.equal(structs3, structs_s), "hbs_index_parse: header structs differ"
+    assert torch.equal(structs3[:used], structs_s[:used]), "hbs_index_parse: header structs differ"
     first = stream2[pay3.clamp(min=0, max=sb2 - 1)]                       # the byte at every slice's payload offset ...
     sl = torch.from_numpy(is_slice).to(dev)
     ent2d = index2[: m * 32].view(torch.int64).view(m, 4)
     want = rbsp2[(ent2d[:, 2] + torch.from_numpy(p2["slice_data_off"].astype(np.int64)).to(dev)).clamp(max=total - 1)]
     assert torch.equal(first[sl], want[sl]), "payload offsets"          # ... is the RBSP byte the arena path's slice_data_off names
+    # ... and with the compact parse behind the scan (hbs_index_parse_compact): no slice structs at all
+    from hevcbitstream_amd.api import COMPACT
+    cc3 = torch.empty(m * COMPACT.itemsize, dtype=torch.uint8, device=dev)
+    parsed4 = torch.empty_like(parsed2)
+    index4 = torch.empty_like(index2)
+    ts = []
+    for i in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = ctx.index_parse_compact_async(stream2[:sb2], index4, cap2, parsed4, cc3, structs3, ssum, psum3)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ms4 = min(ts[1:])
+    assert got == m and int(ctx.read_summary(psum3)["error"]) == 0
+    p4 = parsed4.cpu().numpy().view(PARSED)
+    for f in ("rc", "nal_unit_type", "slice_data_size", "slice_data_off"):
+        assert np.array_equal(p4[f], p2[f]), "hbs_index_parse_compact: record field %s" % f
+    assert torch.equal(index4[: m * 32], index2[: m * 32])
+    res["without_arena_compact"] = {"value": round(sb2 / ms4 / 1e6, 1), "unit": "GB/s of stream, scan + index + compact header parse (hbs_index_parse_compact), host wall time of the call",
+                                    "ms": round(ms4, 3), "nal_per_s": round(m / ms4 * 1e3, 1),
+                                    "note": "index and per-NAL records equal to the arena path's; the slice records are those of parse_headers_compact (compared member by member there)"}
     res["without_arena"] = {"value": round(sb2 / ms3 / 1e6, 1), "unit": "GB/s of stream, scan + index + header parse (hbs_index_parse), host wall time of the call",
                             "ms": round(ms3, 3), "nal_per_s": round(m / ms3 * 1e3, 1),
                             "note": "index, records and structs equal to the arena path's; includes the call's one wait (for the scan's NAL count)"}
@@ -622,6 +666,26 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(5))
     res["parse_headers"] = {"value": round(m / ms / 1e3, 1), "unit": "M NAL/s", "ms": round(ms, 3),
                             "workload": "synthetic 4K30 stream, %d NALs (VPS/SPS/PPS every 60 pictures, 8 slices per picture)" % m}
+    # the compact parse of the same batch (hbs_parse_headers_compact): the same walk into sinks, a 64-byte record per slice instead
+    # of a 4 024-byte struct; every member of every record compared with the struct the full parse filled
+    from hevcbitstream_amd.api import COMPACT
+    cpt = torch.empty(m * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+    cct = torch.empty(m * COMPACT.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.parse_compact_async(rbsp, index, m, cpt, cct, None, sm)
+    cneed = int(ctx.read_summary(sm)["reserved"][0])
+    cst = torch.empty(cneed + 16, dtype=torch.uint8, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    for i in range(6):
+        ctx.parse_compact_async(rbsp, index, m, cpt, cct, cst, sm)
+        ev[i].record()
+    torch.cuda.synchronize()
+    cms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(5))
+    assert int(ctx.read_summary(sm)["error"]) == 0
+    n_slices = cpu_baseline_compact(parsed, structs, cpt, cct) if cpu_parse else None
+    res["parse_headers_compact"] = {"value": round(m / cms / 1e3, 1), "unit": "M NAL/s", "ms": round(cms, 3), "struct_arena_bytes": cneed,
+                                    "full_parse_struct_arena_bytes": int(structs.numel()),
+                                    "check": ("rc, NAL header, slice_data_off / slice_data_size of all %d NALs and the sixteen members of all %d slice records equal "
+                                              "to the full parse's (which is compared with the reference below)" % (m, n_slices)) if cpu_parse else "not run (--cpu-sample-nals 0)"}
     if cpu_parse:
         # config 3 pinned on the reference: the structs of this sequence against read_hevc_nal_unit on the host, all NALs;
         # config3_end_to_end below requires the 2.1 GiB pipeline (with and without arena) to produce these same structs

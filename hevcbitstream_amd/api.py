@@ -38,7 +38,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
            "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_comm_reserve_hint", "hbs_parse_headers_compact", "hbs_parse_materialize", "hbs_index_parse_compact", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
-           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes", "hbs_pair_alloc", "hbs_pair_free", "hbs_pair_pool_trim", "hbs_pair_pool_stats", "hbs_parse_headers_state", "hbs_ctx_last_emit_by_tiles"]
+           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes", "hbs_ctx_set_ingest_window_max", "hbs_pair_alloc", "hbs_pair_free", "hbs_pair_pool_trim", "hbs_pair_pool_stats", "hbs_parse_headers_state", "hbs_ctx_last_emit_by_tiles"]
 
 
 PAIR_REPORT = np.dtype([("chunks", "<u4"), ("probed", "<u4"), ("rejected", "<u4"), ("accepted_fast", "<u4"),
@@ -315,6 +315,11 @@ class Context:
         return ent, arena, s
 
     # ---- K3 and the synthetic workload -------------------------------------------------
+
+    def set_ingest_window_max(self, max_bytes):
+        """ceiling of the window growth of index_extract_host (a NAL longer than the window doubles it); 0: the default, 1 GiB"""
+        self.lib.hbs_ctx_set_ingest_window_max.argtypes = [C.c_void_p, C.c_uint64]
+        self._check(self.lib.hbs_ctx_set_ingest_window_max(self.h, int(max_bytes)), "hbs_ctx_set_ingest_window_max")
 
     def index_extract_host(self, stream, window_bytes=256 << 20, index_cap=None, want_rbsp=True, pinned=True):
         """Windowed ingest of a HOST stream of any length (hbs_index_extract_host): `stream` is a numpy

@@ -18,6 +18,21 @@
 
 namespace hbs {
 
+/* The trace sink of hbs_parse.h's BitIOT::log: record n of a NAL's trace (three words: site, cursor, value), when there is room.
+ * NOT inlined on the device: the trace variants of the parse kernels carry a read site every other line, and with the stores
+ * and their 64-bit address arithmetic inlined at each of them the register allocator gave up (k4_parse<trace>: 3 153 spilled
+ * registers, 2.3 KB of scratch per lane; the plain variants of the same walk: none).  A call costs a few dozen cycles per
+ * syntax element of a reader that exists to print every one of them. */
+#if defined(__HIPCC__)
+static __device__ __host__ __attribute__((noinline))
+#else
+static inline
+#endif
+void trace_put(uint32_t* records, uint32_t cap, uint32_t n, uint32_t site, uint32_t at, uint32_t value)
+{
+    if (n < cap) { records[3u * n] = site; records[3u * n + 1u] = at; records[3u * n + 2u] = value; }
+}
+
 /* the 40 bits starting at byte i0, big-endian, in the low bits of the result; needs i0 + nbytes <= size */
 template <class B>
 HBS_HD uint64_t fast_window(const B& b, uint32_t i0, uint32_t nbytes)

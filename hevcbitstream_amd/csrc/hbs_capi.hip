@@ -38,6 +38,7 @@ struct hbs_ctx {
     int probe_pending;
     int last_index_only;          /* the last hbs_index_extract had no arena: its sparse kernel is the streaming one (5) */
     int parse_sequential;         /* hbs_ctx_set_sequential_parse */
+    uint64_t ingest_window_max;   /* hbs_ctx_set_ingest_window_max (0: the default) */
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
     int emit_blocks, emit_two_pass;   /* K3: resident workgroups of the single-pass kernel; 1 = use the older three-step path */
@@ -170,6 +171,7 @@ __attribute__((visibility("hidden"))) void hbs_ctx_set_error(hbs_ctx* c, const c
 {
     if (c) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString((hipError_t)hip_error));
 }
+__attribute__((visibility("hidden"))) uint64_t hbs_ctx_ingest_window_max(hbs_ctx* c) { return c ? c->ingest_window_max : 0; }
 /* internal (hbs_ingest.hip): one object kept alive with the context, freed with it; not exported */
 __attribute__((visibility("hidden"))) void* hbs_ctx_attachment(hbs_ctx* c) { return c ? c->attachment : nullptr; }
 __attribute__((visibility("hidden"))) void hbs_ctx_attach(hbs_ctx* c, void* p, void (*free_fn)(void*))
@@ -268,6 +270,13 @@ int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
 {
     if (!c) return HBS_E_ARG;
     c->parse_sequential = on ? 1 : 0;
+    return 0;
+}
+
+int hbs_ctx_set_ingest_window_max(hbs_ctx* c, uint64_t max_window_bytes)
+{
+    if (!c) return HBS_E_ARG;
+    c->ingest_window_max = max_window_bytes;
     return 0;
 }
 

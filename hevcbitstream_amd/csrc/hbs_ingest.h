@@ -157,7 +157,12 @@ int ingest_windowed(Backend& be, uint64_t n, uint64_t window_bytes,
         lo = new_lo;
         const uint64_t na = lo & ~15ull;
         const uint64_t again = hi - na;                       /* bytes of this window that the next one scans again */
-        if (again > lead) { res.error = HBS_E_CAPACITY; break; }        /* a NAL (or a gap) longer than the window */
+        if (again > lead) {
+            /* a NAL (or a gap) longer than the window: everything up to `lo` is delivered; the caller may go on from there with
+             * a larger window (reserved[2] = 1, reserved[1] = lo: hbs_index_extract_host does, up to its ceiling) */
+            res.error = HBS_E_CAPACITY; res.reserved[1] = lo; res.reserved[2] = 1;
+            break;
+        }
         rc = be.carry(buf, win_off + (na - a), buf ^ 1, lead - again, again);
         if (rc) return rc;
         hi += next_len;

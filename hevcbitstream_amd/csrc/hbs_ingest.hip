@@ -19,6 +19,7 @@ void* hbs_ctx_get_stream(hbs_ctx* ctx);
 /* internal: an object that lives and dies with the context (hbs_capi.hip) */
 __attribute__((visibility("hidden"))) void* hbs_ctx_attachment(hbs_ctx* ctx);
 __attribute__((visibility("hidden"))) void hbs_ctx_attach(hbs_ctx* ctx, void* p, void (*free_fn)(void*));
+__attribute__((visibility("hidden"))) uint64_t hbs_ctx_ingest_window_max(hbs_ctx* ctx);
 }
 
 namespace {
@@ -141,23 +142,65 @@ extern "C" int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uin
     if (!ctx || !h_summary || (stream_bytes && !h_stream) || (index_cap && !h_index)) return HBS_E_ARG;
     window_bytes &= ~15ull;
     if (window_bytes < 4096) return HBS_E_ARG;
-    /* entries one window can produce: a window (with what it scans again) of 2 x window_bytes, one NAL per 32 bytes */
-    const uint64_t per_window = (2 * window_bytes) / 32 + 64;
-    HipBackend* be = static_cast<HipBackend*>(hbs_ctx_attachment(ctx));
-    if (be && (be->window != window_bytes || (h_rbsp != nullptr && !be->want_rbsp))) {
-        hbs_ctx_attach(ctx, nullptr, nullptr);               /* frees it */
-        be = nullptr;
+    /* A NAL longer than the window used to end the call with HBS_E_CAPACITY (the reference's 32 MiB reader at least parses such a
+     * NAL cut short, hevc_analyze.c:126,190-209).  Since round 5 the window GROWS: the walk has delivered everything up to the
+     * end of the last complete NAL (find_nal_unit is stateless: any NAL end is a place to resume, hevc_analyze.c:176), so the
+     * call goes on from there with device windows of twice the size -- again and again up to hbs_ctx_set_ingest_window_max
+     * (default 1 GiB; a ceiling at or below window_bytes keeps round 4's behaviour).  Later windows keep the larger size. */
+    uint64_t ceiling = hbs_ctx_ingest_window_max(ctx);
+    if (ceiling == 0) ceiling = 1ull << 30;
+    hbs_summary total;
+    total.nal_count = total.nal_found = total.rbsp_bytes = 0; total.stream_bytes = stream_bytes;
+    total.stop_reason = 0; total.error = 0; total.reserved[0] = total.reserved[1] = total.reserved[2] = 0;
+    uint64_t at = 0;                       /* stream offset this run starts at: 0, or the NAL end the previous run reached */
+    uint64_t window = window_bytes;
+    int rc = 0;
+    for (;;) {
+        /* entries one window can produce: a window (with what it scans again) of 2 x window, one NAL per 32 bytes */
+        const uint64_t per_window = (2 * window) / 32 + 64;
+        HipBackend* be = static_cast<HipBackend*>(hbs_ctx_attachment(ctx));
+        if (be && (be->window != window || (h_rbsp != nullptr && !be->want_rbsp))) {
+            hbs_ctx_attach(ctx, nullptr, nullptr);               /* frees it */
+            be = nullptr;
+        }
+        if (!be) {
+            be = new (std::nothrow) HipBackend();
+            if (!be) return HBS_E_HIP;
+            be->ctx = ctx; be->window = window; be->lead = window; be->idx_cap = per_window;
+            be->want_rbsp = h_rbsp != nullptr;
+            hbs_ctx_attach(ctx, be, [](void* p) { HipBackend* b = static_cast<HipBackend*>(p); b->release(); delete b; });
+        }
+        be->h_stream = h_stream + at; be->h_rbsp = h_rbsp ? h_rbsp + total.rbsp_bytes : nullptr;
+        hbs_summary s;
+        const uint64_t had = total.nal_count < index_cap ? total.nal_count : index_cap;
+        rc = hbs::ingest_windowed(*be, stream_bytes - at, window, h_index + had, index_cap - had, h_rbsp != nullptr,
+                                  rbsp_cap > total.rbsp_bytes ? rbsp_cap - total.rbsp_bytes : 0, &s);
+        be->end();
+        if (!be->allocated) hbs_ctx_attach(ctx, nullptr, nullptr);   /* an allocation failed: do not keep the pieces */
+        if (rc) return rc;
+        /* this run's entries are relative to where it started */
+        if (at || total.rbsp_bytes)
+            for (uint64_t k = 0; k < s.nal_count && had + k < index_cap; ++k) {
+                h_index[had + k].start += at; h_index[had + k].end += at; h_index[had + k].rbsp_off += total.rbsp_bytes;
+            }
+        total.nal_count += s.nal_count;
+        total.rbsp_bytes += s.rbsp_bytes;
+        total.stop_reason = s.stop_reason;
+        total.nal_found = total.nal_count + (s.nal_found - s.nal_count);
+        const bool window_too_small = s.error == HBS_E_CAPACITY && s.reserved[2] == 1;
+        if (window_too_small && 2 * window <= ceiling) {
+            at += s.reserved[1];
+            window *= 2;
+            total.reserved[0] = window;                        /* the window the call ended with (0: never grown) */
+            continue;
+        }
+        total.error = s.error;
+        if (window_too_small) { total.reserved[1] = at + s.reserved[1]; total.reserved[2] = 1; }     /* the ceiling was reached: where, in the stream */
+        break;
     }
-    if (!be) {
-        be = new (std::nothrow) HipBackend();
-        if (!be) return HBS_E_HIP;
-        be->ctx = ctx; be->window = window_bytes; be->lead = window_bytes; be->idx_cap = per_window;
-        be->want_rbsp = h_rbsp != nullptr;
-        hbs_ctx_attach(ctx, be, [](void* p) { HipBackend* b = static_cast<HipBackend*>(p); b->release(); delete b; });
-    }
-    be->h_stream = h_stream; be->h_rbsp = h_rbsp;
-    const int rc = hbs::ingest_windowed(*be, stream_bytes, window_bytes, h_index, index_cap, h_rbsp != nullptr, rbsp_cap, h_summary);
-    be->end();
-    if (!be->allocated) hbs_ctx_attach(ctx, nullptr, nullptr);   /* an allocation failed: do not keep the pieces */
-    return rc;
+    /* (a run that ran out of index or arena room and THEN out of window reported only the latter) */
+    if (total.nal_count > index_cap) { total.nal_count = index_cap; if (!total.error) total.error = HBS_E_CAPACITY; }
+    if (h_rbsp && total.rbsp_bytes > rbsp_cap && !total.error) total.error = HBS_E_CAPACITY;
+    *h_summary = total;
+    return 0;
 }

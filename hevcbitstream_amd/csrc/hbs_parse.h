@@ -131,7 +131,7 @@ struct BitIOT {
     HBS_M void log(uint32_t site, uint32_t at, uint32_t value)
     {
         if (kTrace) {
-            if (tr_n < tr_cap) { tr[tr_n].site = site; tr[tr_n].pos = at; tr[tr_n].value = (int32_t)value; }
+            trace_put(reinterpret_cast<uint32_t*>(tr), tr_cap, tr_n, site, at, value);      /* a CALL (hbs_bitfast.h): inlined at every read site, the three stores and their address arithmetic made the trace kernels spill 3 000 registers */
             ++tr_n;
         }
     }

@@ -49,6 +49,29 @@ struct Bits32 {
     HBS_HD int operator[](int k) const { return (int)((bits >> (k & 31)) & 1u); }
 };
 
+/* 32 small integers that ARE read back, a byte each in eight registers (an int[32] indexed by a variable lives in scratch memory):
+ * what reads them back (NumPicTotalCurr, hevc_stream.c:35-59) only asks "is it 0..31, and which" -- anything else, negative
+ * values included, is stored as 255 */
+struct Bytes32 {
+    uint32_t w0, w1, w2, w3, w4, w5, w6, w7;
+    HBS_HD void clear() { w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = 0u; }
+    HBS_HD uint32_t word(int j) const { return j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : j == 3 ? w3 : j == 4 ? w4 : j == 5 ? w5 : j == 6 ? w6 : w7; }
+    HBS_HD void put(int k, int v)
+    {
+        const uint32_t b = (v >= 0 && v < 255) ? (uint32_t)v : 255u, sh = 8u * ((uint32_t)k & 3u), m = ~(0xFFu << sh), j = ((uint32_t)k >> 2) & 7u;
+        if (j == 0) w0 = (w0 & m) | (b << sh); else if (j == 1) w1 = (w1 & m) | (b << sh); else if (j == 2) w2 = (w2 & m) | (b << sh);
+        else if (j == 3) w3 = (w3 & m) | (b << sh); else if (j == 4) w4 = (w4 & m) | (b << sh); else if (j == 5) w5 = (w5 & m) | (b << sh);
+        else if (j == 6) w6 = (w6 & m) | (b << sh); else w7 = (w7 & m) | (b << sh);
+    }
+    struct Ref {
+        Bytes32* p; int k;
+        template <class T> HBS_HD const Ref& operator=(const T& v) const { p->put(k, (int)v); return *this; }
+        HBS_HD operator int() const { return (int)((p->word((k >> 2) & 7) >> (8u * ((uint32_t)k & 3u))) & 0xFFu); }
+    };
+    HBS_HD Ref operator[](int k) { Ref r; r.p = this; r.k = k & 31; return r; }
+    HBS_HD int operator[](int k) const { return (int)((word((k >> 2) & 7) >> (8u * ((uint32_t)k & 3u))) & 0xFFu); }
+};
+
 /* hevc_st_ref_pic_set_t, hevc_ref_pics_lists_mod_t as sinks: the walk reads nothing back from them */
 #define HBS_SINK_F(name)            Discard name;
 #define HBS_SINK_A(name, n)         DiscardArr name;
@@ -85,7 +108,7 @@ struct SliceSink {
     int short_term_ref_pic_set_idx;
     Discard num_long_term_sps;
     int num_long_term_pics;
-    int lt_idx_sps[MAX_NUM_LONG_TERM_REF_PICS];                 /* read back by NumPicTotalCurr */
+    Bytes32 lt_idx_sps;                                         /* read back by NumPicTotalCurr */
     DiscardArr poc_lsb_lt;
     Bits32 used_by_curr_pic_lt_flag;                            /* read back by NumPicTotalCurr */
     DiscardArr delta_poc_msb_present_flag, delta_poc_msb_cycle_lt;
@@ -152,7 +175,7 @@ HBS_D void parse_slice_into_sink(ParserT<kMode>& ps, int nal_unit_type, int cons
     s.num_ref_idx_l0_active_minus1 = s.num_ref_idx_l1_active_minus1 = s.slice_qp_delta = s.num_entry_point_offsets = 0;
     s.used_by_curr_pic_lt_flag.bits = 0u;
     s.pwt.luma_weight_l0_flag.bits = s.pwt.chroma_weight_l0_flag.bits = s.pwt.luma_weight_l1_flag.bits = s.pwt.chroma_weight_l1_flag.bits = 0u;
-    for (int i = 0; i < MAX_NUM_LONG_TERM_REF_PICS; ++i) s.lt_idx_sps[i] = 0;
+    s.lt_idx_sps.clear();
     ps.slice_segment_header(&s, nal_unit_type, last_pps, last_sps, zero_pps, zero_sps);
     out->slice_data_off = (ps.b.pos >> 3) + 1u;                              /* hevc_stream.c:608-616, as parse_one_nal */
     out->slice_data_size = (int32_t)ps.b.size - (int32_t)(ps.b.pos >> 3) - 1;

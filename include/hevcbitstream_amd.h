@@ -181,13 +181,18 @@ int hbs_index_extract(hbs_ctx* ctx,
  * arrive in host memory with offsets relative to h_stream / h_rbsp, identical to what
  * hbs_index_extract returns for the whole stream.  Replaces the windowed reader of
  * hevc_analyze.c:124-210 (and gets a NAL that straddles two reads right).
- * Limits: a NAL (with the zeros in front of it) must fit in one window, and a window must not
- * hold more than window_bytes/16 NALs; HBS_E_CAPACITY in h_summary->error otherwise.
- * Page-locked host buffers make the transfers asynchronous; pageable ones work.
+ * A NAL (with the zeros in front of it) that does not fit the window makes the window GROW (round 5): the walk goes on from
+ * the end of the last complete NAL with device windows of twice the size, as often as it takes, up to the ceiling set with
+ * hbs_ctx_set_ingest_window_max (default 1 GiB; a ceiling at or below window_bytes: no growth); h_summary->reserved[0] = the
+ * window size the call ended with (0: never grown).  Past the ceiling: HBS_E_CAPACITY in h_summary->error, reserved[2] = 1
+ * and reserved[1] = the stream offset of the NAL that did not fit -- everything in front of it has been delivered.  (The
+ * reference's fixed 32 MiB reader parses such a NAL cut short, hevc_analyze.c:126,190-209.)  A window must not hold more than
+ * window_bytes/16 NALs (HBS_E_CAPACITY otherwise).  Page-locked host buffers make the transfers asynchronous; pageable ones work.
  */
 int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t stream_bytes, uint64_t window_bytes,
                            hbs_nal_entry* h_index, uint64_t index_cap,
                            uint8_t* h_rbsp, uint64_t rbsp_cap, hbs_summary* h_summary);
+int hbs_ctx_set_ingest_window_max(hbs_ctx* ctx, uint64_t max_window_bytes /* 0: the default, 1 GiB */);
 
 /*
  * K3: re-emit Annex-B from an RBSP arena: for every NAL, the bytes between the
