@@ -592,6 +592,38 @@ def emit_mixed_lines(torch, ctx, g, n, rb, sb, uniform_ms):
     return res
 
 
+def zero_heavy_line(torch, ctx, check):
+    """hbs_index_extract over S(seed, 1 540 000 NALs, mode = zero-heavy) = ~16 GiB: kernel time by the library's events, fraction of
+    the peak from the algorithmic bytes; the arena and the index against the generator's on the device, and (check) the first
+    200 000 NALs through the reference's loop on the host (cpu_baseline)."""
+    n1 = 1_540_000
+    g1 = ctx.synth_stream(SEED, n1, 1)
+    sb1, rb1 = g1["stream_bytes"], g1["rbsp_bytes"]
+    stream1 = g1["stream"][:sb1]
+    index1, rbsp1, summary1, cap1 = ctx.alloc_outputs(sb1, index_cap=n1 + 8, peer=stream1)
+    ks = []
+    for i in range(5):
+        ctx.index_extract_async(stream1, index1, cap1, rbsp1, summary1)
+        if i:
+            ks.append(ctx.kernel_ms())
+    s1 = ctx.read_summary(summary1)
+    assert int(s1["error"]) == 0 and int(s1["nal_count"]) == n1 and int(s1["rbsp_bytes"]) == rb1, s1
+    assert torch.equal(rbsp1[:rb1], g1["rbsp"][:rb1]), "zero-heavy: extracted RBSP != generated RBSP"
+    a = index1[: n1 * 32].view(torch.int64).view(n1, 4)
+    b = g1["index"][: n1 * 32].view(torch.int64).view(n1, 4)
+    assert torch.equal(a[:, :3], b[:, :3]), "zero-heavy: NAL index != generator's index"
+    ks.sort()
+    k_ms = ks[len(ks) // 2]
+    algo = sb1 + rb1 + 32 * n1
+    line = {"value": round(sb1 / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4"}.get(ctx.last_kernel(), "?"),
+            "kernel_ms": round(k_ms, 4), "stream_bytes": sb1, "nals": n1, "algorithmic_bytes": algo,
+            "roofline": {"bound": "hbm", "achieved": round(algo / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 4)},
+            "workload": "S(seed=0x1234, n_nals=%d, zero-heavy): %.3f GiB, resident in HBM; arena and index equal to the generator's" % (n1, sb1 / 2**30)}
+    if check:
+        line["cpu_baseline"] = cpu_baseline(stream1, index1, rbsp1, n1, 200_000)
+    return line
+
+
 def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     """RBSP -> Annex-B over the bench arena; header parse + writers on BASELINE config 3 (4K30, ~100 k NALs)."""
     import ctypes as C
@@ -600,6 +632,25 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     from tests.hevc_synth import stream_4k30
     res = {}
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+    # the placement pool: the headline arena has just been freed -- its sixteen chunks are on the pool's free list, classed; a new
+    # arena against the same stream takes them (no new chunk, only the stream's sixteen pieces are probed again)
+    t_a = time.perf_counter()
+    again, rep2 = ctx.pair_alloc(g["stream"][:sb], sb + 16)
+    torch.cuda.synchronize()
+    t_again = time.perf_counter() - t_a
+    idx_a = torch.empty((n + 8) * 32, dtype=torch.uint8, device="cuda")
+    sum_a = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    ka = []
+    for i in range(4):
+        ctx.index_extract_async(g["stream"][:sb], idx_a, n + 8, again, sum_a)
+        if i:
+            ka.append(ctx.kernel_ms())
+    ka.sort()
+    assert int(ctx.read_summary(sum_a)["rbsp_bytes"]) == rb
+    del again, idx_a
+    res["placement_pool"] = {"second_placed_allocation": dict(rep2, seconds=round(t_again, 4), kernel_ms=round(ka[len(ka) // 2], 4)),
+                             "note": "hbs_pair_alloc of 16 GiB against the bench stream after the timed loop's arena was freed: chunks off the pool's free list "
+                                     "(from_pool), probes = the stream's pieces only; kernel_ms = hbs_index_extract into it"}
     # BASELINE's own 1 GiB configs (2: scan + nal_to_rbsp, 4: the rbsp_to_nal write path), each with a roofline of its own and the
     # whole stream compared with the reference's walk
     res["configs_1GiB"] = configs_1gib(torch, hbs, ctx, check=cpu_parse)
@@ -623,6 +674,12 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     del index
     res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
     res["mixed_stream"]["index_only"] = mixed_index_only(torch, ctx, g["stream"][:sb], sb, n + 64, ms)
+    # SURVEY 8(d)'s second mode: the zero-heavy stress stream at 16 GiB (every NAL full of zero runs and emulation prevention
+    # bytes: thousands of elements per tile), same call, its own roofline; a sample of it through the reference on the host
+    try:
+        res["zero_heavy_16GiB"] = zero_heavy_line(torch, ctx, cpu_parse)
+    except Exception as e:                                            # noqa: BLE001  (reported, never allowed to take the line down)
+        res["zero_heavy_16GiB"] = {"error": "%s: %s" % (type(e).__name__, e)}
     torch.cuda.empty_cache()                                          # (what torch keeps cached is not free memory to hbs_pair_alloc's candidates)
     out, emit_placement = ctx.pair_alloc(g["rbsp"], sb + 4096)       # the emitted stream placed against the arena it is read from
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
@@ -1017,22 +1074,10 @@ def main():
             kp.sort()
             del rbsp_p, index_p
             torch.cuda.empty_cache()
-            t_a = time.perf_counter()
-            again, rep2 = ctx.pair_alloc(stream, sb + 16)
-            torch.cuda.synchronize()
-            t_again = time.perf_counter() - t_a
-            ka = []
-            for i in range(4):
-                ctx.index_extract_async(stream, index, cap, again, summary)
-                if i:
-                    ka.append(ctx.kernel_ms())
-            ka.sort()
-            del again
             out["roofline"]["placement"] = {"kernel_ms_placed_arena": round(k_ms, 4), "kernel_ms_plain_arena": round(kp[len(kp) // 2], 4),
                                             "plain_over_placed": round(kp[len(kp) // 2] / k_ms, 4),
-                                            "second_placed_allocation": dict(rep2, seconds=round(t_again, 4), kernel_ms=round(ka[len(ka) // 2], 4)),
-                                            "note": "same process, same stream: the timed steps' arena (hbs_pair_alloc) against an arena from torch's allocator, "
-                                                    "then a SECOND hbs_pair_alloc of the same size while the first is alive (the pool's chunks are classed once)"}
+                                            "note": "same process, same stream: the timed steps' arena (hbs_pair_alloc) against an arena from torch's allocator; "
+                                                    "other_kernels.placement_pool: what the next placed allocations cost"}
         if world == 1 and args.cpu_sample_nals > 0:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(stream, index, rbsp, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:

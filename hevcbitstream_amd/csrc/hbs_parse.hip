@@ -352,7 +352,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               const uint8_t* __restrict__ init_pps, uint32_t* __restrict__ err,
               TraceRec* __restrict__ trace, uint32_t trace_cap, uint32_t* __restrict__ trace_count,
               RpsRow* __restrict__ own_rows /* 64 per wavefront of the grid */, unsigned parse_blocks, uint32_t* __restrict__ div_flag,
-              uint32_t* __restrict__ deps, SliceCompact* __restrict__ compact = nullptr)
+              uint32_t* __restrict__ deps, SliceCompact* __restrict__ compact = nullptr, int psets_cleared = 0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[4][64 * kLaneWinStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -395,7 +395,7 @@ void k4_parse(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
             uint4* q = reinterpret_cast<uint4*>(my_rows);
             const uint4 z = make_uint4(0, 0, 0, 0);
             for (uint32_t i = (uint32_t)lane; i < (uint32_t)(64 * sizeof(RpsRow) / 16); i += 64) q[i] = z;
-        } else {                                               /* the slots of my parameter sets, by the whole wave */
+        } else if (!psets_cleared) {                           /* the slots of my parameter sets, by the whole wave (k4_zero_psets did it otherwise) */
             uint64_t todo = __ballot(active);
             while (todo) {
                 const int j = (int)__builtin_ctzll(todo);
@@ -880,6 +880,36 @@ void k5_write(const ParsedNal* __restrict__ parsed, uint64_t n, int pass, uint8_
     }
 }
 
+/* The slots of the parameter sets, cleared by whole workgroups in front of the pass that parses them (round 5).  A hevc_vps_t is
+ * 428 136 bytes and an SPS slot 93 KiB: cleared by the one wavefront that then parses the set (round 4), every VPS cost its
+ * wavefront 418 rounds of stores before the first bit was read -- 67 us for the 627 parameter sets of BASELINE config 3, longer
+ * than the 100 000 slices behind them took.  A workgroup looks at 256 consecutive NALs and clears what they need, 4 KiB a round. */
+__global__ __launch_bounds__(256)
+void k4_zero_psets(const ParsedNal* __restrict__ parsed, uint64_t n, uint8_t* __restrict__ structs, uint64_t structs_cap)
+{
+    __shared__ unsigned long long off[256];
+    __shared__ uint32_t bytes[256];
+    __shared__ uint32_t count;
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k < n) {
+        const int t = parsed[k].nal_unit_type;
+        const uint64_t o = parsed[k].struct_off;
+        if ((t == HEVC_NAL_UNIT_TYPE_VPS_NUT || t == HEVC_NAL_UNIT_TYPE_SPS_NUT || t == HEVC_NAL_UNIT_TYPE_PPS_NUT) && o != ~0ull &&
+            o + slot_bytes_of(t) <= structs_cap) {
+            const uint32_t i = atomicAdd(&count, 1u);
+            off[i] = o; bytes[i] = (uint32_t)slot_bytes_of(t);
+        }
+    }
+    __syncthreads();
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = 0; i < count; ++i) {
+        uint4* q = reinterpret_cast<uint4*>(structs + off[i]);
+        for (uint32_t j = threadIdx.x; j < bytes[i] / 16u; j += 256u) q[j] = z;          /* slots are multiples of 16 */
+    }
+}
+
 __global__ void k4_summary(uint64_t n, const unsigned long long* total, const uint32_t* err, hbs_summary* sum)
 {
     sum->nal_count = n; sum->nal_found = n; sum->rbsp_bytes = 0; sum->stream_bytes = 0;
@@ -928,9 +958,10 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (!a.structs) { k4_summary<<<1, 1, 0, st>>>(a.n, a.total, a.err, a.summary); return hipGetLastError(); }     /* plan only */
         const unsigned pblocks = parse_grid_blocks(a.n);
-        /* parameter sets (and, when slices are wanted in full, the clearing of their slots by the spare workgroups) */
+        /* parameter sets, their slots cleared in front (and, when slices are wanted in full, the clearing of THEIR slots by the spare workgroups) */
+        k4_zero_psets<<<dim3((unsigned)((a.n + 255) / 256)), 256, 0, st>>>(a.parsed, a.n, a.structs, a.structs_cap);
         k4_parse<kModeRead, false><<<pblocks + (a.want_n ? kZeroBlocks : 0u), 256, 0, st>>>(a.rbsp, a.index, a.n, 0, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps,
-            a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, a.compact);
+            a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, a.compact, 1);
         k4_parse<kModeRead, true><<<pblocks, 256, 0, st>>>(a.rbsp, a.index, a.n, 1, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps,
             a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, a.compact);
         if (a.want_n)
@@ -1002,12 +1033,13 @@ hipError_t launch_parse_headers(const ParseArgs& a, hipStream_t st)
         k4_scan_apply<true><<<kScan4Blocks, 256, 0, st>>>(a.parsed, a.slot_size, a.n, part, a.ctx_sps, a.ctx_pps);
         if (a.structs) {
             const unsigned pblocks = parse_grid_blocks(a.n);
+            k4_zero_psets<<<dim3((unsigned)((a.n + 255) / 256)), 256, 0, st>>>(a.parsed, a.n, a.structs, a.structs_cap);
             for (int pass = 0; pass < 2; ++pass) {
                 const unsigned grid = pblocks + (pass == 0 ? kZeroBlocks : 0u);
                 if (a.trace)
-                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks, a.div_flag, a.deps);
+                    k4_parse<kModeTrace><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, a.trace, a.trace_cap, a.trace_count, a.own_rows, pblocks, a.div_flag, a.deps, nullptr, 1);
                 else
-                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps);
+                    k4_parse<kModeRead><<<grid, 256, 0, st>>>(a.rbsp, a.index, a.n, pass, a.parsed, a.structs, a.structs_cap, a.ctx_sps, a.ctx_pps, a.zeros, a.initial_sps_slot, a.initial_pps, a.err, nullptr, 0, nullptr, a.own_rows, pblocks, a.div_flag, a.deps, nullptr, 1);
             }
         }
     }

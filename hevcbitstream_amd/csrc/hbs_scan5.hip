@@ -666,23 +666,26 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
 /* ---- host side ---------------------------------------------------------------------------- */
 
 /* Tile height (KiB), grid and schedule for a stream of n bytes on at most `waves` resident wavefronts.  From 4 GiB up: tiles of
- * k5TileRowsLarge by ticket on every wavefront.  Below: the largest tiles the LDS mask holds (fewer, larger tiles measured
- * faster in a single round: 2048 wavefronts x 512 KiB beat 2980 x 352 KiB on 1 GiB), no fewer than ~2048 of them, dealt in
- * whole rounds: grid = tiles / rounds, wavefront w takes tiles w, w + grid, ... */
+ * k5TileRowsLarge by ticket on every wavefront.  Below: the fewest rounds r such that a tile fits the LDS mask (k5MaxTileRows),
+ * the tile height that gives EVERY resident wavefront exactly r tiles, grid = tiles / r, wavefront w takes tiles w, w + grid, ...
+ * (Fewer, larger tiles -- 2048 wavefronts x 512 KiB on 1 GiB -- measured 3 % faster still on ~10 KiB NALs and 20 % slower on
+ * 0.5-1 KiB NALs, where the element batches make the kernel VALU-bound and a third fewer wavefronts is a third less of that:
+ * the host cannot know which it is.) */
 Geo5 scan5_geometry(uint64_t n, uint64_t waves)
 {
     Geo5 g;
     g.rows = k5TileRowsLarge; g.strided = 0; g.grid = waves;
     if (n >= (4ull << 30) || waves == 0) { g.tiles = (n + 1024ull * (uint64_t)g.rows - 1) / (1024ull * (uint64_t)g.rows); if (g.grid > g.tiles) g.grid = g.tiles; return g; }
-    uint64_t rows = k5MaxTileRows;
-    if (n < 2048ull * 1024ull * (uint64_t)k5MaxTileRows) {
-        rows = (n / 2048u + k5SpanBytes - 1) / k5SpanBytes * (uint64_t)k5SpanRows;
-        if (rows < (uint64_t)k5MinTileRows) rows = k5MinTileRows;
-    }
+    const uint64_t cap = waves * 1024ull * (uint64_t)k5MaxTileRows;
+    const uint64_t rounds = n ? (n + cap - 1) / cap : 1;
+    const uint64_t per = (n + waves * rounds - 1) / (waves * rounds);
+    uint64_t rows = (per + k5SpanBytes - 1) / k5SpanBytes * (uint64_t)k5SpanRows;
+    if (rows < (uint64_t)k5MinTileRows) rows = k5MinTileRows;
+    if (rows > (uint64_t)k5MaxTileRows) rows = k5MaxTileRows;
     g.rows = (int)rows;
     g.tiles = (n + 1024ull * rows - 1) / (1024ull * rows);
-    const uint64_t rounds = g.tiles ? (g.tiles + waves - 1) / waves : 1;
-    g.grid = g.tiles ? (g.tiles + rounds - 1) / rounds : 0;
+    const uint64_t r2 = g.tiles ? (g.tiles + waves - 1) / waves : 1;
+    g.grid = g.tiles ? (g.tiles + r2 - 1) / r2 : 0;
     g.strided = 1;
     return g;
 }

@@ -81,7 +81,7 @@ def test_a_nal_longer_than_the_window_grows_the_window(ctx, orc):
     got_idx, got_arena, s = ctx.index_extract_host(mixed, window_bytes=65536)
     import torch
     ref_idx, ref_arena, _ = ctx.index_extract(torch.from_numpy(mixed).cuda())
-    assert int(s["error"]) == 0 and int(s["reserved"][0]) == 4 << 20
+    assert int(s["error"]) == 0 and int(s["reserved"][0]) == 2 << 20          # (a window buffer holds what is scanned again + a window: a NAL fits when 2 windows hold it)
     for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
         assert np.array_equal(got_idx[f], ref_idx[f]), f
     assert np.array_equal(got_arena, ref_arena)
