@@ -1061,7 +1061,7 @@ def main():
         if tr is not None:
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
-        if world == 1 and not args.plain_alloc:
+        if world == 1 and not args.plain_alloc and args.other_kernels:
             # what placement buys, in THIS process: the same steps into an arena from torch's allocator (placement left to chance;
             # outside the timed region), and what a second placed allocation costs now that the pool knows its chunks
             index_p, rbsp_p, summary_p, cap_p = ctx.alloc_outputs(sb, index_cap=n + 8)

@@ -61,3 +61,29 @@ for kind in ("torch", "paired"):
     res.append("%s %.3f ms (%.4f)" % (kind, ms, (rb + sb) / ms / 8e9))
     del out
 print("K3 emit: " + "  ".join(res) + ("  report %s" % rep), flush=True)
+
+# round 5: the pool.  The arena above is given back and asked for again (its chunks come off the free list: no new chunk, the
+# stream's sixteen pieces are probed again), then K3's output against THAT arena (a pool buffer: classes by lookup)
+del rbsp2
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+index3, rbsp3, summary3, cap3 = ctx.alloc_outputs(sb, index_cap=n + 8, peer=stream)
+torch.cuda.synchronize()
+t_alloc2 = time.perf_counter() - t0
+rep3 = dict(ctx.last_pair_report)
+t_pair2 = k12(rbsp3, index3, cap3, summary3)
+assert torch.equal(rbsp3[:rb], g["rbsp"][:rb]), "second paired arena: wrong bytes"
+t0 = time.perf_counter()
+out4, rep4 = ctx.pair_alloc(rbsp3, sb + 4096)
+torch.cuda.synchronize()
+t_alloc3 = time.perf_counter() - t0
+idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+for i in range(5):
+    ev[i].record()
+    if i < 4:
+        ctx.emit_annexb_async(rbsp3, rb, index3, n, 1, out4, idx_out, summary3)
+torch.cuda.synchronize()
+ms4 = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(1, 4))[1]
+assert torch.equal(out4[:sb], stream)
+print("pool: second arena alloc %.4f s %s K12 %.3f ms (%.4f); K3 output against it alloc %.4f s %s K3 %.3f ms (%.4f)" % (
+    t_alloc2, rep3, t_pair2, algo / t_pair2 / 8e9, t_alloc3, rep4, ms4, (rb + sb) / ms4 / 8e9), flush=True)
