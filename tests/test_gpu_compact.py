@@ -128,3 +128,71 @@ def test_index_parse_compact_equals_index_parse(ctx):
     (i0, p0, _, s0, y0), (i1, p1, c1, s1, y1) = outs
     assert np.array_equal(i0, i1) and np.array_equal(y0, y1)
     check(p0, s0, p1, c1, s1)
+
+
+def test_small_batches_and_odd_lists(ctx):
+    """batches of 1 ... 70 NALs (the full parse takes its one-launch path below 65, the compact parse has one way only), an empty
+    list, a list with duplicates, non-slices and numbers past the batch"""
+    nals = sequence(77)
+    for m in (1, 3, 4, 16, len(nals)):
+        _, _, _, n, fp, fs, cp, cc, cs, _, _ = both(ctx, annexb(nals[:m]))
+        assert n == m
+        check(fp, fs, cp, cc, cs)
+    many = []
+    for seed in range(400, 406):
+        many += sequence(seed)
+    _, _, _, n, fp, fs, cp, cc, cs, w, _ = both(ctx, annexb(many), want=lambda fp: [])
+    check(fp, fs, cp, cc, cs, want=[])
+    t = None
+
+    def odd(fp):
+        tt = fp["nal_unit_type"]
+        sl = np.flatnonzero(((tt >= 0) & (tt <= 9)) | ((tt >= 16) & (tt <= 21))).tolist()
+        return [sl[0], sl[0], sl[3], 0, len(fp) + 5, 10 ** 12, sl[-1]]
+
+    d, index, rbsp, n, fp, fs, cp, cc, cs, w, _ = both(ctx, annexb(many), want=odd)
+    inside = sorted({k for k in w if k < n})
+    check(fp, fs, cp, cc, cs, want=inside)
+    del t
+
+
+def test_compact_parse_continues_a_stream(ctx):
+    """initial parameter sets handed in (a batch that continues a stream): the second half of a sequence parsed compactly from the
+    state behind its first half equals the full parse of the same call"""
+    import torch
+    import hevcbitstream_amd as hbs
+    from hevcbitstream_amd.api import COMPACT, PARSED, SUMMARY
+    stream, n = stream_4k30(31, n_pictures=240, slices_per_picture=4, idr_every=60, payload_bytes=(60, 200), forbidden_every=17)
+    d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+    index, rbsp, summary, cap = ctx.alloc_outputs(d.numel())
+    ctx.index_extract_async(d, index, cap, rbsp, summary)
+    assert int(ctx.read_summary(summary)["nal_count"]) == n
+    half = n // 2 + 3                                           # (in the middle of a group of pictures: the second half starts with slices)
+    lib = ctx.lib
+    import ctypes as C
+    sps_slot = torch.zeros(int(lib.hbs_sps_slot_bytes()), dtype=torch.uint8, device="cuda")
+    pps = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    parsed = torch.zeros(n * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+    structs = torch.zeros(n * 4200 + (4 << 20), dtype=torch.uint8, device="cuda")
+    sm = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+    lib.hbs_parse_headers_state.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ctx._bind_stream()
+    p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None         # noqa: E731
+    assert lib.hbs_parse_headers_state(ctx.h, p(rbsp), p(index), half, p(parsed), p(structs), structs.numel(), None, None, None, 0, None, p(sm),
+                                       p(sps_slot), p(pps)) == 0
+    assert int(ctx.read_summary(sm)["error"]) == 0
+    rest = n - half
+    idx2 = index[half * 32:]
+    lib.hbs_parse_headers_ctx.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    fp_d = torch.zeros(rest * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+    fs_d = torch.zeros_like(structs)
+    assert lib.hbs_parse_headers_ctx(ctx.h, p(rbsp), p(idx2), rest, p(fp_d), p(fs_d), fs_d.numel(), p(sps_slot), p(pps), p(sm)) == 0
+    assert int(ctx.read_summary(sm)["error"]) == 0
+    cp_d = torch.zeros(rest * PARSED.itemsize, dtype=torch.uint8, device="cuda")
+    cc_d = torch.zeros(rest * COMPACT.itemsize, dtype=torch.uint8, device="cuda")
+    cs_d = torch.zeros_like(structs)
+    ctx.parse_compact_async(rbsp, idx2, rest, cp_d, cc_d, cs_d, sm, None, sps_slot, pps)
+    assert int(ctx.read_summary(sm)["error"]) == 0
+    check(fp_d.cpu().numpy().view(PARSED), fs_d.cpu().numpy(), cp_d.cpu().numpy().view(PARSED), cc_d.cpu().numpy().view(COMPACT), cs_d.cpu().numpy())
+    del hbs
