@@ -34,7 +34,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_ctx_synchronize", "hbs_last_error", "hbs_index_extract", "hbs_index_extract_host", "hbs_read_summary",
            "hbs_workspace_bytes", "hbs_write_headers", "hbs_parse_headers_trace", "hbs_emit_annexb", "hbs_annexb_bound", "hbs_synth_rbsp",
            "hbs_synth_rbsp_bound", "hbs_ctx_enable_timing", "hbs_ctx_kernel_ms", "hbs_ctx_kernel_ms_back", "hbs_ctx_grid",
-           "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
+           "hbs_parse_headers", "hbs_ctx_set_kernel", "hbs_ctx_set_count_ahead", "hbs_ctx_get_kernel", "hbs_ctx_last_kernel",
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
            "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_comm_reserve_hint", "hbs_parse_headers_compact", "hbs_parse_materialize", "hbs_index_parse_compact", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
@@ -110,6 +110,7 @@ def load_library():
     lib.hbs_ctx_kernel_ms_back.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     lib.hbs_ctx_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hbs_ctx_set_kernel.argtypes = [C.c_void_p, C.c_int]
+    lib.hbs_ctx_set_count_ahead.argtypes = [C.c_void_p, C.c_int]
     lib.hbs_ctx_get_kernel.argtypes = [C.c_void_p]
     lib.hbs_ctx_last_kernel.argtypes = [C.c_void_p]
     lib.hbs_last_error.argtypes = [C.c_void_p]
@@ -192,6 +193,10 @@ class Context:
         """0 = automatic (density probe picks 4 or 2 on the device; the default), 2 = LDS-image
         scan/extract kernel, 4 = event-sparse one, 5 = index-only streaming one"""
         self._check(self.lib.hbs_ctx_set_kernel(self.h, variant), "hbs_ctx_set_kernel")
+
+    def set_count_ahead(self, mode=1):
+        """kernel 4's dense tiles counted ahead of it: 0 never, 1 on streams of 4 GiB and more (default), 2 always"""
+        self._check(self.lib.hbs_ctx_set_count_ahead(self.h, mode), "hbs_ctx_set_count_ahead")
 
     def kernel(self):
         return self.lib.hbs_ctx_get_kernel(self.h)

@@ -38,6 +38,7 @@ struct hbs_ctx {
     int probe_pending;
     int last_index_only;          /* the last hbs_index_extract had no arena: its sparse kernel is the streaming one (5) */
     int parse_sequential;         /* hbs_ctx_set_sequential_parse */
+    int count_ahead;              /* hbs_ctx_set_count_ahead: 0 never, 1 streams from 4 GiB up, 2 always */
     uint64_t ingest_window_max;   /* hbs_ctx_set_ingest_window_max (0: the default) */
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
@@ -55,6 +56,7 @@ struct hbs_ctx {
     uint8_t* tail;                      /* padded copy of the stream's last tile (event-sparse kernel) */
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
+    void* ahead; uint64_t ahead_tiles; uint32_t ahead_calls;   /* K12's dense tiles counted ahead: a table entry and a byte per 192 KiB tile (streams from 4 GiB up) */
     void* ws2; uint64_t ws2_bytes;   /* hbs_index_parse: header windows and the index that points into them (alive across the parse, which carves ws) */
     uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
     /* optional timing of the dominant kernel */
@@ -139,6 +141,8 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     c->grid_env = (g && atoi(g) > 0) ? atoi(g) : 0;
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
+    const char* ca = getenv("HBS_COUNT_AHEAD");
+    c->count_ahead = (ca && ca[0] >= '0' && ca[0] <= '2') ? ca[0] - '0' : 1;
     const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 4 event-sparse, 5 index-only streaming */
     const char* sv = getenv("HBS_SCHED");
     c->sched = (sv && atoi(sv) >= 0 && atoi(sv) <= 2) ? atoi(sv) : HBS_DEFAULT_SCHED;
@@ -158,6 +162,7 @@ void hbs_ctx_destroy(hbs_ctx* c)
     if (c->hdr) (void)hipFree(c->hdr);
     if (c->tail) (void)hipFree(c->tail);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->ahead) (void)hipFree(c->ahead);
     if (c->zeros) (void)hipFree(c->zeros);
     if (c->emit_verdict) (void)hipFree(c->emit_verdict);
     if (c->ws2) (void)hipFree(c->ws2);
@@ -264,6 +269,13 @@ int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 }
 
 int hbs_ctx_get_kernel(hbs_ctx* c) { return c ? c->variant : HBS_E_ARG; }
+
+int hbs_ctx_set_count_ahead(hbs_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) return HBS_E_ARG;
+    c->count_ahead = mode;
+    return 0;
+}
 int hbs_ctx_device(hbs_ctx* c) { return c ? c->device : HBS_E_ARG; }
 
 int hbs_ctx_set_sequential_parse(hbs_ctx* c, int on)
@@ -344,7 +356,7 @@ uint64_t hbs_ctx_device_bytes(hbs_ctx* c)
 {
     if (!c) return 0;
     const uint64_t zb = c->zeros ? ((sizeof(hevc_sps_t) + 255) & ~(uint64_t)255) : 0;
-    return c->desc_tiles * 16 + sizeof(hbs::RunHeader) + hbs::scan4_tail_bytes() + c->ws_bytes + c->ws2_bytes + zb;
+    return c->desc_tiles * 16 + sizeof(hbs::RunHeader) + hbs::scan4_tail_bytes() + c->ws_bytes + c->ws2_bytes + (c->ahead_tiles ? 64 + c->ahead_tiles * hbs::scan4_ahead_entry_bytes() : 0) + zb;
 }
 
 uint64_t hbs_workspace_bytes(uint64_t stream_bytes)
@@ -375,6 +387,27 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
         rc = ensure_ws(c, hbs::scan5_workspace_bytes(n));
         if (rc) return rc;
         a.ws5 = c->ws;
+    }
+    a.ahead_cand = nullptr; a.ahead_tab = nullptr; a.ahead_list = nullptr; a.ahead_ctl = nullptr; a.ahead_parity = 0;
+    if (d_rbsp && (c->count_ahead == 2 || (c->count_ahead == 1 && hbs::scan4_counts_ahead(n))) && n > (uint64_t)hbs::scan4_tile_bytes() &&
+        (c->variant == 0 || c->variant == 4 || c->variant == 5) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) {
+        /* K12's dense tiles counted ahead: [two counters | table | list | bytes] */
+        const uint64_t tiles = (n + (uint64_t)hbs::scan4_tile_bytes() - 1) / (uint64_t)hbs::scan4_tile_bytes();
+        if (tiles > c->ahead_tiles) {
+            if (c->ahead) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ahead); c->ahead = nullptr; c->ahead_tiles = 0; }
+            hipError_t e = hipMalloc(&c->ahead, 64 + tiles * hbs::scan4_ahead_entry_bytes());
+            if (e != hipSuccess) return fail(c, e, "hipMalloc(count-ahead table)");
+            e = hipMemsetAsync(c->ahead, 0, 64, c->stream);
+            if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(count-ahead counters)");
+            c->ahead_tiles = tiles;
+        }
+        uint8_t* const p = static_cast<uint8_t*>(c->ahead);
+        a.ahead_ctl = reinterpret_cast<uint32_t*>(p);
+        a.ahead_tab = p + 64;
+        a.ahead_list = reinterpret_cast<uint32_t*>(p + 64 + c->ahead_tiles * 64);
+        a.ahead_cand = p + 64 + c->ahead_tiles * 68;
+        a.ahead_parity = (int)(c->ahead_calls & 1u);
+        c->ahead_calls += 1;
     }
     c->last_index_only = (hbs::scan_uses_index_only(n, c->variant, d_rbsp) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;

@@ -20,6 +20,12 @@ struct ScanArgs {
     void* ws5;                    /* workspace of scan5_workspace_bytes(n): tile aggregates and recorded elements of the index-only
                                      kernels (hbs_scan5.hip); needed only when rbsp == nullptr */
     hbs_summary* summary;         /* device                                       */
+    uint8_t* ahead_cand;          /* workspace: a byte per 192 KiB tile -- the prologue's sample says "dense" (event-sparse kernel with count-ahead), or nullptr */
+    uint32_t* ahead_list;         /* workspace: the tiles so marked, a word per tile of the stream at most                                */
+    uint32_t* ahead_ctl;          /* workspace: two counters; [ahead_parity] = entries of the list in this call, the other is cleared for the next */
+    int ahead_parity;
+    void* ahead_tab;              /* workspace: scan4_ahead_entry_bytes() per tile: the aggregates of the tiles counted ahead           */
+              /* this call's number on its context (never 0): stamps the entries                                  */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
     int grid_blocks4;                 /* ... of the event-sparse kernel                                        */
     int spare_wgs;                    /* hbs_ctx_reserve_workgroups: slots (of 256 threads) every scan kernel leaves free     */
@@ -50,6 +56,10 @@ int scan4_tail_bytes();
 /* header, probe, padded last tile, cleared index and look-back words: one launch in front of the main kernel */
 void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, int tail_tile_bytes /* 0: no padded copy */, hipStream_t st);
 void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
+/* dense tiles counted ahead (round 5): bytes per tile of the table, the stream size from which a call uses it, the launch */
+uint64_t scan4_ahead_entry_bytes();
+bool scan4_counts_ahead(uint64_t n);
+void launch_scan_ahead4(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 
 /* index-only streaming kernel (hbs_scan5.hip) */
 uint64_t scan5_workspace_bytes(uint64_t stream_bytes);     /* for any tile height the launcher may pick */

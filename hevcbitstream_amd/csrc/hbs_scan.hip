@@ -689,6 +689,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
         if (index_only && !automatic) {
             launch_scan_index5(a, kGateNone, st);
         } else if (!automatic && sparse_variant == 4) {
+            launch_scan_ahead4(a, tiles4, kGateNone, st);           /* (does nothing unless the call carries the count-ahead's workspace) */
             launch_scan_extract4_kernel(a, tiles4, kGateNone, st);
         } else if (automatic) {
             /* Both kernels are enqueued; each reads the probe's verdict from the run header and the
@@ -697,7 +698,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
             /* (a side stream for the kernel that rules itself out, forked and joined with events, was tried in round 4: the two
              * event waits cost more than the empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
             if (index_only) launch_scan_index5(a, kGateIfSparseIdx, st);
-            else launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st);
+            else { launch_scan_ahead4(a, tiles4, kGateIfSparse, st); launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st); }
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, index_only ? kGateIfDenseIdx : kGateIfDense);
         } else {

@@ -53,10 +53,18 @@ __device__ unsigned long long g_phase_cycles4[1024][8];
 #define HBS4_T_COUNT(i, v) { t_acc[i] += (v); }
 #define HBS4_T_FLUSH if (threadIdx.x == 0 && blockIdx.x < 1024) { for (int i = 0; i < 8; ++i) g_phase_cycles4[blockIdx.x][i] = t_acc[i]; }
 __device__ uint32_t g_dbg4[4096];
+/* a timeline per tile (wall clock, 10 ns): taken / aggregate known / look-back done / finished; bit 0 of [1]: walked as a dense tile */
+constexpr unsigned kTl4Tiles = 1u << 17;
+__device__ unsigned long long g_tl4[kTl4Tiles][4];
+__device__ unsigned long long g_tlwho4[kTl4Tiles];      /* who took the tile: workgroup | HW_ID << 32, XCC_ID in bits 28-31 of the low word */
+#define HBS4_TL(tile, k, bit) { if (threadIdx.x == 0 && (tile) < kTl4Tiles) { g_tl4[tile][k] = (wall_clock64() & ~1ull) | (unsigned long long)(bit); \
+    if ((k) == 0) g_tlwho4[tile] = (unsigned long long)blockIdx.x | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15u) << 28) | \
+                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32); } }
 __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all (wrong results, timing only) */
 #define HBS4_DBG(code) code
 #else
 #define HBS4_DBG(code)
+#define HBS4_TL(tile, k, bit)
 #define HBS4_T_DECL
 #define HBS4_T_MARK(i)
 #define HBS4_T_COUNT(i, v)
@@ -65,6 +73,9 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 
 #ifndef HBS4_WG_PER_CU
 #define HBS4_WG_PER_CU 2      /* workgroups per CU = wavefronts per SIMD the register budget is cut for */
+#endif
+#ifndef HBS4_TICKET_BARRIER
+#define HBS4_TICKET_BARRIER 0  /* 1: a barrier in front of the ordinary tile's ticket too (wavefront 0, which takes it, is nearly always the last to finish) */
 #endif
 #ifndef HBS4_PROGRESSIVE
 #define HBS4_PROGRESSIVE 1     /* the fetch inside the flag pass, four rows at a time */
@@ -312,6 +323,30 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
 /* One dense tile, by the whole workgroup (every thread calls it): aggregates, look-back, emission, the next ticket.  A function
  * of its own, not inlined: inlined, its registers add to the 192 the rows occupy and the COMMON path spills 33 of them around
  * every tile's first barrier (index-only scans ran 23 % slower).  false: a look-back timed out, the workgroup gives up. */
+/* ---- dense tiles counted ahead (round 5) ---------------------------------------------------------------------------------
+ * A dense tile's aggregate is out only when its four wavefronts have walked their 48 rows each -- 40-45 us after the tile was
+ * taken, where an ordinary tile's is out after ~15 -- and every tile behind it waits for it in its look-back: 25 us of the
+ * whole GPU wherever a stretch of padding or zero stuffing begins (the tiles inside the stretch are walked at the same time as
+ * its first one).  But a tile's aggregate does not depend on anything in front of the tile.  So, as k3_tiles does since round 4:
+ * the prologue samples every tile (a chunk in every 4 KiB: a tile is dense from 512 flagged chunks = 8 KiB of such a stretch,
+ * which holds two or three neighbouring samples; coded video flags one sample in 500) and leaves a byte per tile and a list
+ * of the tiles it marked; k_scan_ahead4 takes the tiles so marked, in front of the main kernel and with nobody waiting -- counts their flagged chunks roughly, and walks the
+ * ones that may be dense: their four wavefront aggregates go to a table, the tile's byte becomes kAheadDone; dense_tile takes
+ * such a tile's entry instead of walking its rows a first time (marks and entries are this call's: the prologue writes every
+ * tile's byte).  A dense tile the sample misses is walked in place as before; a marked tile that turns out ordinary costs its
+ * rows once more, read by a kernel that has the memory system to itself.  From kAheadMinBytes up (below, the extra launch
+ * costs a call more than mixed content is likely to; hbs_ctx_set_count_ahead).  The bench's mixed stream (16 GiB, 1 % of it in
+ * 640 KiB stretches): 7.65 -> 6.4-6.5 ms, 1.29 -> 1.05-1.10 x the uniform stream's time. */
+struct AheadEntry { TileAgg w[k4Waves]; };
+static_assert(sizeof(AheadEntry) == 64, "four aggregates");
+constexpr uint64_t kAheadMinBytes = 4ull << 30;          /* the launch costs ~10 us where nothing is marked: 1.3 % of a 2 GiB call, 0.6 % at 4 GiB, 0.15 % at 16 */
+constexpr int kAheadSample = 48;                         /* chunks sampled per tile, 4 KiB apart */
+constexpr int kAheadMinHits = 8;                         /* marked from this many flagged samples, or from three in a row (streams of 512-byte NALs
+                                                            flag a sample in 20: two in a row marked a tile in 9, and the kernel below took 0.23 ms of 1.2) */
+constexpr uint32_t kAheadRoughMin = 400;                 /* k_scan_ahead4 walks a marked tile when its rough count reaches this (chunks taken by themselves:
+                                                            a pattern across two chunks is missed, one in eight) */
+constexpr uint8_t kAheadMarked = 1, kAheadDone = 2;
+
 __device__ __attribute__((noinline))
 bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
                 uint64_t tile, bool last_tile, uint8_t* rbsp, uint64_t rbsp_cap, unsigned long long* desc, RunHeader* hdr,
@@ -322,7 +357,9 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk0 = (uint32_t)(64 * k4Rows * wv);
-    const TileAgg wa = dense_aggregate(src, wseg, n, before, before2, after, chunk0, lane);
+    /* counted ahead in this call (k_scan_ahead4)?  then the table has what the walk below would find */
+    const bool counted = hdr->ahead_tab != 0ull && !last_tile && reinterpret_cast<const uint8_t*>(hdr->ahead_cand)[tile] == kAheadDone;
+    const TileAgg wa = counted ? reinterpret_cast<const AheadEntry*>(hdr->ahead_tab)[tile].w[wv] : dense_aggregate(src, wseg, n, before, before2, after, chunk0, lane);
     if (lane == 0) l.wagg[wv] = wa;
     __syncthreads();
     TileAgg before_me = agg_identity(), tagg = agg_identity();
@@ -331,7 +368,9 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     if (wv == 0) {
         Prefix ex;
         uint32_t it, stl;
+        HBS4_TL(tile, 1, 1)
         const bool ok = look_back4(desc, tile, tagg, hdr, lane, ex, it, stl);
+        HBS4_TL(tile, 2, 0)
         HBS4_PRIO(0);
         const uint32_t tile_kept = tagg.known + (ex.inside ? tagg.sig : 0u);
         const bool can = rbsp != nullptr && ex.kept + tile_kept <= rbsp_cap;
@@ -357,9 +396,72 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     }
     dense_emit(src, wseg, n, before, before2, after, chunk0, lane, before_me, excl, rbsp != nullptr && l.ex_ok == 1u, rbsp + excl.kept, tgt,
                &l.dep[wv][lane & (kDepCap - 1)].xpp);
+    /* The next ticket only when EVERY wavefront is through with its rows (round 5).  Where a stretch of padding begins inside a
+     * tile, wavefront 0's rows are ordinary and the others' are not: it came here 35 us before them, took a ticket, and sat on
+     * it at the barrier below -- and every tile behind that ticket waited in its look-back for a tile nobody had started.  That,
+     * once per stretch, was the bench's mixed stream (1 % of it in 640 KiB stretches): 1.32-1.34 x the uniform time, 2 ms of 8. */
+    __syncthreads();
     if (tid == 0) l.ticket = (HBS4_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(&hdr->ticket, 1u);
     __syncthreads();
+    HBS4_TL(tile, 3, 0)
     return true;
+}
+
+/* the tiles the prologue marked, a workgroup each: a rough count, then the first half of dense_tile, into the table */
+__global__ __launch_bounds__(k4Threads)
+void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, uint8_t* __restrict__ cand,
+                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ ctl, int parity,
+                   AheadEntry* __restrict__ tab, const RunHeader* __restrict__ hdr, int gate)
+{
+    const uint32_t marked = ctl[parity];
+    if (blockIdx.x >= marked || gate_closed(gate, hdr)) return;
+    __shared__ uint32_t rough[k4Waves];
+    __shared__ TileAgg wagg[k4Waves];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t i = blockIdx.x; i < marked; i += gridDim.x) {
+        const uint64_t tile = list[i];
+        /* (the stream's last tile is read from a padded copy by the main kernel: never counted ahead) */
+        if (tile + 1 >= num_tiles) continue;
+        const uint64_t base = tile * (uint64_t)k4TileBytes;
+        const uint64_t wseg = base + (uint64_t)(wv * k4WaveBytes);
+        /* roughly: chunks that hold a zero pair by themselves (the tile is whole: not the stream's last) */
+        uint32_t mine = 0;
+#pragma unroll 4
+        for (int r = 0; r < k4Rows; ++r) {
+            const Quad q = *reinterpret_cast<const Quad*>(stream + wseg + (uint64_t)r * k4RowBytes + (uint64_t)lane * 16u);
+            mine += (uint32_t)__builtin_popcountll(__ballot(chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu)));
+        }
+        __syncthreads();                                 /* the previous tile is done with rough / wagg */
+        if (lane == 0) rough[wv] = mine;
+        __syncthreads();
+        const bool walk = rough[0] + rough[1] + rough[2] + rough[3] >= kAheadRoughMin;
+        if (!walk) continue;
+        const uint32_t before = (wseg >= 4) ? stream_load4(stream + wseg - 4) : 0xFFFFFFFFu;
+        const uint32_t before2 = (wseg >= 8) ? stream_load4(stream + wseg - 8) : 0xFFFFFFFFu;
+        const uint32_t after = (wv != k4Waves - 1) ? stream_load4(stream + wseg + k4WaveBytes) : load_dword_guarded(stream, (int64_t)(wseg + k4WaveBytes), n);
+        const TileAgg wa = dense_aggregate(stream, wseg, n, before, before2, after, (uint32_t)(64 * k4Rows * wv), lane);
+        if (lane == 0) wagg[wv] = wa;
+        __syncthreads();
+        if (tid == 0) {
+            AheadEntry e;
+#pragma unroll
+            for (int w = 0; w < k4Waves; ++w) e.w[w] = wagg[w];
+            tab[tile] = e;
+            cand[tile] = kAheadDone;
+        }
+    }
+}
+
+uint64_t scan4_ahead_entry_bytes() { return sizeof(AheadEntry) + sizeof(uint32_t) + 1; }     /* table entry, list word, byte */
+bool scan4_counts_ahead(uint64_t n) { return n >= kAheadMinBytes; }
+
+void launch_scan_ahead4(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st)
+{
+    if (!a.ahead_cand || !a.ahead_tab || num_tiles < 2) return;
+    /* four workgroups a CU (119 registers): a stretch's tiles at the same time; with nothing marked they all leave at once */
+    k_scan_ahead4<<<dim3(1024), dim3(k4Threads), 0, st>>>(a.stream, a.n, num_tiles, a.ahead_cand, a.ahead_list, a.ahead_ctl, a.ahead_parity,
+                                                         static_cast<AheadEntry*>(a.ahead_tab), a.hdr, gate);
 }
 
 __global__ __launch_bounds__(k4Threads, HBS4_WG_PER_CU)
@@ -392,6 +494,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         int lane = tid & 63;
         const uint64_t tile = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)l.ticket);
         if (tile >= num_tiles) break;
+        HBS4_TL(tile, 0, 0)
         const uint64_t base = tile * (uint64_t)k4TileBytes;
         const uint64_t tile_end = base + (uint64_t)k4TileBytes;
         const uint64_t wseg = base + (uint64_t)(wv * k4WaveBytes);
@@ -601,6 +704,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             const uint64_t last_end = (nflag > 0) ? base + 16ull * (list_at(l, nflag - 1u, wb1, wb2, wb3) + 1u) : base;
             const TileAgg tagg = combine(acc, gap_agg(span_bytes(last_end, tile_end, n)));
             HBS4_T_MARK(2)
+            HBS4_TL(tile, 1, 0)
 
             uint32_t it, stl;
             HBS4_DBG(if (g_fake_lb4) { ok = true; it = 0; stl = 0; ex.kept = tile * (uint64_t)(k4TileBytes - 4096); ex.nals = tile * 16; ex.inside = 1; } else)
@@ -620,6 +724,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                 }
             }
             HBS4_T_MARK(3)
+            HBS4_TL(tile, 2, 0)
             } else {
                 HBS4_PRIO(0);
             }
@@ -702,9 +807,13 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
          * out in stripes instead (tile = workgroup + k x grid, no atomic, no drain of this wavefront's stores
          * in front of it) ran 8.6 ms against 7.06 on the 16 GiB bench stream: workgroups do not progress
          * evenly, and with stripes the fast ones wait in their look-backs for the slow ones. */
+#if HBS4_TICKET_BARRIER
+        __syncthreads();
+#endif
         if (tid == 0) l.ticket = (HBS4_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(&hdr->ticket, 1u);
         __syncthreads();
         HBS4_T_MARK(5)
+        HBS4_TL(tile, 3, 0)
 #undef HBS_ROW_PRE
 #undef HBS_ROW_FM
     }
@@ -729,6 +838,14 @@ extern "C" int hbs_debug_dump4(uint32_t* host_out /* [4096] */)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg4), sizeof(uint32_t) * 4096);
 }
+extern "C" int hbs_debug_timeline4(unsigned long long* host_out /* [tiles][4] */, unsigned tiles)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tl4), sizeof(unsigned long long) * 4 * (tiles < kTl4Tiles ? tiles : kTl4Tiles));
+}
+extern "C" int hbs_debug_timeline_who4(unsigned long long* host_out /* [tiles] */, unsigned tiles)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tlwho4), sizeof(unsigned long long) * (tiles < kTl4Tiles ? tiles : kTl4Tiles));
+}
 extern "C" int hbs_debug_phase_cycles4(unsigned long long* host_out /* [1024][8] */)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles4), sizeof(unsigned long long) * 1024 * 8);
@@ -751,14 +868,44 @@ constexpr int kClearBlocksMin = 32, kClearBlocksMax = 4096;      /* sized by the
 __global__ __launch_bounds__(256)
 void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr, uint8_t* __restrict__ tail,
                      unsigned long long* __restrict__ index_words, uint64_t n_index_words,
-                     unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int tail_tile_bytes)
+                     unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int tail_tile_bytes,
+                     uint8_t* __restrict__ ahead_cand, void* ahead_tab, uint32_t* __restrict__ ahead_list, uint32_t* __restrict__ ahead_ctl, int ahead_parity,
+                     int sample_blocks)
 {
+    if ((int)blockIdx.x >= (int)gridDim.x - sample_blocks) {
+        /* the sample of the count-ahead (see dense_tile): a wavefront per tile, kAheadSample lanes a chunk each, 4 KiB apart, with
+         * the exact question the flag pass asks (neighbouring chunks ignored) */
+        const int lane = threadIdx.x & 63;
+        const uint64_t wave = ((uint64_t)(blockIdx.x - ((int)gridDim.x - sample_blocks)) * blockDim.x + threadIdx.x) >> 6;
+        const uint64_t nwaves = ((uint64_t)sample_blocks * blockDim.x) >> 6;
+        const uint64_t tiles = (n + (uint64_t)k4TileBytes - 1) / (uint64_t)k4TileBytes;
+        static_assert(kAheadSample * 4096 == k4TileBytes, "a sample every 4 KiB");
+        for (uint64_t t = wave; t < tiles; t += nwaves) {
+            const uint64_t off = t * (uint64_t)k4TileBytes + (uint64_t)lane * 4096u + 2048u;
+            bool f = false;
+            if (lane < kAheadSample && off + 16 <= n) {
+                const Quad q = *reinterpret_cast<const Quad*>(stream + off);
+                f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) && chunk_pattern_any_dev(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+            }
+            const unsigned long long hits = __ballot(f);
+            if (lane == 0) {
+                const bool mark = __builtin_popcountll(hits) >= kAheadMinHits || (hits & (hits >> 1) & (hits >> 2)) != 0ull;
+                ahead_cand[t] = mark ? kAheadMarked : 0;
+                if (mark) ahead_list[atomicAdd(&ahead_ctl[ahead_parity], 1u)] = (uint32_t)t;
+            }
+        }
+        return;
+    }
     const int b = blockIdx.x;
     if (b < kProbeBlocks) {
         if (b == 0 && threadIdx.x == 0) {
             hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
             hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
             hdr->probe_chunks = 0; hdr->probe_flagged = 0;
+            hdr->pad_a = 0;
+            hdr->ahead_cand = ahead_tab ? reinterpret_cast<unsigned long long>(ahead_cand) : 0ull;
+            hdr->ahead_tab = ahead_cand ? reinterpret_cast<unsigned long long>(ahead_tab) : 0ull;
+            if (ahead_ctl) ahead_ctl[ahead_parity ^ 1] = 0u;        /* the next call's counter (this call's was cleared by the one before, or at allocation) */
         }
         /* Density probe: kProbeBlocks windows of 16 KiB spread evenly over the stream; counts the chunks that
          * chunk_flag() would hand to the element path (neighbouring chunks ignored: an estimate is all the
@@ -809,7 +956,7 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
         }
     } else {
         const uint64_t t0 = (uint64_t)(b - kProbeBlocks - kTailBlocks) * 256u + threadIdx.x;
-        const uint64_t step = (uint64_t)((int)gridDim.x - kProbeBlocks - kTailBlocks) * 256u;
+        const uint64_t step = (uint64_t)((int)gridDim.x - sample_blocks - kProbeBlocks - kTailBlocks) * 256u;
         for (uint64_t i = t0; i < n_index_words; i += step) index_words[i] = 0ull;
         for (uint64_t i = t0; i < n_desc_words; i += step) desc[i] = 0ull;
     }
@@ -821,9 +968,16 @@ void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, in
     uint64_t clear_blocks = (index_words + desc_words) / (256u * 16u);
     if (clear_blocks < (uint64_t)kClearBlocksMin) clear_blocks = kClearBlocksMin;
     if (clear_blocks > (uint64_t)kClearBlocksMax) clear_blocks = kClearBlocksMax;
-    k_scan_prologue<<<dim3(kProbeBlocks + kTailBlocks + (unsigned)clear_blocks), dim3(256), 0, st>>>(
+    /* the count-ahead's sample rides in this launch: a wavefront per 192 KiB tile, at most 2048 workgroups of four */
+    unsigned sample_blocks = 0;
+    if (a.ahead_cand && a.ahead_tab) {
+        const uint64_t tiles = (a.n + (uint64_t)k4TileBytes - 1) / (uint64_t)k4TileBytes;
+        const uint64_t want = (tiles + 3) / 4;
+        sample_blocks = (unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want);
+    }
+    k_scan_prologue<<<dim3(kProbeBlocks + kTailBlocks + (unsigned)clear_blocks + sample_blocks), dim3(256), 0, st>>>(
         a.stream, a.n, a.hdr, a.tail, reinterpret_cast<unsigned long long*>(a.index), index_words,
-        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes);
+        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes, a.ahead_cand, a.ahead_tab, a.ahead_list, a.ahead_ctl, a.ahead_parity, (int)sample_blocks);
 }
 
 int scan4_grid_blocks(int device, int* blocks_per_cu_out)

@@ -141,6 +141,13 @@ int  hbs_ctx_reserve_workgroups(hbs_ctx* ctx, int spare);
  * hbs_index_extract and says which kernel ran it. */
 int  hbs_ctx_set_kernel(hbs_ctx* ctx, int variant);
 int  hbs_ctx_get_kernel(hbs_ctx* ctx);
+/* Kernel 4 walks a DENSE tile (one with more than 512 candidate chunks in its 192 KiB: padding, zero stuffing) chunk by chunk,
+ * and every tile behind it waits for its count.  From round 5 such tiles are counted AHEAD of the main kernel: the call's first
+ * launch samples every tile, a small kernel counts the ones the sample marks, and the main kernel takes those counts instead of
+ * walking the tile a first time (hbs_scan4.hip, "dense tiles counted ahead").  mode 1 (default): streams of 4 GiB and more;
+ * 0: never; 2: any stream that has more than one tile.  Results are identical in all three.  Environment HBS_COUNT_AHEAD=0|1|2
+ * sets the default.  The table costs 69 bytes of device memory per 192 KiB of stream. */
+int  hbs_ctx_set_count_ahead(hbs_ctx* ctx, int mode);
 int  hbs_ctx_last_kernel(hbs_ctx* ctx);
 /* Text of the last HIP/driver error seen by this context. */
 const char* hbs_last_error(hbs_ctx* ctx);

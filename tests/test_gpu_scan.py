@@ -247,6 +247,67 @@ def test_tiles_with_several_batches_of_elements(ctx, orc, shape):
     check(ctx, orc, s)
 
 
+@pytest.mark.parametrize("kernel", [0, 4], ids=["automatic", "sparse-kernel"])
+def test_dense_tiles_counted_ahead(orc, kernel):
+    """round 5: the event-sparse kernel's dense tiles counted ahead of it (hbs_ctx_set_count_ahead; by default only from 4 GiB up,
+    here on every stream): stretches of padding / zeros / tiny NALs in a sparse stream -- inside a tile, across tiles, at the
+    stream's start and in its last tile; a tile the sample marks and which is not dense (zero pairs exactly where the sample
+    looks), one that is walked ahead and still is not (400 flagged chunks); a dense tile the sample misses (dense everywhere but there).  Modes 0 and 2 must give what the oracle gives."""
+    import hevcbitstream_amd as hbs
+    tile = 192 << 10
+    rng = np.random.RandomState(77)
+    n = 17 * tile + 7777
+    base = rng.randint(1, 256, size=n).astype(np.uint8)
+    at = 0
+    while at + 8 < n:
+        base[at:at + 4] = (0, 0, 1, 0x40)
+        at += int(rng.randint(3000, 20000))
+    pats = [b"\x00\x00\x03", b"\x00", b"\x00\x00\x01\x42\x55", b"\x00\x00\x03\x00\x00\x03\x01"]
+
+    def fill(s, a, b, k):
+        p = np.frombuffer(pats[k % len(pats)], dtype=np.uint8)
+        s[a:b] = np.tile(p, (b - a) // len(p) + 1)[:b - a]
+
+    streams = []
+    s = base.copy(); fill(s, 2 * tile + 100, 3 * tile - 100, 0); streams.append(s)                      # inside one tile
+    s = base.copy(); fill(s, 4 * tile + 50_000, 8 * tile + 20_000, 1); streams.append(s)                # across tiles, zeros
+    s = base.copy(); fill(s, 0, tile + 999, 2); fill(s, 16 * tile, n, 3); streams.append(s)             # first tile(s), last tiles
+    s = base.copy(); fill(s, 15 * tile - 5, 17 * tile + 5, 0); streams.append(s)                        # up to the last full tile and beyond
+    s = base.copy()                                                                                      # marked, not dense
+    for t in (3, 9):
+        for lane in range(48):
+            o = t * tile + lane * 4096 + 2048
+            s[o:o + 16] = (0, 0, 3, 1) * 4
+    streams.append(s)
+    s = base.copy()                                                                                      # marked and walked ahead, not dense
+    for t in (2, 10):
+        for k in range(400):
+            o = t * tile + k * 480
+            s[o:o + 4] = (0, 0, 3, 1)
+        for lane in range(0, 48, 3):
+            o = t * tile + lane * 4096 + 2048
+            s[o:o + 32] = (0, 0, 3, 1) * 8
+    streams.append(s)
+    s = base.copy()                                                                                      # dense, not marked
+    for t in (5, 6):
+        fill(s, t * tile, (t + 1) * tile, 0)
+        for k in range(48):
+            s[t * tile + k * 4096 + 2048 - 8:t * tile + k * 4096 + 2048 + 24] = 0x77
+    streams.append(s)
+    s = base.copy()                                                                                      # every tile dense
+    fill(s, 0, n, 0); s[0:4] = (0, 0, 1, 0x40); streams.append(s)
+    for mode in (2, 0):
+        c = hbs.Context(0)
+        c.set_kernel(kernel)
+        c.set_count_ahead(mode)
+        try:
+            for s in streams:
+                check(c, orc, s)
+                check(c, orc, s[:len(s) - 3 * tile - 13])       # another tile count, another last tile
+        finally:
+            c.close()
+
+
 def test_automatic_choice_follows_density(orc):
     """the default mode picks the event-sparse kernel for coded-video-like bytes and the LDS-image kernel for
     zero-heavy ones, on the device; the answer is the oracle's either way"""
