@@ -388,26 +388,32 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
         if (rc) return rc;
         a.ws5 = c->ws;
     }
-    a.ahead_cand = nullptr; a.ahead_tab = nullptr; a.ahead_list = nullptr; a.ahead_ctl = nullptr; a.ahead_parity = 0;
+    a.ahead_cand = nullptr; a.ahead_tab = nullptr; a.ahead_list = nullptr; a.ahead_ctl = nullptr; a.ahead_parity = 0; a.ahead_stamp = 0;
     if (d_rbsp && (c->count_ahead == 2 || (c->count_ahead == 1 && hbs::scan4_counts_ahead(n))) && n > (uint64_t)hbs::scan4_tile_bytes() &&
         (c->variant == 0 || c->variant == 4 || c->variant == 5) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) {
-        /* K12's dense tiles counted ahead: [two counters | table | list | bytes] */
+        /* K12's dense tiles counted ahead: [two counters | table | list | a word per tile] */
         const uint64_t tiles = (n + (uint64_t)hbs::scan4_tile_bytes() - 1) / (uint64_t)hbs::scan4_tile_bytes();
-        if (tiles > c->ahead_tiles) {
+        const bool wrap = c->ahead_calls >= (1u << 30) - 2u;             /* (the stamp is the call's number: start over with cleared words) */
+        if (tiles > c->ahead_tiles || wrap) {
+            const uint64_t want = tiles > c->ahead_tiles ? tiles : c->ahead_tiles;
             if (c->ahead) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ahead); c->ahead = nullptr; c->ahead_tiles = 0; }
-            hipError_t e = hipMalloc(&c->ahead, 64 + tiles * hbs::scan4_ahead_entry_bytes());
+            hipError_t e = hipMalloc(&c->ahead, 64 + want * hbs::scan4_ahead_entry_bytes());
             if (e != hipSuccess) return fail(c, e, "hipMalloc(count-ahead table)");
+            /* the counters and the tiles' words start at zero (the table and the list are written before they are read) */
             e = hipMemsetAsync(c->ahead, 0, 64, c->stream);
-            if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(count-ahead counters)");
-            c->ahead_tiles = tiles;
+            if (e == hipSuccess) e = hipMemsetAsync(static_cast<uint8_t*>(c->ahead) + 64 + want * 68, 0, want * 4, c->stream);
+            if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(count-ahead words)");
+            c->ahead_tiles = want;
+            c->ahead_calls = 0;
         }
         uint8_t* const p = static_cast<uint8_t*>(c->ahead);
         a.ahead_ctl = reinterpret_cast<uint32_t*>(p);
         a.ahead_tab = p + 64;
         a.ahead_list = reinterpret_cast<uint32_t*>(p + 64 + c->ahead_tiles * 64);
-        a.ahead_cand = p + 64 + c->ahead_tiles * 68;
+        a.ahead_cand = reinterpret_cast<uint32_t*>(p + 64 + c->ahead_tiles * 68);
         a.ahead_parity = (int)(c->ahead_calls & 1u);
         c->ahead_calls += 1;
+        a.ahead_stamp = c->ahead_calls << 2;
     }
     c->last_index_only = (hbs::scan_uses_index_only(n, c->variant, d_rbsp) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;

@@ -75,11 +75,13 @@ struct RunHeader {
     uint32_t abort_flag;      /* set when a look-back wait timed out             */
     uint32_t probe_chunks;    /* density probe: 16-byte chunks sampled ...                      */
     uint32_t probe_flagged;   /* ... and how many of them may hold a 00 00 pair (hbs_sparse.h)  */
-    /* dense tiles counted ahead of the event-sparse kernel (hbs_scan4.hip, round 5): the byte per tile the prologue's sample
-     * leaves and the table k_scan_ahead4 fills for the tiles so marked; set by the prologue of every call (0: not this call) */
-    uint32_t pad_a;
+    /* dense tiles counted ahead of the event-sparse kernel (hbs_scan4.hip, round 5): this call's stamp, the word per tile the
+     * prologue's sample and k_scan_ahead4 leave (stamp | 1 marked, stamp | 2 counted) and the table of the tiles counted; set by
+     * the prologue of every call (ahead_tab = 0: not this call) */
+    uint32_t ahead_stamp;
     unsigned long long ahead_cand, ahead_tab;
-    uint32_t pad0[16];
+    uint32_t rewalk_count;    /* index-only scan (hbs_scan5.hip): tiles walked by rows, listed for the emit pass's helpers; cleared by the prologue */
+    uint32_t pad0[15];
     uint32_t ticket;          /* next unclaimed tile (dynamic tile schedules); alone on its 128-byte line */
     uint32_t pad1[31];
     uint32_t probe_slot[64][2];   /* density probe, one pair per probe workgroup: chunks sampled, chunks flagged.  Plain

@@ -2020,7 +2020,7 @@ constexpr int kSampleMin = 8;       /* 8 of 48 sampled chunks (two of twelve sec
 __global__ __launch_bounds__(256)
 void k3t_sample(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict__ idx, uint64_t n,
                 uint32_t* __restrict__ cand_list, uint32_t* __restrict__ cand_count, uint64_t cand_cap, uint32_t* __restrict__ dz_table,
-                const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag)
+                const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag, uint32_t call_no)
 {
     if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
     const uint64_t a0 = idx[0].rbsp_off;
@@ -2061,8 +2061,17 @@ void k3t_sample(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restric
             if (lane < 48 && x + 16u <= arena_len) qq = *reinterpret_cast<const u32x4*>(rbsp + a0 + x);
             const uint32_t hits = (uint32_t)__builtin_popcountll(__ballot(hit(qq)));
             if (hits >= (uint32_t)kSampleMin && lane == 0) {
-                const uint32_t slot = atomicAdd(cand_count, 1u);
-                if (slot < cand_cap) cand_list[slot] = (uint32_t)tile;
+                /* ... and the tile on either side, where the stretch begins and ends (round 5): a row of it makes that tile a dense
+                 * one, the sample above sees a sixth of a tile at best, and the tiles behind waited for its count as before.  Word 25
+                 * of a tile's entry says who listed it in this call (a stale word that happens to carry this call's number costs the
+                 * listing, nothing else; listed twice it would be counted twice, with the same result) */
+                for (int dt = -1; dt <= 1; ++dt) {
+                    const uint64_t u = tile + (uint64_t)(int64_t)dt;
+                    if ((dt < 0 && tile == 0) || u >= ntiles) continue;
+                    if (atomicExch(&dz_table[u * (uint64_t)kDzTableWords + 25u], call_no) == call_no) continue;
+                    const uint32_t slot = atomicAdd(cand_count, 1u);
+                    if (slot < cand_cap) cand_list[slot] = (uint32_t)u;
+                }
             }
         }
     }
@@ -2440,7 +2449,7 @@ static void launch_tiles(const EmitArgs& a, unsigned tb, const uint32_t* probe, 
 {
     const bool ahead = a.dz_table && a.cand_list && a.cand_cap;
     if (ahead) {
-        k3t_sample<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.cand_list, a.cand_count, a.cand_cap, a.dz_table, probe, tflag);
+        k3t_sample<<<1024, 256, 0, st>>>(a.rbsp, a.index_in, a.n, a.cand_list, a.cand_count, a.cand_cap, a.dz_table, probe, tflag, a.call_no);
         /* (a workgroup per 64 tiles of the arena, at least 64, at most all: the list is short or empty, and a launch of workgroups
          * with 77 KiB of LDS each is not free -- 10 us for 512 of them, under the profiler) */
         const uint64_t want = a.rbsp_bytes / kTTileBytes / 64u + 1u;

@@ -328,15 +328,17 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
  * taken, where an ordinary tile's is out after ~15 -- and every tile behind it waits for it in its look-back: 25 us of the
  * whole GPU wherever a stretch of padding or zero stuffing begins (the tiles inside the stretch are walked at the same time as
  * its first one).  But a tile's aggregate does not depend on anything in front of the tile.  So, as k3_tiles does since round 4:
- * the prologue samples every tile (a chunk in every 4 KiB: a tile is dense from 512 flagged chunks = 8 KiB of such a stretch,
- * which holds two or three neighbouring samples; coded video flags one sample in 500) and leaves a byte per tile and a list
- * of the tiles it marked; k_scan_ahead4 takes the tiles so marked, in front of the main kernel and with nobody waiting -- counts their flagged chunks roughly, and walks the
- * ones that may be dense: their four wavefront aggregates go to a table, the tile's byte becomes kAheadDone; dense_tile takes
- * such a tile's entry instead of walking its rows a first time (marks and entries are this call's: the prologue writes every
- * tile's byte).  A dense tile the sample misses is walked in place as before; a marked tile that turns out ordinary costs its
- * rows once more, read by a kernel that has the memory system to itself.  From kAheadMinBytes up (below, the extra launch
- * costs a call more than mixed content is likely to; hbs_ctx_set_count_ahead).  The bench's mixed stream (16 GiB, 1 % of it in
- * 640 KiB stretches): 7.65 -> 6.4-6.5 ms, 1.29 -> 1.05-1.10 x the uniform stream's time. */
+ * the prologue samples every tile -- first a chunk in every 64 KiB, which a stretch that long cannot avoid; a tile that shows
+ * something, and the tile on either side of it (where the stretch begins and ends), get the full look: a chunk in every 4 KiB (a
+ * tile is dense from 512 flagged chunks = 8 KiB of such a stretch; coded video flags one sample in 500) -- and lists the tiles
+ * it marks; k_scan_ahead4 takes the tiles so marked, in front of the main kernel and with nobody waiting -- counts their flagged
+ * chunks roughly, and walks the ones that may be dense: their four wavefront aggregates go to a table, the tile's word becomes
+ * "counted"; dense_tile takes such a tile's entry instead of walking its rows a first time (the words carry the call's stamp:
+ * nothing has to be cleared).  A dense tile the sample misses -- a stretch shorter than 64 KiB may be -- is walked in place as
+ * before; a marked tile that turns out ordinary costs its rows once more, read by a kernel that has the memory system to
+ * itself.  From kAheadMinBytes up (below, the extra launch costs a call more than mixed content is likely to;
+ * hbs_ctx_set_count_ahead).  The bench's mixed stream (16 GiB, 1 % of it in 640 KiB stretches): 7.65 -> 6.4-6.5 ms, 1.29 ->
+ * 1.05-1.10 x the uniform stream's time. */
 struct AheadEntry { TileAgg w[k4Waves]; };
 static_assert(sizeof(AheadEntry) == 64, "four aggregates");
 constexpr uint64_t kAheadMinBytes = 4ull << 30;          /* the launch costs ~10 us where nothing is marked: 1.3 % of a 2 GiB call, 0.6 % at 4 GiB, 0.15 % at 16 */
@@ -345,7 +347,8 @@ constexpr int kAheadMinHits = 8;                         /* marked from this man
                                                             flag a sample in 20: two in a row marked a tile in 9, and the kernel below took 0.23 ms of 1.2) */
 constexpr uint32_t kAheadRoughMin = 400;                 /* k_scan_ahead4 walks a marked tile when its rough count reaches this (chunks taken by themselves:
                                                             a pattern across two chunks is missed, one in eight) */
-constexpr uint8_t kAheadMarked = 1, kAheadDone = 2;
+constexpr uint32_t kAheadMarked = 1u, kAheadDone = 2u;     /* or-ed to the call's stamp in a tile's word */
+constexpr int kAheadCoarse = 3;                          /* chunks of the first look, 64 KiB apart */
 
 __device__ __attribute__((noinline))
 bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
@@ -358,7 +361,7 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk0 = (uint32_t)(64 * k4Rows * wv);
     /* counted ahead in this call (k_scan_ahead4)?  then the table has what the walk below would find */
-    const bool counted = hdr->ahead_tab != 0ull && !last_tile && reinterpret_cast<const uint8_t*>(hdr->ahead_cand)[tile] == kAheadDone;
+    const bool counted = hdr->ahead_tab != 0ull && !last_tile && reinterpret_cast<const uint32_t*>(hdr->ahead_cand)[tile] == (hdr->ahead_stamp | kAheadDone);
     const TileAgg wa = counted ? reinterpret_cast<const AheadEntry*>(hdr->ahead_tab)[tile].w[wv] : dense_aggregate(src, wseg, n, before, before2, after, chunk0, lane);
     if (lane == 0) l.wagg[wv] = wa;
     __syncthreads();
@@ -409,7 +412,7 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
 
 /* the tiles the prologue marked, a workgroup each: a rough count, then the first half of dense_tile, into the table */
 __global__ __launch_bounds__(k4Threads)
-void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, uint8_t* __restrict__ cand,
+void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, uint32_t* __restrict__ cand, uint32_t stamp,
                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ ctl, int parity,
                    AheadEntry* __restrict__ tab, const RunHeader* __restrict__ hdr, int gate)
 {
@@ -448,19 +451,19 @@ void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
 #pragma unroll
             for (int w = 0; w < k4Waves; ++w) e.w[w] = wagg[w];
             tab[tile] = e;
-            cand[tile] = kAheadDone;
+            cand[tile] = stamp | kAheadDone;
         }
     }
 }
 
-uint64_t scan4_ahead_entry_bytes() { return sizeof(AheadEntry) + sizeof(uint32_t) + 1; }     /* table entry, list word, byte */
+uint64_t scan4_ahead_entry_bytes() { return sizeof(AheadEntry) + 2 * sizeof(uint32_t); }     /* table entry, list word, the tile's word */
 bool scan4_counts_ahead(uint64_t n) { return n >= kAheadMinBytes; }
 
 void launch_scan_ahead4(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st)
 {
     if (!a.ahead_cand || !a.ahead_tab || num_tiles < 2) return;
     /* four workgroups a CU (119 registers): a stretch's tiles at the same time; with nothing marked they all leave at once */
-    k_scan_ahead4<<<dim3(1024), dim3(k4Threads), 0, st>>>(a.stream, a.n, num_tiles, a.ahead_cand, a.ahead_list, a.ahead_ctl, a.ahead_parity,
+    k_scan_ahead4<<<dim3(1024), dim3(k4Threads), 0, st>>>(a.stream, a.n, num_tiles, a.ahead_cand, a.ahead_stamp, a.ahead_list, a.ahead_ctl, a.ahead_parity,
                                                          static_cast<AheadEntry*>(a.ahead_tab), a.hdr, gate);
 }
 
@@ -869,29 +872,47 @@ __global__ __launch_bounds__(256)
 void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr, uint8_t* __restrict__ tail,
                      unsigned long long* __restrict__ index_words, uint64_t n_index_words,
                      unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int tail_tile_bytes,
-                     uint8_t* __restrict__ ahead_cand, void* ahead_tab, uint32_t* __restrict__ ahead_list, uint32_t* __restrict__ ahead_ctl, int ahead_parity,
-                     int sample_blocks)
+                     uint32_t* __restrict__ ahead_cand, void* ahead_tab, uint32_t* __restrict__ ahead_list, uint32_t* __restrict__ ahead_ctl, int ahead_parity,
+                     uint32_t ahead_stamp, int sample_blocks)
 {
     if ((int)blockIdx.x >= (int)gridDim.x - sample_blocks) {
-        /* the sample of the count-ahead (see dense_tile): a wavefront per tile, kAheadSample lanes a chunk each, 4 KiB apart, with
-         * the exact question the flag pass asks (neighbouring chunks ignored) */
+        /* the sample of the count-ahead (see dense_tile), with the exact question the flag pass asks (neighbouring chunks ignored).
+         * A wavefront takes sixteen tiles at a time: lanes 0-47 a chunk each of the first look */
         const int lane = threadIdx.x & 63;
         const uint64_t wave = ((uint64_t)(blockIdx.x - ((int)gridDim.x - sample_blocks)) * blockDim.x + threadIdx.x) >> 6;
         const uint64_t nwaves = ((uint64_t)sample_blocks * blockDim.x) >> 6;
         const uint64_t tiles = (n + (uint64_t)k4TileBytes - 1) / (uint64_t)k4TileBytes;
-        static_assert(kAheadSample * 4096 == k4TileBytes, "a sample every 4 KiB");
-        for (uint64_t t = wave; t < tiles; t += nwaves) {
-            const uint64_t off = t * (uint64_t)k4TileBytes + (uint64_t)lane * 4096u + 2048u;
-            bool f = false;
-            if (lane < kAheadSample && off + 16 <= n) {
-                const Quad q = *reinterpret_cast<const Quad*>(stream + off);
-                f = chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) && chunk_pattern_any_dev(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
-            }
-            const unsigned long long hits = __ballot(f);
-            if (lane == 0) {
-                const bool mark = __builtin_popcountll(hits) >= kAheadMinHits || (hits & (hits >> 1) & (hits >> 2)) != 0ull;
-                ahead_cand[t] = mark ? kAheadMarked : 0;
-                if (mark) ahead_list[atomicAdd(&ahead_ctl[ahead_parity], 1u)] = (uint32_t)t;
+        static_assert(kAheadSample * 4096 == k4TileBytes && kAheadCoarse * 65536 == k4TileBytes, "a sample every 4 KiB, a coarse one every 64 KiB");
+        auto hit = [&](uint64_t off) -> bool {
+            if (off + 16 > n) return false;
+            const Quad q = *reinterpret_cast<const Quad*>(stream + off);
+            return chunk_flag(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu) && chunk_pattern_any_dev(0xFFFFFFFFu, q.x, q.y, q.z, q.w, 0xFFFFFFFFu);
+        };
+        /* (its sixteen tiles are nwaves apart: the tiles of one stretch are looked at by different wavefronts) */
+        for (uint64_t t0 = wave; t0 < tiles; t0 += nwaves * 16u) {
+            const uint64_t ct = t0 + (uint64_t)(lane / kAheadCoarse) * nwaves;
+            const bool ch = lane < 16 * kAheadCoarse && ct < tiles &&
+                            hit(ct * (uint64_t)k4TileBytes + (uint64_t)(lane % kAheadCoarse) * 65536u + 32768u + 2048u);      /* (one of the full look's places) */
+            unsigned long long coarse = __ballot(ch);
+            while (coarse != 0ull) {                                 /* (coded video: not once) */
+                const int slot = __builtin_ctzll(coarse) / kAheadCoarse;
+                const uint64_t t = t0 + (uint64_t)slot * nwaves;
+                coarse &= ~(7ull << (kAheadCoarse * slot));
+                static_assert(kAheadCoarse == 3, "three bits a tile");
+                for (int dt = -1; dt <= 1; ++dt) {
+                    const uint64_t u = t + (uint64_t)(int64_t)dt;
+                    if ((dt < 0 && t == 0) || u >= tiles) continue;
+                    /* (looked at already, as the neighbour of its neighbour?  stamp | 0: looked at and not marked) */
+                    if (__hip_atomic_load(&ahead_cand[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ahead_stamp) continue;
+                    const unsigned long long hits = __ballot(lane < kAheadSample && hit(u * (uint64_t)k4TileBytes + (uint64_t)lane * 4096u + 2048u));
+                    /* a sixth of the tile, or 12 KiB in one piece, or 8 KiB at the edge a stretch comes in by */
+                    const bool mark = __builtin_popcountll(hits) >= kAheadMinHits || (hits & (hits >> 1) & (hits >> 2)) != 0ull ||
+                                      (hits & 3ull) == 3ull || ((hits >> (kAheadSample - 2)) & 3ull) == 3ull;
+                    if (lane == 0) {
+                        const uint32_t word = ahead_stamp | (mark ? kAheadMarked : 0u);
+                        if (atomicMax(&ahead_cand[u], word) < word && mark) ahead_list[atomicAdd(&ahead_ctl[ahead_parity], 1u)] = (uint32_t)u;
+                    }
+                }
             }
         }
         return;
@@ -901,8 +922,8 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
         if (b == 0 && threadIdx.x == 0) {
             hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
             hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
-            hdr->probe_chunks = 0; hdr->probe_flagged = 0;
-            hdr->pad_a = 0;
+            hdr->probe_chunks = 0; hdr->probe_flagged = 0; hdr->rewalk_count = 0;
+            hdr->ahead_stamp = ahead_stamp;
             hdr->ahead_cand = ahead_tab ? reinterpret_cast<unsigned long long>(ahead_cand) : 0ull;
             hdr->ahead_tab = ahead_cand ? reinterpret_cast<unsigned long long>(ahead_tab) : 0ull;
             if (ahead_ctl) ahead_ctl[ahead_parity ^ 1] = 0u;        /* the next call's counter (this call's was cleared by the one before, or at allocation) */
@@ -968,16 +989,16 @@ void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, in
     uint64_t clear_blocks = (index_words + desc_words) / (256u * 16u);
     if (clear_blocks < (uint64_t)kClearBlocksMin) clear_blocks = kClearBlocksMin;
     if (clear_blocks > (uint64_t)kClearBlocksMax) clear_blocks = kClearBlocksMax;
-    /* the count-ahead's sample rides in this launch: a wavefront per 192 KiB tile, at most 2048 workgroups of four */
+    /* the count-ahead's sample rides in this launch: a wavefront per sixteen 192 KiB tiles, at most 512 workgroups of four */
     unsigned sample_blocks = 0;
     if (a.ahead_cand && a.ahead_tab) {
         const uint64_t tiles = (a.n + (uint64_t)k4TileBytes - 1) / (uint64_t)k4TileBytes;
-        const uint64_t want = (tiles + 3) / 4;
-        sample_blocks = (unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want);
+        const uint64_t want = (tiles + 63) / 64;
+        sample_blocks = (unsigned)(want < 1 ? 1 : want > 512 ? 512 : want);
     }
     k_scan_prologue<<<dim3(kProbeBlocks + kTailBlocks + (unsigned)clear_blocks + sample_blocks), dim3(256), 0, st>>>(
         a.stream, a.n, a.hdr, a.tail, reinterpret_cast<unsigned long long*>(a.index), index_words,
-        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes, a.ahead_cand, a.ahead_tab, a.ahead_list, a.ahead_ctl, a.ahead_parity, (int)sample_blocks);
+        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes, a.ahead_cand, a.ahead_tab, a.ahead_list, a.ahead_ctl, a.ahead_parity, a.ahead_stamp, (int)sample_blocks);
 }
 
 int scan4_grid_blocks(int device, int* blocks_per_cu_out)

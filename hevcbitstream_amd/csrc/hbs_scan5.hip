@@ -282,11 +282,22 @@ struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a P
 __host__ __device__ inline uint32_t rec_cap5(int rows) { return 4u * (uint32_t)rows; }   /* elements recorded per tile: four a KiB (12.5 % of the stream's size as workspace; two until round 4:
                                                                              NALs of 512 bytes passed it in every other tile, and such a tile is streamed twice; three: NALs of 384) */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
+/* ... a tile that was walked by rows (a stretch of padding, of zeros): in parts of kPartRows rows, by different wavefronts
+ * (round 5).  One wavefront took ~400 us over the 256 rows of such a tile, and k_index5_emit took as long as its slowest tile:
+ * 0.47 ms instead of 0.07 on the bench's mixed stream (1 % of it in 640 KiB stretches), all of the index-only scan's 1.16 x.
+ * The stream pass leaves the aggregate in front of every part where the tile's records would be (it has none) and lists the
+ * tile; the tile's own wavefront takes part 0, kEmitHelpers extra wavefronts of the same launch share the other parts of all
+ * listed tiles. */
+constexpr uint32_t k5RewalkParts = 0xFFFFFFFEu;
+constexpr int kPartRows = 32;
+constexpr unsigned kEmitHelpers = 4096;
+static_assert(kPartRows % k5SpanRows == 0 && k5MaxTileRows / kPartRows <= 16, "a part is whole spans; its aggregates fit the tile's record space many times over");
 constexpr int k5ChunkTiles = 64;
 
 struct Ws5 {
     TileAgg* tagg;       /* [tiles]                  */
     uint32_t* nrec;      /* [tiles]                  */
+    uint32_t* rwlist;    /* [tiles]: tiles walked by rows, in the order the stream pass met them (RunHeader::rewalk_count of them) */
     TileAgg* cagg;       /* [chunks]                 */
     Pre5* cpre;          /* [chunks]                 */
     Rec5* rec;           /* [tiles][rec_cap5(rows)]  */
@@ -301,7 +312,8 @@ __host__ __device__ inline Ws5 ws5_carve(void* base, uint64_t tiles, int rows)
     w.tagg = reinterpret_cast<TileAgg*>(p); p += ((tiles * sizeof(TileAgg) + 255) & ~255ull);
     w.cagg = reinterpret_cast<TileAgg*>(p); p += ((ch * sizeof(TileAgg) + 255) & ~255ull);
     w.cpre = reinterpret_cast<Pre5*>(p); p += ((ch * sizeof(Pre5) + 255) & ~255ull);
-    w.nrec = reinterpret_cast<uint32_t*>(p);
+    w.nrec = reinterpret_cast<uint32_t*>(p); p += ((tiles * sizeof(uint32_t) + 255) & ~255ull);
+    w.rwlist = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 uint64_t scan5_workspace_bytes(uint64_t stream_bytes)
@@ -311,7 +323,7 @@ uint64_t scan5_workspace_bytes(uint64_t stream_bytes)
     const uint64_t rec = (stream_bytes / 1024u + 2u * (uint64_t)k5MaxTileRows) * 4u * sizeof(Rec5);
     const uint64_t tiles = stream_bytes / (1024u * (uint64_t)k5MinTileRows) + 2, ch = ws5_chunks(tiles);
     return rec + ((tiles * sizeof(TileAgg) + 255) & ~255ull) + ((ch * sizeof(TileAgg) + 255) & ~255ull) +
-           ((ch * sizeof(Pre5) + 255) & ~255ull) + tiles * sizeof(uint32_t) + 256;
+           ((ch * sizeof(Pre5) + 255) & ~255ull) + 2 * ((tiles * sizeof(uint32_t) + 255) & ~255ull) + 256;
 }
 
 /* the streaming half of a tile: its flag words into l.words, one span at a time, the next span's loads in flight meanwhile */
@@ -468,9 +480,21 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
             acc = agg_identity();                                     /* (what was walked before the tile turned out dense is dropped) */
             prev_end = base;
             const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
+            /* the aggregate in front of every part of kPartRows rows, for the emit pass (k5RewalkParts): taken in front of the first
+             * row visited at or behind the part's first (rows without a flagged chunk are not visited: their bytes are a gap) */
+            TileAgg* const parts = reinterpret_cast<TileAgg*>(&w5.rec[tile * k5RecCap]);
+            int next_part = 1;
+            auto parts_upto = [&](int r) {
+                while (next_part * kPartRows <= r && next_part * kPartRows < rows) {
+                    const TileAgg sn = combine(acc, gap_agg(span_bytes(prev_end, base + 1024ull * (uint64_t)(kPartRows * next_part), n)));
+                    if (lane == 0) parts[next_part - 1] = sn;
+                    ++next_part;
+                }
+            };
             tile_rows(stream, n, base, rows, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
                 DenseRow d;
                 uint32_t quick = 0;
+                parts_upto(r);
                 if (row_visit<false>(d, qp, qc, qn, r, rows, edges, stream, n, base, lane, prev_end, quick) == 1) { acc = combine(acc, gap_agg(quick)); return; }
                 const uint32_t gap0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.el.gap);
                 if (!d.row_has_event) {
@@ -480,6 +504,8 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                     acc = combine(acc, agg_readlane(ea, 63));
                 }
             });
+            parts_upto(rows);
+            if (lane == 0) w5.rwlist[atomicAdd(&hdr->rewalk_count, 1u)] = (uint32_t)tile;
         } else {                                                      /* spilled: the tile's elements from its flag words, their bytes from the stream */
             acc = agg_identity();
             prev_end = base;
@@ -496,7 +522,7 @@ void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         const TileAgg tagg = combine(acc, gap_agg(span_bytes(prev_end, tile_end, n)));
         if (lane == 0) {
             w5.tagg[tile] = tagg;
-            w5.nrec[tile] = (by_rows || nelem > k5RecCap) ? k5Rewalk : nelem;
+            w5.nrec[tile] = by_rows ? k5RewalkParts : nelem > k5RecCap ? k5Rewalk : nelem;
         }
         __builtin_amdgcn_wave_barrier();                       /* l is reused by the next tile */
         if (strided) tile += gridDim.x;
@@ -590,56 +616,31 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
     __shared__ Lds5 l;
     const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane = threadIdx.x;
-    const uint64_t tile = blockIdx.x;
     const uint64_t k5TileBytes = 1024ull * (uint64_t)rows;
     const uint32_t k5RecCap = rec_cap5(rows), wpl = words_per_lane5(rows);
-    const uint64_t base = tile * k5TileBytes, tile_end = base + k5TileBytes;
+    const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
-    /* the prefix in front of my tile: in front of its chunk, then the tiles of the chunk in front of it */
-    const uint64_t c = tile / k5ChunkTiles, t0 = c * k5ChunkTiles;
-    TileAgg mine = agg_identity();
-    if (t0 + (uint64_t)lane < tile) mine = w5.tagg[t0 + (uint64_t)lane];
-    const TileAgg infront = agg_readlane(wave_scan_combine(mine, lane), 63);
-    const Pre5 cp = w5.cpre[c];
-    Prefix ex; ex.kept = cp.kept; ex.nals = cp.nals; ex.inside = cp.inside;
-    const Prefix excl = prefix_uniform4(fold(ex, infront));
-    if (lane == 0 && tile == num_tiles - 1) {
-        const Prefix incl = fold(excl, w5.tagg[tile]);
-        hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside;
-    }
-    const uint32_t nrec = w5.nrec[tile];
-    if (nrec != k5Rewalk) {
-        TileAgg acc = agg_identity();
-#pragma unroll 1
-        for (uint32_t p0 = 0; p0 < nrec; p0 += 64u) {
-            Elem el;
-            const bool have = p0 + (uint32_t)lane < nrec;
-            TileAgg ea = agg_identity();
-            if (have) { rec_load(&w5.rec[tile * k5RecCap + p0 + (uint32_t)lane], el, base, n); ea = elem_agg(el.gap, el.s); }
-            ea = wave_scan_combine(ea, lane);
-            TileAgg up = agg_prev_lane(ea);
-            if (lane == 0) up = agg_identity();
-            const TileAgg e = combine(acc, up);
-            acc = combine(acc, agg_readlane(ea, 63));
-            if (have) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
-        }
-        return;
-    }
-    /* the tile again, the prefix known: by rows, or its elements 64 at a time */
-    const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
-    for (int i = rows + lane; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;
-    tile_words(l, stream, n, base, rows, cut, lane);
-    bool by_rows;
-    const uint32_t nelem = tile_census(l, lane, wpl, by_rows);
-    TileAgg accb = agg_identity();
-    uint64_t prev_end = base;
-    if (by_rows) {
-        const RowEdges5 edges = rows_edges(stream, n, base, tile_end);
-        tile_rows(stream, n, base, rows, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
+    /* the prefix in front of a tile: in front of its chunk, then the tiles of the chunk in front of it */
+    auto prefix_of = [&](uint64_t tile) -> Prefix {
+        const uint64_t c = tile / k5ChunkTiles, t0 = c * k5ChunkTiles;
+        TileAgg mine = agg_identity();
+        if (t0 + (uint64_t)lane < tile) mine = w5.tagg[t0 + (uint64_t)lane];
+        const TileAgg infront = agg_readlane(wave_scan_combine(mine, lane), 63);
+        const Pre5 cp = w5.cpre[c];
+        Prefix ex; ex.kept = cp.kept; ex.nals = cp.nals; ex.inside = cp.inside;
+        return prefix_uniform4(fold(ex, infront));
+    };
+    /* `prows` rows from `pbase` on, by rows, the tile's prefix and the aggregate in front of them inside the tile known */
+    auto walk_rows = [&](uint64_t pbase, int prows, TileAgg accb, const Prefix& excl) {
+        for (int i = prows + lane; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;
+        tile_words(l, stream, n, pbase, prows, cut, lane);
+        uint64_t prev_end = pbase;
+        const RowEdges5 edges = rows_edges(stream, n, pbase, pbase + 1024ull * (uint64_t)prows);
+        tile_rows(stream, n, pbase, prows, lane, l, [&](int r, const u32x4& qp, const u32x4& qc, const u32x4& qn) {
             DenseRow d;
             uint32_t quick = 0;
-            if (row_visit<true>(d, qp, qc, qn, r, rows, edges, stream, n, base, lane, prev_end, quick) == 1) { accb = combine(accb, gap_agg(quick)); return; }   /* nothing to write for such a row */
+            if (row_visit<true>(d, qp, qc, qn, r, prows, edges, stream, n, pbase, lane, prev_end, quick) == 1) { accb = combine(accb, gap_agg(quick)); return; }   /* nothing to write for such a row */
             const TileAgg ea = wave_scan_combine(elem_agg(d.el.gap, d.el.s), lane);
             TileAgg up = agg_prev_lane(ea);
             if (lane == 0) up = agg_identity();
@@ -647,19 +648,84 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             accb = combine(accb, agg_readlane(ea, 63));
             if (d.el.v.g0 < n) elem_emit(d.el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
         });
-    } else {
-        const uint32_t npass = (nelem + 63u) >> 6;
-#pragma unroll 1
-        for (uint32_t p = 0; p < npass; ++p) {
-            Elem el;
-            TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end, wpl);
-            ea = wave_scan_combine(ea, lane);
-            TileAgg up = agg_prev_lane(ea);
-            if (lane == 0) up = agg_identity();
-            const TileAgg eb = combine(accb, up);
-            accb = combine(accb, agg_readlane(ea, 63));
-            if (64u * p + (uint32_t)lane < nelem) elem_emit(el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+    };
+    const int nparts = (rows + kPartRows - 1) / kPartRows;
+    const bool helper = blockIdx.x >= num_tiles;
+    /* what is walked by rows below (ONE place in the code: inlined three times the kernel needed 248 registers instead of 144):
+     * a helper's jobs -- parts 1 .. of the tiles the stream pass walked by rows, consecutive helpers the parts of one tile --
+     * or the one job of a tile's own wavefront */
+    uint64_t job = helper ? blockIdx.x - num_tiles : 0, jobs = helper ? (uint64_t)hdr->rewalk_count * (uint64_t)(nparts - 1) : 0;
+    const uint64_t step = helper ? kEmitHelpers : 1;
+    int own_rows = 0;
+    if (!helper) {
+        const uint64_t tile = blockIdx.x;
+        const uint64_t base = tile * k5TileBytes;
+        const uint32_t nrec = w5.nrec[tile];
+        if (tile == num_tiles - 1) {
+            const Prefix incl = fold(prefix_of(tile), w5.tagg[tile]);       /* (prefix_of: every lane) */
+            if (lane == 0) { hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside; }
         }
+        if (nrec == k5RewalkParts) {                               /* walked by rows: my part is the first, the helpers have the others */
+            own_rows = rows < kPartRows ? rows : kPartRows;
+            jobs = 1;
+        } else if (nrec != k5Rewalk) {
+            const Prefix excl = prefix_of(tile);
+            TileAgg acc = agg_identity();
+#pragma unroll 1
+            for (uint32_t p0 = 0; p0 < nrec; p0 += 64u) {
+                Elem el;
+                const bool have = p0 + (uint32_t)lane < nrec;
+                TileAgg ea = agg_identity();
+                if (have) { rec_load(&w5.rec[tile * k5RecCap + p0 + (uint32_t)lane], el, base, n); ea = elem_agg(el.gap, el.s); }
+                ea = wave_scan_combine(ea, lane);
+                TileAgg up = agg_prev_lane(ea);
+                if (lane == 0) up = agg_identity();
+                const TileAgg e = combine(acc, up);
+                acc = combine(acc, agg_readlane(ea, 63));
+                if (have) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+            }
+            return;
+        } else {
+            /* the tile again, the prefix known: its elements 64 at a time (more of them than are recorded) */
+            for (int i = rows + lane; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;
+            tile_words(l, stream, n, base, rows, cut, lane);
+            bool by_rows;
+            const uint32_t nelem = tile_census(l, lane, wpl, by_rows);
+            if (by_rows) {                                          /* (the stream pass's census said otherwise: not expected) */
+                own_rows = rows;
+                jobs = 1;
+            } else {
+                const Prefix excl = prefix_of(tile);
+                TileAgg accb = agg_identity();
+                uint64_t prev_end = base;
+                const uint32_t npass = (nelem + 63u) >> 6;
+#pragma unroll 1
+                for (uint32_t p = 0; p < npass; ++p) {
+                    Elem el;
+                    TileAgg ea = make_batch(el, l, 64u * p, nelem, lane, stream, base, n, prev_end, wpl);
+                    ea = wave_scan_combine(ea, lane);
+                    TileAgg up = agg_prev_lane(ea);
+                    if (lane == 0) up = agg_identity();
+                    const TileAgg eb = combine(accb, up);
+                    accb = combine(accb, agg_readlane(ea, 63));
+                    if (64u * p + (uint32_t)lane < nelem) elem_emit(el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
+                }
+                return;
+            }
+        }
+    }
+#pragma unroll 1
+    for (; job < jobs; job += step) {
+        const uint64_t tile = helper ? (uint64_t)w5.rwlist[job / (uint64_t)(nparts - 1)] : (uint64_t)blockIdx.x;
+        const int p = helper ? 1 + (int)(job % (uint64_t)(nparts - 1)) : 0;
+        const uint64_t pbase = tile * k5TileBytes + 1024ull * (uint64_t)(kPartRows * p);
+        if (pbase >= n) continue;
+        const int prows = helper ? (rows - kPartRows * p < kPartRows ? rows - kPartRows * p : kPartRows) : own_rows;
+        const Prefix excl = prefix_of(tile);
+        TileAgg infront = agg_identity();
+        if (p != 0) infront = reinterpret_cast<const TileAgg*>(&w5.rec[tile * k5RecCap])[p - 1];
+        walk_rows(pbase, prows, infront, excl);
+        __builtin_amdgcn_wave_barrier();                           /* l is reused by the next part */
     }
 }
 
@@ -724,7 +790,7 @@ void launch_scan_index5(const ScanArgs& a, int gate, hipStream_t st)
         k_index5_chunks<<<dim3((unsigned)ws5_chunks(num_tiles)), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
         k_index5_prefix<<<dim3(1), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
     }
-    k_index5_emit<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
+    k_index5_emit<<<dim3((unsigned)num_tiles + kEmitHelpers), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
 }
 
 } // namespace hbs

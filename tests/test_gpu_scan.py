@@ -154,6 +154,54 @@ def test_index_only_streams(ctx, orc):
             assert np.array_equal(got_idx[f], want_idx[f]), (rep, size, f)
 
 
+_PARTS_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import torch, hevcbitstream_amd as hbs
+from tests import _orc
+orc = _orc.oracle()
+ctx = hbs.Context(0)
+ctx.set_kernel(5)
+rng = np.random.RandomState(5)
+n = 9 * (1 << 20) + 4321
+base = rng.randint(1, 256, size=n).astype(np.uint8)
+at = 0
+while at + 8 < n:
+    base[at:at + 4] = (0, 0, 1, 0x40)
+    at += int(rng.randint(2000, 30000))
+pats = [b"\x00\x00\x03", b"\x00", b"\x00\x00\x01\x42\x55", b"\x00\x00\x03\x00\x00\x02\x01", b"\x00\x00\x03\x04"]
+for k, (a, b) in enumerate([(300_000, 1_400_000), (2_000_000, 2_070_000), (3_100_000, 5_900_000), (7_000_000, 7_000_000 + 33_000), (n - 700_000, n)]):
+    s = base.copy()
+    p = np.frombuffer(pats[k %% len(pats)], dtype=np.uint8)
+    s[a:b] = np.tile(p, (b - a) // len(p) + 1)[:b - a]
+    want, _, why = orc.index_extract(s)
+    for cut in (0, 5, 1 << 20):
+        t = s[:len(s) - cut]
+        if cut:
+            want, _, why = orc.index_extract(t)
+        got, arena, sm = ctx.index_extract(torch.from_numpy(np.ascontiguousarray(t)).cuda(), want_rbsp=False)
+        assert int(sm["error"]) == 0 and int(sm["stop_reason"]) == why and len(got) == len(want), (k, cut, len(got), len(want))
+        for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+            assert np.array_equal(got[f], want[f]), (k, cut, f)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("rows", [0, 64, 96, 256, 512], ids=["height-of-the-call", "64", "96", "256", "512"])
+def test_index_only_tiles_walked_by_rows_in_parts(rows):
+    """round 5: a tile the index-only scan walks by rows (a stretch of padding, zeros, tiny NALs, patterns that mark errors) is
+    walked again by the emit pass in parts of 32 rows, by helper wavefronts, from the aggregates the stream pass left in front of
+    every part -- at the tile height the call picks and at pinned ones (HBS5_TILE_ROWS is read once: a process each); stretches
+    that begin and end inside tiles, cover whole tiles, and run to the stream's end; ends cut inside a part."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if rows:
+        env["HBS5_TILE_ROWS"] = str(rows)
+    r = subprocess.run([sys.executable, "-c", _PARTS_WORKER % os.path.dirname(HERE)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_index_only_ring_of_flagged_chunks(ctx, orc):
     """round 4: the index-only scan leaves the flagged chunks' bytes in a ring of 192 entries in LDS and walks them 64 at a time
     inside its streaming loop.  Streams that fill, wrap and overflow the ring: NALs of 512 bytes and of 1 KiB (several batches
@@ -273,6 +321,8 @@ def test_dense_tiles_counted_ahead(orc, kernel):
     s = base.copy(); fill(s, 4 * tile + 50_000, 8 * tile + 20_000, 1); streams.append(s)                # across tiles, zeros
     s = base.copy(); fill(s, 0, tile + 999, 2); fill(s, 16 * tile, n, 3); streams.append(s)             # first tile(s), last tiles
     s = base.copy(); fill(s, 15 * tile - 5, 17 * tile + 5, 0); streams.append(s)                        # up to the last full tile and beyond
+    s = base.copy(); fill(s, 12 * tile - 9000, 13 * tile + 9000, 0); streams.append(s)                  # 9 KB of the tiles on either side: dense, marked by their edge
+    s = base.copy(); fill(s, 7 * tile + 70_000, 7 * tile + 130_000, 1); streams.append(s)               # 60 KB inside a tile: the first look may miss it
     s = base.copy()                                                                                      # marked, not dense
     for t in (3, 9):
         for lane in range(48):
