@@ -110,7 +110,6 @@ def load_library():
     lib.hbs_ctx_kernel_ms_back.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     lib.hbs_ctx_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hbs_ctx_set_kernel.argtypes = [C.c_void_p, C.c_int]
-    lib.hbs_ctx_set_count_ahead.argtypes = [C.c_void_p, C.c_int]
     lib.hbs_ctx_get_kernel.argtypes = [C.c_void_p]
     lib.hbs_ctx_last_kernel.argtypes = [C.c_void_p]
     lib.hbs_last_error.argtypes = [C.c_void_p]
@@ -196,6 +195,7 @@ class Context:
 
     def set_count_ahead(self, mode=1):
         """kernel 4's dense tiles counted ahead of it: 0 never, 1 on streams of 4 GiB and more (default), 2 always"""
+        self.lib.hbs_ctx_set_count_ahead.argtypes = [C.c_void_p, C.c_int]     # (bound here: development libraries of earlier rounds load too)
         self._check(self.lib.hbs_ctx_set_count_ahead(self.h, mode), "hbs_ctx_set_count_ahead")
 
     def kernel(self):
