@@ -194,7 +194,7 @@ class Context:
         self._check(self.lib.hbs_ctx_set_kernel(self.h, variant), "hbs_ctx_set_kernel")
 
     def set_count_ahead(self, mode=1):
-        """kernel 4's dense tiles counted ahead of it: 0 never, 1 on streams of 4 GiB and more (default), 2 always"""
+        """kernel 4's dense tiles counted ahead of it: 0 never, 1 on streams of 3 GiB and more (default), 2 always"""
         self.lib.hbs_ctx_set_count_ahead.argtypes = [C.c_void_p, C.c_int]     # (bound here: development libraries of earlier rounds load too)
         self._check(self.lib.hbs_ctx_set_count_ahead(self.h, mode), "hbs_ctx_set_count_ahead")
 

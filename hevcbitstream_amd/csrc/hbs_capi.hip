@@ -38,7 +38,7 @@ struct hbs_ctx {
     int probe_pending;
     int last_index_only;          /* the last hbs_index_extract had no arena: its sparse kernel is the streaming one (5) */
     int parse_sequential;         /* hbs_ctx_set_sequential_parse */
-    int count_ahead;              /* hbs_ctx_set_count_ahead: 0 never, 1 streams from 4 GiB up, 2 always */
+    int count_ahead;              /* hbs_ctx_set_count_ahead: 0 never, 1 streams from 3 GiB up, 2 always */
     uint64_t ingest_window_max;   /* hbs_ctx_set_ingest_window_max (0: the default) */
     void* attachment;             /* state another translation unit keeps with the context (the windowed ingest's buffers) */
     void (*attachment_free)(void*);
@@ -56,7 +56,7 @@ struct hbs_ctx {
     uint8_t* tail;                      /* padded copy of the stream's last tile (event-sparse kernel) */
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
-    void* ahead; uint64_t ahead_tiles; uint32_t ahead_calls;   /* K12's dense tiles counted ahead: a table entry and a byte per 192 KiB tile (streams from 4 GiB up) */
+    void* ahead; uint64_t ahead_tiles; uint32_t ahead_calls;   /* K12's dense tiles counted ahead: a table entry and a byte per 192 KiB tile (streams from 3 GiB up) */
     void* ws2; uint64_t ws2_bytes;   /* hbs_index_parse: header windows and the index that points into them (alive across the parse, which carves ws) */
     uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
     /* optional timing of the dominant kernel */

@@ -341,7 +341,7 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
  * 1.05-1.10 x the uniform stream's time. */
 struct AheadEntry { TileAgg w[k4Waves]; };
 static_assert(sizeof(AheadEntry) == 64, "four aggregates");
-constexpr uint64_t kAheadMinBytes = 4ull << 30;          /* the launch costs ~10 us where nothing is marked: 1.3 % of a 2 GiB call, 0.6 % at 4 GiB, 0.15 % at 16 */
+constexpr uint64_t kAheadMinBytes = 3ull << 30;          /* the launch costs ~10 us where nothing is marked: 1.3 % of a 2 GiB call, 0.9 % at 3 GiB, 0.15 % at 16 */
 constexpr int kAheadSample = 48;                         /* chunks sampled per tile, 4 KiB apart */
 constexpr int kAheadMinHits = 8;                         /* marked from this many flagged samples, or from three in a row (streams of 512-byte NALs
                                                             flag a sample in 20: two in a row marked a tile in 9, and the kernel below took 0.23 ms of 1.2) */

@@ -144,7 +144,7 @@ int  hbs_ctx_get_kernel(hbs_ctx* ctx);
 /* Kernel 4 walks a DENSE tile (one with more than 512 candidate chunks in its 192 KiB: padding, zero stuffing) chunk by chunk,
  * and every tile behind it waits for its count.  From round 5 such tiles are counted AHEAD of the main kernel: the call's first
  * launch samples every tile, a small kernel counts the ones the sample marks, and the main kernel takes those counts instead of
- * walking the tile a first time (hbs_scan4.hip, "dense tiles counted ahead").  mode 1 (default): streams of 4 GiB and more;
+ * walking the tile a first time (hbs_scan4.hip, "dense tiles counted ahead").  mode 1 (default): streams of 3 GiB and more;
  * 0: never; 2: any stream that has more than one tile.  Results are identical in all three.  Environment HBS_COUNT_AHEAD=0|1|2
  * sets the default.  The table costs 72 bytes of device memory per 192 KiB of stream. */
 int  hbs_ctx_set_count_ahead(hbs_ctx* ctx, int mode);

@@ -297,7 +297,7 @@ def test_tiles_with_several_batches_of_elements(ctx, orc, shape):
 
 @pytest.mark.parametrize("kernel", [0, 4], ids=["automatic", "sparse-kernel"])
 def test_dense_tiles_counted_ahead(orc, kernel):
-    """round 5: the event-sparse kernel's dense tiles counted ahead of it (hbs_ctx_set_count_ahead; by default only from 4 GiB up,
+    """round 5: the event-sparse kernel's dense tiles counted ahead of it (hbs_ctx_set_count_ahead; by default only from 3 GiB up,
     here on every stream): stretches of padding / zeros / tiny NALs in a sparse stream -- inside a tile, across tiles, at the
     stream's start and in its last tile; a tile the sample marks and which is not dense (zero pairs exactly where the sample
     looks), one that is walked ahead and still is not (400 flagged chunks); a dense tile the sample misses (dense everywhere but there).  Modes 0 and 2 must give what the oracle gives."""
