@@ -63,6 +63,9 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
 }
 
+#ifndef HBS_LOOKBACK_GROUPS
+#define HBS_LOOKBACK_GROUPS 4
+#endif
 /* Four 16-byte descriptor loads that bypass the non-coherent cache levels (sc1: the writer is on
  * another XCD), issued together and awaited together.  A descriptor's two 8-byte words are each
  * self-validating, so reading them with one 16-byte load is as good as two 8-byte atomics. */
@@ -80,12 +83,30 @@ __device__ __forceinline__ void load_desc4(u32x4& d0, u32x4& d1, u32x4& d2, u32x
                  : "memory");
 }
 
+/* ... eight of them (round 5: a window of 512 tiles) */
+__device__ __forceinline__ void load_desc8(u32x4* d, const unsigned long long* const* p)
+{
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                 : "memory");
+}
+
 /*
- * Decoupled look-back by ONE wavefront, 256 predecessors per step.  Lane l reads the descriptors
- * of the tiles at distance l, 64 + l, 128 + l, 192 + l in front of win_hi: each of the four loads
- * covers 64 consecutive descriptors, 1 KiB, eight cache lines.  The four groups are folded nearest
- * first up to the nearest tile that already has its prefix.  Returns false on timeout/abort.
- * Called by every lane of wavefront 0.
+ * Decoupled look-back by ONE wavefront, 64 * kGroups predecessors per step (kGroups = 4 or 8).  Lane l reads the descriptors
+ * of the tiles at distance l, 64 + l, 128 + l, ... in front of win_hi: each of the loads covers 64 consecutive descriptors,
+ * 1 KiB, eight cache lines.  The groups are folded nearest first up to the nearest tile that already has its prefix.
+ * Returns false on timeout/abort.  Called by every lane of wavefront 0.
+ * (Round 5, HBS_LOOKBACK_GROUPS: with 512 tiles in flight that move nearly in step, the nearest tile that has its prefix is
+ * 300-500 tiles back: two steps of 256, two round trips at loaded latency -- ~4 us of a tile's 34.)
  */
 /* first half: the tile's aggregate goes out (tile 0 publishes its prefix straight away, in the second half) */
 __device__ __forceinline__ void look_back_publish(unsigned long long* desc, uint64_t tile, const TileAgg& mine, int lane)
@@ -98,9 +119,11 @@ __device__ __forceinline__ void look_back_publish(unsigned long long* desc, uint
 
 /* second half: fold the tiles in front, publish the inclusive prefix.  May run long after the first (an experiment of round 2
  * did other work in between, so that the predecessors had published by the time it asked). */
+template <int kGroups>
 __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint64_t tile, const TileAgg& mine,
                                                   RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
 {
+    static_assert(kGroups == 4 || kGroups == 8, "four or eight groups of 64 descriptors");
     dbg_iters = 0; dbg_stalls = 0;
     bool ok = true;
     excl.kept = 0; excl.nals = 0; excl.inside = 0;
@@ -108,7 +131,7 @@ __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint
         TileAgg acc = agg_identity();                 /* tiles between the window and `tile` */
         int64_t win_hi = (int64_t)tile - 1;
         uint32_t spins = 0;
-        uint64_t w0[4], w1[4];
+        uint64_t w0[kGroups], w1[kGroups];
         bool fresh = true;                            /* the window moved: read all of it */
         for (;;) {
             ++dbg_iters;
@@ -116,22 +139,23 @@ __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint
              * a prefix): while waiting, only lanes that still miss one read again. */
             bool need = fresh;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kGroups; ++j) {
                 const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
                 need = need || !((s0 == s1) && (s0 != kDescEmpty));
             }
             if (need) {
                 const int64_t t0 = win_hi - lane;
-                u32x4 d[4];
-                const unsigned long long* p[4];
+                u32x4 d[kGroups];
+                const unsigned long long* p[kGroups];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < kGroups; ++j) {
                     const int64_t t = t0 - 64 * j;
                     p[j] = &desc[2 * (t > 0 ? t : 0)];
                 }
-                load_desc4(d[0], d[1], d[2], d[3], p[0], p[1], p[2], p[3]);
+                if constexpr (kGroups == 4) load_desc4(d[0], d[1], d[2], d[3], p[0], p[1], p[2], p[3]);
+                else load_desc8(d, p);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < kGroups; ++j) {
                     w0[j] = ((uint64_t)d[j].y << 32) | d[j].x;
                     w1[j] = ((uint64_t)d[j].w << 32) | d[j].z;
                     if (t0 - 64 * j < 0) { w0[j] = kDescPrefix; w1[j] = kDescPrefix; }   /* virtual tile -1: empty prefix */
@@ -143,7 +167,7 @@ __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint
             bool stall = false;
             uint64_t pw0 = 0, pw1 = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kGroups; ++j) {
                 const uint32_t s0 = (uint32_t)(w0[j] & 3u), s1 = (uint32_t)(w1[j] & 3u);
                 const bool ready = (s0 == s1) && (s0 != kDescEmpty);
                 const uint64_t m_ready = __ballot(ready);
@@ -169,7 +193,7 @@ __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint
             }
             TileAgg total = acc;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kGroups; ++j) {
                 if (j0 < 0 || j <= j0) {
                     const TileAgg win = window_fold3(unpack_agg(w0[j], w1[j]), (j == j0) ? lstar : 64, lane);
                     total = combine(win, total);
@@ -181,7 +205,7 @@ __device__ __forceinline__ bool look_back_resolve(unsigned long long* desc, uint
                 break;
             }
             acc = total;
-            win_hi -= 256;
+            win_hi -= 64 * kGroups;
             fresh = true;
         }
     }
@@ -202,7 +226,7 @@ __device__ __forceinline__ bool look_back4(unsigned long long* desc, uint64_t ti
                                            RunHeader* hdr, int lane, Prefix& excl, uint32_t& dbg_iters, uint32_t& dbg_stalls)
 {
     look_back_publish(desc, tile, mine, lane);
-    return look_back_resolve(desc, tile, mine, hdr, lane, excl, dbg_iters, dbg_stalls);
+    return look_back_resolve<HBS_LOOKBACK_GROUPS>(desc, tile, mine, hdr, lane, excl, dbg_iters, dbg_stalls);
 }
 
 __device__ __forceinline__ Prefix prefix_uniform4(const Prefix& p)
