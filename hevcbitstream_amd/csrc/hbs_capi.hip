@@ -56,7 +56,7 @@ struct hbs_ctx {
     uint8_t* tail;                      /* padded copy of the stream's last tile (event-sparse kernel) */
     /* K3 / generator workspace */
     void* ws; uint64_t ws_bytes;
-    void* ahead; uint64_t ahead_tiles; uint32_t ahead_calls;   /* K12's dense tiles counted ahead: a table entry and a byte per 192 KiB tile (streams from 3 GiB up) */
+    void* ahead; uint64_t ahead_tiles;   /* K12's dense tiles counted ahead: a table entry and a byte per 192 KiB tile (streams from 3 GiB up) */
     void* ws2; uint64_t ws2_bytes;   /* hbs_index_parse: header windows and the index that points into them (alive across the parse, which carves ws) */
     uint8_t* zeros;              /* sizeof(hevc_sps_t) zero bytes: the "no parameter set yet" structs */
     /* optional timing of the dominant kernel */
@@ -388,32 +388,25 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
         if (rc) return rc;
         a.ws5 = c->ws;
     }
-    a.ahead_cand = nullptr; a.ahead_tab = nullptr; a.ahead_list = nullptr; a.ahead_ctl = nullptr; a.ahead_parity = 0; a.ahead_stamp = 0;
+    a.ahead_cand = nullptr; a.ahead_tab = nullptr; a.ahead_list = nullptr; a.ahead_ctl = nullptr;
     if (d_rbsp && (c->count_ahead == 2 || (c->count_ahead == 1 && hbs::scan4_counts_ahead(n))) && n > (uint64_t)hbs::scan4_tile_bytes() &&
         (c->variant == 0 || c->variant == 4 || c->variant == 5) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) {
-        /* K12's dense tiles counted ahead: [two counters | table | list | a word per tile] */
+        /* K12's dense tiles counted ahead: [AheadCtl | table | a word per tile | list] */
         const uint64_t tiles = (n + (uint64_t)hbs::scan4_tile_bytes() - 1) / (uint64_t)hbs::scan4_tile_bytes();
-        const bool wrap = c->ahead_calls >= (1u << 30) - 2u;             /* (the stamp is the call's number: start over with cleared words) */
-        if (tiles > c->ahead_tiles || wrap) {
-            const uint64_t want = tiles > c->ahead_tiles ? tiles : c->ahead_tiles;
+        if (tiles > c->ahead_tiles) {
             if (c->ahead) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ahead); c->ahead = nullptr; c->ahead_tiles = 0; }
-            hipError_t e = hipMalloc(&c->ahead, 64 + want * hbs::scan4_ahead_entry_bytes());
+            hipError_t e = hipMalloc(&c->ahead, 64 + tiles * hbs::scan4_ahead_entry_bytes());
             if (e != hipSuccess) return fail(c, e, "hipMalloc(count-ahead table)");
-            /* the counters and the tiles' words start at zero (the table and the list are written before they are read) */
-            e = hipMemsetAsync(c->ahead, 0, 64, c->stream);
-            if (e == hipSuccess) e = hipMemsetAsync(static_cast<uint8_t*>(c->ahead) + 64 + want * 68, 0, want * 4, c->stream);
+            /* the call number, the list's count and the tiles' words start at zero (table and list are written before they are read) */
+            e = hipMemsetAsync(c->ahead, 0, 64 + tiles * 72, c->stream);
             if (e != hipSuccess) return fail(c, e, "hipMemsetAsync(count-ahead words)");
-            c->ahead_tiles = want;
-            c->ahead_calls = 0;
+            c->ahead_tiles = tiles;
         }
         uint8_t* const p = static_cast<uint8_t*>(c->ahead);
-        a.ahead_ctl = reinterpret_cast<uint32_t*>(p);
+        a.ahead_ctl = reinterpret_cast<hbs::AheadCtl*>(p);
         a.ahead_tab = p + 64;
-        a.ahead_list = reinterpret_cast<uint32_t*>(p + 64 + c->ahead_tiles * 64);
-        a.ahead_cand = reinterpret_cast<uint32_t*>(p + 64 + c->ahead_tiles * 68);
-        a.ahead_parity = (int)(c->ahead_calls & 1u);
-        c->ahead_calls += 1;
-        a.ahead_stamp = c->ahead_calls << 2;
+        a.ahead_cand = reinterpret_cast<unsigned long long*>(p + 64 + c->ahead_tiles * 64);
+        a.ahead_list = reinterpret_cast<uint32_t*>(p + 64 + c->ahead_tiles * 72);
     }
     c->last_index_only = (hbs::scan_uses_index_only(n, c->variant, d_rbsp) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;

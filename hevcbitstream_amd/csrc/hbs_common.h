@@ -78,16 +78,24 @@ struct RunHeader {
     /* dense tiles counted ahead of the event-sparse kernel (hbs_scan4.hip, round 5): this call's stamp, the word per tile the
      * prologue's sample and k_scan_ahead4 leave (stamp | 1 marked, stamp | 2 counted) and the table of the tiles counted; set by
      * the prologue of every call (ahead_tab = 0: not this call) */
-    uint32_t ahead_stamp;
-    unsigned long long ahead_cand, ahead_tab;
+    uint32_t pad_a;
+    unsigned long long ahead_cand, ahead_tab, ahead_stamp;
     uint32_t rewalk_count;    /* index-only scan (hbs_scan5.hip): tiles walked by rows, listed for the emit pass's helpers; cleared by the prologue */
-    uint32_t pad0[15];
+    uint32_t pad0[13];
     uint32_t ticket;          /* next unclaimed tile (dynamic tile schedules); alone on its 128-byte line */
     uint32_t pad1[31];
     uint32_t probe_slot[64][2];   /* density probe, one pair per probe workgroup: chunks sampled, chunks flagged.  Plain
                                      stores by the prologue kernel (no zeroing needed in front); readers add them up */
 };
 static_assert(sizeof(RunHeader) == 768, "RunHeader layout");
+
+/* What the count-ahead keeps between calls, in device memory and written by kernels only, so that a call captured into a HIP
+ * graph and replayed behaves like a call made again: `call` numbers the calls that used the workspace (the last launch of a
+ * call, k_scan_finish, adds one: the next call's stamp is another one, and the words the tiles carry from this call mean nothing
+ * to it), `listed` counts the tiles the prologue's sample marked in the call in progress (k_scan_finish clears it). */
+struct AheadCtl { unsigned long long call; uint32_t listed; uint32_t pad[13]; };
+static_assert(sizeof(AheadCtl) == 64, "one line");
+HBS_HD unsigned long long ahead_stamp_of(unsigned long long call) { return (call + 1ull) << 2; }
 
 /* The kernel-choice rule of the automatic mode (hbs_scan.hip launch_scan_extract): the event-sparse
  * kernel handles flagged chunks 64 at a time on one wavefront, so once more than one chunk in

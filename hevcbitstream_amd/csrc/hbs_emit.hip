@@ -2054,7 +2054,7 @@ void k3t_sample(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restric
         for (int i = 0; i < kAtOnce; ++i) {
             const uint64_t tile = tile0 + (uint64_t)i;
             if (tile >= ntiles) break;
-            if (lane == 0) dz_table[tile * (uint64_t)kDzTableWords + 24u] = 0u;     /* (the workspace is not cleared: no stale entry may carry this call's number) */
+            if (lane == 0) { dz_table[tile * (uint64_t)kDzTableWords + 24u] = 0u; dz_table[tile * (uint64_t)kDzTableWords + 25u] = 0u; }   /* (the workspace is not cleared: no stale entry may carry this call's number -- a call replayed from a HIP graph has the number it was captured with) */
             if (__ballot(hit(q[i])) == 0ull) continue;
             const uint64_t x = sample_at(tile, lane >> 2, lane & 3);
             u32x4 qq = none;

@@ -20,11 +20,9 @@ struct ScanArgs {
     void* ws5;                    /* workspace of scan5_workspace_bytes(n): tile aggregates and recorded elements of the index-only
                                      kernels (hbs_scan5.hip); needed only when rbsp == nullptr */
     hbs_summary* summary;         /* device                                       */
-    uint32_t* ahead_cand;         /* workspace: a word per 192 KiB tile -- ahead_stamp | 1: the prologue's sample says "dense", | 2: counted (event-sparse kernel with count-ahead), or nullptr */
+    unsigned long long* ahead_cand;  /* workspace: a word per 192 KiB tile -- stamp | 1: the prologue's sample says "dense", | 2: counted (event-sparse kernel with count-ahead), or nullptr */
     uint32_t* ahead_list;         /* workspace: the tiles so marked, a word per tile of the stream at most                                */
-    uint32_t* ahead_ctl;          /* workspace: two counters; [ahead_parity] = entries of the list in this call, the other is cleared for the next */
-    int ahead_parity;
-    uint32_t ahead_stamp;         /* this call's number on its context << 2 (never 0): older words of ahead_cand mean nothing        */
+    AheadCtl* ahead_ctl;          /* workspace: the call's number (-> its stamp) and the entries of the list (hbs_common.h)               */
     void* ahead_tab;              /* workspace: scan4_ahead_entry_bytes() per tile: the aggregates of the tiles counted ahead           */
               /* this call's number on its context (never 0): stamps the entries                                  */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */

@@ -560,8 +560,10 @@ constexpr int kFinishBlocksMin = 128, kFinishBlocksMax = 2048;   /* sized by the
 __global__ __launch_bounds__(256)
 void k_scan_finish(const uint8_t* __restrict__ stream, uint64_t n,
                    hbs_nal_entry* index, uint64_t index_cap,
-                   uint8_t* rbsp, uint64_t rbsp_cap, RunHeader* hdr, hbs_summary* sum)
+                   uint8_t* rbsp, uint64_t rbsp_cap, RunHeader* hdr, hbs_summary* sum, AheadCtl* ahead_ctl)
 {
+    /* the call's last launch: the count-ahead's workspace (hbs_scan4.hip) is the next call's from here on */
+    if (ahead_ctl && blockIdx.x == 0 && threadIdx.x == 0) { ahead_ctl->listed = 0u; ahead_ctl->call += 1ull; }
     const uint64_t found0 = hdr->final_nals;
     const uint64_t lim = found0 < index_cap ? found0 : index_cap;
     /* a wavefront takes 64 consecutive entries: each lane loads the second half of its entry (rbsp_off, rbsp_len, status) in
@@ -711,7 +713,7 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     const uint64_t may = a.index_cap < a.n / 3 + 1 ? a.index_cap : a.n / 3 + 1;
     uint64_t fb = (may + 1023) / 1024;
     fb = fb < (uint64_t)kFinishBlocksMin ? (uint64_t)kFinishBlocksMin : fb > (uint64_t)kFinishBlocksMax ? (uint64_t)kFinishBlocksMax : fb;
-    k_scan_finish<<<dim3((unsigned)fb), 256, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary);
+    k_scan_finish<<<dim3((unsigned)fb), 256, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary, a.ahead_ctl);
     return hipGetLastError();
 }
 

@@ -333,7 +333,8 @@ __device__ __forceinline__ TileAgg elem_make(Elem& el, const Lds4& l, uint32_t i
  * tile is dense from 512 flagged chunks = 8 KiB of such a stretch; coded video flags one sample in 500) -- and lists the tiles
  * it marks; k_scan_ahead4 takes the tiles so marked, in front of the main kernel and with nobody waiting -- counts their flagged
  * chunks roughly, and walks the ones that may be dense: their four wavefront aggregates go to a table, the tile's word becomes
- * "counted"; dense_tile takes such a tile's entry instead of walking its rows a first time (the words carry the call's stamp:
+ * "counted"; dense_tile takes such a tile's entry instead of walking its rows a first time (the words carry the call's stamp --
+ * a number kept on the device and advanced by the call's last launch, so that a call replayed from a HIP graph is a new call --:
  * nothing has to be cleared).  A dense tile the sample misses -- a stretch shorter than 64 KiB may be -- is walked in place as
  * before; a marked tile that turns out ordinary costs its rows once more, read by a kernel that has the memory system to
  * itself.  From kAheadMinBytes up (below, the extra launch costs a call more than mixed content is likely to;
@@ -347,7 +348,7 @@ constexpr int kAheadMinHits = 8;                         /* marked from this man
                                                             flag a sample in 20: two in a row marked a tile in 9, and the kernel below took 0.23 ms of 1.2) */
 constexpr uint32_t kAheadRoughMin = 400;                 /* k_scan_ahead4 walks a marked tile when its rough count reaches this (chunks taken by themselves:
                                                             a pattern across two chunks is missed, one in eight) */
-constexpr uint32_t kAheadMarked = 1u, kAheadDone = 2u;     /* or-ed to the call's stamp in a tile's word */
+constexpr unsigned long long kAheadMarked = 1ull, kAheadDone = 2ull;     /* or-ed to the call's stamp in a tile's word */
 constexpr int kAheadCoarse = 3;                          /* chunks of the first look, 64 KiB apart */
 
 __device__ __attribute__((noinline))
@@ -361,7 +362,7 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t chunk0 = (uint32_t)(64 * k4Rows * wv);
     /* counted ahead in this call (k_scan_ahead4)?  then the table has what the walk below would find */
-    const bool counted = hdr->ahead_tab != 0ull && !last_tile && reinterpret_cast<const uint32_t*>(hdr->ahead_cand)[tile] == (hdr->ahead_stamp | kAheadDone);
+    const bool counted = hdr->ahead_tab != 0ull && !last_tile && reinterpret_cast<const unsigned long long*>(hdr->ahead_cand)[tile] == (hdr->ahead_stamp | kAheadDone);
     const TileAgg wa = counted ? reinterpret_cast<const AheadEntry*>(hdr->ahead_tab)[tile].w[wv] : dense_aggregate(src, wseg, n, before, before2, after, chunk0, lane);
     if (lane == 0) l.wagg[wv] = wa;
     __syncthreads();
@@ -412,11 +413,12 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
 
 /* the tiles the prologue marked, a workgroup each: a rough count, then the first half of dense_tile, into the table */
 __global__ __launch_bounds__(k4Threads)
-void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, uint32_t* __restrict__ cand, uint32_t stamp,
-                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ ctl, int parity,
+void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, unsigned long long* __restrict__ cand,
+                   const uint32_t* __restrict__ list, const AheadCtl* __restrict__ ctl,
                    AheadEntry* __restrict__ tab, const RunHeader* __restrict__ hdr, int gate)
 {
-    const uint32_t marked = ctl[parity];
+    const uint32_t marked = ctl->listed;
+    const unsigned long long stamp = ahead_stamp_of(ctl->call);
     if (blockIdx.x >= marked || gate_closed(gate, hdr)) return;
     __shared__ uint32_t rough[k4Waves];
     __shared__ TileAgg wagg[k4Waves];
@@ -456,14 +458,14 @@ void k_scan_ahead4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
     }
 }
 
-uint64_t scan4_ahead_entry_bytes() { return sizeof(AheadEntry) + 2 * sizeof(uint32_t); }     /* table entry, list word, the tile's word */
+uint64_t scan4_ahead_entry_bytes() { return sizeof(AheadEntry) + sizeof(unsigned long long) + sizeof(uint32_t); }     /* table entry, the tile's word, list word */
 bool scan4_counts_ahead(uint64_t n) { return n >= kAheadMinBytes; }
 
 void launch_scan_ahead4(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st)
 {
     if (!a.ahead_cand || !a.ahead_tab || num_tiles < 2) return;
     /* four workgroups a CU (119 registers): a stretch's tiles at the same time; with nothing marked they all leave at once */
-    k_scan_ahead4<<<dim3(1024), dim3(k4Threads), 0, st>>>(a.stream, a.n, num_tiles, a.ahead_cand, a.ahead_stamp, a.ahead_list, a.ahead_ctl, a.ahead_parity,
+    k_scan_ahead4<<<dim3(1024), dim3(k4Threads), 0, st>>>(a.stream, a.n, num_tiles, a.ahead_cand, a.ahead_list, a.ahead_ctl,
                                                          static_cast<AheadEntry*>(a.ahead_tab), a.hdr, gate);
 }
 
@@ -872,13 +874,14 @@ __global__ __launch_bounds__(256)
 void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* __restrict__ hdr, uint8_t* __restrict__ tail,
                      unsigned long long* __restrict__ index_words, uint64_t n_index_words,
                      unsigned long long* __restrict__ desc, uint64_t n_desc_words, int do_probe, int tail_tile_bytes,
-                     uint32_t* __restrict__ ahead_cand, void* ahead_tab, uint32_t* __restrict__ ahead_list, uint32_t* __restrict__ ahead_ctl, int ahead_parity,
-                     uint32_t ahead_stamp, int sample_blocks)
+                     unsigned long long* __restrict__ ahead_cand, void* ahead_tab, uint32_t* __restrict__ ahead_list, AheadCtl* __restrict__ ahead_ctl,
+                     int sample_blocks)
 {
     if ((int)blockIdx.x >= (int)gridDim.x - sample_blocks) {
         /* the sample of the count-ahead (see dense_tile), with the exact question the flag pass asks (neighbouring chunks ignored).
          * A wavefront takes sixteen tiles at a time: lanes 0-47 a chunk each of the first look */
         const int lane = threadIdx.x & 63;
+        const unsigned long long ahead_stamp = ahead_stamp_of(ahead_ctl->call);       /* (left by the finish launch of the call before, or the allocation) */
         const uint64_t wave = ((uint64_t)(blockIdx.x - ((int)gridDim.x - sample_blocks)) * blockDim.x + threadIdx.x) >> 6;
         const uint64_t nwaves = ((uint64_t)sample_blocks * blockDim.x) >> 6;
         const uint64_t tiles = (n + (uint64_t)k4TileBytes - 1) / (uint64_t)k4TileBytes;
@@ -909,8 +912,8 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
                     const bool mark = __builtin_popcountll(hits) >= kAheadMinHits || (hits & (hits >> 1) & (hits >> 2)) != 0ull ||
                                       (hits & 3ull) == 3ull || ((hits >> (kAheadSample - 2)) & 3ull) == 3ull;
                     if (lane == 0) {
-                        const uint32_t word = ahead_stamp | (mark ? kAheadMarked : 0u);
-                        if (atomicMax(&ahead_cand[u], word) < word && mark) ahead_list[atomicAdd(&ahead_ctl[ahead_parity], 1u)] = (uint32_t)u;
+                        const unsigned long long word = ahead_stamp | (mark ? kAheadMarked : 0ull);
+                        if (atomicMax(&ahead_cand[u], word) < word && mark) ahead_list[atomicAdd(&ahead_ctl->listed, 1u)] = (uint32_t)u;
                     }
                 }
             }
@@ -923,10 +926,9 @@ void k_scan_prologue(const uint8_t* __restrict__ stream, uint64_t n, RunHeader* 
             hdr->final_kept = 0; hdr->final_nals = 0; hdr->final_inside = 0;
             hdr->error = 0; hdr->first_empty = ~0ull; hdr->abort_flag = 0; hdr->ticket = 0;
             hdr->probe_chunks = 0; hdr->probe_flagged = 0; hdr->rewalk_count = 0;
-            hdr->ahead_stamp = ahead_stamp;
+            hdr->pad_a = 0; hdr->ahead_stamp = ahead_ctl ? ahead_stamp_of(ahead_ctl->call) : 0ull;
             hdr->ahead_cand = ahead_tab ? reinterpret_cast<unsigned long long>(ahead_cand) : 0ull;
             hdr->ahead_tab = ahead_cand ? reinterpret_cast<unsigned long long>(ahead_tab) : 0ull;
-            if (ahead_ctl) ahead_ctl[ahead_parity ^ 1] = 0u;        /* the next call's counter (this call's was cleared by the one before, or at allocation) */
         }
         /* Density probe: kProbeBlocks windows of 16 KiB spread evenly over the stream; counts the chunks that
          * chunk_flag() would hand to the element path (neighbouring chunks ignored: an estimate is all the
@@ -998,7 +1000,7 @@ void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, in
     }
     k_scan_prologue<<<dim3(kProbeBlocks + kTailBlocks + (unsigned)clear_blocks + sample_blocks), dim3(256), 0, st>>>(
         a.stream, a.n, a.hdr, a.tail, reinterpret_cast<unsigned long long*>(a.index), index_words,
-        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes, a.ahead_cand, a.ahead_tab, a.ahead_list, a.ahead_ctl, a.ahead_parity, a.ahead_stamp, (int)sample_blocks);
+        a.desc, desc_words, probe ? 1 : 0, tail_tile_bytes, a.ahead_cand, a.ahead_tab, a.ahead_list, a.ahead_ctl, (int)sample_blocks);
 }
 
 int scan4_grid_blocks(int device, int* blocks_per_cu_out)

@@ -146,7 +146,7 @@ int  hbs_ctx_get_kernel(hbs_ctx* ctx);
  * launch samples every tile, a small kernel counts the ones the sample marks, and the main kernel takes those counts instead of
  * walking the tile a first time (hbs_scan4.hip, "dense tiles counted ahead").  mode 1 (default): streams of 3 GiB and more;
  * 0: never; 2: any stream that has more than one tile.  Results are identical in all three.  Environment HBS_COUNT_AHEAD=0|1|2
- * sets the default.  The table costs 72 bytes of device memory per 192 KiB of stream. */
+ * sets the default.  The table costs 76 bytes of device memory per 192 KiB of stream; nothing of it lives on the host, so a call captured into a HIP graph may be replayed. */
 int  hbs_ctx_set_count_ahead(hbs_ctx* ctx, int mode);
 int  hbs_ctx_last_kernel(hbs_ctx* ctx);
 /* Text of the last HIP/driver error seen by this context. */

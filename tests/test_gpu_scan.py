@@ -456,6 +456,62 @@ def test_calls_capture_into_a_hip_graph(orc):
     ctx.close()
 
 
+def test_count_ahead_replayed_from_a_hip_graph(orc):
+    """round 5: what the count-ahead keeps between calls (the call's number, the list of marked tiles, a word per tile) lives
+    in device memory and is advanced by the call's last launch -- a captured call replayed on other bytes must not take the
+    aggregates the previous replay left: stretches of padding that move from replay to replay, disappear, come back."""
+    import torch
+    import hevcbitstream_amd as hbs
+    from tests._orc import NAL_ENTRY
+    from hevcbitstream_amd.api import SUMMARY
+    ctx = hbs.Context(0)
+    ctx.set_kernel(4)
+    ctx.set_count_ahead(2)
+    tile = 192 << 10
+    n = 14 * tile + 999
+    rng = np.random.RandomState(92)
+    base = rng.randint(1, 256, size=n).astype(np.uint8)
+    at = 0
+    while at + 8 < n:
+        base[at:at + 4] = (0, 0, 1, 0x40)
+        at += int(rng.randint(3000, 20000))
+
+    def with_stretch(a, b, pat):
+        s = base.copy()
+        if b > a:
+            p = np.frombuffer(pat, dtype=np.uint8)
+            s[a:b] = np.tile(p, (b - a) // len(p) + 1)[:b - a]
+        return s
+
+    versions = [with_stretch(3 * tile + 5000, 6 * tile + 70_000, b"\x00\x00\x03"),
+                with_stretch(3 * tile + 5000, 6 * tile + 70_000, b"\x00\x00\x03\x00\x00\x01\x41"),      # same tiles, other aggregates
+                with_stretch(0, 0, b""),                                                                # nothing dense
+                with_stretch(8 * tile - 30_000, 11 * tile + 10, b"\x00"),                             # elsewhere
+                with_stretch(3 * tile + 5000, 6 * tile + 70_000, b"\x00\x00\x03")]
+    d_stream = torch.from_numpy(versions[0]).cuda()
+    index, rbsp, summary, cap = ctx.alloc_outputs(n)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx.index_extract_async(d_stream, index, cap, rbsp, summary)        # warm-up: workspaces get their size
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ctx.index_extract_async(d_stream, index, cap, rbsp, summary)
+    for k, data in enumerate(versions[1:] + versions):
+        d_stream.copy_(torch.from_numpy(data))
+        g.replay()
+        torch.cuda.synchronize()
+        want_idx, want_arena, why = orc.index_extract(data)
+        sm = np.frombuffer(summary.cpu().numpy().tobytes(), dtype=SUMMARY)[0]
+        assert int(sm["error"]) == 0 and int(sm["nal_count"]) == len(want_idx) and int(sm["stop_reason"]) == why, k
+        got = index[: len(want_idx) * 32].cpu().numpy().view(NAL_ENTRY)
+        for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+            assert np.array_equal(got[f], want_idx[f]), (k, f)
+        tot = int(want_idx["rbsp_off"][-1] + want_idx["rbsp_len"][-1]) if len(want_idx) else 0
+        assert np.array_equal(rbsp[:tot].cpu().numpy(), want_arena[:tot]), k
+    ctx.close()
+
+
 def test_timing_ring_keeps_the_last_calls(ctx, orc):
     """hbs_ctx_kernel_ms_back: the event pairs of the last 64 timed calls stay readable (bench.py reads every step of its timed
     loop behind the loop's fence); calls further back, or before timing was enabled, are refused"""

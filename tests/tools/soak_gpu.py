@@ -13,6 +13,7 @@ orc = _orc.oracle()
 ctxs = {v: hbs.Context(0) for v in (0, 2, 4)}
 for v, c in ctxs.items():
     c.set_kernel(v)
+    c.set_count_ahead(2)              # round 5: the event-sparse kernel's dense tiles counted ahead at every size (default: from 3 GiB)
 ctx5 = hbs.Context(0)
 ctx5.set_kernel(5)
 ctx_tiles = hbs.Context(0)
