@@ -744,6 +744,19 @@ Geo5 scan5_geometry(uint64_t n, uint64_t waves)
     if (n >= (4ull << 30) || waves == 0) { g.tiles = (n + 1024ull * (uint64_t)g.rows - 1) / (1024ull * (uint64_t)g.rows); if (g.grid > g.tiles) g.grid = g.tiles; return g; }
     const uint64_t cap = waves * 1024ull * (uint64_t)k5MaxTileRows;
     const uint64_t rounds = n ? (n + cap - 1) / cap : 1;
+    if (rounds >= 2) {
+        /* More than one tile a wavefront (1.5 - 4 GiB): a WORKGROUP per tile of k5TileRowsLarge rows, the grid = the tiles, and the
+         * hardware's dispatcher deals them out as wavefronts leave -- dynamic balance without a ticket (round 5).  On uniform
+         * streams the same time as whole rounds of taller tiles (2 GiB: 0.420-0.428 ms either way); a stream with stretches that
+         * are walked by rows (the bench's mixed stream) 1.14-1.19 x its uniform time instead of 1.46-1.54 x: the wavefront that
+         * has such a tile is no longer the one the launch waits for with a second tile still to do.  With ONE tile a wavefront
+         * (below 1.5 GiB) a workgroup per smaller tile measured 1.5-3 % slower on uniform streams (BASELINE's config 2), 1.24-1.28 x
+         * instead of 1.65-1.71 x on the mixed one: not taken (scripts/experiments/README.md). */
+        g.tiles = (n + 1024ull * (uint64_t)g.rows - 1) / (1024ull * (uint64_t)g.rows);
+        g.grid = g.tiles;
+        g.strided = 1;
+        return g;
+    }
     const uint64_t per = (n + waves * rounds - 1) / (waves * rounds);
     uint64_t rows = (per + k5SpanBytes - 1) / k5SpanBytes * (uint64_t)k5SpanRows;
     if (rows < (uint64_t)k5MinTileRows) rows = k5MinTileRows;
