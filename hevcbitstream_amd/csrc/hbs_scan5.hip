@@ -286,11 +286,10 @@ constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nre
  * (round 5).  One wavefront took ~400 us over the 256 rows of such a tile, and k_index5_emit took as long as its slowest tile:
  * 0.47 ms instead of 0.07 on the bench's mixed stream (1 % of it in 640 KiB stretches), all of the index-only scan's 1.16 x.
  * The stream pass leaves the aggregate in front of every part where the tile's records would be (it has none) and lists the
- * tile; the tile's own wavefront takes part 0, kEmitHelpers extra wavefronts of the same launch share the other parts of all
- * listed tiles. */
+ * tile; the tile's own wavefront takes part 0, and all wavefronts of the launch share the other parts of all listed tiles once
+ * their own tile is done. */
 constexpr uint32_t k5RewalkParts = 0xFFFFFFFEu;
 constexpr int kPartRows = 32;
-constexpr unsigned kEmitHelpers = 4096;
 static_assert(kPartRows % k5SpanRows == 0 && k5MaxTileRows / kPartRows <= 16, "a part is whole spans; its aggregates fit the tile's record space many times over");
 constexpr int k5ChunkTiles = 64;
 
@@ -650,14 +649,15 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
         });
     };
     const int nparts = (rows + kPartRows - 1) / kPartRows;
-    const bool helper = blockIdx.x >= num_tiles;
-    /* what is walked by rows below (ONE place in the code: inlined three times the kernel needed 248 registers instead of 144):
-     * a helper's jobs -- parts 1 .. of the tiles the stream pass walked by rows, consecutive helpers the parts of one tile --
-     * or the one job of a tile's own wavefront */
-    uint64_t job = helper ? blockIdx.x - num_tiles : 0, jobs = helper ? (uint64_t)hdr->rewalk_count * (uint64_t)(nparts - 1) : 0;
-    const uint64_t step = helper ? kEmitHelpers : 1;
+    /* What is walked by rows below (ONE place in the code: inlined three times the kernel needed 248 registers instead of 144):
+     * first the wavefront's own job, if its tile has one -- part 0 of a tile the stream pass walked by rows --, then the parts
+     * 1 .. of ALL such tiles, shared by all wavefronts of the launch once their own tile is done (job j = part 1 + j % (nparts - 1)
+     * of list entry j / (nparts - 1); this wavefront takes j = its number, + the grid, ...: consecutive wavefronts the parts of
+     * one tile).  A launch without such tiles has no jobs: nothing but one load of the count.  (The first form had 4 096 extra
+     * helper wavefronts for the parts: 1.4 us more on every call.) */
+    const uint64_t jobs = (uint64_t)hdr->rewalk_count * (uint64_t)(nparts - 1);
     int own_rows = 0;
-    if (!helper) {
+    {
         const uint64_t tile = blockIdx.x;
         const uint64_t base = tile * k5TileBytes;
         const uint32_t nrec = w5.nrec[tile];
@@ -665,9 +665,8 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             const Prefix incl = fold(prefix_of(tile), w5.tagg[tile]);       /* (prefix_of: every lane) */
             if (lane == 0) { hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside; }
         }
-        if (nrec == k5RewalkParts) {                               /* walked by rows: my part is the first, the helpers have the others */
+        if (nrec == k5RewalkParts) {                               /* walked by rows: my part is the first */
             own_rows = rows < kPartRows ? rows : kPartRows;
-            jobs = 1;
         } else if (nrec != k5Rewalk) {
             const Prefix excl = prefix_of(tile);
             TileAgg acc = agg_identity();
@@ -684,7 +683,6 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
                 acc = combine(acc, agg_readlane(ea, 63));
                 if (have) elem_emit(el, e, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
             }
-            return;
         } else {
             /* the tile again, the prefix known: its elements 64 at a time (more of them than are recorded) */
             for (int i = rows + lane; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;
@@ -693,7 +691,6 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             const uint32_t nelem = tile_census(l, lane, wpl, by_rows);
             if (by_rows) {                                          /* (the stream pass's census said otherwise: not expected) */
                 own_rows = rows;
-                jobs = 1;
             } else {
                 const Prefix excl = prefix_of(tile);
                 TileAgg accb = agg_identity();
@@ -710,17 +707,26 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
                     accb = combine(accb, agg_readlane(ea, 63));
                     if (64u * p + (uint32_t)lane < nelem) elem_emit(el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
                 }
-                return;
             }
         }
     }
+    if (own_rows == 0 && jobs == 0) return;
+    __builtin_amdgcn_wave_barrier();                               /* l is reused */
+    uint64_t job = blockIdx.x;
 #pragma unroll 1
-    for (; job < jobs; job += step) {
-        const uint64_t tile = helper ? (uint64_t)w5.rwlist[job / (uint64_t)(nparts - 1)] : (uint64_t)blockIdx.x;
-        const int p = helper ? 1 + (int)(job % (uint64_t)(nparts - 1)) : 0;
+    for (;;) {
+        uint64_t tile;
+        int p, prows;
+        if (own_rows != 0) { tile = blockIdx.x; p = 0; prows = own_rows; own_rows = 0; }
+        else {
+            if (job >= jobs) break;
+            tile = (uint64_t)w5.rwlist[job / (uint64_t)(nparts - 1)];
+            p = 1 + (int)(job % (uint64_t)(nparts - 1));
+            prows = rows - kPartRows * p < kPartRows ? rows - kPartRows * p : kPartRows;
+            job += num_tiles;
+        }
         const uint64_t pbase = tile * k5TileBytes + 1024ull * (uint64_t)(kPartRows * p);
         if (pbase >= n) continue;
-        const int prows = helper ? (rows - kPartRows * p < kPartRows ? rows - kPartRows * p : kPartRows) : own_rows;
         const Prefix excl = prefix_of(tile);
         TileAgg infront = agg_identity();
         if (p != 0) infront = reinterpret_cast<const TileAgg*>(&w5.rec[tile * k5RecCap])[p - 1];
@@ -803,7 +809,7 @@ void launch_scan_index5(const ScanArgs& a, int gate, hipStream_t st)
         k_index5_chunks<<<dim3((unsigned)ws5_chunks(num_tiles)), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
         k_index5_prefix<<<dim3(1), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
     }
-    k_index5_emit<<<dim3((unsigned)num_tiles + kEmitHelpers), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
+    k_index5_emit<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
 }
 
 } // namespace hbs
