@@ -29,8 +29,10 @@ build/obj/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(LIB): $(HIP_OBJS) $(LEGACY_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) $(LEGACY_OBJ) -ldl -lpthread
+# only the C ABI is exported (csrc/exports.map; tests/test_abi_exports.py checks nm -D against include/*.h)
+EXPORTS := -Wl,--version-script=hevcbitstream_amd/csrc/exports.map
+$(LIB): $(HIP_OBJS) $(LEGACY_OBJ) hevcbitstream_amd/csrc/exports.map
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(HIP_OBJS) $(LEGACY_OBJ) -ldl -lpthread
 	ln -sf libhevcbitstream_amd.so hevcbitstream_amd/libhevcbitstream.so
 
 # the reference's own CLI, unmodified, against OUR headers and library (dev container only)
@@ -56,7 +58,7 @@ DIAG_OBJS := $(patsubst $(CSRC)/%.hip,build/diag/%.o,$(HIP_SRCS))
 build/diag/%.o: $(CSRC)/%.hip $(HDRS)
 	mkdir -p build/diag && $(HIPCC) $(HIPFLAGS) -DHBS_PHASE_TIMING -c -o $@ $<
 diag: $(DIAG_OBJS) $(LEGACY_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/diag/libhbs_diag.so $(DIAG_OBJS) $(LEGACY_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o build/diag/libhbs_diag.so $(DIAG_OBJS) $(LEGACY_OBJ)
 
 # development variant of the library with extra -D flags, for A/B timing (HBS_LIB=build/variants/<NAME>/libhbs.so)
 #   make variant NAME=ntload DEFS="-DHBS_NT_LOAD=1"
@@ -68,6 +70,6 @@ build/variants/$(NAME)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/variants/$(NAME)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $@ $<
 variant: $(VAR_OBJS) $(VAR_REST) $(LEGACY_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/variants/$(NAME)/libhbs.so $(VAR_OBJS) $(VAR_REST) $(LEGACY_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o build/variants/$(NAME)/libhbs.so $(VAR_OBJS) $(VAR_REST) $(LEGACY_OBJ)
 
 .PHONY: all lib oracle sim clean analyze diag variant

@@ -38,7 +38,7 @@ EXPORTS = ["hbs_version", "hbs_ctx_create", "hbs_ctx_destroy", "hbs_ctx_set_stre
            "hbs_host_alloc", "hbs_host_free", "hbs_copy_to_device_async", "hbs_copy_device",
            "hbs_ctx_set_sequential_parse", "hbs_ctx_set_emit_path", "hbs_parse_extended",
            "hbs_comm_unique_id", "hbs_comm_create", "hbs_comm_adopt", "hbs_comm_destroy", "hbs_comm_rank", "hbs_comm_world", "hbs_comm_reserve_hint", "hbs_parse_headers_compact", "hbs_parse_materialize", "hbs_index_parse_compact", "hbs_gather_parts", "hbs_index_parse", "hbs_ctx_reserve_workgroups",
-           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes", "hbs_ctx_set_ingest_window_max", "hbs_pair_alloc", "hbs_pair_free", "hbs_pair_pool_trim", "hbs_pair_pool_stats", "hbs_parse_headers_state", "hbs_ctx_last_emit_by_tiles"]
+           "hbs_gather_index", "hbs_ctx_device", "hbs_find_cut_host", "hbs_trim_part", "hbs_annexb_bound_gaps", "hbs_ctx_device_bytes", "hbs_ctx_set_ingest_window_max", "hbs_pair_alloc", "hbs_pair_free", "hbs_pair_pool_trim", "hbs_pair_pool_stats", "hbs_parse_headers_state", "hbs_ctx_last_emit_by_tiles", "hbs_ctx_set_device_exclusive"]
 
 
 PAIR_REPORT = np.dtype([("chunks", "<u4"), ("probed", "<u4"), ("rejected", "<u4"), ("accepted_fast", "<u4"),
@@ -86,6 +86,28 @@ def source_digest():
 _lib = None
 
 
+class _DevLibrary:
+    """HBS_LIB only (A/B timing against a development build, possibly an older round's): an entry point the build lacks
+    becomes a stub that raises when CALLED, instead of failing the load.  Never used for the shipped library."""
+
+    def __init__(self, lib):
+        self.__dict__["_lib"] = lib
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._lib, name)
+        except AttributeError:
+            class _Missing:
+                argtypes = None
+                restype = None
+
+                def __call__(self, *a):
+                    raise HbsError("%s: not in the development build %s" % (name, os.environ["HBS_LIB"]))
+            m = _Missing()
+            self.__dict__[name] = m
+            return m
+
+
 def load_library():
     """Load the gfx950 library.  Raises (never falls back) when it is missing."""
     global _lib
@@ -96,6 +118,8 @@ def load_library():
         raise HbsError("%s not built: run `make lib` (hipcc --offload-arch=gfx950); "
                        "there is no CPU fallback" % p)
     lib = C.CDLL(p)
+    if os.environ.get("HBS_LIB"):
+        lib = _DevLibrary(lib)
     lib.hbs_version.restype = C.c_char_p
     lib.hbs_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.hbs_ctx_destroy.argtypes = [C.c_void_p]
@@ -218,6 +242,13 @@ class Context:
         """leave `spare` workgroup slots of the persistent scan kernels free (for RCCL's kernels beside the scan)"""
         self.lib.hbs_ctx_reserve_workgroups.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.hbs_ctx_reserve_workgroups(self.h, int(spare)), "hbs_ctx_reserve_workgroups")
+
+    def set_device_exclusive(self, on):
+        """1: this context's calls are the only persistent kernels on the device while they run (first tiles by workgroup
+        number); 0 (default): every tile by ticket -- safe with several contexts or processes on one device"""
+        self.lib.hbs_ctx_set_device_exclusive.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.hbs_ctx_set_device_exclusive(self.h, int(on)), "hbs_ctx_set_device_exclusive")
+        self.exclusive = int(on)
 
     def device_bytes(self):
         """device memory the context itself holds (grow-only scratch; caller-owned buffers are not counted)"""

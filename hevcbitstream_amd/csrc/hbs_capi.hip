@@ -33,6 +33,7 @@ struct hbs_ctx {
     int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
     int grid_full, grid_full4;          /* ... what the GPU holds; grid_blocks / grid_blocks4 may be cut (hbs_ctx_reserve_workgroups) */
     int grid_env, spare_wgs;            /* HBS_GRID_BLOCKS (0: unset); workgroup slots left free for other streams' kernels */
+    int exclusive;                      /* hbs_ctx_set_device_exclusive: no other persistent kernel shares the device */
     int variant;                  /* 0 = automatic */
     int last_variant;             /* the kernel the last hbs_index_extract ran (automatic mode: once read back) */
     int probe_pending;
@@ -251,6 +252,18 @@ int hbs_ctx_reserve_workgroups(hbs_ctx* c, int spare)
     return 0;
 }
 
+/* Default 0: every tile of the persistent kernels (scan + extraction, arena-tile emit) comes by ticket, which needs no assumption
+ * about what else runs on the device.  1: the caller says this context's calls are the only persistent kernels on the device while
+ * they run; a workgroup's first tile is then its number (no queue of 512 atomics on one address at the start of a call: ~1 % of a
+ * 1 GiB call).  Two contexts or processes that scan ONE device at the same time must leave it at 0: with static first tiles each
+ * could hold workgroup slots the other's low-numbered workgroups need, and wait until the look-back guard gives up (HBS_E_TIMEOUT). */
+int hbs_ctx_set_device_exclusive(hbs_ctx* c, int on)
+{
+    if (!c || (on != 0 && on != 1)) return HBS_E_ARG;
+    c->exclusive = on;
+    return 0;
+}
+
 int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 {
     if (!c) return HBS_E_ARG;
@@ -411,7 +424,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     c->last_index_only = (hbs::scan_uses_index_only(n, c->variant, d_rbsp) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;
     a.sched = c->sched;
-    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4; a.spare_wgs = c->spare_wgs;
+    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4; a.spare_wgs = c->spare_wgs; a.first_static = c->exclusive;
     c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
     if (hbs::scan_takes_small_path(n, index_cap, c->variant)) { c->probe_pending = 0; c->last_variant = 2; }
     if (c->timing && n) {                                     /* this call's slot of the ring */
@@ -476,6 +489,7 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.dz_table = reinterpret_cast<uint32_t*>(tail + 1024 + b_first + b_cand);
     c->emit_calls += 1; if (c->emit_calls == 0) c->emit_calls = 1;
     a.call_no = c->emit_calls;
+    a.first_static = c->exclusive;
     a.tiles = c->emit_tiles; a.tile_blocks = c->emit_tile_blocks;
     a.clear_bytes = b_desc + 1024;                          /* look-back words and the counters behind them */
     a.grid_blocks = c->emit_blocks; a.two_pass = c->emit_two_pass;

@@ -2085,7 +2085,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
               unsigned long long* __restrict__ total, uint32_t* __restrict__ err,
               const uint32_t* __restrict__ probe, const uint32_t* __restrict__ tflag,
               const uint32_t* __restrict__ cand_list, const uint32_t* __restrict__ cand_count, uint64_t cand_cap, uint32_t* __restrict__ cand_ticket,
-              uint32_t* __restrict__ dz_table, uint32_t call_no)
+              uint32_t* __restrict__ dz_table, uint32_t call_no, int first_static)
 {
     if ((probe && emit_probe_dense_tiles(probe)) || !tile_path_on(tflag)) return;
     constexpr int ahead = kAheadMode;
@@ -2102,10 +2102,7 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     unsigned long long dz_tile_t0 = 0;
 #endif
     uint64_t d_tile = 0;
-#ifndef HBS3_FIRST_BY_TICKET
-#define HBS3_FIRST_BY_TICKET 0         /* 1: a workgroup's first tile by ticket too (round 4's way; A/B timing) */
-#endif
-    bool first_tile = true;
+    bool first_tile = first_static != 0;
     for (;;) {
     int pending = 0;                   /* 1: a dense tile -- walked below the tile loop, where no row is live (as in hbs_scan4.hip) */
     for (;;) {
@@ -2118,8 +2115,8 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
                 const uint64_t have = *cand_count < cand_cap ? *cand_count : cand_cap;
                 l.ticket = tk < have ? cand_list[tk] : 0xFFFFFFFFu;
             } else {
-                /* the first tile is the workgroup's number, the others come by ticket (as hbs_scan4.hip) */
-                l.ticket = (!HBS3_FIRST_BY_TICKET && first_tile) ? blockIdx.x : (HBS3_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(ticket, 1u);
+                /* every tile by ticket; first_static (the context owns the device): the first one is the workgroup's number (as hbs_scan4.hip) */
+                l.ticket = first_tile ? blockIdx.x : (first_static ? gridDim.x : 0u) + atomicAdd(ticket, 1u);
             }
         }
         first_tile = false;
@@ -2455,10 +2452,10 @@ static void launch_tiles(const EmitArgs& a, unsigned tb, const uint32_t* probe, 
         const uint64_t want = a.rbsp_bytes / kTTileBytes / 64u + 1u;
         const unsigned tb_ahead = (unsigned)(want < 64u ? (tb < 64u ? tb : 64u) : (want > tb ? tb : want));
         k3_tiles<1><<<dim3(tb_ahead), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
-                                                 probe, tflag, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, a.dz_table, a.call_no);
+                                                 probe, tflag, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, a.dz_table, a.call_no, 0);
     }
     k3_tiles<0><<<dim3(tb), kTThreads, 0, st>>>(a.rbsp, a.index_in, a.n, a.gap_mode, a.first_k, a.desc, a.ticket, a.out, a.out_cap, a.index_out, a.total, a.err,
-                                             probe, tflag, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, ahead ? a.dz_table : nullptr, a.call_no);
+                                             probe, tflag, a.cand_list, a.cand_count, a.cand_cap, a.cand_ticket, ahead ? a.dz_table : nullptr, a.call_no, a.first_static);
 }
 
 hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)

@@ -45,6 +45,7 @@ struct EmitArgs {
     uint64_t cand_cap;
     uint32_t* dz_table;               /* emit_dz_table_words() words per arena tile; an entry is valid when it carries call_no */
     uint32_t call_no;                 /* this call's number on its context (never 0)                                    */
+    int first_static;                 /* hbs_ctx_set_device_exclusive: the tile kernel's first tile by workgroup number (else by ticket) */
 };
 
 struct SynthArgs {

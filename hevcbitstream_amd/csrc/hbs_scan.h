@@ -27,6 +27,7 @@ struct ScanArgs {
               /* this call's number on its context (never 0): stamps the entries                                  */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
     int grid_blocks4;                 /* ... of the event-sparse kernel                                        */
+    int first_static;                 /* hbs_ctx_set_device_exclusive: persistent kernels take their first tile by workgroup number (else by ticket) */
     int spare_wgs;                    /* hbs_ctx_reserve_workgroups: slots (of 256 threads) every scan kernel leaves free     */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
     int sched;                    /* tile schedule of the LDS-image kernel: 0 striped, 1 ticket at loop top, 2 ticket after prefix */

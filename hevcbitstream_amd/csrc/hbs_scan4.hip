@@ -95,9 +95,6 @@ __device__ int g_fake_lb4 = 0;       /* experiments: 1 = do not look back at all
 #ifndef HBS4_COPY_DEPTH
 #define HBS4_COPY_DEPTH 3      /* stores of a wavefront in flight during the copy (-1: no limit) */
 #endif
-#ifndef HBS4_FIRST_BY_TICKET
-#define HBS4_FIRST_BY_TICKET 0 /* 1: a workgroup's first tile by ticket too (round 4's way; A/B timing) */
-#endif
 #ifdef HBS4_NO_PRIO
 #define HBS4_PRIO(p)
 #else
@@ -354,7 +351,7 @@ constexpr int kAheadCoarse = 3;                          /* chunks of the first 
 __device__ __attribute__((noinline))
 bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t before, uint32_t before2, uint32_t after,
                 uint64_t tile, bool last_tile, uint8_t* rbsp, uint64_t rbsp_cap, unsigned long long* desc, RunHeader* hdr,
-                hbs_nal_entry* index, uint64_t index_cap)
+                hbs_nal_entry* index, uint64_t index_cap, uint32_t ticket_base)
 {
     EmitTarget tgt;                      /* built here: handed over by reference it had to live in scratch memory for the whole kernel */
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
@@ -405,7 +402,7 @@ bool dense_tile(Lds4& l, const uint8_t* src, uint64_t wseg, uint64_t n, uint32_t
      * it at the barrier below -- and every tile behind that ticket waited in its look-back for a tile nobody had started.  That,
      * once per stretch, was the bench's mixed stream (1 % of it in 640 KiB stretches): 1.32-1.34 x the uniform time, 2 ms of 8. */
     __syncthreads();
-    if (tid == 0) l.ticket = (HBS4_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(&hdr->ticket, 1u);
+    if (tid == 0) l.ticket = ticket_base + atomicAdd(&hdr->ticket, 1u);
     __syncthreads();
     HBS4_TL(tile, 3, 0)
     return true;
@@ -474,7 +471,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
                      hbs_nal_entry* __restrict__ index, uint64_t index_cap,
                      uint8_t* __restrict__ rbsp, uint64_t rbsp_cap,
                      unsigned long long* __restrict__ desc, RunHeader* __restrict__ hdr, const uint8_t* __restrict__ tail,
-                     int gate)
+                     int gate, int first_static)
 {
     if (gate_closed(gate, hdr)) return;
     __shared__ Lds4 l;
@@ -482,11 +479,16 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
-    /* The first tile is the workgroup's number, the others come by ticket (tile = gridDim.x + ticket).  512 workgroups asking ONE
-     * address for a ticket in the kernel's first microsecond are served one after the other -- microseconds that a 1 GiB call
-     * notices.  The grid is at most what the GPU holds (scan4_grid_blocks), so every first tile is being worked on when the
-     * tickets start: a look-back still only ever waits for tiles in progress. */
-    if (tid0 == 0) l.ticket = HBS4_FIRST_BY_TICKET ? atomicAdd(&hdr->ticket, 1u) : blockIdx.x;
+    /* Every tile by ticket (the default): tiles are looked back in ticket order, so a workgroup only ever waits for tiles that a
+     * RUNNING workgroup has claimed -- no assumption about which workgroups are resident, whatever else runs on the device.
+     * `first_static` (hbs_ctx_set_device_exclusive: the caller says this context has the device to itself): the first tile is the
+     * workgroup's number and the others are gridDim.x + ticket.  512 workgroups asking ONE address for a ticket in the kernel's
+     * first microsecond are served one after the other -- ~1 % of a 1 GiB call -- but static first tiles are safe only while
+     * every workgroup of the grid is resident at once: two persistent scans on one device (two contexts, two processes) could
+     * each hold the slots the other's low-numbered workgroups need, and wait for each other until the look-back's guard fires
+     * (round 5's advice). */
+    const uint32_t ticket_base = first_static ? gridDim.x : 0u;
+    if (tid0 == 0) l.ticket = first_static ? blockIdx.x : atomicAdd(&hdr->ticket, 1u);
     __syncthreads();
     HBS4_T_DECL
 
@@ -815,7 +817,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
 #if HBS4_TICKET_BARRIER
         __syncthreads();
 #endif
-        if (tid == 0) l.ticket = (HBS4_FIRST_BY_TICKET ? 0u : gridDim.x) + atomicAdd(&hdr->ticket, 1u);
+        if (tid == 0) l.ticket = ticket_base + atomicAdd(&hdr->ticket, 1u);
         __syncthreads();
         HBS4_T_MARK(5)
         HBS4_TL(tile, 3, 0)
@@ -828,7 +830,7 @@ void k_scan_extract4(const uint8_t* __restrict__ stream, uint64_t n, uint64_t nu
         const bool last_tile = d_tile == num_tiles - 1;
         const uint8_t* const src = last_tile
             ? reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(tail) + (uintptr_t)k4TailLead - (uintptr_t)base) : stream;
-        if (!dense_tile(l, src, base + (uint64_t)(wv * k4WaveBytes), n, d_before, d_before2, d_after, d_tile, last_tile, rbsp, rbsp_cap, desc, hdr, index, index_cap)) return;
+        if (!dense_tile(l, src, base + (uint64_t)(wv * k4WaveBytes), n, d_before, d_before2, d_after, d_tile, last_tile, rbsp, rbsp_cap, desc, hdr, index, index_cap, ticket_base)) return;
     }
     }
     HBS4_T_FLUSH
@@ -1019,7 +1021,7 @@ void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate
     uint64_t grid = (uint64_t)a.grid_blocks4;
     if (grid > num_tiles) grid = num_tiles;
     k_scan_extract4<<<dim3((unsigned)grid), dim3(k4Threads), 0, st>>>(
-        a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.tail, gate);
+        a.stream, a.n, num_tiles, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.tail, gate, a.first_static);
 }
 
 } // namespace hbs

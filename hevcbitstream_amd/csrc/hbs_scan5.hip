@@ -21,6 +21,9 @@
 
 namespace hbs {
 
+#ifndef HBS5_ROWS_KERNEL
+#define HBS5_ROWS_KERNEL 0     /* 1: the emit pass's row walks (tiles of padding or zeros) as a launch of their own */
+#endif
 #ifndef HBS5_SPAN_ROWS
 #define HBS5_SPAN_ROWS 16
 #define HBS5_TILE_ROWS 256
@@ -289,6 +292,7 @@ constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nre
  * tile; the tile's own wavefront takes part 0, and all wavefronts of the launch share the other parts of all listed tiles once
  * their own tile is done. */
 constexpr uint32_t k5RewalkParts = 0xFFFFFFFEu;
+constexpr uint32_t k5RewalkWhole = 0xFFFFFFFDu;                           /* ... and one that only the emit pass found dense (not expected): all its rows by its own wavefront */
 constexpr int kPartRows = 32;
 static_assert(kPartRows % k5SpanRows == 0 && k5MaxTileRows / kPartRows <= 16, "a part is whole spans; its aggregates fit the tile's record space many times over");
 constexpr int k5ChunkTiles = 64;
@@ -433,12 +437,17 @@ __device__ __forceinline__ void rec_load(const Rec5* r, Elem& el, uint64_t base,
     el.v.xpp = el.v.xp = el.v.x0 = el.v.x1 = el.v.x2 = el.v.x3 = el.v.xn = 0;      /* bytes: only a copy would want them */
 }
 
+/* kRows: the tile height when it is the large streams' (a compile-time constant again: as a launch parameter -- round 5 -- the words
+ * per lane, the record capacity and every loop bound over a tile's rows lived in SGPRs, 160 of them spilled where round 4's kernel
+ * spilled 80, and the uniform 16 GiB scan lost 4-6 %); 0: any height, `rows_arg` (calls below 1.5 GiB) */
+template <int kRows>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, int rows, int strided, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+void k_index5_stream(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, int rows_arg, int strided, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
 {
     if (gate_closed(gate, hdr)) return;
     __shared__ Lds5 l;
     __shared__ Deposit ring[k5Ring];
+    const int rows = kRows ? kRows : rows_arg;
     const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane0 = threadIdx.x;
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
@@ -607,31 +616,56 @@ void k_index5_chunks_prefix(uint64_t num_tiles, int rows, void* __restrict__ ws,
     }
 }
 
-__global__ __launch_bounds__(64)
-void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
-                   hbs_nal_entry* __restrict__ index, uint64_t index_cap, int rows, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+/* the prefix in front of a tile: in front of its chunk of 64 tiles, then the tiles of the chunk in front of it (every lane calls) */
+__device__ __forceinline__ Prefix tile_prefix5(const Ws5& w5, uint64_t tile, int lane)
 {
-    if (gate_closed(gate, hdr)) return;
-    __shared__ Lds5 l;
+    const uint64_t c = tile / k5ChunkTiles, t0 = c * k5ChunkTiles;
+    TileAgg mine = agg_identity();
+    if (t0 + (uint64_t)lane < tile) mine = w5.tagg[t0 + (uint64_t)lane];
+    const TileAgg infront = agg_readlane(wave_scan_combine(mine, lane), 63);
+    const Pre5 cp = w5.cpre[c];
+    Prefix ex; ex.kept = cp.kept; ex.nals = cp.nals; ex.inside = cp.inside;
+    return prefix_uniform4(fold(ex, infront));
+}
+
+/* What the emit pass walks by rows (ONE place in the code, and since round 6 a function of its own: inlined, the walk's registers
+ * were the kernel's -- 162 VGPRs and 193 spilled SGPRs where round 4's kernel had 143 and 33 -- on a path that a launch without
+ * such tiles never takes): first the wavefront's own job, if its tile has one -- part 0 of a tile the stream pass walked by rows
+ * (`own_rows` rows of it) --, then the parts 1 .. of ALL such tiles, shared by all wavefronts of the launch once their own tile is
+ * done (job j = part 1 + j % (nparts - 1) of list entry j / (nparts - 1); this wavefront takes j = its number, + the grid, ...:
+ * consecutive wavefronts the parts of one tile).  (The first form had 4 096 extra helper wavefronts for the parts: 1.4 us more on
+ * every call.) */
+__device__ __forceinline__
+void emit_row_jobs5(Lds5& l, const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles, hbs_nal_entry* __restrict__ index, uint64_t index_cap,
+                    int rows, void* __restrict__ ws, RunHeader* __restrict__ hdr, int own_rows, uint64_t jobs)
+{
     const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
     const int lane = threadIdx.x;
     const uint64_t k5TileBytes = 1024ull * (uint64_t)rows;
-    const uint32_t k5RecCap = rec_cap5(rows), wpl = words_per_lane5(rows);
+    const uint32_t k5RecCap = rec_cap5(rows);
     const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
+    const int nparts = (rows + kPartRows - 1) / kPartRows;
     EmitTarget tgt;
     tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
-    /* the prefix in front of a tile: in front of its chunk, then the tiles of the chunk in front of it */
-    auto prefix_of = [&](uint64_t tile) -> Prefix {
-        const uint64_t c = tile / k5ChunkTiles, t0 = c * k5ChunkTiles;
-        TileAgg mine = agg_identity();
-        if (t0 + (uint64_t)lane < tile) mine = w5.tagg[t0 + (uint64_t)lane];
-        const TileAgg infront = agg_readlane(wave_scan_combine(mine, lane), 63);
-        const Pre5 cp = w5.cpre[c];
-        Prefix ex; ex.kept = cp.kept; ex.nals = cp.nals; ex.inside = cp.inside;
-        return prefix_uniform4(fold(ex, infront));
-    };
-    /* `prows` rows from `pbase` on, by rows, the tile's prefix and the aggregate in front of them inside the tile known */
-    auto walk_rows = [&](uint64_t pbase, int prows, TileAgg accb, const Prefix& excl) {
+    uint64_t job = blockIdx.x;
+#pragma unroll 1
+    for (;;) {
+        uint64_t tile;
+        int p, prows;
+        if (own_rows != 0) { tile = blockIdx.x; p = 0; prows = own_rows; own_rows = 0; }
+        else {
+            if (job >= jobs) break;
+            tile = (uint64_t)w5.rwlist[job / (uint64_t)(nparts - 1)];
+            p = 1 + (int)(job % (uint64_t)(nparts - 1));
+            prows = rows - kPartRows * p < kPartRows ? rows - kPartRows * p : kPartRows;
+            job += num_tiles;
+        }
+        const uint64_t pbase = tile * k5TileBytes + 1024ull * (uint64_t)(kPartRows * p);
+        if (pbase >= n) continue;
+        const Prefix excl = tile_prefix5(w5, tile, lane);
+        TileAgg accb = agg_identity();                              /* the aggregate in front of the part inside its tile */
+        if (p != 0) accb = reinterpret_cast<const TileAgg*>(&w5.rec[tile * k5RecCap])[p - 1];
+        /* `prows` rows from `pbase` on, by rows */
         for (int i = prows + lane; i < k5MaxTileRows; i += 64) l.words[i] = 0ull;
         tile_words(l, stream, n, pbase, prows, cut, lane);
         uint64_t prev_end = pbase;
@@ -647,14 +681,27 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             accb = combine(accb, agg_readlane(ea, 63));
             if (d.el.v.g0 < n) elem_emit(d.el, eb, excl, false, nullptr, tgt, &l.seg_dummy[lane]);
         });
-    };
+        __builtin_amdgcn_wave_barrier();                           /* l is reused by the next part */
+    }
+}
+
+template <int kRows>
+__global__ __launch_bounds__(64)
+void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
+                   hbs_nal_entry* __restrict__ index, uint64_t index_cap, int rows_arg, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate_closed(gate, hdr)) return;
+    __shared__ Lds5 l;
+    const int rows = kRows ? kRows : rows_arg;
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
+    const int lane = threadIdx.x;
+    const uint64_t k5TileBytes = 1024ull * (uint64_t)rows;
+    const uint32_t k5RecCap = rec_cap5(rows), wpl = words_per_lane5(rows);
+    const uint64_t cut = (n & 15ull) ? (n >> 4) : ~0ull;
+    EmitTarget tgt;
+    tgt.index = index; tgt.index_cap = index_cap; tgt.hdr = hdr;
     const int nparts = (rows + kPartRows - 1) / kPartRows;
-    /* What is walked by rows below (ONE place in the code: inlined three times the kernel needed 248 registers instead of 144):
-     * first the wavefront's own job, if its tile has one -- part 0 of a tile the stream pass walked by rows --, then the parts
-     * 1 .. of ALL such tiles, shared by all wavefronts of the launch once their own tile is done (job j = part 1 + j % (nparts - 1)
-     * of list entry j / (nparts - 1); this wavefront takes j = its number, + the grid, ...: consecutive wavefronts the parts of
-     * one tile).  A launch without such tiles has no jobs: nothing but one load of the count.  (The first form had 4 096 extra
-     * helper wavefronts for the parts: 1.4 us more on every call.) */
+    /* (a launch without tiles walked by rows has no jobs: nothing but one load of the count) */
     const uint64_t jobs = (uint64_t)hdr->rewalk_count * (uint64_t)(nparts - 1);
     int own_rows = 0;
     {
@@ -662,13 +709,13 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
         const uint64_t base = tile * k5TileBytes;
         const uint32_t nrec = w5.nrec[tile];
         if (tile == num_tiles - 1) {
-            const Prefix incl = fold(prefix_of(tile), w5.tagg[tile]);       /* (prefix_of: every lane) */
+            const Prefix incl = fold(tile_prefix5(w5, tile, lane), w5.tagg[tile]);       /* (every lane) */
             if (lane == 0) { hdr->final_kept = incl.kept; hdr->final_nals = incl.nals; hdr->final_inside = incl.inside; }
         }
         if (nrec == k5RewalkParts) {                               /* walked by rows: my part is the first */
             own_rows = rows < kPartRows ? rows : kPartRows;
         } else if (nrec != k5Rewalk) {
-            const Prefix excl = prefix_of(tile);
+            const Prefix excl = tile_prefix5(w5, tile, lane);
             TileAgg acc = agg_identity();
 #pragma unroll 1
             for (uint32_t p0 = 0; p0 < nrec; p0 += 64u) {
@@ -691,8 +738,9 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             const uint32_t nelem = tile_census(l, lane, wpl, by_rows);
             if (by_rows) {                                          /* (the stream pass's census said otherwise: not expected) */
                 own_rows = rows;
+                if (HBS5_ROWS_KERNEL && lane == 0) w5.nrec[tile] = k5RewalkWhole;
             } else {
-                const Prefix excl = prefix_of(tile);
+                const Prefix excl = tile_prefix5(w5, tile, lane);
                 TileAgg accb = agg_identity();
                 uint64_t prev_end = base;
                 const uint32_t npass = (nelem + 63u) >> 6;
@@ -710,30 +758,31 @@ void k_index5_emit(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_
             }
         }
     }
+#if !HBS5_ROWS_KERNEL
     if (own_rows == 0 && jobs == 0) return;
     __builtin_amdgcn_wave_barrier();                               /* l is reused */
-    uint64_t job = blockIdx.x;
-#pragma unroll 1
-    for (;;) {
-        uint64_t tile;
-        int p, prows;
-        if (own_rows != 0) { tile = blockIdx.x; p = 0; prows = own_rows; own_rows = 0; }
-        else {
-            if (job >= jobs) break;
-            tile = (uint64_t)w5.rwlist[job / (uint64_t)(nparts - 1)];
-            p = 1 + (int)(job % (uint64_t)(nparts - 1));
-            prows = rows - kPartRows * p < kPartRows ? rows - kPartRows * p : kPartRows;
-            job += num_tiles;
-        }
-        const uint64_t pbase = tile * k5TileBytes + 1024ull * (uint64_t)(kPartRows * p);
-        if (pbase >= n) continue;
-        const Prefix excl = prefix_of(tile);
-        TileAgg infront = agg_identity();
-        if (p != 0) infront = reinterpret_cast<const TileAgg*>(&w5.rec[tile * k5RecCap])[p - 1];
-        walk_rows(pbase, prows, infront, excl);
-        __builtin_amdgcn_wave_barrier();                           /* l is reused by the next part */
-    }
+    emit_row_jobs5(l, stream, n, num_tiles, index, index_cap, rows, ws, hdr, own_rows, jobs);
+#endif
 }
+
+#if HBS5_ROWS_KERNEL
+/* the row jobs as a launch of their own behind k_index5_emit (same grid: a wavefront per tile; all leave at once when no tile
+ * was walked by rows) */
+__global__ __launch_bounds__(64)
+void k_index5_emit_rows(const uint8_t* __restrict__ stream, uint64_t n, uint64_t num_tiles,
+                        hbs_nal_entry* __restrict__ index, uint64_t index_cap, int rows, void* __restrict__ ws, RunHeader* __restrict__ hdr, int gate)
+{
+    if (gate_closed(gate, hdr)) return;
+    __shared__ Lds5 l;
+    const Ws5 w5 = ws5_carve(ws, num_tiles, rows);
+    const int nparts = (rows + kPartRows - 1) / kPartRows;
+    const uint64_t jobs = (uint64_t)hdr->rewalk_count * (uint64_t)(nparts - 1);
+    const uint32_t nrec = w5.nrec[blockIdx.x];
+    const int own_rows = nrec == k5RewalkParts ? (rows < kPartRows ? rows : kPartRows) : nrec == k5RewalkWhole ? rows : 0;
+    if (own_rows == 0 && jobs == 0) return;
+    emit_row_jobs5(l, stream, n, num_tiles, index, index_cap, rows, ws, hdr, own_rows, jobs);
+}
+#endif
 
 /* ---- host side ---------------------------------------------------------------------------- */
 
@@ -794,6 +843,12 @@ void launch_scan_index5(const ScanArgs& a, int gate, hipStream_t st)
      * event-sparse kernel); these one-wavefront workgroups fill every SIMD otherwise */
     if (a.spare_wgs > 0) waves = waves > 4ull * (uint64_t)a.spare_wgs + 64 ? waves - 4ull * (uint64_t)a.spare_wgs : 64;
     Geo5 g = scan5_geometry(a.n, waves);
+    static const int env_ticket = [] { const char* e = getenv("HBS5_FORCE_TICKET"); return e ? atoi(e) : 0; }();   /* debugging aid: 256-row tiles by ticket at any size (round 4's schedule) */
+    if (env_ticket) {
+        g.rows = k5TileRowsLarge; g.strided = 0;
+        g.tiles = (a.n + 1024ull * (uint64_t)g.rows - 1) / (1024ull * (uint64_t)g.rows);
+        g.grid = waves < g.tiles ? waves : g.tiles;
+    }
     if (env_rows) {                                            /* (the debugging aid: that height, by ticket) */
         g.rows = env_rows; g.strided = 0;
         g.tiles = (a.n + 1024ull * (uint64_t)env_rows - 1) / (1024ull * (uint64_t)env_rows);
@@ -802,14 +857,19 @@ void launch_scan_index5(const ScanArgs& a, int gate, hipStream_t st)
     const int rows = g.rows;
     const uint64_t num_tiles = g.tiles;
     if (num_tiles == 0) return;
-    k_index5_stream<<<dim3((unsigned)(g.grid < 1 ? 1 : g.grid)), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, rows, g.strided, a.ws5, a.hdr, gate);
+    if (rows == k5TileRowsLarge) k_index5_stream<k5TileRowsLarge><<<dim3((unsigned)(g.grid < 1 ? 1 : g.grid)), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, rows, g.strided, a.ws5, a.hdr, gate);
+    else k_index5_stream<0><<<dim3((unsigned)(g.grid < 1 ? 1 : g.grid)), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, rows, g.strided, a.ws5, a.hdr, gate);
     if (ws5_chunks(num_tiles) <= (uint64_t)k5FusedChunks) {
         k_index5_chunks_prefix<<<dim3(1), dim3(64 * k5FusedWaves), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
     } else {
         k_index5_chunks<<<dim3((unsigned)ws5_chunks(num_tiles)), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
         k_index5_prefix<<<dim3(1), dim3(64), 0, st>>>(num_tiles, rows, a.ws5, a.hdr, gate);
     }
-    k_index5_emit<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
+    if (rows == k5TileRowsLarge) k_index5_emit<k5TileRowsLarge><<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
+    else k_index5_emit<0><<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
+#if HBS5_ROWS_KERNEL
+    k_index5_emit_rows<<<dim3((unsigned)num_tiles), dim3(64), 0, st>>>(a.stream, a.n, num_tiles, a.index, a.index_cap, rows, a.ws5, a.hdr, gate);
+#endif
 }
 
 } // namespace hbs

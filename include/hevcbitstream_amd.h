@@ -128,6 +128,13 @@ int  hbs_ctx_grid(hbs_ctx* ctx, int* blocks, int* blocks_per_cu);
  * Covers every scan kernel: the register-tile and LDS-image kernels launch `spare` workgroups fewer, the index-only streaming
  * kernel 4 x `spare` one-wavefront workgroups fewer.  An HBS_GRID_BLOCKS debugging cap stays a ceiling of its own. */
 int  hbs_ctx_reserve_workgroups(hbs_ctx* ctx, int spare);
+/* Tile hand-out of the persistent kernels (scan + extraction, arena-tile emit).  Default (0): every tile by atomic ticket, in
+ * arrival order -- a workgroup's look-back only ever waits for tiles that a RUNNING workgroup has claimed, so calls of several
+ * contexts or processes may share a device.  on = 1: the caller states that while this context's calls run, no other persistent
+ * kernel uses the device; a workgroup's first tile is then its own number (later ones by ticket), which saves the start-of-call
+ * queue on the ticket word (~1 % of a 1 GiB call, nothing at 16 GiB).  With static first tiles, forward progress assumes every
+ * workgroup of the grid is resident at once: do NOT set it when two contexts (or ranks) scan one device concurrently. */
+int  hbs_ctx_set_device_exclusive(hbs_ctx* ctx, int on);
 /* Three implementations of the scan kernel exist, with identical results:
  * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
  *     pairs are rare, and the slowest on zero-heavy data),

@@ -14,12 +14,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--exclusive", type=int, default=1, help="hbs_ctx_set_device_exclusive (bench.py sets 1: one process per GPU)")
     args = ap.parse_args()
     import torch
     import hevcbitstream_amd as hbs
     import bench
     ctx = hbs.Context(0)
     ctx.enable_timing(True)
+    if args.exclusive:
+        ctx.set_device_exclusive(1)
     res = bench.configs_1gib(torch, hbs, ctx, check=False, reps=args.reps)
     res["lib"] = os.environ.get("HBS_LIB", "default")
     print(json.dumps(res))

@@ -35,14 +35,16 @@ def test_library_exports_everything_declared():
 
 
 def test_nothing_is_exported_that_no_header_declares():
-    """the other direction (round 3's verdict found three undeclared exports): every function the library exports is
-    declared in include/ -- internal hooks are hidden, test hooks are documented where a user can see them"""
+    """the other direction: EVERY defined dynamic symbol of the library -- functions and data, C++ names included (round 5's
+    library exported 77 mangled launchers and 43 kernel handles beside the C ABI) -- is a function declared in include/ or the
+    reference's data symbol h264_dbgfile; csrc/exports.map makes everything else local"""
     import subprocess
     so = os.path.join(ROOT, "hevcbitstream_amd", "libhevcbitstream_amd.so")
     out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
-    exported = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW"}
-    exported = {n for n in exported if not n.startswith(("_Z", "__hip", "_init", "_fini"))}
-    extra = exported - declared_functions()
+    exported = {ln.split()[2].split("@")[0] for ln in out.splitlines() if len(ln.split()) == 3}
+    mangled = {n for n in exported if n.startswith("_Z")}
+    assert not mangled, "C++ symbols exported: %s ..." % sorted(mangled)[:5]
+    extra = exported - declared_functions() - {"h264_dbgfile"}
     assert not extra, "exported but declared in no header of include/: %s" % sorted(extra)
 
 

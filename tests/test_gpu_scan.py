@@ -540,3 +540,62 @@ def test_timing_ring_keeps_the_last_calls(ctx, orc):
             ctx.kernel_ms_back(64)                         # the ring holds 64
     finally:
         ctx.enable_timing(False)
+
+
+@pytest.mark.parametrize("exclusive", [0, 1], ids=["tickets", "device-exclusive"])
+def test_two_contexts_scan_one_device_at_the_same_time(orc, exclusive):
+    """round 5's advice: the persistent kernels of TWO contexts on ONE device, enqueued on two streams so that their workgroups
+    share the CUs.  With every tile by ticket (the default) a workgroup only waits for tiles that a running workgroup has claimed,
+    so both calls finish whatever the interleaving, exact; K3's tile kernel behind each scan the same.  hbs_ctx_set_device_exclusive
+    is what a caller sets when it does NOT do this: one context at a time, first tiles by workgroup number, same results."""
+    import torch
+    import hevcbitstream_amd as hbs
+    from hevcbitstream_amd.api import SUMMARY
+    n_nals = 30_000                                          # ~300 MiB each: ~1 600 tiles over 512 workgroups, several rounds of tickets
+    ctxs = [hbs.Context(0) for _ in range(2)]
+    try:
+        work = []
+        for k, c in enumerate(ctxs):
+            c.set_kernel(4)
+            c.set_device_exclusive(exclusive)
+            g = c.synth_stream(0x77 + k, n_nals, 0)
+            sb, rb = g["stream_bytes"], g["rbsp_bytes"]
+            index, rbsp, summary, cap = c.alloc_outputs(sb, index_cap=n_nals + 8)
+            out = torch.empty(sb + 4096, dtype=torch.uint8, device="cuda")
+            esum = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
+            work.append((c, g, sb, rb, index, rbsp, summary, cap, out, esum, torch.cuda.Stream()))
+        torch.cuda.synchronize()
+        for rep in range(3):
+            if exclusive:
+                # one context at a time (what the flag promises)
+                for c, g, sb, rb, index, rbsp, summary, cap, out, esum, side in work:
+                    c.index_extract_async(g["stream"][:sb], index, cap, rbsp, summary)
+                    c.emit_annexb_async(rbsp, rb, index, n_nals, 1, out, None, esum)
+                    torch.cuda.synchronize()
+            else:
+                for c, g, sb, rb, index, rbsp, summary, cap, out, esum, side in work:
+                    with torch.cuda.stream(side):
+                        c.index_extract_async(g["stream"][:sb], index, cap, rbsp, summary)
+                        c.emit_annexb_async(rbsp, rb, index, n_nals, 1, out, None, esum)
+                torch.cuda.synchronize()
+            for c, g, sb, rb, index, rbsp, summary, cap, out, esum, side in work:
+                s = c.read_summary(summary)
+                assert int(s["error"]) == 0 and int(s["nal_count"]) == n_nals and int(s["rbsp_bytes"]) == rb, s
+                assert torch.equal(rbsp[:rb], g["rbsp"][:rb])
+                a = index[: n_nals * 32].view(torch.int64).view(n_nals, 4)
+                b = g["index"][: n_nals * 32].view(torch.int64).view(n_nals, 4)
+                assert torch.equal(a[:, :3], b[:, :3])
+                es = c.read_summary(esum)
+                assert int(es["error"]) == 0 and int(es["stream_bytes"]) == sb
+                assert torch.equal(out[:sb], g["stream"][:sb])
+        # the first stream through the oracle as well (the generator is the product's own)
+        c, g, sb, rb, index, rbsp, summary, cap, out, esum, side = work[0]
+        head = g["stream"][: 4 << 20].cpu().numpy()
+        want_idx, want_arena, why = orc.index_extract(head)
+        m = len(want_idx) - 1                                # (the last NAL of the cut is cut)
+        got = index[: m * 32].cpu().numpy().view(hbs.NAL_ENTRY)
+        for f in ("start", "end", "rbsp_off", "rbsp_len"):
+            assert np.array_equal(got[f], want_idx[f][:m]), f
+    finally:
+        for c in ctxs:
+            c.close()
