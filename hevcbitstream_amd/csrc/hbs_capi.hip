@@ -31,6 +31,7 @@ struct hbs_ctx {
     int grid_blocks;
     int blocks_per_cu;
     int grid_blocks4, blocks_per_cu4;   /* event-sparse kernel */
+    int grid_blocks6, grid_full6, blocks_per_cu6;   /* ... its 24-row geometry (variant 6) */
     int grid_full, grid_full4;          /* ... what the GPU holds; grid_blocks / grid_blocks4 may be cut (hbs_ctx_reserve_workgroups) */
     int grid_env, spare_wgs;            /* HBS_GRID_BLOCKS (0: unset); workgroup slots left free for other streams' kernels */
     int exclusive;                      /* hbs_ctx_set_device_exclusive: no other persistent kernel shares the device */
@@ -137,17 +138,20 @@ int hbs_ctx_create(hbs_ctx** out, int device)
     if (c->grid_blocks <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
     c->grid_blocks4 = hbs::scan4_grid_blocks(device, &c->blocks_per_cu4);
     if (c->grid_blocks4 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
-    c->grid_full = c->grid_blocks; c->grid_full4 = c->grid_blocks4;
+    c->grid_blocks6 = hbs::scan4r24_grid_blocks(device, &c->blocks_per_cu6);
+    if (c->grid_blocks6 <= 0) { (void)hipFree(c->hdr); (void)hipStreamDestroy(c->own_stream); delete c; return HBS_E_HIP; }
+    c->grid_full = c->grid_blocks; c->grid_full4 = c->grid_blocks4; c->grid_full6 = c->grid_blocks6;
     const char* g = getenv("HBS_GRID_BLOCKS");          /* debugging aid: 1 = fully sequential tiles */
     c->grid_env = (g && atoi(g) > 0) ? atoi(g) : 0;
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks) c->grid_blocks = atoi(g);
     if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks4) c->grid_blocks4 = atoi(g);
+    if (g && atoi(g) > 0 && atoi(g) < c->grid_blocks6) c->grid_blocks6 = atoi(g);
     const char* ca = getenv("HBS_COUNT_AHEAD");
     c->count_ahead = (ca && ca[0] >= '0' && ca[0] <= '2') ? ca[0] - '0' : 1;
-    const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 4 event-sparse, 5 index-only streaming */
+    const char* kv = getenv("HBS_KERNEL");              /* 0 automatic, 2 LDS-image, 4 event-sparse, 5 index-only streaming, 6 event-sparse with 24 rows */
     const char* sv = getenv("HBS_SCHED");
     c->sched = (sv && atoi(sv) >= 0 && atoi(sv) <= 2) ? atoi(sv) : HBS_DEFAULT_SCHED;
-    c->variant = (kv && (atoi(kv) == 0 || atoi(kv) == 2 || atoi(kv) == 4 || atoi(kv) == 5)) ? atoi(kv) : HBS_DEFAULT_KERNEL;
+    c->variant = (kv && (atoi(kv) == 0 || atoi(kv) == 2 || atoi(kv) == 4 || atoi(kv) == 5 || atoi(kv) == 6)) ? atoi(kv) : HBS_DEFAULT_KERNEL;
     c->last_variant = c->variant ? c->variant : 4;
     *out = c;
     return 0;
@@ -246,9 +250,11 @@ int hbs_ctx_reserve_workgroups(hbs_ctx* c, int spare)
     c->spare_wgs = spare;
     c->grid_blocks = c->grid_full - spare > 1 ? c->grid_full - spare : 1;
     c->grid_blocks4 = c->grid_full4 - spare > 1 ? c->grid_full4 - spare : 1;
+    c->grid_blocks6 = c->grid_full6 - spare > 1 ? c->grid_full6 - spare : 1;
     /* the HBS_GRID_BLOCKS debugging cap is a ceiling of its own: reserving workgroups never raises it */
     if (c->grid_env > 0 && c->grid_env < c->grid_blocks) c->grid_blocks = c->grid_env;
     if (c->grid_env > 0 && c->grid_env < c->grid_blocks4) c->grid_blocks4 = c->grid_env;
+    if (c->grid_env > 0 && c->grid_env < c->grid_blocks6) c->grid_blocks6 = c->grid_env;
     return 0;
 }
 
@@ -268,14 +274,14 @@ int hbs_ctx_grid(hbs_ctx* c, int* blocks, int* blocks_per_cu)
 {
     if (!c) return HBS_E_ARG;
     const int v = c->variant ? c->variant : c->last_variant;
-    if (blocks) *blocks = (v == 4) ? c->grid_blocks4 : c->grid_blocks;
-    if (blocks_per_cu) *blocks_per_cu = (v == 4) ? c->blocks_per_cu4 : c->blocks_per_cu;
+    if (blocks) *blocks = (v == 4) ? c->grid_blocks4 : (v == 6) ? c->grid_blocks6 : c->grid_blocks;
+    if (blocks_per_cu) *blocks_per_cu = (v == 4) ? c->blocks_per_cu4 : (v == 6) ? c->blocks_per_cu6 : c->blocks_per_cu;
     return 0;
 }
 
 int hbs_ctx_set_kernel(hbs_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant == 1 || variant == 3 || variant > 5) return HBS_E_ARG;
+    if (!c || variant < 0 || variant == 1 || variant == 3 || variant > 6) return HBS_E_ARG;
     c->variant = variant;
     if (variant) c->last_variant = variant;
     return 0;
@@ -342,7 +348,7 @@ int hbs_ctx_last_kernel(hbs_ctx* c)
     if (e != hipSuccess) return fail(c, e, "read-back of the density probe");
     uint64_t chunks = 0, flagged = 0;
     for (int i = 0; i < 64; ++i) { chunks += h.probe_slot[i][0]; flagged += h.probe_slot[i][1]; }
-    c->last_variant = hbs::probe_says_dense((uint32_t)chunks, (uint32_t)flagged, c->last_index_only ? hbs::kDenseOneInIndexOnly : hbs::kDenseOneIn) ? 2 : (c->last_index_only ? 5 : 4);
+    c->last_variant = hbs::probe_variant((uint32_t)chunks, (uint32_t)flagged, c->last_index_only != 0);
     c->probe_pending = 0;
     return c->last_variant;
 }
@@ -403,7 +409,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     }
     a.ahead_cand = nullptr; a.ahead_tab = nullptr; a.ahead_list = nullptr; a.ahead_ctl = nullptr;
     if (d_rbsp && (c->count_ahead == 2 || (c->count_ahead == 1 && hbs::scan4_counts_ahead(n))) && n > (uint64_t)hbs::scan4_tile_bytes() &&
-        (c->variant == 0 || c->variant == 4 || c->variant == 5) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) {
+        (c->variant == 0 || c->variant == 4 || c->variant == 5) /* (6: the 24-row geometry counts nothing ahead) */ && !hbs::scan_takes_small_path(n, index_cap, c->variant)) {
         /* K12's dense tiles counted ahead: [AheadCtl | table | a word per tile | list] */
         const uint64_t tiles = (n + (uint64_t)hbs::scan4_tile_bytes() - 1) / (uint64_t)hbs::scan4_tile_bytes();
         if (tiles > c->ahead_tiles) {
@@ -424,7 +430,7 @@ int hbs_index_extract(hbs_ctx* c, const uint8_t* d_stream, uint64_t n,
     c->last_index_only = (hbs::scan_uses_index_only(n, c->variant, d_rbsp) && !hbs::scan_takes_small_path(n, index_cap, c->variant)) ? 1 : 0;
     a.variant = c->variant;
     a.sched = c->sched;
-    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4; a.spare_wgs = c->spare_wgs; a.first_static = c->exclusive;
+    a.grid_blocks = c->grid_blocks; a.grid_blocks4 = c->grid_blocks4; a.grid_blocks4r24 = c->grid_blocks6; a.spare_wgs = c->spare_wgs; a.first_static = c->exclusive;
     c->probe_pending = (c->variant == 0 && n) ? 1 : 0;
     if (hbs::scan_takes_small_path(n, index_cap, c->variant)) { c->probe_pending = 0; c->last_variant = 2; }
     if (c->timing && n) {                                     /* this call's slot of the ring */
@@ -487,6 +493,10 @@ int hbs_emit_annexb(hbs_ctx* c, const uint8_t* d_rbsp, uint64_t rbsp_bytes,
     a.cand_count = reinterpret_cast<uint32_t*>(tail + 640); a.cand_ticket = reinterpret_cast<uint32_t*>(tail + 704);   /* cleared with the counters */
     a.cand_list = reinterpret_cast<uint32_t*>(tail + 1024 + b_first); a.cand_cap = first_cap;
     a.dz_table = reinterpret_cast<uint32_t*>(tail + 1024 + b_first + b_cand);
+    /* dense tiles counted ahead of the tile kernel (k3t_sample + a pass over the tiles it lists): from 3 GiB of arena up, as the scan's
+     * (hbs_ctx_set_count_ahead: 0 never, 1 from 3 GiB, 2 always).  Until round 6 every call paid for it -- two launches, 11.5 us of a
+     * 1 GiB call's 445 with nothing listed -- where mixed content is as unlikely as in the scan. */
+    if (c->count_ahead == 0 || (c->count_ahead == 1 && !hbs::scan4_counts_ahead(rbsp_bytes))) a.dz_table = nullptr;
     c->emit_calls += 1; if (c->emit_calls == 0) c->emit_calls = 1;
     a.call_no = c->emit_calls;
     a.first_static = c->exclusive;

@@ -102,39 +102,58 @@ HBS_HD unsigned long long ahead_stamp_of(unsigned long long call) { return (call
  * kDenseOneIn may hold a zero pair the LDS-image kernel, whose cost does not depend on the data,
  * is the faster of the two. */
 #ifndef HBS_DENSE_ONE_IN
-#define HBS_DENSE_ONE_IN 26
+#define HBS_DENSE_ONE_IN 44
 #endif
-constexpr uint32_t kDenseOneIn = HBS_DENSE_ONE_IN;    /* Round 3: the probe counts ELEMENTS (chunks a pattern 00 00 {<=3} ends in, neighbours seen), and the event-sparse
-                                           kernel keeps 0.42-0.53 of peak up to the density at which tiles pass kDenseElems = 512 of 12288 chunks
-                                           (4.2 %; 512-byte NALs: 3.7 %, zero-heavy data: 2-3 %), against 0.30-0.34 for the LDS-image kernel; beyond,
-                                           its tiles are walked chunk by chunk (0.12 at 384-byte NALs).  1 in 26 = 3.85 % leaves the spread of a
-                                           tile's count below the limit.  (Round 2: 1 in 40 of the chunks with a zero PAIR, i.e. ~6 x fewer elements.) */
+constexpr uint32_t kDenseOneIn = HBS_DENSE_ONE_IN;    /* Round 3: the probe counts ELEMENTS (chunks a pattern 00 00 {<=3} ends in, neighbours seen).  Round 6: beyond one
+                                           element in 44 chunks the event-sparse kernel's 24-row geometry takes over from the 48-row one (2 GiB sweep, profiles/r06:
+                                           NALs of 1 KiB -- one in 53 -- 0.58 of peak on 48 rows against 0.55 on 24; 768 bytes -- one in 40 -- 0.535 / 0.530;
+                                           512 bytes 0.485 / 0.516; the zero-heavy stress stream -- one in 41 -- 0.524 / 0.561), where until round 5 the 48-row
+                                           geometry ran up to one in 26 and the LDS-image kernel took the rest at 0.25-0.31. */
 constexpr int kExactFlagMin = 2;        /* rows of 1 KiB with more flagged chunks than this are asked again, exactly (chunk_pattern_any_dev): one or two
                                            are a start code, most likely, and the second test would buy nothing */
-/* Without an arena (round 4): the streaming index-only kernel keeps its pace to about twice that density -- a 2 GiB stream of
- * 448-byte NALs (one chunk in 24 an element) 0.66 ms against the LDS-image kernel's 1.48, of 384-byte NALs 1.13 against 1.50, of
- * 256-byte NALs (1 in 14) 1.47 against 1.57, of 128-byte NALs 2.5 against 1.8 (scripts/pin_time.py) -- so its calls ask the
- * probe with a threshold of their own. */
-constexpr uint32_t kDenseOneInIndexOnly = 15;
+/* Without an arena: the streaming index-only kernel (hbs_scan5.hip) records eight elements a KiB since round 6 and keeps its pace to
+ * one chunk in 9 an element -- 2 GiB of 384 / 320 / 256 / 192-byte NALs 0.45 / 0.42 / 0.39 / 0.33 of peak (read), where the 24-row
+ * geometry without an arena reaches 0.34 / 0.32 / 0.32 / 0.29 and the LDS-image kernel 0.21; at 128 bytes (one in 6.7) its tiles pass
+ * the record space and are streamed twice -- so its calls ask the probe with a threshold of their own. */
+constexpr uint32_t kDenseOneInIndexOnly = 9;
 HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged, uint32_t one_in = kDenseOneIn) { return (uint64_t)flagged * one_in > (uint64_t)chunks; }
-enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2, kGateIfSparseIdx = 3, kGateIfDenseIdx = 4 };   /* ...Idx: an index-only call's threshold */
+/* Round 6: three classes.  Between "sparse" (above) and "dense" lies what the 24-row geometry of the event-sparse kernel is for
+ * (hbs_scan4_r24.hip: 1024 elements per 96 KiB tile = one chunk in 6): streams of NALs of ~120 to ~450 bytes.  A 2 GiB sweep
+ * (profiles/r06): extract 0.32 / 0.38 / 0.43 / 0.45 of peak at 128 / 192 / 256 / 384-byte NALs against the LDS-image kernel's
+ * 0.25 / 0.27 / 0.29 / 0.31, and 0.15 against 0.23 at 64 bytes, where its tiles pass the limit and are walked by rows -- so
+ * "dense" begins at 2 elements in kMidTwoIn chunks (one in 6.5; 128-byte NALs: one in 6.7).  Index-only calls go there from
+ * where the streaming kernel gives out (kDenseOneInIndexOnly): 0.25 against the LDS-image kernel's 0.22 at 128 bytes. */
+constexpr uint32_t kMidTwoIn = 13;
+enum : int { kProbeSparse = 0, kProbeMid = 1, kProbeDense = 2 };
+HBS_HD int probe_class(uint32_t chunks, uint32_t flagged, bool index_only)
+{
+    if (!probe_says_dense(chunks, flagged, index_only ? kDenseOneInIndexOnly : kDenseOneIn)) return kProbeSparse;
+    return (uint64_t)flagged * kMidTwoIn > 2ull * (uint64_t)chunks ? kProbeDense : kProbeMid;
+}
+/* the kernel an automatic call runs: 4 event-sparse (48 rows), 5 streaming index-only, 6 event-sparse with 24 rows, 2 LDS image */
+HBS_HD int probe_variant(uint32_t chunks, uint32_t flagged, bool index_only)
+{
+    const int c = probe_class(chunks, flagged, index_only);
+    return c == kProbeSparse ? (index_only ? 5 : 4) : c == kProbeMid ? 6 : 2;
+}
+enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2, kGateIfSparseIdx = 3, kGateIfDenseIdx = 4, kGateIfMid = 5, kGateIfMidIdx = 6 };   /* ...Idx: an index-only call's thresholds */
 #ifdef __HIPCC__
-/* the density probe's verdict (hbs_common.h), by a whole wavefront: lane l reads slot l */
-__device__ __forceinline__ bool probe_dense_dev(const RunHeader* __restrict__ hdr, uint32_t one_in = kDenseOneIn)
+/* the density probe's verdict, by a whole wavefront: lane l reads slot l */
+__device__ __forceinline__ int probe_class_dev(const RunHeader* __restrict__ hdr, bool index_only)
 {
     const int lane = threadIdx.x & 63;
     uint32_t c = hdr->probe_slot[lane][0], f = hdr->probe_slot[lane][1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); f += __shfl_xor(f, d, 64); }
-    return probe_says_dense(c, f, one_in);
+    return probe_class(c, f, index_only);
 }
 /* a kernel of the automatic mode launched with `gate`: true = the probe rules it out, it returns at once */
 __device__ __forceinline__ bool gate_closed(int gate, const RunHeader* __restrict__ hdr)
 {
     if (gate == kGateNone) return false;
-    const bool idx = gate == kGateIfSparseIdx || gate == kGateIfDenseIdx;
-    const bool dense = probe_dense_dev(hdr, idx ? kDenseOneInIndexOnly : kDenseOneIn);
-    return (gate == kGateIfSparse || gate == kGateIfSparseIdx) ? dense : !dense;
+    const bool idx = gate == kGateIfSparseIdx || gate == kGateIfDenseIdx || gate == kGateIfMidIdx;
+    const int want = (gate == kGateIfSparse || gate == kGateIfSparseIdx) ? kProbeSparse : (gate == kGateIfMid || gate == kGateIfMidIdx) ? kProbeMid : kProbeDense;
+    return probe_class_dev(hdr, idx) != want;
 }
 #endif
 

@@ -27,6 +27,7 @@ struct ScanArgs {
               /* this call's number on its context (never 0): stamps the entries                                  */
     int grid_blocks;              /* persistent workgroups (<= resident capacity) of the LDS-image kernel */
     int grid_blocks4;                 /* ... of the event-sparse kernel                                        */
+    int grid_blocks4r24;              /* ... of its 24-row geometry (hbs_scan4_r24.hip)                        */
     int first_static;                 /* hbs_ctx_set_device_exclusive: persistent kernels take their first tile by workgroup number (else by ticket) */
     int spare_wgs;                    /* hbs_ctx_reserve_workgroups: slots (of 256 threads) every scan kernel leaves free     */
     hipEvent_t ev_begin, ev_end;  /* when non-null: recorded around the main kernel only */
@@ -55,7 +56,11 @@ int scan4_tile_bytes();
 int scan4_tail_bytes();
 /* header, probe, padded last tile, cleared index and look-back words: one launch in front of the main kernel */
 void launch_scan_prologue(const ScanArgs& a, uint64_t desc_words, bool probe, int tail_tile_bytes /* 0: no padded copy */, hipStream_t st);
-void launch_scan_extract4_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
+void scan4_launch_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
+/* ... its 24-row geometry (hbs_scan4_r24.hip: 96 KiB tiles, 1024 elements a tile; variant 6) */
+int scan4r24_grid_blocks(int device, int* blocks_per_cu_out);
+int scan4r24_tile_bytes();
+void scan4r24_launch_kernel(const ScanArgs& a, uint64_t num_tiles, int gate, hipStream_t st);
 /* dense tiles counted ahead (round 5): bytes per tile of the table, the stream size from which a call uses it, the launch */
 uint64_t scan4_ahead_entry_bytes();
 bool scan4_counts_ahead(uint64_t n);

@@ -677,12 +677,13 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
     const bool index_only = scan_uses_index_only(a.n, a.variant, a.rbsp);
     const int sparse_variant = ((a.variant == 5 && !index_only) || automatic) ? 4 : a.variant;
     const uint64_t tiles4 = (a.n + (uint64_t)scan4_tile_bytes() - 1) / (uint64_t)scan4_tile_bytes();
+    const uint64_t tiles6 = (a.n + (uint64_t)scan4r24_tile_bytes() - 1) / (uint64_t)scan4r24_tile_bytes();
     const uint64_t tiles2 = (a.n + (uint64_t)kTileBytes - 1) / (uint64_t)kTileBytes;
     /* the finest tiling any kernel of this call may use sizes the look-back words to clear */
-    const uint64_t num_tiles = (sparse_variant == 4 && !automatic) ? tiles4 : tiles2;
-    /* one launch: run header, density probe (automatic mode), padded copy of the last tile (event-sparse kernels),
-     * cleared index and look-back words */
-    const int tail_tile = (!index_only && sparse_variant == 4) ? scan4_tile_bytes() : 0;
+    const uint64_t num_tiles = automatic ? tiles2 : sparse_variant == 4 ? tiles4 : sparse_variant == 6 ? tiles6 : tiles2;
+    /* one launch: run header, density probe (automatic mode), padded copy of the stream's last 192 KiB (event-sparse kernels, either
+     * geometry), cleared index and look-back words */
+    const int tail_tile = ((!index_only && sparse_variant == 4) || sparse_variant == 6 || automatic) ? scan4_tile_bytes() : 0;
     launch_scan_prologue(a, num_tiles * 2, automatic && a.n != 0, tail_tile, st);
     if (num_tiles) {
         uint64_t grid = (uint64_t)a.grid_blocks;
@@ -692,15 +693,19 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
             launch_scan_index5(a, kGateNone, st);
         } else if (!automatic && sparse_variant == 4) {
             launch_scan_ahead4(a, tiles4, kGateNone, st);           /* (does nothing unless the call carries the count-ahead's workspace) */
-            launch_scan_extract4_kernel(a, tiles4, kGateNone, st);
+            scan4_launch_kernel(a, tiles4, kGateNone, st);
+        } else if (!automatic && sparse_variant == 6) {
+            scan4r24_launch_kernel(a, tiles6, kGateNone, st);
         } else if (automatic) {
-            /* Both kernels are enqueued; each reads the probe's verdict from the run header and the
-             * one it rules out returns at once (no host round trip, the call stays asynchronous).
+            /* All the kernels the probe may pick are enqueued; each reads the probe's verdict from the run header and the
+             * ones it rules out return at once (no host round trip, the call stays asynchronous, capturable).
              * They share the descriptor array and the ticket: whichever runs finds both untouched. */
-            /* (a side stream for the kernel that rules itself out, forked and joined with events, was tried in round 4: the two
-             * event waits cost more than the empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
+            /* (a side stream for the kernels that rule themselves out, forked and joined with events, was tried in round 4: the two
+             * event waits cost more than an empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
             if (index_only) launch_scan_index5(a, kGateIfSparseIdx, st);
-            else { launch_scan_ahead4(a, tiles4, kGateIfSparse, st); launch_scan_extract4_kernel(a, tiles4, kGateIfSparse, st); }
+            else { launch_scan_ahead4(a, tiles4, kGateIfSparse, st); scan4_launch_kernel(a, tiles4, kGateIfSparse, st); }
+            /* dense but regular (NALs of ~120-450 bytes): the 24-row geometry, with or without an arena */
+            scan4r24_launch_kernel(a, tiles6, index_only ? kGateIfMidIdx : kGateIfMid, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, index_only ? kGateIfDenseIdx : kGateIfDense);
         } else {

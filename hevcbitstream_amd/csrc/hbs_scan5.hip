@@ -282,8 +282,9 @@ __device__ __forceinline__ int row_visit(DenseRow& d, const u32x4& qp, const u32
 struct Rec5 { uint32_t chunk, gap, pa, pb, pc, z, e1, e3; };             /* one element, as the emit half needs it */
 static_assert(sizeof(Rec5) == 32, "two 16-byte stores per element");
 struct Pre5 { unsigned long long kept, nals; uint32_t inside, pad; };     /* a Prefix in memory */
-__host__ __device__ inline uint32_t rec_cap5(int rows) { return 4u * (uint32_t)rows; }   /* elements recorded per tile: four a KiB (12.5 % of the stream's size as workspace; two until round 4:
-                                                                             NALs of 512 bytes passed it in every other tile, and such a tile is streamed twice; three: NALs of 384) */
+__host__ __device__ inline uint32_t rec_cap5(int rows) { return 8u * (uint32_t)rows; }   /* elements recorded per tile: eight a KiB (25 % of the stream's size as workspace).  A tile with more is streamed twice:
+                                                                             two a KiB until round 4 (NALs of 512 bytes passed it in every other tile), four until round 6 (NALs of 384 held, of 256 -- 4.8 elements
+                                                                             a KiB -- did not: 0.22 of peak, against 0.39 with eight; 192-byte NALs 0.19 -> 0.33) */
 constexpr uint32_t k5Rewalk = 0xFFFFFFFFu;                                /* nrec: the emit pass walks the tile again */
 /* ... a tile that was walked by rows (a stretch of padding, of zeros): in parts of kPartRows rows, by different wavefronts
  * (round 5).  One wavefront took ~400 us over the 256 rows of such a tile, and k_index5_emit took as long as its slowest tile:
@@ -321,9 +322,9 @@ __host__ __device__ inline Ws5 ws5_carve(void* base, uint64_t tiles, int rows)
 }
 uint64_t scan5_workspace_bytes(uint64_t stream_bytes)
 {
-    /* whatever the tile height of the call will be: the records are four a KiB (plus one tile's worth of rounding at the largest
+    /* whatever the tile height of the call will be: the records are eight a KiB (plus one tile's worth of rounding at the largest
      * height), the per-tile and per-chunk arrays are counted at the smallest */
-    const uint64_t rec = (stream_bytes / 1024u + 2u * (uint64_t)k5MaxTileRows) * 4u * sizeof(Rec5);
+    const uint64_t rec = (stream_bytes / 1024u + 2u * (uint64_t)k5MaxTileRows) * 8u * sizeof(Rec5);
     const uint64_t tiles = stream_bytes / (1024u * (uint64_t)k5MinTileRows) + 2, ch = ws5_chunks(tiles);
     return rec + ((tiles * sizeof(TileAgg) + 255) & ~255ull) + ((ch * sizeof(TileAgg) + 255) & ~255ull) +
            ((ch * sizeof(Pre5) + 255) & ~255ull) + 2 * ((tiles * sizeof(uint32_t) + 255) & ~255ull) + 256;

@@ -30,14 +30,17 @@ namespace hbs {
  * rows of 1 KiB in registers.  Few wavefronts with many registers each: the ~100 registers the
  * control code needs are paid per wavefront, so two fat wavefronts per SIMD keep twice the
  * bytes in flight of four lean ones. */
+#ifndef HBS4_ROWS
+#define HBS4_ROWS 48              /* the main geometry; hbs_scan4_r24.hip compiles the kernel's source again with 24 (96 KiB tiles) */
+#endif
 constexpr int k4Waves         = 4;
-constexpr int k4Rows          = 48;
+constexpr int k4Rows          = HBS4_ROWS;
 constexpr int k4Threads       = 64 * k4Waves;
 constexpr int k4RowBytes      = 1024;
-constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 48 KiB  */
-constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 192 KiB */
-constexpr int k4TileRows      = k4Waves * k4Rows;            /* 192     */
-constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 12288   */
+constexpr int k4WaveBytes     = k4Rows * k4RowBytes;         /* 48 KiB  (24 rows: 24 KiB) */
+constexpr int k4TileBytes     = k4Waves * k4WaveBytes;       /* 192 KiB (96 KiB)          */
+constexpr int k4TileRows      = k4Waves * k4Rows;            /* 192     (96)              */
+constexpr int k4ChunksPerTile = k4TileBytes / kChunk;        /* 12288   (6144)            */
 constexpr int k4ElemPass      = 64;                          /* elements handled per pass: wavefront 0, one per lane */
 constexpr int k4TailLead      = 16;                          /* bytes of the padded last-tile copy in front of the tile */
 constexpr int k4TailBytes     = k4TailLead + k4TileBytes + 64;

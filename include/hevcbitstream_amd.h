@@ -135,16 +135,18 @@ int  hbs_ctx_reserve_workgroups(hbs_ctx* ctx, int spare);
  * queue on the ticket word (~1 % of a 1 GiB call, nothing at 16 GiB).  With static first tiles, forward progress assumes every
  * workgroup of the grid is resident at once: do NOT set it when two contexts (or ranks) scan one device concurrently. */
 int  hbs_ctx_set_device_exclusive(hbs_ctx* ctx, int on);
-/* Three implementations of the scan kernel exist, with identical results:
- * 4 = event-sparse, tile held in registers (hbs_scan4.hip; the fastest on coded video, where zero
- *     pairs are rare, and the slowest on zero-heavy data),
+/* Implementations of the scan kernel, with identical results:
+ * 4 = event-sparse, tile held in registers: 48 rows of 1 KiB per wavefront, 192 KiB tiles, up to 512 candidate chunks a tile
+ *     (hbs_scan4.hip; the fastest on coded video, where zero pairs are rare, and the slowest on zero-heavy data),
+ * 6 = the same kernel with 24 rows per wavefront: 96 KiB tiles, up to 1024 candidate chunks a tile, all four wavefronts on them
+ *     (hbs_scan4_r24.hip, round 6; streams that are dense but regular -- NALs of ~120 to ~450 bytes --, with or without an arena),
  * 2 = tile staged in an LDS image (hbs_scan.hip; same speed on any data),
  * 5 = index only (no RBSP arena asked for): nothing has to stay in registers, so the bytes are
  *     streamed and only the flagged chunks are looked at again (hbs_scan5.hip); with an arena it means 4,
- * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and kernel 4 (5
- *     when no arena is asked for and the stream is 1 GiB or more) or kernel 2 is picked from it on the
- *     device, without a host round trip.
- * Environment HBS_KERNEL=0|2|3|4|5 sets the default.  hbs_ctx_last_kernel waits for the last
+ * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and the kernel is picked from it on the
+ *     device, without a host round trip: 4 (5 when no arena is asked for and the stream is 1 GiB or more) up to one candidate
+ *     chunk in 26 (in 15 for 5), 6 up to one in 6.5, 2 beyond.
+ * Environment HBS_KERNEL=0|2|4|5|6 sets the default.  hbs_ctx_last_kernel waits for the last
  * hbs_index_extract and says which kernel ran it. */
 int  hbs_ctx_set_kernel(hbs_ctx* ctx, int variant);
 int  hbs_ctx_get_kernel(hbs_ctx* ctx);

@@ -261,6 +261,7 @@ def test_emit_arena_tiles_count_dense_tiles_ahead(ctx, orc):
     arena[7 * T + 70_000: 7 * T + 90_000] = 0                                                               # dense (a full row of zeros), seen or not
     idx = fake_index(lens, [3 + (k & 1) for k in range(len(lens))])
     want = orc.emit_annexb(arena, idx)
+    ctx.set_count_ahead(2)                               # (round 6: by default only arenas from 3 GiB up are sampled, like the scan's streams)
     ctx.set_emit_path(2)
     got, got_idx = ctx.emit_annexb(dev(arena), idx)
     stayed = ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h)
@@ -275,8 +276,10 @@ def test_emit_arena_tiles_count_dense_tiles_ahead(ctx, orc):
     want2 = orc.emit_annexb(arena2, idx)
     got2, _ = ctx.emit_annexb(dev(arena2), idx)
     got3, _ = ctx.emit_annexb(dev(arena), idx)
+    ctx.set_count_ahead(1)
+    got4, _ = ctx.emit_annexb(dev(arena), idx)           # ... and counted in place (the default at this size)
     ctx.set_emit_path(-1)
-    assert np.array_equal(got2, want2) and np.array_equal(got3, want)
+    assert np.array_equal(got2, want2) and np.array_equal(got3, want) and np.array_equal(got4, want)
 
 
 def test_emit_arena_tiles_refuse_an_index_outside_the_arena(ctx, orc):

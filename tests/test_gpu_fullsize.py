@@ -30,7 +30,7 @@ def test_index_arena_and_reemission_against_the_reference(mode, n_nals):
 
     # scan + index + extraction on the GPU: the default (automatic) path, then every kernel pinned
     index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_nals + 16)
-    for kernel in (0, 4, 2):
+    for kernel in (0, 4, 6, 2):
         ctx.set_kernel(kernel)
         index.zero_()
         rbsp.zero_()

@@ -12,11 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ALPHA = np.array([0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 0x40, 0x80, 0xFF], dtype=np.uint8)
 
 
-@pytest.fixture(scope="module", params=[0, 2, 4, 5],
-                ids=["automatic", "lds-image-kernel", "sparse-kernel", "index-only-passes"])
+@pytest.fixture(scope="module", params=[0, 2, 4, 5, 6],
+                ids=["automatic", "lds-image-kernel", "sparse-kernel", "index-only-passes", "sparse-kernel-24-rows"])
 def ctx(request):
-    """the two implementations of the fused kernel (hbs_scan.hip 2, hbs_scan4.hip 4), the index-only streaming kernel
-    (hbs_scan5.hip) and the automatic choice between them (the default)"""
+    """the implementations of the fused kernel (hbs_scan.hip 2, hbs_scan4.hip 4 and its 24-row geometry hbs_scan4_r24.hip 6),
+    the index-only streaming kernel (hbs_scan5.hip) and the automatic choice between them (the default)"""
     import torch
     import hevcbitstream_amd as hbs
     assert torch.cuda.is_available()
@@ -359,8 +359,8 @@ def test_dense_tiles_counted_ahead(orc, kernel):
 
 
 def test_automatic_choice_follows_density(orc):
-    """the default mode picks the event-sparse kernel for coded-video-like bytes and the LDS-image kernel for
-    zero-heavy ones, on the device; the answer is the oracle's either way"""
+    """the default mode picks the event-sparse kernel for coded-video-like bytes, its 24-row geometry for streams of small NALs
+    (one chunk in ~13 an element) and the LDS-image kernel for zero-heavy ones, on the device; the answer is the oracle's each time"""
     import hevcbitstream_amd as hbs
     c = hbs.Context(0)
     try:
@@ -370,10 +370,55 @@ def test_automatic_choice_follows_density(orc):
         sparse = rng.integers(1, 256, size=n, dtype=np.uint8)
         for p in range(5000, n - 8, 9973):
             sparse[p:p + 4] = (0, 0, 1, 0x40)
+        small = rng.integers(1, 256, size=n, dtype=np.uint8)             # NALs of 200-300 bytes, 3- and 4-byte start codes
+        p = 7
+        while p < n - 8:
+            small[p:p + 4] = (0, 0, 1, 0x40) if (p & 1) else (0, 0, 0, 1)
+            p += int(rng.integers(200, 300))
         dense = ALPHA[rng.integers(0, len(ALPHA), size=n)]
-        for stream, want in ((sparse, 4), (dense, 2), (sparse, 4)):
+        for stream, want in ((sparse, 4), (small, 6), (dense, 2), (sparse, 4), (small, 6)):
             check(c, orc, stream)
             assert c.last_kernel() == want
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("mean", [100, 128, 200, 330, 450])
+def test_streams_of_small_nals_on_the_24_row_geometry(orc, mean):
+    """round 6: 40 MiB of NALs of `mean` +- 25 % bytes (start codes of 3 and 4 bytes, some emulation prevention bytes, a few runs of
+    zeros that make single tiles pass 1024 elements) through kernel 6 pinned, with and without an arena, and through the
+    automatic mode: every entry and every RBSP byte against the oracle"""
+    import hevcbitstream_amd as hbs
+    rng = np.random.default_rng(1000 + mean)
+    n = 40 << 20
+    s = rng.integers(1, 256, size=n, dtype=np.uint8)
+    s[rng.random(n) < 0.002] = 0                                   # stray zeros: pairs, EPB candidates
+    p = 3
+    while p < n - 8:
+        if p & 2:
+            s[p:p + 4] = (0, 0, 1, 0x42)
+        else:
+            s[p:p + 5] = (0, 0, 0, 1, 0x26)
+        p += int(rng.integers(max(8, mean * 3 // 4), mean * 5 // 4 + 1))
+    for q in rng.integers(0, n - 70000, size=6):                   # stretches that turn their tiles dense
+        s[q:q + 20000:3] = 0
+        s[q + 1:q + 20000:3] = 0
+        s[q + 2:q + 20000:3] = 3
+    want_idx, want_arena, why = orc.index_extract(s)
+    tot = int(want_idx["rbsp_off"][-1] + want_idx["rbsp_len"][-1])
+    c = hbs.Context(0)
+    try:
+        for kernel in (6, 0):
+            c.set_kernel(kernel)
+            got_idx, got_arena, sm = run(c, s, index_cap=len(want_idx) + 16)
+            assert int(sm["error"]) == 0 and int(sm["stop_reason"]) == why and len(got_idx) == len(want_idx), (kernel, sm)
+            for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+                assert np.array_equal(got_idx[f], want_idx[f]), (kernel, f)
+            assert np.array_equal(got_arena[:tot], want_arena[:tot]), kernel
+            got2, _, sm2 = run(c, s, index_cap=len(want_idx) + 16, want_rbsp=False)
+            assert int(sm2["error"]) == 0 and len(got2) == len(want_idx)
+            for f in ("start", "end", "rbsp_off", "rbsp_len", "status"):
+                assert np.array_equal(got2[f], want_idx[f]), (kernel, "no arena", f)
     finally:
         c.close()
 

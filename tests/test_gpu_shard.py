@@ -149,9 +149,11 @@ def test_two_ranks_share_one_gpu(orc, tmp_path):
             shm.unlink()
 
 
-@pytest.mark.parametrize("how", ["launcher", "env"])
-def test_bench_with_two_ranks_on_one_gpu(tmp_path, how):
-    """bench.py's whole N > 1 path with world = 2 on this one GPU: the pipelined C-ABI gather (over the stand-in for RCCL), the
+@pytest.mark.parametrize("how,world", [("launcher", 2), ("env", 2), ("launcher", 8)], ids=["launcher", "env", "launcher-world-8"])
+def test_bench_with_two_ranks_on_one_gpu(tmp_path, how, world):
+    """bench.py's whole N > 1 path with world = 2 -- and, round 6, world = 8 with small shards: what `python3 bench.py --gpus 8`
+    does on a node, rehearsed as eight child processes on this one GPU (their persistent kernels share the device: every tile by
+    ticket, see hbs_ctx_set_device_exclusive) --: the pipelined C-ABI gather (over the stand-in for RCCL), the
     max-over-ranks timing, the per-rank lines and the checks of the gathered rows -- so that the line is right the first time a
     node with several GPUs runs it (torch.distributed over gloo here: RCCL refuses two ranks on one device)"""
     import ctypes as C
@@ -166,7 +168,7 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path, how):
     lib = C.CDLL(fake)
     lib.fake_rccl_segment_bytes.restype = C.c_uint64
     lib.fake_rccl_segment_bytes.argtypes = [C.c_int, C.c_uint64]
-    world, nals, slot = 2, 40000, 8 << 20
+    nals, slot = (40000, 8 << 20) if world == 2 else (12000, 4 << 20)
     shm = shared_memory.SharedMemory(create=True, size=int(lib.fake_rccl_segment_bytes(world, slot)))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -180,9 +182,9 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path, how):
             # the driver's command as typed: no RANK / WORLD_SIZE in the environment, bench.py starts its ranks itself
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
             p = subprocess.Popen(cmd, env=dict(env, **hooks), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
-            o, e = p.communicate(timeout=600)
+            o, e = p.communicate(timeout=900)
             assert p.returncode == 0, e.decode()[-3000:]
-            outs = [(o, e), (b"", b"")]
+            outs = [(o, e)] + [(b"", b"")] * (world - 1)
             assert o.decode().strip().count("\n") == 0, "the launcher's stdout is the JSON line and nothing else"
         else:
             procs = []
@@ -193,10 +195,14 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path, how):
             for r, (p, (o, e)) in enumerate(zip(procs, outs)):
                 assert p.returncode == 0, "rank %d:\n%s" % (r, e.decode()[-3000:])
         line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
-        assert line["n_gpus"] == 2 and line["gather"]["rccl_world"] == 2 and len(line["per_rank"]) == 2
-        assert line["gather"]["bytes_received_per_rank_per_step"] == 2 * nals * 32
-        assert line["gather"]["gather_ms"] > 0 and all(r["kernel_ms"] > 0 for r in line["per_rank"])
-        assert line["value"] > 0 and line["config"]["nals_per_gpu"] == nals
+        # what a SCALE record needs: the world the line claims, the world the communicator saw, every rank's kernel and gather time
+        assert line["n_gpus"] == world and line["gather"]["rccl_world"] == world and len(line["per_rank"]) == world
+        assert [r["rank"] for r in line["per_rank"]] == list(range(world))
+        assert line["gather"]["bytes_received_per_rank_per_step"] == world * nals * 32
+        assert line["gather"]["gather_ms"] > 0 and all(r["kernel_ms"] > 0 and r["gather_ms"] > 0 for r in line["per_rank"])
+        assert line["gather"]["gather_ms_max_over_ranks"] >= max(r["gather_ms"] for r in line["per_rank"]) - 1e-3
+        assert line["scaling"] == "weak" and line["steps"] == 4 and line["ms_per_step"] > 0
+        assert line["value"] > 0 and line["config"]["nals_per_gpu"] == nals and line["config"]["device_exclusive"] == 0
         assert outs[1][0].decode().strip() == "" or "metric" not in outs[1][0].decode()      # one JSON line, from rank 0
     finally:
         shm.close()

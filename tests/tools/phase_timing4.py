@@ -23,7 +23,8 @@ else:
     rep = int(os.environ.get('HBS4_REPEAT', 64))
     d = torch.from_numpy(base).cuda().repeat(rep)
     ncap = 1600 * rep + 16
-ctx.set_kernel(4)
+variant = int(os.environ.get("HBS4_VARIANT", 4))          # 6: the 24-row geometry (HBS4_TILE=98304)
+ctx.set_kernel(variant)
 blocks, per_cu = ctx.grid()
 index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=ncap)
 lib = api.load_library()
@@ -37,12 +38,13 @@ e0.record(); ctx.index_extract_async(d, index, cap, rbsp if want_rbsp else None,
 print('one call %.3f ms -> %.1f GB/s' % (e0.elapsed_time(e1), d.numel() / e0.elapsed_time(e1) / 1e6))
 out = np.zeros((1024, 8), dtype=np.uint64)
 lib = api.load_library()
-lib.hbs_debug_phase_cycles4.argtypes = [C.c_void_p]
-assert lib.hbs_debug_phase_cycles4(out.ctypes.data) == 0
+fn = lib.hbs_debug_phase_cycles4 if variant == 4 else lib.hbs_debug_phase_cycles4_r24
+fn.argtypes = [C.c_void_p]
+assert fn(out.ctypes.data) == 0
 names = ["ticket+fetch issue", "flags+list", "elements A", "lookback", "elements B", "copy"]
 nwg = min(blocks, 1024)
 act = out[:nwg, :6].astype(np.float64)
-tile_bytes = int(os.environ.get("HBS4_TILE", 196608))
+tile_bytes = int(os.environ.get("HBS4_TILE", 196608 if variant == 4 else 98304))
 tiles = d.numel() / tile_bytes / blocks
 tot = act.sum(axis=1).mean()
 print("v4 mode", mode, "rbsp", want_rbsp, "grid", blocks, "per CU", per_cu, "tiles/WG %.1f -> cycles/tile %.0f" % (tiles, tot / tiles))
