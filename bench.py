@@ -155,7 +155,7 @@ def cpu_baseline(stream_dev, index_dev, rbsp_dev, n_nals, sample_nals):
     return res
 
 
-def cpu_baseline_parse(stream_dev, index_dev, rbsp_dev, m, parsed, structs_dev):
+def cpu_baseline_parse(stream_dev, index_dev, rbsp_dev, m, parsed, structs_dev, compact=None):
     """The CPU-baseline leg of BASELINE config 3: the reference's read_hevc_nal_unit (hevc_stream.c:155-240) fed the m NALs of
     the 4K30 sequence in stream order on one host core -- the compiled reference when its prebuilt library travelled with the
     tree, else the oracle's restatement -- timed, and EVERY NAL's rc, NAL header, struct (every member) and slice payload
@@ -175,7 +175,25 @@ def cpu_baseline_parse(stream_dev, index_dev, rbsp_dev, m, parsed, structs_dev):
         kind, what = "port", "orc_read_hevc_nal_unit (oracle/hbs_oracle_parse.c, gcc -O2), one call per NAL through ctypes"
     arena = rbsp_dev[: int(idx["rbsp_off"][-1]) + int(idx["rbsp_len"][-1])].cpu().numpy()
     compare(parsed, structs_dev.cpu().numpy(), arena, idx, exp)
-    return {"value": round(m / tm[0], 1), "unit": "NAL/s", "cores": 1, "kind": kind,
+    n_compact = None
+    if compact is not None:
+        # the compact parse against the SAME walk, directly (round 5's verdict: it was compared with the full parse only): rc and the NAL
+        # header of every NAL, the sixteen members of every slice's record against the struct the reference filled for that slice
+        from hevcbitstream_amd.api import COMPACT, COMPACT_FIELDS, PARSED
+        cp_h = compact[0].cpu().numpy().view(PARSED)
+        cc_h = compact[1].cpu().numpy().view(COMPACT)
+        where = {name: i for name, i, cnt in _orc.flat_fields("hevc_slice_header_t")}
+        cols = np.array([where[f] for f in COMPACT_FIELDS])
+        n_compact = 0
+        for k, e in enumerate(exp):
+            assert int(cp_h["rc"][k]) == e["rc"], "compact parse: rc of NAL %d differs from the %s's" % (k, kind)
+            assert [int(cp_h["nal_unit_type"][k]), int(cp_h["nal_layer_id"][k]), int(cp_h["nal_temporal_id_plus1"][k])] == list(e["nal"])[1:], k
+            if e.get("kind") == "sh" and e["rc"] >= 0:
+                got = np.array([cc_h[f][k] for f in COMPACT_FIELDS])
+                assert np.array_equal(got, e["struct"][cols]), "compact parse: slice record of NAL %d differs from the %s's struct" % (k, kind)
+                assert int(cp_h["slice_data_size"][k]) == e["slice_data"][0], k
+                n_compact += 1
+    return {"value": round(m / tm[0], 1), "unit": "NAL/s", "cores": 1, "kind": kind, "compact_slices_checked": n_compact,
             "sample": "all %d NALs of the sequence: %s, %.2f s inside the calls; the GPU parse's rc, NAL header, every struct member and "
                       "every slice payload compared with this walk's: equal" % (m, what, tm[0]),
             "parity_checked_nals": m}
@@ -652,7 +670,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     import ctypes as C
     import numpy as np
     from hevcbitstream_amd.api import PARSED, SUMMARY
-    from tests.hevc_synth import stream_4k30
+    from hevcbitstream_amd.hevc_synth import stream_4k30
     res = {}
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
     # the placement pool: the headline arena has just been freed -- its sixteen chunks are on the pool's free list, classed; a new
@@ -765,11 +783,12 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     res["parse_headers_compact"] = {"value": round(m / cms / 1e3, 1), "unit": "M NAL/s", "ms": round(cms, 3), "struct_arena_bytes": cneed,
                                     "full_parse_struct_arena_bytes": int(structs.numel()),
                                     "check": ("rc, NAL header, slice_data_off / slice_data_size of all %d NALs and the sixteen members of all %d slice records equal "
-                                              "to the full parse's (which is compared with the reference below)" % (m, n_slices)) if cpu_parse else "not run (--cpu-sample-nals 0)"}
+                                              "to the full parse's, and (below) to the reference's own structs" % (m, n_slices)) if cpu_parse else "not run (--cpu-sample-nals 0)"}
     if cpu_parse:
         # config 3 pinned on the reference: the structs of this sequence against read_hevc_nal_unit on the host, all NALs;
         # config3_end_to_end below requires the 2.1 GiB pipeline (with and without arena) to produce these same structs
-        res["parse_headers"]["cpu_baseline"] = cpu_baseline_parse(d, index, rbsp, m, parsed, structs)
+        res["parse_headers"]["cpu_baseline"] = cpu_baseline_parse(d, index, rbsp, m, parsed, structs, compact=(cpt, cct))
+        res["parse_headers_compact"]["checked_against_the_reference_directly"] = res["parse_headers"]["cpu_baseline"]["compact_slices_checked"]
     res["config3_end_to_end"] = config3_end_to_end(torch, hbs, ctx, d, index, rbsp, m, parsed, structs)
     if cpu_parse:
         res["config3_end_to_end"]["parity"] = ("header structs equal to those of parse_headers' sequence, which were compared "

@@ -63,7 +63,10 @@ __device__ __forceinline__ bool three_steps_run(const uint32_t* probe, const uin
  * caller's RBSP buffer.  The call then ends with HBS_E_ARG and nothing is read through the index. */
 __device__ __forceinline__ bool index_bad(const uint32_t* vflag) { return vflag[3] != 0u; }
 
-enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2, kWhenEither = 3, kWhenNoTiles = 4 };
+/* tflag[4] (k3t_check): the index is NOT one stretch of the arena with gaps below 16 bytes.  While it is -- and the arena tiles
+ * have not done the call -- arenas of tiny NALs go through the group kernel (hbs_emit_groups.h) instead of a lane per NAL. */
+__device__ __forceinline__ bool group_path_on(const uint32_t* tflag);
+enum : int { kWhenAlways = 0, kWhenSparse = 1, kWhenDense = 2, kWhenEither = 3, kWhenNoTiles = 4, kWhenGroups = 5 };
 /* the helper kernels of the two fall-back chains: those of the kernel by NALs (its item list) run when the data is sparse and
  * the tile kernel, in front of them since round 3, has not done the call; those of the three steps when these run */
 __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when, const uint32_t* tflag)
@@ -71,7 +74,8 @@ __device__ __forceinline__ bool emit_skip(const uint32_t* probe, int when, const
     if (when == kWhenAlways) return false;
     if (when == kWhenSparse) return (probe && emit_probe_dense(probe)) || tile_path_done(tflag);
     if (when == kWhenEither) return emit_skip(probe, kWhenSparse, tflag) && !three_steps_run(probe, tflag);
-    if (when == kWhenNoTiles) return tile_path_on(tflag);           /* small NALs: a lane per NAL unless the arena tiles do the call */
+    if (when == kWhenGroups) return !group_path_on(tflag);        /* the scan between the group kernel's two passes */
+    if (when == kWhenNoTiles) return tile_path_on(tflag) || group_path_on(tflag);   /* small NALs: a lane per NAL unless the arena tiles or the group kernel do the call */
     return !three_steps_run(probe, tflag);
 }
 /* kWhenEither (the automatic mode, probe != nullptr: one scan serves whichever chain runs): where the scan's total goes */
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256)
 void k3_count_tiny(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
                    unsigned long long* __restrict__ nal_total, const uint32_t* __restrict__ vflag)
 {
-    if (index_bad(vflag) || tile_path_on(vflag)) return;           /* (the arena tiles, in front, do the call when the index allows them) */
+    if (index_bad(vflag) || tile_path_on(vflag) || group_path_on(vflag)) return;   /* (the arena tiles or the group kernel, in front, do the call when the index allows them) */
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t len = idx[k].rbsp_len;
         nal_total[k] = gap_of(idx, k, gap_mode) + len + tiny_count(rbsp, rbsp_bytes, idx[k].rbsp_off, len);
@@ -584,7 +588,7 @@ void k3_emit_tiny(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const h
                   uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out, uint32_t* __restrict__ err,
                   const uint32_t* __restrict__ vflag)
 {
-    if (index_bad(vflag) || tile_path_on(vflag)) return;
+    if (index_bad(vflag) || tile_path_on(vflag) || group_path_on(vflag)) return;
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t begin = idx[k].rbsp_off;
         const uint32_t len = idx[k].rbsp_len;
@@ -1249,7 +1253,7 @@ void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
         probe_window(rbsp, rbsp_bytes, probe, blockIdx.x - kCheckBlocks);
         return;
     }
-    bool bad = false, outside = false;
+    bool bad = false, outside = false, apart = false;
     /* first_k[t] = the first NAL that begins at or behind arena tile t (k3t_first's table, filled on the way since round 4: one
      * launch and one pass over the index less).  The index is not trusted yet: tile numbers are clamped to the table, so a
      * corrupt index costs time, not memory -- and then nobody reads the table. */
@@ -1259,9 +1263,11 @@ void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
         const uint64_t off = idx[k].rbsp_off;
         if (off > rbsp_bytes || idx[k].rbsp_len > rbsp_bytes - off) outside = true;      /* every kernel behind this one trusts the index */
         const uint64_t prev_off = k > 0 ? idx[k - 1].rbsp_off : 0ull;
-        if (k > 0 && off != prev_off + idx[k - 1].rbsp_len) bad = true;
-        if (gap_of(idx, k, gap_mode) >= (uint64_t)kTMaxGap) bad = true;
-        if (k + kTMaxStarts < n && idx[k + kTMaxStarts].rbsp_off - off < (uint64_t)kTTileBytes) bad = true;
+        if (k > 0 && off != prev_off + idx[k - 1].rbsp_len) { bad = true; apart = true; }
+        const uint64_t gap_k = gap_of(idx, k, gap_mode);
+        if (gap_k >= (uint64_t)kTMaxGap) bad = true;
+        if (gap_k >= 16u) apart = true;                            /* (kGMaxGap, hbs_emit_groups.h) */
+        if (want_tiles && k + kTMaxStarts < n && idx[k + kTMaxStarts].rbsp_off - off < (uint64_t)kTTileBytes) bad = true;   /* (nobody asks when the tiles are not tried) */
         if (fill) {
             const uint64_t lo = k == 0 ? 0ull : (prev_off - a0) / kTTileBytes + 1ull;
             uint64_t hi = (off - a0) / kTTileBytes;
@@ -1276,6 +1282,7 @@ void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
         for (uint64_t t = lo; t <= hi; ++t) first_k[t] = n;
     }
     if (bad) atomicOr(&tflag[0], 1u);
+    if (apart) atomicOr(&tflag[4], 1u);
     if (outside) { atomicOr(&tflag[3], 1u); atomicMax(err, (uint32_t)(-HBS_E_ARG)); }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint64_t arena_len = idx[n - 1].rbsp_off + idx[n - 1].rbsp_len - a0;
@@ -2432,6 +2439,10 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
     HBS3_T_FLUSH
 }
 
+} // namespace hbs
+#include "hbs_emit_groups.h"
+namespace hbs {
+
 int emit_tile_grid_blocks(int device)
 {
     hipDeviceProp_t prop;
@@ -2472,13 +2483,30 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         /* the index checked against the arena (tflag[3]) and, for means the arena tiles can hold (up to 1024 NAL starts per 192 KiB),
          * against their conditions: the tile kernel when they hold, a lane per NAL otherwise -- sizes, their scan, the bytes */
         const bool try_tiles = a.rbsp_bytes >= kTMinArena && a.rbsp_bytes / a.n >= kTilesMinMeanBytes;
-        k3t_check<<<kCheckBlocks, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap),
-                                                try_tiles ? 1 : 0, 0, a.tflag, a.err, a.probe, a.first_k);
+        /* (means the arena tiles cannot hold: the group kernel's sizes pass checks the index itself -- one pass over it less, 0.35 ms
+         * of 2.9 over 2 GiB of 64-byte NALs) */
         if (try_tiles) {
+            k3t_check<<<kCheckBlocks, 256, 0, st>>>(a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.first_cap, emit_desc_words(a.items_cap),
+                                                    1, 0, a.tflag, a.err, a.probe, a.first_k);
             uint64_t tb = (uint64_t)a.tile_blocks;
             const uint64_t max_tiles = a.rbsp_bytes / kTTileBytes + 2;
             if (tb > max_tiles) tb = max_tiles;
             launch_tiles(a, (unsigned)tb, nullptr, a.tflag, st);
+        }
+        /* an index that is one stretch of the arena: 64 consecutive NALs a wavefront, cooperatively (hbs_emit_groups.h: sizes,
+         * the scan of the wavefronts' sums, the bytes); the lane per NAL behind it is what other indexes get */
+        {
+            const uint32_t gcap = groups_region_cap(a.rbsp_bytes / a.n), npw = groups_nals_per_wave(a.rbsp_bytes / a.n);
+            const uint64_t nw = (a.n + npw - 1u) / npw, wgs = (nw + kGWaves - 1) / kGWaves;
+            static const int cus = [] { int d = 0, c = 256; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
+            const size_t per_cu_lds = (size_t)160 * 1024 / (groups_lds_bytes(gcap) + 64);
+            const uint64_t gmax_emit = (uint64_t)cus * (uint64_t)(per_cu_lds > 16 ? 16 : per_cu_lds < 1 ? 1 : per_cu_lds);
+            const uint64_t gmax_sizes = (uint64_t)cus * 16u;
+            k3g_sizes<<<dim3((unsigned)(wgs < gmax_sizes ? wgs : gmax_sizes)), dim3(64 * kGWaves), 0, st>>>(
+                a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.tflag, a.err, gcap, npw, try_tiles ? 0 : 1);
+            launch_scan_u64(a.nal_total, a.out_off, nw, a.total_dense, a.scan_tmp, st, nullptr, kWhenGroups, a.tflag);
+            k3g_emit<<<dim3((unsigned)(wgs < gmax_emit ? wgs : gmax_emit)), dim3(64 * kGWaves), groups_lds_bytes(gcap), st>>>(
+                a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.out_off, a.out, a.out_cap, a.index_out, a.err, a.tflag, gcap, npw);
         }
         const uint64_t want = (a.n + 255) / 256;
         const unsigned tgrid = (unsigned)(want < 8192 ? want : 8192);

@@ -15,7 +15,7 @@ def main():
     import torch
     import hevcbitstream_amd as hbs
     from hevcbitstream_amd.api import COMPACT, NAL_ENTRY, PARSED, SUMMARY
-    from tests.hevc_synth import stream_4k30
+    from hevcbitstream_amd.hevc_synth import stream_4k30
     ctx = hbs.Context(0)
     stream, _ = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
     d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()

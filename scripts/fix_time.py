@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import hevcbitstream_amd as hbs
 from hevcbitstream_amd.api import PARSED, SUMMARY
-from tests.hevc_synth import stream_4k30
+from hevcbitstream_amd.hevc_synth import stream_4k30
 
 pics = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 100

@@ -3,7 +3,7 @@ through ctypes on a small parseable stream."""
 import ctypes as C, sys, time
 import numpy as np
 sys.path.insert(0, ".")
-from tests.hevc_synth import stream_4k30
+from hevcbitstream_amd.hevc_synth import stream_4k30
 import hevcbitstream_amd.api as api
 lib = C.CDLL(api.library_path())
 u8p = C.POINTER(C.c_uint8)

@@ -8,7 +8,7 @@ if os.environ.get("HBS_LIB"):
     _api.library_path = lambda: os.environ["HBS_LIB"]
 import hevcbitstream_amd as hbs
 from hevcbitstream_amd.api import PARSED, SUMMARY
-from tests.hevc_synth import stream_4k30
+from hevcbitstream_amd.hevc_synth import stream_4k30
 stream, n = stream_4k30(11, n_pictures=12500, slices_per_picture=8, idr_every=60, payload_bytes=(60, 120))
 s = np.frombuffer(stream, dtype=np.uint8).copy()
 ctx = hbs.Context(0)

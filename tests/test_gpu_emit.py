@@ -391,6 +391,51 @@ def test_emit_arenas_of_tiny_nals(ctx, orc):
         ctx.emit_annexb(dev(arena), idx, out_cap=300 * 44 + 100)      # the inserted 03s do not fit
 
 
+@pytest.mark.parametrize("mean", [24, 64, 100, 160, 215])
+def test_emit_tiny_nals_by_groups_of_64(ctx, orc, mean):
+    """round 6: arenas of tiny NALs whose index is one stretch of the arena go through the group kernel (hbs_emit_groups.h): 64
+    consecutive NALs a wavefront, the stretch staged in LDS, the output written by aligned chunks.  Random payload with a few
+    patterns that need a 03 (their groups take the exact walk), NALs of every length from 0 to 2 x mean (several begin inside one
+    output chunk), gaps of 3-15 bytes, the synthetic gap rule, the output index, a capacity that is too small; then the same NALs
+    through an index that is NOT one stretch (every other NAL skipped: the lane per NAL) -- all against the oracle's rbsp_to_nal."""
+    import hevcbitstream_amd as hbs
+    rng = np.random.RandomState(600 + mean)
+    nn = 30_000
+    lens = [int(x) for x in rng.randint(0, 2 * mean + 1, size=nn)]
+    lens[:8] = [0, 1, 2, 15, 16, 17, 0, 0]
+    total = sum(lens)
+    arena = rng.randint(0, 256, size=total).astype(np.uint8)
+    for q in rng.randint(0, total - 8, size=40):                  # groups that need the exact walk
+        arena[q:q + 3] = (0, 0, int(rng.randint(0, 4)))
+    for gaps in ([int(rng.randint(3, 16)) for _ in lens], [4 if k % 4 == 0 else 3 for k in range(nn)]):
+        idx = fake_index(lens, gaps)
+        want = orc.emit_annexb(arena, idx)
+        got, got_idx = ctx.emit_annexb(dev(arena), idx)
+        assert np.array_equal(got, want), (mean, "gaps from the index")
+        prev_end = np.concatenate([[0], got_idx["end"][:-1].astype(np.int64)])
+        assert np.array_equal(got_idx["start"].astype(np.int64), prev_end + np.array(gaps)) and int(got_idx["end"][-1]) == len(want)
+        assert np.all(got_idx["end"].astype(np.int64) - got_idx["start"].astype(np.int64) >= np.array(lens))
+        for k in range(0, nn, 997):
+            assert int(got_idx["rbsp_len"][k]) == lens[k] and int(got_idx["rbsp_off"][k]) == int(idx["rbsp_off"][k])
+        if gaps[0] == 4 and gaps[1] == 3:
+            got1, _ = ctx.emit_annexb(dev(arena), idx, gap_mode=1)
+            assert np.array_equal(got1, want), (mean, "synthetic gaps")
+    with pytest.raises(hbs.HbsError):
+        ctx.emit_annexb(dev(arena), idx, out_cap=len(want) - 1000)
+    # not one stretch: every other NAL (the arena bytes between them are nobody's)
+    sub = idx[::2].copy()
+    pos = 0
+    for k in range(len(sub)):
+        g = 3 + (k & 1)
+        sub["start"][k] = pos + g
+        sub["end"][k] = pos + g + int(sub["rbsp_len"][k])
+        pos = int(sub["end"][k])
+    # (the oracle counts the 03s a NAL takes: ends as the reference's loop would leave them are not needed for the bytes)
+    want2 = orc.emit_annexb(arena, sub)
+    got2, _ = ctx.emit_annexb(dev(arena), sub)
+    assert np.array_equal(got2, want2), (mean, "an index with holes")
+
+
 def test_emit_arena_tiles_hold_up_to_1024_nal_starts(ctx, orc):
     """round 4: a 192 KiB tile takes up to 1024 NAL starts (512 before), the ones past the first 512 fetched behind the flag
     pass -- arenas of 224-448 byte NALs go to the tile kernel instead of a lane per NAL.  Pinned to the tiles on small arenas:
