@@ -39,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PLACED = False                 # --placed-arena: outputs through hbs_pair_alloc (main() sets it; the helper lines below follow it)
 N_NALS_16GIB = 1_677_000       # S(seed, n) with ~10 KiB NALs: 16.0 GiB of Annex-B
 SEED = 0x1234
 
@@ -252,8 +253,8 @@ def configs_1gib(torch, hbs, ctx, check=True, reps=12):
     g = ctx.synth_stream(SEED, n, 0)
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
     stream = g["stream"][:sb]
-    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=stream)
-    place_arena = dict(ctx.last_pair_report)
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=stream if PLACED else None)
+    place_arena = dict(ctx.last_pair_report) if PLACED else None
 
     def timed(fn, with_kernel_ms):
         ks = []
@@ -311,7 +312,7 @@ def configs_1gib(torch, hbs, ctx, check=True, reps=12):
                                               "frac": round(algo5 / k_ms / 1e6 / HBM_PEAK_GBS, 4), "frac_of_call": round(algo5 / c_med / 1e6 / HBM_PEAK_GBS, 4)}}
     # config 4: the arena the scan extracted, re-emitted (default path)
     torch.cuda.empty_cache()
-    out, place_out = ctx.pair_alloc(rbsp, sb + 4096)
+    out, place_out = ctx.pair_alloc(rbsp, sb + 4096) if PLACED else (torch.empty(sb + 4096, dtype=torch.uint8, device="cuda"), None)
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     esum = torch.zeros(64, dtype=torch.uint8, device="cuda")
     _, c_med, c_min = timed(lambda: ctx.emit_annexb_async(rbsp, rb, index, n, 1, out, idx_out, esum), False)
@@ -518,7 +519,7 @@ def mixed_stream_line(torch, ctx, stream, sb, n_cap, uniform_ms):
     """the automatic mode on the mixed stream against the uniform one; outputs checked against the LDS-image kernel (whose
     cost does not depend on the data) entry by entry and byte by byte on the device"""
     mixed, dense_bytes = make_mixed(torch, stream, sb)
-    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_cap, peer=mixed)      # placed like the uniform run's arena
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n_cap, peer=mixed if PLACED else None)      # like the uniform run's arena
     ks = []
     for i in range(4):
         ctx.index_extract_async(mixed, index, cap, rbsp, summary)
@@ -598,7 +599,7 @@ def emit_mixed_lines(torch, ctx, g, n, rb, sb, uniform_ms):
                 arena[off: off + region] = pat
                 dense += region
         torch.cuda.empty_cache()
-        out, placement = ctx.pair_alloc(arena, out_cap)              # placed against this arena, as the uniform run's output is against its own
+        out, placement = ctx.pair_alloc(arena, out_cap) if PLACED else (torch.empty(out_cap, dtype=torch.uint8, device="cuda"), None)
         idx_out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
         summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -641,7 +642,7 @@ def zero_heavy_line(torch, ctx, check):
     g1 = ctx.synth_stream(SEED, n1, 1)
     sb1, rb1 = g1["stream_bytes"], g1["rbsp_bytes"]
     stream1 = g1["stream"][:sb1]
-    index1, rbsp1, summary1, cap1 = ctx.alloc_outputs(sb1, index_cap=n1 + 8, peer=stream1)
+    index1, rbsp1, summary1, cap1 = ctx.alloc_outputs(sb1, index_cap=n1 + 8, peer=stream1 if PLACED else None)
     ks = []
     for i in range(5):
         ctx.index_extract_async(stream1, index1, cap1, rbsp1, summary1)
@@ -722,7 +723,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     except Exception as e:                                            # noqa: BLE001  (reported, never allowed to take the line down)
         res["zero_heavy_16GiB"] = {"error": "%s: %s" % (type(e).__name__, e)}
     torch.cuda.empty_cache()                                          # (what torch keeps cached is not free memory to hbs_pair_alloc's candidates)
-    out, emit_placement = ctx.pair_alloc(g["rbsp"], sb + 4096)       # the emitted stream placed against the arena it is read from
+    out, emit_placement = ctx.pair_alloc(g["rbsp"], sb + 4096) if PLACED else (torch.empty(sb + 4096, dtype=torch.uint8, device="cuda"), None)
     idx_out = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
     summary = torch.zeros(64, dtype=torch.uint8, device="cuda")
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -736,7 +737,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     assert torch.equal(out[:sb], g["stream"][:sb]), "emitted stream != generated stream"
     res["emit_annexb"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s emitted", "ms": round(ms, 3),
                           "hbm_traffic_GBs": round((rb + sb) / ms / 1e6, 1), "workload": "the bench arena: %d NALs, %.2f GiB" % (n, rb / 2**30),
-                          "output_placement": "hbs_pair_alloc against the arena: %s" % json.dumps(emit_placement)}
+                          "output_placement": ("hbs_pair_alloc against the arena: %s" % json.dumps(emit_placement)) if PLACED else "torch allocator"}
     uniform_emit_ms = ms
     del out, idx_out
     # K3 on an arena with stretches the density probe does not see (1 % of it in 640 KiB stretches of 00 00 03 padding, then of
@@ -945,7 +946,10 @@ def main():
     ap.add_argument("--cpu-sample-nals", type=int, default=1_000_000, help="0 disables the CPU baseline leg")
     ap.add_argument("--other-kernels", type=int, default=1, help="0 skips the emit / parse / write measurements (N = 1 only)")
     ap.add_argument("--sweep", type=int, default=1, help="0 skips other_kernels' NAL-size sweep (profiling passes)")
-    ap.add_argument("--plain-alloc", type=int, default=0, help="1: the RBSP arena from torch's allocator instead of hbs_pair_alloc (placement left to chance)")
+    ap.add_argument("--placed-arena", type=int, default=0,
+                    help="1: the RBSP arena (and the other lines' outputs) from hbs_pair_alloc, placed against their inputs by measurement, instead of torch's "
+                         "allocator.  Off by default since round 6: over six processes the median gain was 1.3 %% of the kernel's time (profiles/r06/pair_time.txt); "
+                         "the default run still reports both arenas (roofline.kernel_ms_placed_arena / kernel_ms_plain_arena)")
     ap.add_argument("--exercise-gather", action="store_true",
                     help="dev aid: run the N > 1 code path (RCCL group, pipelined index gather) with a one-rank group on one GPU")
     args = ap.parse_args()
@@ -995,13 +999,17 @@ def main():
     sb, rb = g["stream_bytes"], g["rbsp_bytes"]
     stream = g["stream"][:sb]
     gen_rbsp, gen_index = g["rbsp"], g["index"]
-    # the RBSP arena is allocated by the library AGAINST the stream it will be written from (hbs_pair_alloc: on MI355X a
-    # stream / arena pair runs ~5 % slower when both lie in the same one of two classes of physical memory, which plain
-    # allocations hit about every other time -- DESIGN.md section 4); --plain-alloc 1 takes torch's allocator instead
+    # the RBSP arena: torch's allocator by default; --placed-arena 1 has the library allocate it AGAINST the stream it will be
+    # written from (hbs_pair_alloc: on MI355X a stream / arena pair runs a few per cent slower when both lie in the same one of
+    # two classes of physical memory -- DESIGN.md section 3).  Opt-in since round 6: the median gain over six processes was 1.3 %
     t_alloc = time.perf_counter()
-    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=None if args.plain_alloc else stream)
+    global PLACED
+    PLACED = bool(args.placed_arena)
+    if not PLACED:
+        os.environ["HBS_PLAIN_ALLOC"] = "1"                   # (scripts/nal_sweep.py: its outputs from torch's allocator too)
+    index, rbsp, summary, cap = ctx.alloc_outputs(sb, index_cap=n + 8, peer=stream if PLACED else None)
     torch.cuda.synchronize()
-    placement = None if args.plain_alloc else dict(ctx.last_pair_report, seconds=round(time.perf_counter() - t_alloc, 3))
+    placement = dict(ctx.last_pair_report, seconds=round(time.perf_counter() - t_alloc, 3)) if PLACED else None
 
     from hevcbitstream_amd import shard
     # N > 1: the one exchange of the path is the gather of the NAL index -- the C ABI's hbs_gather_index (counts, then exactly
@@ -1132,7 +1140,7 @@ def main():
                        "grid": "%d persistent workgroups (%d per CU) x %s" % (blocks, per_cu, geometry),
                        "device_exclusive": exclusive,
                        "arena_placement": ("hbs_pair_alloc against the stream (1 GiB chunks classed by measurement, outside the timed region): %s"
-                                           % json.dumps(placement)) if placement is not None else "torch allocator (placement left to chance)"},
+                                           % json.dumps(placement)) if placement is not None else "torch allocator (--placed-arena 1: hbs_pair_alloc)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4),
@@ -1160,10 +1168,13 @@ def main():
         if tr is not None:
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
-        if world == 1 and not args.plain_alloc and args.other_kernels:
-            # what placement buys, in THIS process: the same steps into an arena from torch's allocator (placement left to chance;
-            # outside the timed region), and what a second placed allocation costs now that the pool knows its chunks
-            index_p, rbsp_p, summary_p, cap_p = ctx.alloc_outputs(sb, index_cap=n + 8)
+        if world == 1 and args.other_kernels:
+            # what placement buys, in THIS process: the same steps into the other kind of arena (outside the timed region) -- torch's
+            # allocator when the timed steps' arena was placed, hbs_pair_alloc against the stream otherwise
+            t_b = time.perf_counter()
+            index_p, rbsp_p, summary_p, cap_p = ctx.alloc_outputs(sb, index_cap=n + 8, peer=None if PLACED else stream)
+            torch.cuda.synchronize()
+            other_report = None if PLACED else dict(ctx.last_pair_report, seconds=round(time.perf_counter() - t_b, 3))
             kp = []
             for i in range(6):
                 ctx.index_extract_async(stream, index_p, cap_p, rbsp_p, summary_p)
@@ -1173,12 +1184,15 @@ def main():
             kp.sort()
             del rbsp_p, index_p
             torch.cuda.empty_cache()
-            out["roofline"]["kernel_ms_plain_arena"] = round(kp[len(kp) // 2], 4)
-            out["roofline"]["kernel_ms_placed_arena"] = round(k_ms, 4)
-            out["roofline"]["placement"] = {"kernel_ms_placed_arena": round(k_ms, 4), "kernel_ms_plain_arena": round(kp[len(kp) // 2], 4),
-                                            "plain_over_placed": round(kp[len(kp) // 2] / k_ms, 4),
-                                            "note": "same process, same stream: the timed steps' arena (hbs_pair_alloc) against an arena from torch's allocator; "
-                                                    "other_kernels.placement_pool: what the next placed allocations cost"}
+            k_other = kp[len(kp) // 2]
+            k_plain, k_placed = (k_other, k_ms) if PLACED else (k_ms, k_other)
+            out["roofline"]["kernel_ms_plain_arena"] = round(k_plain, 4)
+            out["roofline"]["kernel_ms_placed_arena"] = round(k_placed, 4)
+            out["roofline"]["placement"] = {"timed_steps_arena": "placed" if PLACED else "plain", "kernel_ms_placed_arena": round(k_placed, 4),
+                                            "kernel_ms_plain_arena": round(k_plain, 4), "plain_over_placed": round(k_plain / k_placed, 4),
+                                            "placed_allocation": other_report if not PLACED else placement,
+                                            "note": "same process, same stream: an arena from torch's allocator against one from hbs_pair_alloc (placed against the "
+                                                    "stream by measurement); median of five calls each"}
         if world == 1 and args.cpu_sample_nals > 0:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(stream, index, rbsp, n, min(args.cpu_sample_nals, n))
         if world == 1 and args.other_kernels:

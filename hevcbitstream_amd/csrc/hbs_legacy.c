@@ -273,6 +273,8 @@ static uint32_t g_win_trace_cap = WIN_TRACE_CAP_MAX;     /* trace records a batc
 #define WIN_TRACE_CAP W.trace_cap
 typedef struct {
     int valid, trace;
+    int truncated;                   /* the trace-memory bound cut the batch short of the NALs the window holds: what lies behind its last NAL is
+                                        more NALs, not an unterminated one (round 5's advice) */
     int parsed_ok;                   /* 0: indexed and extracted only -- the parse waits for the first read, which knows the mode (and the caller's sets) */
     uint32_t trace_cap;              /* trace records kept per NAL in THIS batch: g_win_trace_cap, less when n x cap x 12 B would pass WIN_TRACE_BYTES_MAX */
     const uint8_t* base;             /* the caller's buffer the batch was made from, and a copy of those bytes */
@@ -416,6 +418,8 @@ static void window_parse(int trace)
         if (n * (uint64_t)W.trace_cap * sizeof(hbs_trace_rec) > WIN_TRACE_BYTES_MAX) {
             n = WIN_TRACE_BYTES_MAX / ((uint64_t)W.trace_cap * sizeof(hbs_trace_rec));
             W.n = n;
+            W.truncated = 1;
+            if (W.find_next > W.n) W.find_next = W.n;                /* (finds that ran ahead of the reads: the batch answers for its own NALs only) */
             W.rbsp_bytes = W.ent[n - 1].rbsp_off + W.ent[n - 1].rbsp_len;
         }
     }
@@ -494,7 +498,7 @@ static int window_build(uint8_t* buf, int size)
     if (W.rbsp_bytes && (rc = hbs_copy_to_host(g_ctx, W.rbsp, W.d_rbsp, W.rbsp_bytes))) die("hbs_copy_to_host", rc);
     /* The parse waits for the first read: only that call knows the mode (plain or trace -- round 4 parsed every first batch in
      * trace mode and a plain reader paid for a second pass) and the parameter sets the caller's object holds. */
-    W.valid = 1; W.parsed_ok = 0; W.find_next = 0; W.served = 0; W.synced = 0;
+    W.valid = 1; W.parsed_ok = 0; W.truncated = 0; W.find_next = 0; W.served = 0; W.synced = 0;
     DBG("build: %llu NALs in %llu bytes\n", (unsigned long long)n, (unsigned long long)len);
     return 1;
 }
@@ -523,7 +527,7 @@ static int find_nal_unit_unlocked(uint8_t* buf, int size, int* nal_start, int* n
     if (g_no_batch < 0) g_no_batch = getenv("HBS_LEGACY_NO_BATCH") ? 1 : 0;
     if ((uint64_t)size >= WIN_MIN && !g_no_batch) {
         /* a buffer worth a batch (not one this call was already answered from: that is the case above) */
-        const int rest_of_old = W.valid && W.find_next >= W.n && buf == W.base + W.ent[W.n - 1].end &&
+        const int rest_of_old = W.valid && !W.truncated && W.find_next >= W.n && buf == W.base + W.ent[W.n - 1].end &&
                                 (uint64_t)size <= W.len - W.ent[W.n - 1].end;     /* what the batch left: its unterminated last NAL */
         if (!rest_of_old && g_skip_builds > 0) {                                   /* the last batches did not pay: not this time */
             g_skip_builds -= 1;

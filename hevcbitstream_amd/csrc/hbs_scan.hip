@@ -555,7 +555,7 @@ extern "C" int hbs_debug_phase_cycles(unsigned long long* host_out /* [1024][8] 
  * rejected NALs) for the entries whose successor the tiles already wrote.  The last entry the tiles found, and one the
  * end-of-stream rules append, are thread 0's -- it is the only thread that touches them, and nothing here writes
  * hdr->final_nals / final_kept, which every thread reads. */
-constexpr int kFinishBlocksMin = 128, kFinishBlocksMax = 2048;   /* sized by the entries there can be (four a thread): 128 workgroups took 40 us over
+constexpr int kFinishBlocksMin = 128, kFinishBlocksMax = 8192;   /* sized by the entries there can be (four a thread): 128 workgroups took 40 us over
                                                                     the 2 M entries of a 2 GiB stream of 1 KiB NALs, 89 us at 512 bytes */
 __global__ __launch_bounds__(256)
 void k_scan_finish(const uint8_t* __restrict__ stream, uint64_t n,
@@ -685,10 +685,14 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
      * geometry), cleared index and look-back words */
     const int tail_tile = ((!index_only && sparse_variant == 4) || sparse_variant == 6 || automatic) ? scan4_tile_bytes() : 0;
     launch_scan_prologue(a, num_tiles * 2, automatic && a.n != 0, tail_tile, st);
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t x) { if (first == hipSuccess && x != hipSuccess) first = x; };
     if (num_tiles) {
         uint64_t grid = (uint64_t)a.grid_blocks;
         if (grid > tiles2) grid = tiles2;
-        if (a.ev_begin) { e = hipEventRecord(a.ev_begin, st); if (e != hipSuccess) return e; }
+        /* (an error from here on is remembered, not returned at once: the prologue has stamped the count-ahead's workspace with this
+         * call's number, and only the finish launch below hands the workspace to the next call -- round 5's advice) */
+        if (a.ev_begin) note(hipEventRecord(a.ev_begin, st));
         if (index_only && !automatic) {
             launch_scan_index5(a, kGateNone, st);
         } else if (!automatic && sparse_variant == 4) {
@@ -712,14 +716,15 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, kGateNone);
         }
-        if (a.ev_end) { e = hipEventRecord(a.ev_end, st); if (e != hipSuccess) return e; }
+        if (a.ev_end) note(hipEventRecord(a.ev_end, st));
     }
     /* no more entries than start codes fit the stream (3 bytes each) */
     const uint64_t may = a.index_cap < a.n / 3 + 1 ? a.index_cap : a.n / 3 + 1;
     uint64_t fb = (may + 1023) / 1024;
     fb = fb < (uint64_t)kFinishBlocksMin ? (uint64_t)kFinishBlocksMin : fb > (uint64_t)kFinishBlocksMax ? (uint64_t)kFinishBlocksMax : fb;
     k_scan_finish<<<dim3((unsigned)fb), 256, 0, st>>>(a.stream, a.n, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.hdr, a.summary, a.ahead_ctl);
-    return hipGetLastError();
+    note(hipGetLastError());
+    return first;
 }
 
 } // namespace hbs

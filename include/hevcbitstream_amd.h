@@ -155,7 +155,11 @@ int  hbs_ctx_get_kernel(hbs_ctx* ctx);
  * launch samples every tile, a small kernel counts the ones the sample marks, and the main kernel takes those counts instead of
  * walking the tile a first time (hbs_scan4.hip, "dense tiles counted ahead").  mode 1 (default): streams of 3 GiB and more;
  * 0: never; 2: any stream that has more than one tile.  Results are identical in all three.  Environment HBS_COUNT_AHEAD=0|1|2
- * sets the default.  The table costs 76 bytes of device memory per 192 KiB of stream; nothing of it lives on the host, so a call captured into a HIP graph may be replayed. */
+ * sets the default.  The table costs 76 bytes of device memory per 192 KiB of stream; nothing of it lives on the host, so a call captured into a HIP graph may be replayed.
+ * The table is allocated by the first call that needs it (and again by a call on a longer stream): such a call must not be made
+ * inside a stream capture -- make one call of at least that size before capturing (round 5's advice).
+ * Since round 6 the same mode governs hbs_emit_annexb's arena-tile kernel, which samples the arena and counts the dense tiles it
+ * lists ahead in the same way (two launches in front of the main pass): mode 1 = arenas of 3 GiB and more. */
 int  hbs_ctx_set_count_ahead(hbs_ctx* ctx, int mode);
 int  hbs_ctx_last_kernel(hbs_ctx* ctx);
 /* Text of the last HIP/driver error seen by this context. */
