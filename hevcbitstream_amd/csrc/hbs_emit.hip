@@ -2496,7 +2496,11 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
         /* an index that is one stretch of the arena: 64 consecutive NALs a wavefront, cooperatively (hbs_emit_groups.h: sizes,
          * the scan of the wavefronts' sums, the bytes); the lane per NAL behind it is what other indexes get */
         {
-            const uint32_t gcap = groups_region_cap(a.rbsp_bytes / a.n), npw = groups_nals_per_wave(a.rbsp_bytes / a.n);
+            uint32_t gcap = groups_region_cap(a.rbsp_bytes / a.n), npw = groups_nals_per_wave(a.rbsp_bytes / a.n);
+            if (const char* e = getenv("HBS_K3G_NPW")) {                 /* tuning aid: NALs a wavefront takes (16, 32 or 64) */
+                const int v = atoi(e);
+                if (v == 16 || v == 32 || v == 64) { npw = (uint32_t)v; gcap = groups_region_cap_for(npw, a.rbsp_bytes / a.n); }
+            }
             const uint64_t nw = (a.n + npw - 1u) / npw, wgs = (nw + kGWaves - 1) / kGWaves;
             static const int cus = [] { int d = 0, c = 256; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
             const size_t per_cu_lds = (size_t)160 * 1024 / (groups_lds_bytes(gcap) + 64);
@@ -2506,7 +2510,7 @@ hipError_t launch_emit_annexb(const EmitArgs& a, hipStream_t st)
                 a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.nal_total, a.tflag, a.err, gcap, npw, try_tiles ? 0 : 1);
             launch_scan_u64(a.nal_total, a.out_off, nw, a.total_dense, a.scan_tmp, st, nullptr, kWhenGroups, a.tflag);
             k3g_emit<<<dim3((unsigned)(wgs < gmax_emit ? wgs : gmax_emit)), dim3(64 * kGWaves), groups_lds_bytes(gcap), st>>>(
-                a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.out_off, a.out, a.out_cap, a.index_out, a.err, a.tflag, gcap, npw);
+                a.rbsp, a.rbsp_bytes, a.index_in, a.n, a.gap_mode, a.out_off, reinterpret_cast<const uint8_t*>(a.nal_total + nw), a.out, a.out_cap, a.index_out, a.err, a.tflag, gcap, npw);
         }
         const uint64_t want = (a.n + 255) / 256;
         const unsigned tgrid = (unsigned)(want < 8192 ? want : 8192);

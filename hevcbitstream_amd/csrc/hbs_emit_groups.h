@@ -32,19 +32,20 @@ constexpr int kGWaves = 2;                        /* wavefronts per workgroup (e
 constexpr uint32_t kGMaxGap = 16;                 /* gaps (zeros + 01) of up to 15 bytes; k3t_check: tflag[4]   */
 constexpr uint32_t kGHead = 640;                  /* per wavefront in LDS: S[65], PA[64] (and slack)            */
 constexpr uint32_t kGGuard = 32;                  /* bytes in front of the stretch's copy (unaligned 16-byte reads reach back 15) */
-constexpr uint32_t kGCapMin = 4096, kGCapMax = 15360;
+constexpr uint32_t kGCapMin = 2048, kGCapMax = 15360;
 constexpr uint32_t kGQueue = 136;                 /* chunks of a wavefront's output that are not one NAL's payload: each of the 64 NALs' gaps (up to 15 bytes) and
                                                      beginnings touches at most two, and the wavefront's first and last chunk                                    */
 
 /* NALs a wavefront takes, and the LDS share of its stretch, for a call whose NALs average `mean` bytes */
-inline uint32_t groups_nals_per_wave(uint64_t mean) { return mean <= 80u ? 64u : mean <= 160u ? 32u : 16u; }
-inline uint32_t groups_region_cap(uint64_t mean)
+inline uint32_t groups_nals_per_wave(uint64_t mean) { return mean <= 100u ? 64u : 32u; }     /* (2 GiB sweep, profiles/r06/emit_groups_npw.txt: 16 never pays) */
+inline uint32_t groups_region_cap_for(uint32_t npw, uint64_t mean)
 {
-    uint64_t cap = ((uint64_t)groups_nals_per_wave(mean) * mean * 5u / 4u + 512u + 1023u) & ~1023ull;
+    uint64_t cap = ((uint64_t)npw * mean * 5u / 4u + 512u + 1023u) & ~1023ull;
     if (cap < kGCapMin) cap = kGCapMin;
     if (cap > kGCapMax) cap = kGCapMax;
     return (uint32_t)cap;
 }
+inline uint32_t groups_region_cap(uint64_t mean) { return groups_region_cap_for(groups_nals_per_wave(mean), mean); }
 /* a wavefront's share: S, PA | guard | the stretch (+ 32 readable behind it) | per output chunk: T (the NAL it begins in, a byte),
  * Src (where its sixteen bytes lie in the stretch's copy when they are one NAL's payload, else 0xFFFF; two bytes), Rk (its place in
  * the queue otherwise; a byte) | Q (the queued chunks, two bytes each) | Qv (what they come to, sixteen bytes each) */
@@ -100,13 +101,21 @@ constexpr int kGBatch = 4;      /* chunk loads of a lane in flight (a load per s
 template <bool kStage>
 __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t npw, int lane, const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes,
                                              const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode, uint32_t cap, uint8_t* region,
-                                             uint32_t* __restrict__ vflag = nullptr, uint32_t* __restrict__ err = nullptr)
+                                             uint32_t* __restrict__ vflag = nullptr, uint32_t* __restrict__ err = nullptr, int known_dirty = -1)
 {
     const uint64_t k = k0 + (uint64_t)lane;
     z.have = (uint32_t)lane < npw && k < n;
     z.cnt = k0 >= n ? 0u : (n - k0 < (uint64_t)npw ? (uint32_t)(n - k0) : npw);
     uint64_t e_start = 0, e_end = 0;
     z.off = 0; z.len = 0;
+    /* the entry in front of the wavefront's first (lane 0: the gap's other end, and the contiguity check) is asked for together
+     * with the wavefront's own: behind them it was one more round trip a step */
+    u32x4 p0 = u32x4{0u, 0u, 0u, 0u}, p1 = u32x4{0u, 0u, 0u, 0u};
+    const bool want_prev = lane == 0 && k != 0 && z.have && (gap_mode != 1 || vflag != nullptr);
+    if (want_prev) {
+        p1 = reinterpret_cast<const u32x4*>(idx + (k - 1))[1];
+        if (gap_mode != 1) p0 = reinterpret_cast<const u32x4*>(idx + (k - 1))[0];
+    }
     if (z.have) {
         const u32x4 h1 = reinterpret_cast<const u32x4*>(idx + k)[1];
         z.off = ((uint64_t)h1.y << 32) | h1.x; z.len = h1.z;
@@ -119,7 +128,7 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
     if (gap_mode == 1) gap64 = synth_gap(k);
     else {
         uint64_t prev_end = (uint64_t)__shfl_up((unsigned long long)e_end, 1, 64);
-        if (lane == 0) prev_end = (k && z.have) ? idx[k - 1].end : 0ull;
+        if (lane == 0) prev_end = want_prev ? (((uint64_t)p0.w << 32) | p0.z) : 0ull;
         gap64 = e_start - prev_end;
     }
     if (vflag) {
@@ -128,7 +137,7 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
          * NALs that do not lie back to back or gaps of 16 bytes and more (tflag[4]: the lane per NAL takes the call) */
         const uint64_t endk = z.off + z.len;
         uint64_t prev_stop = (uint64_t)__shfl_up((unsigned long long)endk, 1, 64);
-        if (lane == 0 && k && z.have) { const u32x4 hp = reinterpret_cast<const u32x4*>(idx + (k - 1))[1]; prev_stop = (((uint64_t)hp.y << 32) | hp.x) + hp.z; }
+        if (lane == 0 && want_prev) prev_stop = (((uint64_t)p1.y << 32) | p1.x) + p1.z;
         const bool outside = z.have && (z.off > rbsp_bytes || (uint64_t)z.len > rbsp_bytes - z.off);
         const bool apart = z.have && ((k != 0 && z.off != prev_stop) || gap64 >= (uint64_t)kGMaxGap);
         const bool wave_outside = __ballot(outside) != 0ull;
@@ -168,6 +177,7 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
                 for (int i = 0; i < kGBatch; ++i) {
                     const uint32_t c = c0 + 64u * (uint32_t)i + (uint32_t)lane;
                     if (kStage && c < z.nch) *reinterpret_cast<u32x4*>(region + 16u * c) = q[i];
+                    if (known_dirty >= 0) continue;                        /* (the second pass: the first one left its verdict) */
                     const uint32_t xp = from_prev_lane(q[i].w, e_prev);
                     const bool f = c < z.nch && chunk_flag(xp, q[i].x, q[i].y, q[i].z, q[i].w, 0xFFFFFFFFu) &&
                                    chunk_pattern_any_dev(xp, q[i].x, q[i].y, q[i].z, q[i].w, 0xFFFFFFFFu);
@@ -176,7 +186,7 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
                 }
             }
             if (kStage && lane == 0) *reinterpret_cast<u32x4*>(region + 16u * z.nch) = u32x4{~0u, ~0u, ~0u, ~0u};     /* (reads reach 15 bytes past the last chunk) */
-            z.dirty = any != 0ull;
+            z.dirty = known_dirty >= 0 ? known_dirty != 0 : any != 0ull;
         }
     }
     /* bytes that go in: none unless some chunk of the stretch may take one (or the stretch is too long for its LDS share) */
@@ -197,7 +207,7 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
  * the next ticket published a step ahead.  A unit of 256 NALs is 34 KB of traffic behind three dependent round trips, a ticket
  * and three barriers: 12 us a step even with the look-back and the output left out, and a CU holds three such workgroups.
  * Reading the arena and the index twice (+ 60 % traffic) buys units that do not wait for each other. */
-/* npw: NALs a wavefront takes (64, 32 or 16: the call's mean NAL decides, so that a stretch is 4-6 KiB whatever the NALs' size --
+/* npw: NALs a wavefront takes (64 or 32: the call's mean NAL decides, so that a stretch is 4-8 KiB whatever the NALs' size --
  * the LDS share is what bounds the wavefronts a CU holds in the second pass); validate: this pass is the call's index check too */
 __global__ __launch_bounds__(64 * kGWaves)
 void k3g_sizes(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
@@ -211,13 +221,13 @@ void k3g_sizes(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
     for (uint64_t w = wave; w < nw; w += nwaves) {
         GSizes z;
         groups_sizes<false>(z, w * (uint64_t)npw, npw, lane, rbsp, rbsp_bytes, idx, n, gap_mode, cap, nullptr, validate ? tflag : nullptr, err);
-        if (lane == 0) gsum[w] = z.wtot;
+        if (lane == 0) { gsum[w] = z.wtot; reinterpret_cast<uint8_t*>(gsum + nw)[w] = z.dirty ? 1u : 0u; }    /* (the flags live behind the sums) */
     }
 }
 
 __global__ __launch_bounds__(64 * kGWaves)
 void k3g_emit(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_nal_entry* __restrict__ idx, uint64_t n, int gap_mode,
-              const unsigned long long* __restrict__ gbase, uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
+              const unsigned long long* __restrict__ gbase, const uint8_t* __restrict__ gdirty, uint8_t* __restrict__ out, uint64_t out_cap, hbs_nal_entry* __restrict__ idx_out,
               uint32_t* __restrict__ err, const uint32_t* __restrict__ tflag, uint32_t cap, uint32_t npw)
 {
     if (!group_path_on(tflag)) return;
@@ -238,8 +248,9 @@ void k3g_emit(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_n
 #pragma unroll 1
     for (uint64_t w = wave; w < nw; w += nwaves) {
         const unsigned long long wbase = gbase[w];                         /* (asked for first: the entries and the stretch do not wait for it) */
+        const int was_dirty = (int)gdirty[w];                              /* the sizes pass's verdict on this stretch: nothing is flagged twice */
         GSizes z;
-        groups_sizes<true>(z, w * (uint64_t)npw, npw, lane, rbsp, rbsp_bytes, idx, n, gap_mode, cap, region);
+        groups_sizes<true>(z, w * (uint64_t)npw, npw, lane, rbsp, rbsp_bytes, idx, n, gap_mode, cap, region, nullptr, nullptr, was_dirty);
         const uint64_t k = w * (uint64_t)npw + (uint64_t)lane;
         const bool clean = z.fits && !z.dirty;
         const uint64_t my_base = wbase + z.excl;                           /* my NAL's gap begins here */
