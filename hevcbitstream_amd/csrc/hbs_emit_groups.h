@@ -143,10 +143,9 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
         const bool wave_outside = __ballot(outside) != 0ull;
         if (wave_outside && lane == 0) { atomicOr(&vflag[3], 1u); atomicMax(err, (uint32_t)(-HBS_E_ARG)); }
         if (__ballot(apart) != 0ull && lane == 0) atomicOr(&vflag[4], 1u);
-        if (wave_outside) {                                                /* the call ends with HBS_E_ARG: nothing of these entries is followed */
-            z.cnt = 0; z.have = false; z.fits = false; z.dirty = false; z.a0al = 0; z.nch = 0; z.gap = 0; z.tot = 0; z.excl = 0; z.wtot = 0;
-            return;
-        }
+        /* the call ends with HBS_E_ARG: nothing of these entries is followed (no second way out of this function: with a `return` here
+         * the compiler kept z in scratch memory, and the pass took 0.87 ms instead of 0.54 over 2 GiB of 64-byte NALs) */
+        if (wave_outside) { z.cnt = 0; z.have = false; z.len = 0; gap64 = 0; }
     }
     z.gap = z.have ? (uint32_t)gap64 : 0u;
     z.fits = false; z.dirty = false; z.a0al = 0; z.nch = 0;
@@ -177,16 +176,17 @@ __device__ __forceinline__ void groups_sizes(GSizes& z, uint64_t k0, uint32_t np
                 for (int i = 0; i < kGBatch; ++i) {
                     const uint32_t c = c0 + 64u * (uint32_t)i + (uint32_t)lane;
                     if (kStage && c < z.nch) *reinterpret_cast<u32x4*>(region + 16u * c) = q[i];
-                    if (known_dirty >= 0) continue;                        /* (the second pass: the first one left its verdict) */
-                    const uint32_t xp = from_prev_lane(q[i].w, e_prev);
-                    const bool f = c < z.nch && chunk_flag(xp, q[i].x, q[i].y, q[i].z, q[i].w, 0xFFFFFFFFu) &&
-                                   chunk_pattern_any_dev(xp, q[i].x, q[i].y, q[i].z, q[i].w, 0xFFFFFFFFu);
-                    any |= __ballot(f);
-                    e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q[i].w, 63);
+                    if (!kStage) {                                         /* (the second pass stages only: the first one left its verdict) */
+                        const uint32_t xp = from_prev_lane(q[i].w, e_prev);
+                        const bool f = c < z.nch && chunk_flag(xp, q[i].x, q[i].y, q[i].z, q[i].w, 0xFFFFFFFFu) &&
+                                       chunk_pattern_any_dev(xp, q[i].x, q[i].y, q[i].z, q[i].w, 0xFFFFFFFFu);
+                        any |= __ballot(f);
+                        e_prev = (uint32_t)__builtin_amdgcn_readlane((int)q[i].w, 63);
+                    }
                 }
             }
             if (kStage && lane == 0) *reinterpret_cast<u32x4*>(region + 16u * z.nch) = u32x4{~0u, ~0u, ~0u, ~0u};     /* (reads reach 15 bytes past the last chunk) */
-            z.dirty = known_dirty >= 0 ? known_dirty != 0 : any != 0ull;
+            z.dirty = kStage ? known_dirty != 0 : any != 0ull;
         }
     }
     /* bytes that go in: none unless some chunk of the stretch may take one (or the stretch is too long for its LDS share) */
