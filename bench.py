@@ -39,6 +39,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# hbs_ctx_last_kernel -> the kernel's name in a rocprofv3 trace
+KERNEL_NAMES = {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4", 6: "hbs::k_scan_extract4_r24",
+                5: "hbs::k_index5_stream (+ k_index5_chunks, k_index5_prefix, k_index5_emit)"}
+KERNEL_GEOMETRY = {2: "512 threads, 64 KiB tiles (LDS image)",
+                   4: "256 threads, 192 KiB tiles held in registers (48 rows a wavefront), tiles handed out by ticket",
+                   6: "256 threads, 96 KiB tiles held in registers (24 rows a wavefront), tiles handed out by ticket"}
 PLACED = False                 # --placed-arena: outputs through hbs_pair_alloc (main() sets it; the helper lines below follow it)
 N_NALS_16GIB = 1_677_000       # S(seed, n) with ~10 KiB NALs: 16.0 GiB of Annex-B
 SEED = 0x1234
@@ -285,7 +291,7 @@ def configs_1gib(torch, hbs, ctx, check=True, reps=12):
     s = ctx.read_summary(summary)
     assert int(s["error"]) == 0 and int(s["nal_count"]) == n and int(s["rbsp_bytes"]) == rb, s
     algo = sb + rb + 32 * n
-    kern = {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4"}.get(ctx.last_kernel(), "?")
+    kern = KERNEL_NAMES.get(ctx.last_kernel(), "?")
     res["config2_extract"] = {"value": round(sb / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": kern, "kernel_ms": round(k_ms, 4), "call_ms": round(c_med, 4),
                               "call_ms_min": round(c_min, 4), "algorithmic_bytes": algo,
                               "roofline": {"bound": "hbm", "achieved": round(algo / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -305,7 +311,7 @@ def configs_1gib(torch, hbs, ctx, check=True, reps=12):
     s5 = ctx.read_summary(summary5)
     assert int(s5["error"]) == 0 and int(s5["nal_count"]) == n
     algo5 = sb + 32 * n
-    kern5 = {4: "hbs::k_scan_extract4", 5: "hbs::k_index5_stream (+ its aggregate / prefix / entry passes)", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?")
+    kern5 = KERNEL_NAMES.get(ctx.last_kernel(), "?")
     res["config2_index_only"] = {"value": round(sb / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": kern5, "kernel_ms": round(k_ms, 4), "call_ms": round(c_med, 4),
                                  "call_ms_min": round(c_min, 4), "algorithmic_bytes": algo5,
                                  "roofline": {"bound": "hbm", "achieved": round(algo5 / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -657,7 +663,7 @@ def zero_heavy_line(torch, ctx, check):
     ks.sort()
     k_ms = ks[len(ks) // 2]
     algo = sb1 + rb1 + 32 * n1
-    line = {"value": round(sb1 / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4"}.get(ctx.last_kernel(), "?"),
+    line = {"value": round(sb1 / k_ms / 1e6, 1), "unit": "GB/s scanned", "kernel": KERNEL_NAMES.get(ctx.last_kernel(), "?"),
             "kernel_ms": round(k_ms, 4), "stream_bytes": sb1, "nals": n1, "algorithmic_bytes": algo,
             "roofline": {"bound": "hbm", "achieved": round(algo / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 4)},
             "workload": "S(seed=0x1234, n_nals=%d, zero-heavy): %.3f GiB, resident in HBM; arena and index equal to the generator's" % (n1, sb1 / 2**30)}
@@ -711,7 +717,7 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
     ms = sum(kms) / len(kms)
     res["index_only"] = {"value": round(sb / ms / 1e6, 1), "unit": "GB/s scanned", "kernel_ms": round(ms, 4),
                          "read_frac_of_hbm_peak": round((sb + 32 * n) / ms / 1e6 / HBM_PEAK_GBS, 4),
-                         "kernel": {4: "hbs::k_scan_extract4", 5: "hbs::k_index5_stream (+ k_index5_chunks, k_index5_prefix, k_index5_emit)", 2: "hbs::k_scan_extract"}.get(ctx.last_kernel(), "?"),
+                         "kernel": KERNEL_NAMES.get(ctx.last_kernel(), "?"),
                          "workload": "the bench stream, index only (find_nal_unit over the stream, no arena)"}
     del index
     res["mixed_stream"] = mixed_stream_line(torch, ctx, g["stream"][:sb], sb, n + 64, g["uniform_kernel_ms"])
@@ -1113,9 +1119,8 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         blocks, per_cu = ctx.grid()
         variant = ctx.last_kernel()          # automatic mode: the kernel the density probe picked
-        kernel_name = {2: "hbs::k_scan_extract", 4: "hbs::k_scan_extract4"}[variant]
-        geometry = {2: "512 threads, 64 KiB tiles (LDS image)",
-                    4: "256 threads, 192 KiB tiles held in registers, tiles handed out by ticket"}[variant]
+        kernel_name = KERNEL_NAMES[variant]
+        geometry = KERNEL_GEOMETRY[variant]
         out = {
             "metric": "Annex-B GB/s scanned + NAL units/s, 16 GiB synthetic stream, 1/2/4/8 MI355X",
             "value": round(total_bytes * args.steps / dt / 1e9, 2),

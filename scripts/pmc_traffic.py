@@ -7,11 +7,22 @@ import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hevcbitstream_amd
 
+def is_kernel(kernel_name, sub):
+    """`sub` as a whole identifier inside the kernel's name: k_scan_extract4 is not k_scan_extract4_r24 (round 6), but k3_tiles is k3_tiles<0>"""
+    i = kernel_name.find(sub)
+    while i >= 0:
+        nxt = kernel_name[i + len(sub): i + len(sub) + 1]
+        if not (nxt.isalnum() or nxt == "_"):
+            return True
+        i = kernel_name.find(sub, i + 1)
+    return False
+
+
 def rows(d, sub, name):
     out = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if sub in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if is_kernel(r["Kernel_Name"], sub) and r["Counter_Name"] == name:
                 out.append(r)
     by = {}
     for r in out:

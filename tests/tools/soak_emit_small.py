@@ -19,8 +19,8 @@ t_end = time.time() + budget
 it = bad = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 * 7919 + it)
-    nn = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 257, 300]))
-    total = int(rng.choice([0, 1, 17, 1000, 5000, 32767, 32768, 32769, 40000]))
+    nn = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 257, 300, 1000, 5000]))      # (from 257 NALs of a mean below 448 bytes: the group kernel, round 6)
+    total = int(rng.choice([0, 1, 17, 1000, 5000, 32767, 32768, 32769, 40000, 200000, 700000]))
     cuts = np.sort(rng.integers(0, total + 1, size=nn - 1)) if nn > 1 else np.zeros(0, dtype=np.int64)
     lens = np.diff(np.concatenate(([0], cuts, [total]))).astype(np.int64)
     kind = rng.integers(0, 4)

@@ -10,7 +10,7 @@ from tests import _orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = _orc.oracle()
-ctxs = {v: hbs.Context(0) for v in (0, 2, 4)}
+ctxs = {v: hbs.Context(0) for v in (0, 2, 4, 6)}       # 6: the event-sparse kernel's 24-row geometry (round 6)
 for v, c in ctxs.items():
     c.set_kernel(v)
     c.set_count_ahead(2)              # round 5: the event-sparse kernel's dense tiles counted ahead at every size (default: from 3 GiB)
