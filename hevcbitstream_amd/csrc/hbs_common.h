@@ -121,8 +121,9 @@ HBS_HD bool probe_says_dense(uint32_t chunks, uint32_t flagged, uint32_t one_in 
  * (hbs_scan4_r24.hip: 1024 elements per 96 KiB tile = one chunk in 6): streams of NALs of ~120 to ~450 bytes.  A 2 GiB sweep
  * (profiles/r06): extract 0.32 / 0.38 / 0.43 / 0.45 of peak at 128 / 192 / 256 / 384-byte NALs against the LDS-image kernel's
  * 0.25 / 0.27 / 0.29 / 0.31, and 0.15 against 0.23 at 64 bytes, where its tiles pass the limit and are walked by rows -- so
- * "dense" begins at 2 elements in kMidTwoIn chunks (one in 6.5; 128-byte NALs: one in 6.7).  Index-only calls go there from
- * where the streaming kernel gives out (kDenseOneInIndexOnly): 0.25 against the LDS-image kernel's 0.22 at 128 bytes. */
+ * "dense" begins at 2 elements in kMidTwoIn chunks (one in 6.5; 128-byte NALs: one in 6.7).  Index-only calls of 1 GiB and more
+ * (the streaming kernel's) have no middle class: beyond one element in 9 chunks the 24-row geometry without an arena is 0.25 against
+ * the LDS-image kernel's 0.22 at 128 bytes, and the launch that rules itself out on every other stream cost 2 % of a 1 GiB call. */
 constexpr uint32_t kMidTwoIn = 13;
 enum : int { kProbeSparse = 0, kProbeMid = 1, kProbeDense = 2 };
 HBS_HD int probe_class(uint32_t chunks, uint32_t flagged, bool index_only)
@@ -134,9 +135,10 @@ HBS_HD int probe_class(uint32_t chunks, uint32_t flagged, bool index_only)
 HBS_HD int probe_variant(uint32_t chunks, uint32_t flagged, bool index_only)
 {
     const int c = probe_class(chunks, flagged, index_only);
-    return c == kProbeSparse ? (index_only ? 5 : 4) : c == kProbeMid ? 6 : 2;
+    if (index_only) return c == kProbeSparse ? 5 : 2;      /* (no 24-row geometry behind the streaming kernel: see launch_scan_extract) */
+    return c == kProbeSparse ? 4 : c == kProbeMid ? 6 : 2;
 }
-enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2, kGateIfSparseIdx = 3, kGateIfDenseIdx = 4, kGateIfMid = 5, kGateIfMidIdx = 6 };   /* ...Idx: an index-only call's thresholds */
+enum : int { kGateNone = 0, kGateIfSparse = 1, kGateIfDense = 2, kGateIfSparseIdx = 3, kGateIfDenseIdx = 4, kGateIfMid = 5 };   /* ...Idx: an index-only call's threshold (sparse or not) */
 #ifdef __HIPCC__
 /* the density probe's verdict, by a whole wavefront: lane l reads slot l */
 __device__ __forceinline__ int probe_class_dev(const RunHeader* __restrict__ hdr, bool index_only)
@@ -151,9 +153,11 @@ __device__ __forceinline__ int probe_class_dev(const RunHeader* __restrict__ hdr
 __device__ __forceinline__ bool gate_closed(int gate, const RunHeader* __restrict__ hdr)
 {
     if (gate == kGateNone) return false;
-    const bool idx = gate == kGateIfSparseIdx || gate == kGateIfDenseIdx || gate == kGateIfMidIdx;
-    const int want = (gate == kGateIfSparse || gate == kGateIfSparseIdx) ? kProbeSparse : (gate == kGateIfMid || gate == kGateIfMidIdx) ? kProbeMid : kProbeDense;
-    return probe_class_dev(hdr, idx) != want;
+    const bool idx = gate == kGateIfSparseIdx || gate == kGateIfDenseIdx;
+    const int c = probe_class_dev(hdr, idx);
+    if (idx) return (gate == kGateIfSparseIdx) != (c == kProbeSparse);       /* two ways only: the streaming kernel, or the LDS image */
+    const int want = gate == kGateIfSparse ? kProbeSparse : gate == kGateIfMid ? kProbeMid : kProbeDense;
+    return c != want;
 }
 #endif
 

@@ -708,8 +708,9 @@ hipError_t launch_scan_extract(const ScanArgs& a, hipStream_t st)
              * event waits cost more than an empty kernel's 4.7 us -- a 1 GiB call 0.427 ms against 0.410) */
             if (index_only) launch_scan_index5(a, kGateIfSparseIdx, st);
             else { launch_scan_ahead4(a, tiles4, kGateIfSparse, st); scan4_launch_kernel(a, tiles4, kGateIfSparse, st); }
-            /* dense but regular (NALs of ~120-450 bytes): the 24-row geometry, with or without an arena */
-            scan4r24_launch_kernel(a, tiles6, index_only ? kGateIfMidIdx : kGateIfMid, st);
+            /* dense but regular (NALs of ~120-450 bytes): the 24-row geometry (not behind the streaming index-only kernel, which
+             * holds to one element in 9 chunks itself: hbs_common.h) */
+            if (!index_only) scan4r24_launch_kernel(a, tiles6, kGateIfMid, st);
             k_scan_extract<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(
                 a.stream, a.n, tiles2, a.index, a.index_cap, a.rbsp, a.rbsp_cap, a.desc, a.hdr, a.sched, index_only ? kGateIfDenseIdx : kGateIfDense);
         } else {

@@ -144,8 +144,8 @@ int  hbs_ctx_set_device_exclusive(hbs_ctx* ctx, int on);
  * 5 = index only (no RBSP arena asked for): nothing has to stay in registers, so the bytes are
  *     streamed and only the flagged chunks are looked at again (hbs_scan5.hip); with an arena it means 4,
  * 0 = automatic, the default: a density probe (64 windows of 16 KiB) runs in front and the kernel is picked from it on the
- *     device, without a host round trip: 4 (5 when no arena is asked for and the stream is 1 GiB or more) up to one candidate
- *     chunk in 26 (in 15 for 5), 6 up to one in 6.5, 2 beyond.
+ *     device, without a host round trip: 4 up to one candidate chunk in 44, 6 up to one in 6.5, 2 beyond; when no arena is asked
+ *     for and the stream is 1 GiB or more: 5 up to one in 9, 2 beyond.
  * Environment HBS_KERNEL=0|2|4|5|6 sets the default.  hbs_ctx_last_kernel waits for the last
  * hbs_index_extract and says which kernel ran it. */
 int  hbs_ctx_set_kernel(hbs_ctx* ctx, int variant);
