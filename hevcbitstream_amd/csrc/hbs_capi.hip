@@ -107,7 +107,7 @@ extern "C" {
 
 const char* hbs_version(void)
 {
-    return "hevcbitstream_amd 0.5 (gfx950 HIP; K12 fused scan/index/extract)";
+    return "hevcbitstream_amd 0.6 (gfx950 HIP; K12 fused scan/index/extract)";
 }
 
 int hbs_ctx_create(hbs_ctx** out, int device)

@@ -177,7 +177,13 @@ extern "C" int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uin
                                   rbsp_cap > total.rbsp_bytes ? rbsp_cap - total.rbsp_bytes : 0, &s);
         be->end();
         if (!be->allocated) hbs_ctx_attach(ctx, nullptr, nullptr);   /* an allocation failed: do not keep the pieces */
-        if (rc) return rc;
+        if (rc) {
+            /* a hard error in a later run: the runs before it have delivered entries into h_index / h_rbsp -- say how many (round
+             * 5's advice: the summary was left unwritten) */
+            total.error = rc;
+            *h_summary = total;
+            return rc;
+        }
         /* this run's entries are relative to where it started */
         if (at || total.rbsp_bytes)
             for (uint64_t k = 0; k < s.nal_count && had + k < index_cap; ++k) {
@@ -194,7 +200,7 @@ extern "C" int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uin
             total.reserved[0] = window;                        /* the window the call ended with (0: never grown) */
             continue;
         }
-        total.error = s.error;
+        if (!total.error) total.error = s.error;                /* (the first error of the call stays) */
         if (window_too_small) { total.reserved[1] = at + s.reserved[1]; total.reserved[2] = 1; }     /* the ceiling was reached: where, in the stream */
         break;
     }

@@ -212,6 +212,10 @@ int hbs_index_extract(hbs_ctx* ctx,
 int hbs_index_extract_host(hbs_ctx* ctx, const uint8_t* h_stream, uint64_t stream_bytes, uint64_t window_bytes,
                            hbs_nal_entry* h_index, uint64_t index_cap,
                            uint8_t* h_rbsp, uint64_t rbsp_cap, hbs_summary* h_summary);
+/* Device memory: a window of W bytes holds two stream buffers of 2 W, an RBSP buffer of 2 W (when h_rbsp is asked for) and an
+ * index of 2 W / 32 entries -- about 8 W in all; every growth step frees them and allocates the next size, so at the default
+ * ceiling a call may hold ~8 GiB on the device.  Lower the ceiling where that is too much.  When the call returns a hard error
+ * (non-zero return value) h_summary still says what the runs before the failing one delivered (nal_count, rbsp_bytes). */
 int hbs_ctx_set_ingest_window_max(hbs_ctx* ctx, uint64_t max_window_bytes /* 0: the default, 1 GiB */);
 
 /*
