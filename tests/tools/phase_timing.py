@@ -12,10 +12,18 @@ from tests import _orc
 orc = _orc.oracle()
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 want_rbsp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
-d = torch.from_numpy(base).cuda().repeat(64)
 ctx = hbs.Context(0)
-index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * 64 + 16)
+ctx.set_kernel(2)                                        # the LDS-image kernel, whatever the density probe would say
+if os.environ.get("HBS2_NAL_MEAN"):                      # a 1 GiB stream of random payload in NALs of that mean size (scripts/nal_sweep.py)
+    sys.path.insert(0, "scripts")
+    import nal_sweep
+    _, _, _, nn, sbuf, sb = nal_sweep.make_stream(torch, np, ctx, int(os.environ["HBS2_NAL_MEAN"]), 1 << 30)
+    d = sbuf[:sb]
+    index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=nn + 64)
+else:
+    base, idx, arena = orc.gen_stream(0x1234, 1600, mode)
+    d = torch.from_numpy(base).cuda().repeat(64)
+    index, rbsp, summary, cap = ctx.alloc_outputs(d.numel(), index_cap=1600 * 64 + 16)
 for _ in range(3):
     ctx.index_extract_async(d, index, cap, rbsp if want_rbsp else None, summary)
 torch.cuda.synchronize()
