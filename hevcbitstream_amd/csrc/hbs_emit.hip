@@ -1293,7 +1293,14 @@ void k3t_check(const uint8_t* __restrict__ rbsp, uint64_t rbsp_bytes, const hbs_
          * Subtractions only: none of the sums can wrap. */
         const uint64_t last_off = idx[n - 1].rbsp_off, last_len = idx[n - 1].rbsp_len;
         const bool inside = a0 <= last_off && last_off <= rbsp_bytes && last_len <= rbsp_bytes - last_off;
-        const bool ok = want_tiles && inside && arena_len >= 16u &&
+        /* An empty NAL at the very end of an arena of whole chunks begins in a chunk that holds no byte.  The tile loop keeps that
+         * chunk as an element (the mask of the row that holds the arena's end, below), but the walk by rows of a dense tile takes
+         * a chunk at or behind the end for nothing (dz_classify: active = x0 < arena_len) and left the start code out: found by
+         * the long soak of round 6 (seed 66, iterations 47568 and 50920: streams of ~40-byte NALs, every chunk of a row with a
+         * start in it, the output 3 / 4 bytes short).  One in sixteen of the streams that end in an empty NAL; they go by NALs.
+         * (With a partial last chunk the NAL begins in it, and that chunk is an element either way.) */
+        const bool phantom_start = last_len == 0u && (arena_len & 15u) == 0u;
+        const bool ok = want_tiles && inside && arena_len >= 16u && !phantom_start &&
                         ((reinterpret_cast<uintptr_t>(rbsp) + a0) & 15u) == 0 && (pinned || arena_len >= kTMinArena) &&
                         ntiles + 1 <= first_cap && ntiles + 1 <= desc_words;
         tflag[1] = ok ? 1u : 0u;

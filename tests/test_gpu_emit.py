@@ -548,3 +548,72 @@ def test_gap_mode_0_with_long_zero_runs_fits_the_public_bound(orc):
     back, ent2 = ctx.emit_annexb(torch.from_numpy(arena).cuda(), ent, gap_mode=0, out_cap=bound)
     assert np.array_equal(back, stream)
     ctx.close()
+
+
+def _check_emit(ctx, orc, arena, lens, gaps):
+    idx = fake_index(lens, gaps)
+    got, got_idx = ctx.emit_annexb(dev(arena), idx)
+    want = orc.emit_annexb(arena, idx)
+    assert len(got) == len(want) and np.array_equal(got, want), (len(got), len(want), lens[-4:])
+    pos = 0
+    for k, (n, g) in enumerate(zip(lens, gaps)):
+        assert int(got_idx["start"][k]) == pos + g and int(got_idx["end"][k]) - int(got_idx["start"][k]) >= n, k
+        pos = int(got_idx["end"][k])
+    assert pos == len(want)
+
+
+def test_emit_empty_nals_where_an_arena_of_whole_chunks_ends(path_ctx, orc):
+    """Found by the long soak of round 6 (tests/tools/soak_gpu.py 1200 66, iterations 47568 and 50920): an EMPTY last NAL behind an
+    arena whose length is a multiple of 16 begins in a chunk that holds no byte, and the arena-tile kernel's walk by rows (tiles in
+    which every chunk of a KiB has a NAL start or a zero pair) left its start code out: the stream came out 3 / 4 bytes short.
+    Every emit path, arenas of whole chunks and of whole tiles and one byte either
+    side, one to three empty NALs at the end, empty NALs at chunk and tile boundaries inside, few large NALs and many small ones."""
+    ctx = path_ctx
+    rng = np.random.RandomState(606)
+    tile = 192 * 1024
+    for total in (16, 32, 1024, 44784, 52992, tile - 16, tile, tile + 16, 2 * tile, 2 * tile + 1, 2 * tile - 1, 3 * tile + 4096):
+        for n_empty in (1, 2, 3):
+            for many in (False, True):
+                if many:                                       # several hundred small NALs: the group kernel's ground on the automatic path
+                    cuts = np.sort(rng.choice(np.arange(1, total), size=min(total - 1, int(rng.randint(300, 1200))), replace=False)) if total > 1 else np.zeros(0, int)
+                else:
+                    cuts = np.sort(rng.choice(np.arange(1, total), size=min(total - 1, int(rng.randint(1, 6))), replace=False))
+                lens = [int(x) for x in np.diff(np.concatenate(([0], cuts, [total])))]
+                if total >= 2 * tile:                          # an empty NAL exactly where the second tile begins, and one at a chunk boundary
+                    acc = np.cumsum(lens)
+                    k = int(np.searchsorted(acc, tile))
+                    lens[k:k + 1] = [lens[k] - int(acc[k] - tile), 0, int(acc[k] - tile)] if acc[k] > tile else [lens[k], 0]
+                lens = lens + [0] * n_empty
+                gaps = [int(rng.randint(3, 5)) for _ in lens]
+                arena = ALPHA[rng.randint(0, len(ALPHA), size=total)].copy() if rng.rand() < 0.5 else rng.randint(0, 256, size=total).astype(np.uint8)
+                assert sum(lens) == total
+                _check_emit(ctx, orc, arena, lens, gaps)
+        # tiles that are walked by rows (what the soak's streams were): every chunk of some KiB with a NAL start in it, or a KiB of zeros
+        if total >= 16384:
+            for shape in ("starts", "zeros"):
+                head = [16] * 512 if shape == "starts" else [8192]
+                rest = total - sum(head)
+                lens = head + ([rest - 3000, 3000] if rest > 6000 else [rest]) + [0, 0]
+                arena = rng.randint(1, 256, size=total).astype(np.uint8)
+                if shape == "zeros":
+                    arena[2048:5000] = 0
+                _check_emit(ctx, orc, arena, lens, [3 + (k & 1) for k in range(len(lens))])
+
+
+def test_emit_an_empty_last_nal_on_the_automatic_path_at_full_size(ctx, orc):
+    """the same at the size from which the automatic path takes the arena tiles by itself (192 MiB): 10 KiB NALs, an arena of
+    whole chunks, an empty NAL at its end -- and, as a control, the same arena one byte longer"""
+    rng = np.random.RandomState(607)
+    for extra in (0, 1):
+        total = (200 << 20) + extra
+        nn = total // 10240
+        cuts = np.sort(rng.choice(np.arange(1, total, 7), size=nn - 1, replace=False))
+        lens = [int(x) for x in np.diff(np.concatenate(([0], cuts, [total])))] + [0]
+        gaps = [3 + (k & 1) for k in range(len(lens))]
+        arena = rng.randint(0, 256, size=total).astype(np.uint8)
+        arena[rng.randint(0, total, size=total // 5000)] = 0
+        arena[total - 50000: total - 47000] = 0               # three KiB of zeros in the last tile: it is walked by rows
+        ctx.set_emit_path(-1)
+        _check_emit(ctx, orc, arena, lens, gaps)
+        # the control goes by tiles (so the automatic path does take them at this size); the arena of whole chunks by NALs
+        assert ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h) == extra
