@@ -2158,9 +2158,14 @@ void k3_tiles(const uint8_t* __restrict__ rbsp, const hbs_nal_entry* __restrict_
         /* unpredicated (k3t_check: the arena holds at least one chunk and lies inside the caller's buffer): a chunk that would
          * reach past the arena's end reads the arena's last 16 bytes instead (its register is never used: the chunk is behind the
          * end, or it is the partial last chunk, an element that fetches its own bytes) */
-        const uint64_t room = t.arena_len - 16u - t.tile_lo;
+        /* (the arena's last tile may hold fewer than 16 bytes -- none at all when the arena is a whole number of tiles: every load
+         * of such a tile reads the arena's last chunk.  Until round 6 `room` wrapped there and the tile read up to 192 KiB BEHIND the
+         * arena: unused bytes, but a memory fault where the arena ends with its allocation -- found by tests/tools/soak_emit_small.py
+         * once it pinned this path, and then on the automatic path at exactly 1 024 tiles) */
+        const bool short_tile = t.tile_lo + 16u > t.arena_len;
+        const uint64_t room = short_tile ? 0ull : t.arena_len - 16u - t.tile_lo;
         const uint32_t lim = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
-        const uint8_t* const tb = t.arena + t.tile_lo;
+        const uint8_t* const tb = short_tile ? t.arena + (t.arena_len - 16u) : t.arena + t.tile_lo;
         auto load_group = [&](auto gc) {
             constexpr int g0 = 4 * decltype(gc)::value;
             t_for_n<4>([&](auto kc) {

@@ -617,3 +617,18 @@ def test_emit_an_empty_last_nal_on_the_automatic_path_at_full_size(ctx, orc):
         _check_emit(ctx, orc, arena, lens, gaps)
         # the control goes by tiles (so the automatic path does take them at this size); the arena of whole chunks by NALs
         assert ctx.lib.hbs_ctx_last_emit_by_tiles(ctx.h) == extra
+
+
+@pytest.mark.parametrize("case,extra", [("emit-1", 0), ("emit-1", 5), ("emit2", 0), ("scan0r", 0)])
+def test_buffers_that_end_with_their_allocation(case, extra):
+    """An arena of exactly 1 024 tiles (192 MiB, an allocation of its own) through the automatic emit path: until round 6 the
+    arena-tile kernel's last tile -- empty, or shorter than a chunk -- read up to 192 KiB behind the arena (`room` wrapped), a GPU
+    memory fault when nothing is mapped there.  In a process of its own (tests/tools/edge_faults.py: a fault kills it); the scan
+    of a stream of that size beside it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "edge_faults.py"), case, str(192 << 20), str(extra)],
+                       capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and ": ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-300:])
