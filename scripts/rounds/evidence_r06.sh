@@ -27,7 +27,10 @@ rm -f $O/pair_time.txt; for i in 1 2 3 4 5 6; do timeout 300 python scripts/pair
 timeout 300 python tests/tools/cli_time.py > $O/cli_time.txt 2>&1
 timeout 600 python scripts/fix_time.py > $O/fix_time.txt 2>&1
 timeout 400 python tests/tools/soak_gpu.py 200 11 > $O/soak_r06.txt 2>&1
-timeout 400 python tests/tools/soak_emit_small.py > $O/soak_emit_small.txt 2>&1
+timeout 500 python tests/tools/soak_emit_small.py 400 5 > $O/soak_emit_small.txt 2>&1
+# the soak that found the two emit faults of this round (seed 66: iterations 47568 and 50920), again on the fixed library; buffers that end with their allocation
+timeout 1500 python tests/tools/soak_gpu.py 1200 66 > $O/soak_long_seed66.txt 2>&1
+timeout 1200 python tests/tools/edge_faults.py > $O/edge_faults.txt 2>&1
 timeout 600 python tests/tools/fuzz_gpu_parse.py 1000 200 > $O/fuzz_gpu_parse.txt 2>&1
 timeout 600 python tests/tools/fuzz_gpu_legacy.py > $O/fuzz_gpu_legacy.txt 2>&1
 timeout 300 python scripts/config3_time.py > $O/config3_time.txt 2>&1
@@ -36,4 +39,4 @@ timeout 300 python scripts/scan_time.py --nals 209715 > $O/scan_time_2GiB.txt 2>
 timeout 600 python scripts/emit_sweep.py --sizes 48,64,96,128,160,192,224,256,384 > $O/emit_sweep.txt 2>&1
 timeout 600 python scripts/sweep_forced.py --sizes 64,128,192,256,384,512,768,1024 --kernels 0,2,4,6 > $O/sweep_forced.txt 2>&1
 timeout 300 python scripts/experiments/index_stream_placement.py > $O/index_stream_placement.txt 2>&1
-for f in mixed_time_16GiB mixed_time_1GiB mixed_timeline_4GiB nal_sweep emit_paths_16GiB emit_paths_16GiB_mixed emit_paths_16GiB_mixed_zeros emit_paths_16GiB_zero_heavy scan_time_1GiB scan_time_16GiB emit_time_1GiB emit_time_16GiB mixed_time pair_time cli_time fix_time soak_r06 soak_emit_small config3_time config_1gib scan_time_2GiB emit_sweep sweep_forced index_stream_placement fuzz_gpu_parse fuzz_gpu_legacy; do echo "== $f"; tail -3 $O/$f.txt | cut -c1-300; done
+for f in mixed_time_16GiB mixed_time_1GiB mixed_timeline_4GiB nal_sweep emit_paths_16GiB emit_paths_16GiB_mixed emit_paths_16GiB_mixed_zeros emit_paths_16GiB_zero_heavy scan_time_1GiB scan_time_16GiB emit_time_1GiB emit_time_16GiB mixed_time pair_time cli_time fix_time soak_r06 soak_emit_small soak_long_seed66 edge_faults config3_time config_1gib scan_time_2GiB emit_sweep sweep_forced index_stream_placement fuzz_gpu_parse fuzz_gpu_legacy; do echo "== $f"; tail -3 $O/$f.txt | cut -c1-300; done
