@@ -2,6 +2,9 @@
 the capacity it was given overwrites the caller's memory without anybody noticing -- here the canaries notice.  Scan + extraction
 (every kernel; the arena's capacity = the RBSP bytes, + 0 / + 16; the index's = the NALs found) and RBSP -> Annex-B (every path;
 the output's capacity = the bytes that come out), on streams of small and large NALs, plain and zero-heavy, sizes around the tiles.
+A call may answer HBS_E_CAPACITY instead of fitting -- a stream that stops at an empty NAL (stop_reason 1) is judged by the NALs and
+RBSP bytes FOUND, the ones behind the stop included (hbs_summary.nal_found; include/hevcbitstream_amd.h) -- those are counted and
+listed at the end; what may never happen is a changed canary or, without an error, a result that differs from the oracle's.
 usage: python3 tests/tools/canaries.py [seconds] [seed]"""
 import sys, time
 import numpy as np, torch
