@@ -94,10 +94,15 @@ while time.time() < t_end:
     if len(keep):
         want = orc.emit_annexb(want_arena, keep)
         d_idx = torch.from_numpy(np.ascontiguousarray(keep).view(np.uint8).copy()).cuda()
-        arena = torch.from_numpy(want_arena.copy()).cuda()
+        # the arena and the output at any byte alignment (the scan asks for 16-byte aligned pointers; hbs_emit_annexb does not)
+        oa, oo = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+        arena_buf = torch.empty(len(want_arena) + 32, dtype=torch.uint8, device="cuda")
+        arena = arena_buf[oa: oa + len(want_arena)]
+        arena.copy_(torch.from_numpy(want_arena.copy()))
         for p, c in emit.items():
             for slack in (0, 16):
-                out = canary(len(want) + slack)
+                out_buf = canary(len(want) + slack + 16)
+                out = out_buf[oo:]
                 summ = torch.zeros(SUMMARY.itemsize, dtype=torch.uint8, device="cuda")
                 try:
                     c.emit_annexb_async(arena, int(arena.numel()), d_idx, len(keep), 0, out[: len(want) + slack], None, summ)
@@ -105,9 +110,9 @@ while time.time() < t_end:
                     err = int(sm["error"])
                 except hbs.HbsError:
                     sm, err = None, -3
-                if not intact(out, len(want) + slack):
+                if not (intact(out, len(want) + slack) and bool((out_buf[:oo] == CAN).all().item())):
                     bad += 1
-                    print("CANARY emit path", p, "slack", slack, "iter", it, "arena", int(arena.numel()), "nals", len(keep), "out", len(want), "error", err, flush=True)
+                    print("CANARY emit path", p, "offsets", oa, oo, "slack", slack, "iter", it, "arena", int(arena.numel()), "nals", len(keep), "out", len(want), "error", err, flush=True)
                 if err == 0:
                     if int(sm["stream_bytes"]) != len(want) or not np.array_equal(out[: len(want)].cpu().numpy(), want):
                         bad += 1
