@@ -393,7 +393,7 @@ def pmc_traffic(kernel_name, algo_bytes):
     return None
 
 
-def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, structs_s):
+def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, structs_s, cpu_parse=False):
     """BASELINE config 3 as ONE pipeline at the size of a real 4K30 stream: the ~100 k NALs of the synthetic 4K30 sequence with
     slice payloads of 16-28 KiB (about 2.2 GiB; built on the device: every slice's RBSP is its original bytes followed by random
     payload, last byte 80, then K3), timed as start-code scan + index + RBSP extraction followed by the header parse, back to back
@@ -447,6 +447,12 @@ def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, s
     assert np.array_equal(p2["rc"] < 0, parsed_s["rc"] < 0) and np.array_equal(p2["nal_unit_type"], parsed_s["nal_unit_type"])
     used = structs_s.numel() - 16                             # (the arena is allocated 16 bytes longer than the parse fills)
     assert torch.equal(structs2[:used], structs_s[:used]), "header structs differ from those of the same headers in the small stream"
+    full_size_parity = None
+    if cpu_parse:
+        # round 5's verdict, thin spot (ii): this run was pinned on the reference through the short-payload run only.  The reference's
+        # read_hevc_nal_unit over the 2.1 GiB stream itself, NAL by NAL (it strips every whole NAL: ~2.2 GB through nal_to_rbsp), and
+        # rc, NAL header, every struct member and every slice payload of THIS run's outputs compared with it
+        full_size_parity = cpu_baseline_parse(stream2[:sb2], index2, rbsp2, m, p2, structs2)
     res = {"value": round(sb2 / ms / 1e6, 1), "unit": "GB/s of stream, scan + index + extraction + header parse", "ms": round(ms, 3),
            "nal_per_s": round(m / ms * 1e3, 1), "stream_bytes": sb2, "nals": m,
            "workload": "synthetic 4K30 sequence, %d NALs, slice payloads 16-28 KiB (%.2f GiB): hbs_index_extract then hbs_parse_headers, "
@@ -495,6 +501,8 @@ def config3_end_to_end(torch, hbs, ctx, d_small, index_s, rbsp_s, m, parsed_s, s
     res["without_arena_compact"] = {"value": round(sb2 / ms4 / 1e6, 1), "unit": "GB/s of stream, scan + index + compact header parse (hbs_index_parse_compact), host wall time of the call",
                                     "ms": round(ms4, 3), "nal_per_s": round(m / ms4 * 1e3, 1),
                                     "note": "index and per-NAL records equal to the arena path's; the slice records are those of parse_headers_compact (compared member by member there)"}
+    if full_size_parity is not None:
+        res["cpu_baseline_at_full_size"] = full_size_parity
     res["without_arena"] = {"value": round(sb2 / ms3 / 1e6, 1), "unit": "GB/s of stream, scan + index + header parse (hbs_index_parse), host wall time of the call",
                             "ms": round(ms3, 3), "nal_per_s": round(m / ms3 * 1e3, 1),
                             "note": "index, records and structs equal to the arena path's; includes the call's one wait (for the scan's NAL count)"}
@@ -796,10 +804,11 @@ def other_kernels(torch, hbs, ctx, g, n, sweep=True, cpu_parse=True):
         # config3_end_to_end below requires the 2.1 GiB pipeline (with and without arena) to produce these same structs
         res["parse_headers"]["cpu_baseline"] = cpu_baseline_parse(d, index, rbsp, m, parsed, structs, compact=(cpt, cct))
         res["parse_headers_compact"]["checked_against_the_reference_directly"] = res["parse_headers"]["cpu_baseline"]["compact_slices_checked"]
-    res["config3_end_to_end"] = config3_end_to_end(torch, hbs, ctx, d, index, rbsp, m, parsed, structs)
+    res["config3_end_to_end"] = config3_end_to_end(torch, hbs, ctx, d, index, rbsp, m, parsed, structs, cpu_parse=cpu_parse)
     if cpu_parse:
-        res["config3_end_to_end"]["parity"] = ("header structs equal to those of parse_headers' sequence, which were compared "
-                                               "with the %s on all %d NALs" % (res["parse_headers"]["cpu_baseline"]["kind"], m))
+        res["config3_end_to_end"]["parity"] = ("the 2.1 GiB run's own outputs (with the arena) compared with the %s on all %d NALs (cpu_baseline_at_full_size); "
+                                               "the runs without an arena equal to that run's index, records and structs"
+                                               % (res["parse_headers"]["cpu_baseline"]["kind"], m))
     parsed_dev = torch.from_numpy(parsed.view(np.uint8).copy()).cuda()
     wcap = 256
     written, wout = ctx.write_headers(parsed_dev, structs, m, wcap)
